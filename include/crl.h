@@ -1,0 +1,171 @@
+/*
+ * crl.h -- C ABI of the MI355X-native vector-env backend (libcrl_hip.so).
+ *
+ * The reference (ucla-rlcourse/competitive-rl) is pure Python and has NO FFI:
+ * its boundary for this path is the Python VecEnv protocol.  Each entry point
+ * below names the reference interface it stands in for (file:line relative to
+ * /root/reference/competitive_rl/).  The Python host mirror of that protocol
+ * (competitive_rl_amd/vec_env.py) is the only in-tree caller; INTEGRATION.md
+ * shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative CRL_E* code (crl_last_error() has the text); all
+ * device work is enqueued on the caller's HIP stream (`stream` is a
+ * hipStream_t passed as void*); a context is bound to one GPU and is not
+ * thread-safe; `*_dev` pointers are device memory owned by the caller
+ * (e.g. torch tensors), `*_host` pointers are host memory.
+ */
+#ifndef CRL_H_
+#define CRL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- geometry of cPongDouble-v0 (pong/base_pong_env.py:158-211) */
+#define CRL_PONG_W 160
+#define CRL_PONG_H 210
+#define CRL_PONG_TOP 34          /* arena top == top_border_thickness          */
+#define CRL_PONG_BOTTOM 194      /* arena bottom = 34 + window_width (sic)     */
+#define CRL_PONG_BALL 4
+#define CRL_PONG_BAT_W 5
+#define CRL_PONG_BAT_H 15
+#define CRL_PONG_BATL_X 16
+#define CRL_PONG_BATR_X 139
+#define CRL_PONG_MIRROR_ROW 25   /* base_pong_env.py:153-154: rows >= 25 flip  */
+#define CRL_PONG_MAX_ROUNDS 21   /* pong/register.py:20-22                     */
+#define CRL_PONG_MAX_STEPS 10000 /* base_pong_env.py:171                       */
+#define CRL_PONG_CHEAT 999       /* base_pong_env.py:9                         */
+#define CRL_PONG_FRAME_BYTES (CRL_PONG_H * CRL_PONG_W * 3) /* 100 800 */
+/* score band: 22 x 22 (score_l, score_r) images of rows 0..33, gray u8        */
+#define CRL_PONG_ATLAS_SCORES 22
+#define CRL_PONG_ATLAS_BYTES (22 * 22 * CRL_PONG_TOP * CRL_PONG_W)
+
+enum { CRL_OK = 0, CRL_EINVAL = -1, CRL_EHIP = -2, CRL_ENOMEM = -3, CRL_ESTATE = -4 };
+
+enum crl_env_kind { CRL_ENV_PONG_DOUBLE = 1 /* cPongDouble-v0 */ };
+
+enum crl_obs_mode {
+    /* raw env: obs (N,2,210,160,3) u8, 1 step = 1 frame
+       (PongDoublePlayerEnv._step, pong/base_pong_env.py:113-142) */
+    CRL_OBS_RAW_RGB = 0,
+    /* make_env_a2c_atari stack: skip-4 + max-2 + gray + INTER_AREA resize
+       (utils/atari_wrappers.py:40-53,89-219), obs (N,2,K,R,R) u8 with
+       FrameStackTensor roll/zero-on-done semantics for K>1 (utils/utils.py:145-173) */
+    CRL_OBS_GRAY_RESIZED = 1,
+};
+
+/* One raster-ready frame of the game, 8 bytes (what Arena/Ball/Bat/Scoreboard.draw
+ * read: base_pong_env.py:259-266).  ball_x/ball_y are int16 because a bat hit can
+ * place the ball a few px outside the arena rows (it is clipped when drawn). */
+typedef struct crl_pong_frame {
+    int16_t ball_x, ball_y;
+    uint8_t bat_l_y, bat_r_y;
+    uint8_t score_l, score_r; /* score_l == 255 marks a BLANK (all-zero) plane */
+} crl_pong_frame;
+
+/* Per-env state exchanged by crl_get_state / crl_set_state (host side, AoS).
+ * On the device the same fields live in SoA arrays (DESIGN.md "HBM layout"). */
+typedef struct crl_pong_env_state {
+    double speed_x, speed_y;       /* Ball._speed_x/_speed_y (f64)                  */
+    int32_t ball_x, ball_y;        /* Ball._rect.x/.y                               */
+    int32_t bat_l_y, bat_r_y;      /* Bat._rect.y                                   */
+    int32_t score_l, score_r;      /* PongGame._score_left/_right                   */
+    int32_t num_rounds, num_steps; /* PongGame._num_rounds/_num_steps               */
+    uint32_t serve_ctr;            /* serves drawn so far (RNG / replay cursor)     */
+    int32_t wrap_steps;            /* ClipRewardEnv._steps (atari_wrappers.py:169)  */
+    crl_pong_frame keep[2];        /* MaxAndSkipEnv._obs_buffer as frames (:104-116)*/
+    crl_pong_frame hist[3][2];     /* frame_stack>1: the 3 older planes of the stack,
+                                      oldest first, each the (keep0, keep1) pair that
+                                      produced it; BLANK = plane zeroed by a done
+                                      (FrameStackTensor.update, utils/utils.py:158-170) */
+} crl_pong_env_state;              /* 120 bytes */
+
+typedef struct crl_opts {
+    int32_t env_kind;    /* crl_env_kind                                             */
+    int32_t obs_mode;    /* crl_obs_mode                                             */
+    int32_t resized_dim; /* R: 84 or 42 (make_envs.py:67 resized_dim); 0 for raw     */
+    int32_t frame_stack; /* K planes per agent in GRAY_RESIZED mode (1 or 4)         */
+    int64_t num_envs;    /* envs owned by THIS context (one shard)                   */
+    int64_t env_id_base; /* global id of env 0 of this shard: RNG is keyed by global
+                            id so results do not depend on how envs are sharded      */
+    uint64_t seed;       /* make_envs(seed=...)                                      */
+    int32_t device;      /* HIP device ordinal                                       */
+    int32_t reserved;
+} crl_opts;
+
+typedef struct crl_ctx crl_ctx;
+
+/* make_envs(...) -> VecEnv construction (make_envs.py:67-118; DummyVecEnv.__init__
+ * dummy_vec_env.py:26-46).  `score_atlas_host`: CRL_PONG_ATLAS_BYTES gray values of
+ * the top band for every score pair (Scoreboard.draw, base_pong_env.py:474-487). */
+int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out);
+
+/* VecEnv.close (dummy_vec_env.py:77-79; idempotent like subproc_vec_env.py:131-141) */
+void crl_destroy(crl_ctx *ctx);
+
+/* VecEnv.seed(seed): env i gets seed + i (dummy_vec_env.py:65-69).  In the reference
+ * this never reaches Pong's RNG (_seed is a no-op, base_pong_env.py:38-39); here it
+ * re-keys the counter-based serve sampler. */
+int crl_seed(crl_ctx *ctx, uint64_t seed);
+
+/* VecEnv.reset() (dummy_vec_env.py:71-75): resets every env, writes the first
+ * observation into obs_dev (layout per obs_mode). */
+int crl_reset(crl_ctx *ctx, uint8_t *obs_dev, void *stream);
+
+/* VecEnv.step(actions) = step_async + step_wait (base_vec_env.py:178-187,
+ * dummy_vec_env.py:48-63) with auto-reset.  actions_dev: int32 (N,2), each 0/1/2 or
+ * 999.  obs_dev: per obs_mode.  rew_dev: f32 (N,2) (raw: game reward; wrapped:
+ * np.sign of the 4-frame sum).  done_dev: u8 (N).  Any output pointer may be NULL
+ * to skip that output (obs_dev NULL = dynamics only). */
+int crl_step(crl_ctx *ctx, const int32_t *actions_dev, uint8_t *obs_dev, float *rew_dev,
+             uint8_t *done_dev, void *stream);
+
+/* info[i]["real_reward"], info[i]["num_steps"] (ClipRewardEnv.step,
+ * atari_wrappers.py:175-181) as device arrays valid until the next step:
+ * real_reward f32 (N,2), num_steps i32 (N). */
+int crl_info(crl_ctx *ctx, const float **real_reward_dev, const int32_t **num_steps_dev);
+
+/* info[i]["terminal_observation"] (dummy_vec_env.py:55-57), produced lazily: renders,
+ * for `count` env indices (host array), the observation the episode ended on at the
+ * most recent step where that env was done.  out_dev: raw (count,2,210,160,3) or
+ * wrapped (count,2,R,R) u8. */
+int crl_terminal_observation(crl_ctx *ctx, const int64_t *env_idx_host, int64_t count,
+                             uint8_t *out_dev, void *stream);
+
+/* Parity tests + checkpoint/resume: whole-state copy, host AoS <-> device SoA.
+ * Synchronises `stream`. */
+int crl_get_state(crl_ctx *ctx, crl_pong_env_state *state_host, int64_t first, int64_t count,
+                  void *stream);
+int crl_set_state(crl_ctx *ctx, const crl_pong_env_state *state_host, int64_t first,
+                  int64_t count, void *stream);
+
+/* Replay mode for the serve sampler: per env a recorded stream of
+ * `per_env` draws (u in [0,1), bit_x, bit_y); serve k of env i uses entry
+ * [i*per_env + (k % per_env)].  Pass per_env = 0 to return to the Philox sampler. */
+int crl_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *bx_host,
+                   const uint8_t *by_host, int64_t per_env);
+
+/* Render arbitrary frames (tests, get_images()/render(), base_vec_env.py:189-217).
+ * frames_host: `count` frames; out_dev: (count,2,210,160,3) u8. */
+int crl_render_raw(crl_ctx *ctx, const crl_pong_frame *frames_host, int64_t count,
+                   uint8_t *out_dev, void *stream);
+
+/* Bytes of one env's observation in the context's obs_mode. */
+int64_t crl_obs_bytes_per_env(const crl_ctx *ctx);
+
+/* Launch-level timing hook for bench.py: wraps the `which`-th kernel of crl_step
+ * (0 = dynamics, 1 = raster) in hipEvents on the launch stream and accumulates.
+ * crl_kernel_time_ms() synchronises and returns total ms and launch count. */
+int crl_kernel_timing(crl_ctx *ctx, int enable);
+int crl_kernel_time_ms(crl_ctx *ctx, int which, double *total_ms, int64_t *launches);
+
+const char *crl_last_error(void);
+const char *crl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRL_H_ */
