@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the cPongDouble hot path on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raw|fused84] [--gather none|scalars|obs]
+
+A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated,
+device-resident) random actions, auto-reset included, no host sync inside the timed loop.
+Default workload = BASELINE.json configs[1]: cPongDouble-v0, 65 536 envs per GPU, raw
+(N, 2, 210, 160, 3) uint8 observations (1 env-step = 1 frame).  Prints ONE JSON line on rank 0.
+
+Envs shard across GPUs with no data-path collective (weak scaling: 65 536 envs per GPU);
+`--gather obs` adds the RCCL all-gather of BASELINE config #5 (xGMI-bound by construction).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per env per launch, DESIGN.md "Kernels" (201 713 B/env-step
+# for raw = 201 600 obs + 113 state/scalars; the frame-descriptor hand-off adds 8 B each way)
+RAW_RASTER_BYTES = 2 * 100800 + 8
+FUSED_RASTER_BYTES = {84: 2 * 4 * 84 * 84 + 8 * 8}
+HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(workload, budget_s=12.0):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores on a
+    bounded sample of the same workload.  Reported baseline, never the product path."""
+    import numpy as np
+
+    from competitive_rl_amd import _native
+    from oracle import pong_oracle as po
+
+    cores = len(os.sched_getaffinity(0))
+    atlas = _native.load_score_atlas()
+    if workload == "raw":
+        n = 64 * cores
+        env = po.PongOracle(n, atlas, obs_mode=po.RAW, seed=0)
+        threads = cores
+    else:
+        n = 16 * cores
+        env = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=84, frame_stack=4, seed=0)
+        threads = cores
+    env.set_threads(threads)
+    env.reset()
+    rs = np.random.RandomState(0)
+    acts = rs.randint(0, 3, (8, n, 2)).astype(np.int32)
+    env.step(acts[0])
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < budget_s:
+        env.step(acts[k % 8])
+        k += 1
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n * k / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c ({workload}), OpenMP over {threads} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=["raw", "fused84"], default="raw")
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import competitive_rl_amd as crl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.envs
+    if args.workload == "raw":
+        env = crl.HipPongVecEnv(n, seed=0, mode="raw", device=dev, env_id_base=rank * n)
+        raster_bytes, kernel = RAW_RASTER_BYTES, "pong_raster_raw_kernel"
+        desc = f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)"
+    else:
+        env = crl.HipPongVecEnv(n, seed=0, mode="wrapped", resized_dim=84, frame_stack=4, device=dev,
+                                env_id_base=rank * n)
+        raster_bytes, kernel = FUSED_RASTER_BYTES[84], "pong_raster_gray_kernel"
+        desc = (f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack (N,2,4,84,84) u8, "
+                "1 step = 4 frames (BASELINE config #3)")
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pool = [torch.randint(0, 3, (n, 2), generator=g, device=dev, dtype=torch.int32) for _ in range(16)]
+
+    def gather(buf, rew, done):
+        if world == 1 or args.gather == "none":
+            return
+        if args.gather == "scalars":
+            crl.all_gather_step((rew, done))
+        else:
+            crl.all_gather_step((buf, rew, done))
+
+    for i in range(args.warmup):
+        out = env.step_device(pool[i % 16])
+        gather(*out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    env.kernel_time_ms(0), env.kernel_time_ms(1)
+    env.kernel_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = env.step_device(pool[i % 16])
+        gather(*out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    env.kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dyn_ms, dyn_n = env.kernel_time_ms(0)
+    ras_ms, ras_n = env.kernel_time_ms(1)
+    done_frac = float(out[2].float().mean().item())
+    env.close()
+
+    if rank == 0:
+        value = world * n * args.steps / dt
+        ras_avg_s = ras_ms / max(ras_n, 1) * 1e-3
+        achieved = raster_bytes * n / ras_avg_s if ras_avg_s > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "env-steps/sec (whole node), cPongDouble 65536 envs per GPU",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",
+                       "actions": "uniform {0,1,2}, pre-generated on device", "auto_reset": True},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "bytes_per_launch": raster_bytes * n, "avg_kernel_us": ras_avg_s * 1e6,
+                         "launches_timed": ras_n,
+                         "dynamics_kernel_avg_us": dyn_ms / max(dyn_n, 1) * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,12 @@
+"""competitive_rl_amd -- MI355X-native vector-env backend for competitive-rl's env.step() hot path.
+
+Importing the package does not touch the GPU; constructing an env loads libcrl_hip.so and
+fails loudly if it is missing (no CPU fallback exists in this package).
+"""
+from .make_envs import make_envs
+from .vec_env import CHEAT_CODES, HipPongVecEnv, LazyInfos, VecEnv
+from .frame_stack import FrameStackTensor
+from .sharding import ShardSpec, all_gather_step, shard_of
+
+__all__ = ["make_envs", "HipPongVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "CHEAT_CODES",
+           "ShardSpec", "shard_of", "all_gather_step"]

@@ -1,0 +1,91 @@
+"""ctypes binding of libcrl_hip.so (include/crl.h).  There is NO fallback: if the HIP
+library is missing or fails to load, importing the backend raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libcrl_hip.so")
+
+CRL_ENV_PONG_DOUBLE = 1
+CRL_OBS_RAW_RGB, CRL_OBS_GRAY_RESIZED = 0, 1
+PONG_FRAME_BYTES = 210 * 160 * 3
+ATLAS_BYTES = 22 * 22 * 34 * 160
+
+# every symbol include/crl.h declares (tests check the library exports all of them)
+SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "crl_info", "crl_copy_info",
+           "crl_terminal_observation", "crl_get_state", "crl_set_state", "crl_set_replay", "crl_render_raw",
+           "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version"]
+
+FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
+                     ("score_l", "u1"), ("score_r", "u1")])
+STATE_DT = np.dtype([
+    ("speed_x", "<f8"), ("speed_y", "<f8"), ("ball_x", "<i4"), ("ball_y", "<i4"),
+    ("bat_l_y", "<i4"), ("bat_r_y", "<i4"), ("score_l", "<i4"), ("score_r", "<i4"),
+    ("num_rounds", "<i4"), ("num_steps", "<i4"), ("serve_ctr", "<u4"), ("wrap_steps", "<i4"),
+    ("keep", FRAME_DT, (2,)), ("hist", FRAME_DT, (3, 2)),
+])
+
+
+class CrlOpts(C.Structure):
+    _fields_ = [("env_kind", C.c_int32), ("obs_mode", C.c_int32), ("resized_dim", C.c_int32),
+                ("frame_stack", C.c_int32), ("num_envs", C.c_int64), ("env_id_base", C.c_int64),
+                ("seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CrlError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libcrl_hip.so or raise -- the product path never silently degrades."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m competitive_rl_amd.build` "
+            "(hipcc, gfx950).  competitive_rl_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, u64, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int
+    L.crl_create.argtypes = [C.POINTER(CrlOpts), vp, C.POINTER(vp)]
+    L.crl_destroy.argtypes = [vp]
+    L.crl_destroy.restype = None
+    L.crl_seed.argtypes = [vp, u64]
+    L.crl_reset.argtypes = [vp, vp, vp]
+    L.crl_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.crl_info.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.crl_copy_info.argtypes = [vp, vp, vp, vp]
+    L.crl_terminal_observation.argtypes = [vp, vp, i64, vp, vp]
+    L.crl_get_state.argtypes = [vp, vp, i64, i64, vp]
+    L.crl_set_state.argtypes = [vp, vp, i64, i64, vp]
+    L.crl_set_replay.argtypes = [vp, vp, vp, vp, i64]
+    L.crl_render_raw.argtypes = [vp, vp, i64, vp, vp]
+    L.crl_obs_bytes_per_env.argtypes = [vp]
+    L.crl_obs_bytes_per_env.restype = i64
+    L.crl_kernel_timing.argtypes = [vp, i32]
+    L.crl_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.crl_last_error.restype = C.c_char_p
+    L.crl_version.restype = C.c_char_p
+    for name in SYMBOLS:
+        getattr(L, name)
+        if name not in ("crl_destroy", "crl_obs_bytes_per_env", "crl_last_error", "crl_version"):
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise CrlError(f"crl error {rc}: {load().crl_last_error().decode()}")
+
+
+def load_score_atlas():
+    a = np.load(os.path.join(PKG, "assets", "pong_score_atlas.npz"))["atlas"]
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.size == ATLAS_BYTES
+    return a

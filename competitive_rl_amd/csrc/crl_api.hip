@@ -1,0 +1,518 @@
+// crl_api.hip -- the C ABI of include/crl.h: context, HBM allocations, launches.
+//
+// Host-side only; every entry point cites the reference interface it replaces in
+// include/crl.h.  No torch types cross this boundary.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "pong_device.h"
+
+namespace crl {
+void launch_pong_gray_templates(const GrayParams &p, const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
+                                const uint8_t *y_last, int band_rows, int band_chunks, uint8_t *band, uint8_t *rest,
+                                hipStream_t st);
+void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int zero_row0, int zero_row1,
+                                const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
+                                const uint8_t *y_last, int band_chunks, hipStream_t st);
+}  // namespace crl
+
+using namespace crl;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(CRL_EHIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+struct AreaTab {
+    std::vector<int32_t> ofs, si;  // ofs[d] .. ofs[d+1]: taps of output index d
+    std::vector<float> alpha;
+};
+
+// cv2.resize INTER_AREA weight table for one axis (OpenCV computeResizeAreaTab; SURVEY
+// C.3): table math in f64, weights stored as f32.
+static AreaTab area_table(int ssize, int dsize) {
+    AreaTab t;
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    for (int d = 0; d < dsize; d++) {
+        t.ofs.push_back((int32_t)t.si.size());
+        const double f1 = d * scale, f2 = f1 + scale;
+        const double cell = std::min(scale, ssize - f1);
+        int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+        s2 = std::min(s2, ssize - 1);
+        s1 = std::min(s1, s2);
+        if (s1 - f1 > 1e-3) t.si.push_back(s1 - 1), t.alpha.push_back((float)((s1 - f1) / cell));
+        for (int s = s1; s < s2; s++) t.si.push_back(s), t.alpha.push_back((float)(1.0 / cell));
+        if (f2 - s2 > 1e-3) t.si.push_back(s2), t.alpha.push_back((float)(std::min(std::min(f2 - s2, 1.0), cell) / cell));
+    }
+    t.ofs.push_back((int32_t)t.si.size());
+    return t;
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct crl_ctx {
+    crl_opts o;
+    int64_t n;
+    PongSoA s{};
+    ServeSrc src{};
+    std::vector<void *> allocs;
+    // raw mode
+    uint8_t *atlas_rgb = nullptr;
+    int ink_row0 = 0, ink_row1 = 0;
+    // gray mode
+    uint8_t *atlas_gray = nullptr, *band = nullptr, *rest = nullptr;
+    uint8_t *x_first = nullptr, *x_last = nullptr, *y_first = nullptr, *y_last = nullptr;
+    int32_t *xofs = nullptr, *yofs = nullptr, *xsi = nullptr, *ysi = nullptr;
+    float *xalpha = nullptr, *yalpha = nullptr;
+    int band_rows = 0, band_chunks = 0, zero_row0 = 0, zero_row1 = 0;
+    // replay
+    double *ru = nullptr;
+    uint8_t *rbx = nullptr, *rby = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<EventPair> ev[2];
+    double ev_ms[2] = {0, 0};
+    int64_t ev_n[2] = {0, 0};
+    std::vector<uint8_t> atlas_host;
+};
+
+template <class T>
+static int dev_alloc(crl_ctx *c, T **p, size_t count) {
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16)));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return CRL_OK;
+}
+
+template <class T>
+static int dev_upload(crl_ctx *c, T **p, const std::vector<T> &v, size_t pad_to = 0) {
+    size_t cnt = std::max(v.size(), pad_to);
+    int rc = dev_alloc(c, p, cnt);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(*p, 0, std::max<size_t>(cnt * sizeof(T), 16)));
+    HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return CRL_OK;
+}
+
+static void begin_timed(crl_ctx *c, int which, hipStream_t st) {
+    if (!c->timing) return;
+    EventPair p;
+    hipEventCreate(&p.a), hipEventCreate(&p.b);
+    hipEventRecord(p.a, st);
+    c->ev[which].push_back(p);
+}
+static void end_timed(crl_ctx *c, int which, hipStream_t st) {
+    if (!c->timing) return;
+    hipEventRecord(c->ev[which].back().b, st);
+}
+
+static int setup_gray(crl_ctx *c) {
+    const int R = c->o.resized_dim;
+    AreaTab xt = area_table(CRL_PONG_W, R), yt = area_table(CRL_PONG_H, R);
+    std::vector<uint8_t> xf(CRL_PONG_W, 255), xl(CRL_PONG_W, 0), yf(CRL_PONG_H, 255), yl(CRL_PONG_H, 0);
+    int band_rows = 0;
+    for (int d = 0; d < R; d++) {
+        for (int k = xt.ofs[d]; k < xt.ofs[d + 1]; k++) {
+            xf[xt.si[k]] = std::min<uint8_t>(xf[xt.si[k]], (uint8_t)d), xl[xt.si[k]] = std::max<uint8_t>(xl[xt.si[k]], (uint8_t)d);
+        }
+        for (int k = yt.ofs[d]; k < yt.ofs[d + 1]; k++) {
+            yf[yt.si[k]] = std::min<uint8_t>(yf[yt.si[k]], (uint8_t)d), yl[yt.si[k]] = std::max<uint8_t>(yl[yt.si[k]], (uint8_t)d);
+            if (yt.si[k] < CRL_PONG_TOP) band_rows = d + 1;
+        }
+    }
+    for (int i = 0; i < CRL_PONG_W; i++)
+        if (xf[i] == 255) return fail(CRL_ESTATE, "source col %d feeds no output col", i);
+    for (int i = 0; i < CRL_PONG_H; i++)
+        if (yf[i] == 255) return fail(CRL_ESTATE, "source row %d feeds no output row", i);
+    c->band_rows = band_rows;
+    c->band_chunks = (band_rows * R + 15) / 16;
+    const int chunks = (R * R + 15) / 16;
+    int rc;
+    if ((rc = dev_upload(c, &c->xofs, xt.ofs))) return rc;
+    if ((rc = dev_upload(c, &c->yofs, yt.ofs))) return rc;
+    if ((rc = dev_upload(c, &c->xsi, xt.si))) return rc;
+    if ((rc = dev_upload(c, &c->ysi, yt.si))) return rc;
+    if ((rc = dev_upload(c, &c->xalpha, xt.alpha))) return rc;
+    if ((rc = dev_upload(c, &c->yalpha, yt.alpha))) return rc;
+    if ((rc = dev_upload(c, &c->x_first, xf))) return rc;
+    if ((rc = dev_upload(c, &c->x_last, xl))) return rc;
+    if ((rc = dev_upload(c, &c->y_first, yf))) return rc;
+    if ((rc = dev_upload(c, &c->y_last, yl))) return rc;
+    if ((rc = dev_upload(c, &c->atlas_gray, c->atlas_host))) return rc;
+    if ((rc = dev_alloc(c, &c->band, (size_t)484 * 2 * c->band_chunks * 16))) return rc;
+    if ((rc = dev_alloc(c, &c->rest, (size_t)chunks * 16))) return rc;
+    HIP_TRY(hipMemset(c->rest, 0, (size_t)chunks * 16));
+    GrayParams p{};
+    p.R = R, p.K = c->o.frame_stack, p.atlas_gray = c->atlas_gray;
+    p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
+    launch_pong_gray_templates(p, c->x_first, c->x_last, c->y_first, c->y_last, c->band_rows, c->band_chunks, c->band,
+                               c->rest, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    // longest run of all-zero template rows below the score rows = the empty court
+    std::vector<uint8_t> rest((size_t)R * R);
+    HIP_TRY(hipMemcpy(rest.data(), c->rest, rest.size(), hipMemcpyDeviceToHost));
+    int best0 = 0, best1 = 0, run0 = -1;
+    for (int r = band_rows; r <= R; r++) {
+        bool zero = r < R;
+        if (zero)
+            for (int x = 0; x < R; x++)
+                if (rest[(size_t)r * R + x]) { zero = false; break; }
+        if (zero && run0 < 0) run0 = r;
+        if (!zero && run0 >= 0) {
+            if (r - run0 > best1 - best0) best0 = run0, best1 = r;
+            run0 = -1;
+        }
+    }
+    c->zero_row0 = best0, c->zero_row1 = best1;
+    return CRL_OK;
+}
+
+extern "C" {
+
+const char *crl_last_error(void) { return g_err.c_str(); }
+const char *crl_version(void) { return "crl-hip 0.1 (gfx950)"; }
+
+int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out) {
+    if (!opts || !out || !score_atlas_host) return fail(CRL_EINVAL, "null argument");
+    if (opts->env_kind != CRL_ENV_PONG_DOUBLE) return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
+    if (opts->num_envs <= 0) return fail(CRL_EINVAL, "num_envs must be positive");
+    if (opts->obs_mode == CRL_OBS_GRAY_RESIZED) {
+        if (opts->resized_dim < 8 || opts->resized_dim > 84 || (opts->resized_dim * opts->resized_dim) % 4)
+            return fail(CRL_EINVAL, "resized_dim %d unsupported (8..84, R*R %% 4 == 0)", opts->resized_dim);
+        if (opts->frame_stack < 1 || opts->frame_stack > 4) return fail(CRL_EINVAL, "frame_stack must be 1..4");
+    } else if (opts->obs_mode != CRL_OBS_RAW_RGB) {
+        return fail(CRL_EINVAL, "unknown obs_mode %d", opts->obs_mode);
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (opts->device < 0 || opts->device >= ndev) return fail(CRL_EINVAL, "device %d of %d", opts->device, ndev);
+    HIP_TRY(hipSetDevice(opts->device));
+    crl_ctx *c = new crl_ctx();
+    c->o = *opts;
+    const int64_t n = c->n = opts->num_envs;
+    c->atlas_host.assign(score_atlas_host, score_atlas_host + CRL_PONG_ATLAS_BYTES);
+    int rc = 0;
+#define A(field, count) if (!rc) rc = dev_alloc(c, &c->s.field, (size_t)(count))
+    A(speed_x, n); A(speed_y, n); A(ball_x, n); A(ball_y, n); A(bat_l, n); A(bat_r, n); A(score_l, n); A(score_r, n);
+    A(rounds, n); A(steps, n); A(wrap_steps, n); A(serve_ctr, n); A(keep, 2 * n); A(ring, 8 * n); A(obs_frames, 2 * n);
+    A(term_frames, 2 * n); A(real_reward, 2 * n); A(num_steps, n);
+#undef A
+    if (rc) { crl_destroy(c); return rc; }
+    // zero state, BLANK kept frames (MaxAndSkipEnv._obs_buffer starts as zeros)
+    hipMemset(c->s.serve_ctr, 0, n * 4), hipMemset(c->s.wrap_steps, 0, n * 4), hipMemset(c->s.num_steps, 0, n * 4);
+    hipMemset(c->s.real_reward, 0, n * 8);
+    {
+        std::vector<uint64_t> blank((size_t)8 * n, kBlankFrame);
+        hipMemcpy(c->s.keep, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
+        hipMemcpy(c->s.ring, blank.data(), 8 * n * 8, hipMemcpyHostToDevice);
+        hipMemcpy(c->s.obs_frames, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
+        hipMemcpy(c->s.term_frames, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
+    }
+    c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
+    // score band: ink rows and the RGB-expanded copy used by the raw writer
+    int r0 = CRL_PONG_TOP, r1 = 0;
+    for (int sp = 0; sp < 484; sp++)
+        for (int r = 0; r < CRL_PONG_TOP; r++)
+            for (int x = 0; x < CRL_PONG_W; x++)
+                if (c->atlas_host[((size_t)sp * CRL_PONG_TOP + r) * CRL_PONG_W + x] != 255) r0 = std::min(r0, r), r1 = std::max(r1, r + 1);
+    if (r1 <= r0) r0 = r1 = 0;
+    c->ink_row0 = r0, c->ink_row1 = r1;
+    if (opts->obs_mode == CRL_OBS_RAW_RGB) {
+        std::vector<uint8_t> rgb((size_t)CRL_PONG_ATLAS_BYTES * 3);
+        for (size_t i = 0; i < (size_t)CRL_PONG_ATLAS_BYTES; i++) rgb[3 * i] = rgb[3 * i + 1] = rgb[3 * i + 2] = c->atlas_host[i];
+        rc = dev_upload(c, &c->atlas_rgb, rgb);
+    } else {
+        rc = setup_gray(c);
+    }
+    if (rc) { crl_destroy(c); return rc; }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { crl_destroy(c); return fail(CRL_EHIP, "create: %s", hipGetErrorString(e)); }
+    *out = c;
+    return CRL_OK;
+}
+
+void crl_destroy(crl_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->o.device);
+    hipDeviceSynchronize();
+    for (void *p : c->allocs) hipFree(p);
+    for (int w = 0; w < 2; w++)
+        for (auto &p : c->ev[w]) hipEventDestroy(p.a), hipEventDestroy(p.b);
+    delete c;
+}
+
+int crl_seed(crl_ctx *c, uint64_t seed) {
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    c->src.seed = seed;
+    return CRL_OK;
+}
+
+static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
+    if (!obs_dev) return CRL_OK;
+    begin_timed(c, 1, st);
+    if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
+        launch_pong_raster_raw(c->s.obs_frames, c->n, c->atlas_rgb, c->ink_row0, c->ink_row1, obs_dev, st);
+    } else {
+        GrayParams p{};
+        p.ring = c->s.ring, p.n = c->n, p.R = c->o.resized_dim, p.K = c->o.frame_stack;
+        p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
+        p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
+        p.obs = obs_dev;
+        launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
+                                   c->band_chunks, st);
+    }
+    end_timed(c, 1, st);
+    HIP_TRY(hipGetLastError());
+    return CRL_OK;
+}
+
+int crl_reset(crl_ctx *c, uint8_t *obs_dev, void *stream) {
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    hipStream_t st = (hipStream_t)stream;
+    launch_pong_reset(c->s, c->src, c->n, st);
+    HIP_TRY(hipGetLastError());
+    return draw_obs(c, obs_dev, st);
+}
+
+int crl_step(crl_ctx *c, const int32_t *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, void *stream) {
+    if (!c || !actions_dev) return fail(CRL_EINVAL, "null ctx/actions");
+    hipStream_t st = (hipStream_t)stream;
+    begin_timed(c, 0, st);
+    launch_pong_dynamics(c->s, c->src, actions_dev, c->n, c->o.obs_mode == CRL_OBS_GRAY_RESIZED, rew_dev, done_dev, st);
+    end_timed(c, 0, st);
+    HIP_TRY(hipGetLastError());
+    return draw_obs(c, obs_dev, st);
+}
+
+int crl_info(crl_ctx *c, const float **real_reward_dev, const int32_t **num_steps_dev) {
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    if (real_reward_dev) *real_reward_dev = c->s.real_reward;
+    if (num_steps_dev) *num_steps_dev = c->s.num_steps;
+    return CRL_OK;
+}
+
+int crl_copy_info(crl_ctx *c, float *rr_out, int32_t *ns_out, void *stream) {
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    hipStream_t st = (hipStream_t)stream;
+    if (rr_out) HIP_TRY(hipMemcpyAsync(rr_out, c->s.real_reward, (size_t)c->n * 8, hipMemcpyDeviceToDevice, st));
+    if (ns_out) HIP_TRY(hipMemcpyAsync(ns_out, c->s.num_steps, (size_t)c->n * 4, hipMemcpyDeviceToDevice, st));
+    return CRL_OK;
+}
+
+int64_t crl_obs_bytes_per_env(const crl_ctx *c) {
+    if (!c) return 0;
+    if (c->o.obs_mode == CRL_OBS_RAW_RGB) return 2 * (int64_t)CRL_PONG_FRAME_BYTES;
+    return 2 * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim;
+}
+
+// Renders `count` frame pairs (host) through a temporary context-less launch.
+static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::vector<uint64_t> &f1, uint8_t *out_dev,
+                        hipStream_t st) {
+    const int64_t m = (int64_t)f0.size();
+    if (m == 0) return CRL_OK;
+    uint64_t *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, (size_t)8 * m * 8));
+    if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
+        HIP_TRY(hipMemcpyAsync(tmp, f0.data(), m * 8, hipMemcpyHostToDevice, st));
+        launch_pong_raster_raw(tmp, m, c->atlas_rgb, c->ink_row0, c->ink_row1, out_dev, st);
+    } else {
+        // single-plane ring: only plane 3 is drawn with K = 1
+        std::vector<uint64_t> ring((size_t)8 * m, kBlankFrame);
+        std::copy(f0.begin(), f0.end(), ring.begin() + 6 * m);
+        std::copy(f1.begin(), f1.end(), ring.begin() + 7 * m);
+        HIP_TRY(hipMemcpyAsync(tmp, ring.data(), ring.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // `ring` is a local
+        GrayParams p{};
+        p.ring = tmp, p.n = m, p.R = c->o.resized_dim, p.K = 1;
+        p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
+        p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
+        p.obs = out_dev;
+        launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
+                                   c->band_chunks, st);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipFree(tmp));
+    return CRL_OK;
+}
+
+int crl_terminal_observation(crl_ctx *c, const int64_t *env_idx_host, int64_t count, uint8_t *out_dev, void *stream) {
+    if (!c || (count > 0 && (!env_idx_host || !out_dev))) return fail(CRL_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<uint64_t> all((size_t)2 * c->n);
+    HIP_TRY(hipMemcpyAsync(all.data(), c->s.term_frames, all.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<uint64_t> f0(count), f1(count);
+    for (int64_t k = 0; k < count; k++) {
+        const int64_t i = env_idx_host[k];
+        if (i < 0 || i >= c->n) return fail(CRL_EINVAL, "env index %lld out of range", (long long)i);
+        f0[k] = all[i], f1[k] = all[c->n + i];
+    }
+    return render_pairs(c, f0, f1, out_dev, st);
+}
+
+int crl_render_raw(crl_ctx *c, const crl_pong_frame *frames_host, int64_t count, uint8_t *out_dev, void *stream) {
+    if (!c || !frames_host || !out_dev) return fail(CRL_EINVAL, "null argument");
+    if (c->o.obs_mode != CRL_OBS_RAW_RGB) return fail(CRL_ESTATE, "crl_render_raw needs a RAW_RGB context");
+    std::vector<uint64_t> f(count);
+    memcpy(f.data(), frames_host, (size_t)count * 8);
+    return render_pairs(c, f, f, out_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- state exchange: device SoA <-> host AoS
+template <class T>
+static int d2h(std::vector<T> &v, const T *dev, int64_t first, int64_t count, hipStream_t st) {
+    v.resize(count);
+    HIP_TRY(hipMemcpyAsync(v.data(), dev + first, count * sizeof(T), hipMemcpyDeviceToHost, st));
+    return CRL_OK;
+}
+template <class T>
+static int h2d(const std::vector<T> &v, T *dev, int64_t first, hipStream_t st) {
+    HIP_TRY(hipMemcpyAsync(dev + first, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return CRL_OK;
+}
+
+static crl_pong_frame to_frame(uint64_t u) {
+    crl_pong_frame f;
+    memcpy(&f, &u, 8);
+    return f;
+}
+static uint64_t from_frame(const crl_pong_frame &f) {
+    uint64_t u;
+    memcpy(&u, &f, 8);
+    return u;
+}
+
+extern "C" {
+
+int crl_get_state(crl_ctx *c, crl_pong_env_state *out, int64_t first, int64_t count, void *stream) {
+    if (!c || !out || first < 0 || count < 0 || first + count > c->n) return fail(CRL_EINVAL, "bad range");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> sx, sy;
+    std::vector<int32_t> bx, by, bl, br, sl, sr, ro, stp, ws;
+    std::vector<uint32_t> sc;
+    std::vector<uint64_t> keep[2], ring[8];
+    int rc = 0;
+    rc |= d2h(sx, c->s.speed_x, first, count, st), rc |= d2h(sy, c->s.speed_y, first, count, st);
+    rc |= d2h(bx, c->s.ball_x, first, count, st), rc |= d2h(by, c->s.ball_y, first, count, st);
+    rc |= d2h(bl, c->s.bat_l, first, count, st), rc |= d2h(br, c->s.bat_r, first, count, st);
+    rc |= d2h(sl, c->s.score_l, first, count, st), rc |= d2h(sr, c->s.score_r, first, count, st);
+    rc |= d2h(ro, c->s.rounds, first, count, st), rc |= d2h(stp, c->s.steps, first, count, st);
+    rc |= d2h(ws, c->s.wrap_steps, first, count, st), rc |= d2h(sc, c->s.serve_ctr, first, count, st);
+    for (int k = 0; k < 2; k++) rc |= d2h(keep[k], c->s.keep + k * c->n, first, count, st);
+    for (int k = 0; k < 8; k++) rc |= d2h(ring[k], c->s.ring + k * c->n, first, count, st);
+    if (rc) return CRL_EHIP;
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < count; i++) {
+        crl_pong_env_state &e = out[i];
+        e.speed_x = sx[i], e.speed_y = sy[i], e.ball_x = bx[i], e.ball_y = by[i], e.bat_l_y = bl[i], e.bat_r_y = br[i];
+        e.score_l = sl[i], e.score_r = sr[i], e.num_rounds = ro[i], e.num_steps = stp[i];
+        e.serve_ctr = sc[i], e.wrap_steps = ws[i];
+        e.keep[0] = to_frame(keep[0][i]), e.keep[1] = to_frame(keep[1][i]);
+        // exchange format: the 3 most recent planes, oldest first = ring planes 1..3
+        for (int h = 0; h < 3; h++) e.hist[h][0] = to_frame(ring[2 * (h + 1)][i]), e.hist[h][1] = to_frame(ring[2 * (h + 1) + 1][i]);
+    }
+    return CRL_OK;
+}
+
+int crl_set_state(crl_ctx *c, const crl_pong_env_state *in, int64_t first, int64_t count, void *stream) {
+    if (!c || !in || first < 0 || count < 0 || first + count > c->n) return fail(CRL_EINVAL, "bad range");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> sx(count), sy(count);
+    std::vector<int32_t> bx(count), by(count), bl(count), br(count), sl(count), sr(count), ro(count), stp(count), ws(count);
+    std::vector<uint32_t> sc(count);
+    std::vector<uint64_t> keep[2], ring[8], of[2];
+    for (auto &v : keep) v.resize(count);
+    for (auto &v : ring) v.resize(count);
+    for (auto &v : of) v.resize(count);
+    for (int64_t i = 0; i < count; i++) {
+        const crl_pong_env_state &e = in[i];
+        sx[i] = e.speed_x, sy[i] = e.speed_y, bx[i] = e.ball_x, by[i] = e.ball_y, bl[i] = e.bat_l_y, br[i] = e.bat_r_y;
+        sl[i] = e.score_l, sr[i] = e.score_r, ro[i] = e.num_rounds, stp[i] = e.num_steps, sc[i] = e.serve_ctr, ws[i] = e.wrap_steps;
+        keep[0][i] = from_frame(e.keep[0]), keep[1][i] = from_frame(e.keep[1]);
+        ring[0][i] = ring[1][i] = kBlankFrame;  // the plane that the next roll drops
+        for (int h = 0; h < 3; h++) ring[2 * (h + 1)][i] = from_frame(e.hist[h][0]), ring[2 * (h + 1) + 1][i] = from_frame(e.hist[h][1]);
+        of[0][i] = ring[6][i], of[1][i] = ring[7][i];
+    }
+    int rc = 0;
+    rc |= h2d(sx, c->s.speed_x, first, st), rc |= h2d(sy, c->s.speed_y, first, st);
+    rc |= h2d(bx, c->s.ball_x, first, st), rc |= h2d(by, c->s.ball_y, first, st);
+    rc |= h2d(bl, c->s.bat_l, first, st), rc |= h2d(br, c->s.bat_r, first, st);
+    rc |= h2d(sl, c->s.score_l, first, st), rc |= h2d(sr, c->s.score_r, first, st);
+    rc |= h2d(ro, c->s.rounds, first, st), rc |= h2d(stp, c->s.steps, first, st);
+    rc |= h2d(ws, c->s.wrap_steps, first, st), rc |= h2d(sc, c->s.serve_ctr, first, st);
+    for (int k = 0; k < 2; k++) rc |= h2d(keep[k], c->s.keep + k * c->n, first, st);
+    for (int k = 0; k < 8; k++) rc |= h2d(ring[k], c->s.ring + k * c->n, first, st);
+    if (c->o.obs_mode == CRL_OBS_GRAY_RESIZED)
+        for (int k = 0; k < 2; k++) rc |= h2d(of[k], c->s.obs_frames + k * c->n, first, st);
+    if (rc) return CRL_EHIP;
+    HIP_TRY(hipStreamSynchronize(st));
+    return CRL_OK;
+}
+
+int crl_set_replay(crl_ctx *c, const double *u, const uint8_t *bx, const uint8_t *by, int64_t per_env) {
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->ru) hipFree(c->ru), hipFree(c->rbx), hipFree(c->rby), c->ru = nullptr, c->rbx = c->rby = nullptr;
+    c->src.ru = nullptr, c->src.rbx = c->src.rby = nullptr, c->src.per_env = 0;
+    if (per_env <= 0) return CRL_OK;
+    if (!u || !bx || !by) return fail(CRL_EINVAL, "null replay arrays");
+    const size_t m = (size_t)c->n * per_env;
+    HIP_TRY(hipMalloc((void **)&c->ru, m * 8));
+    HIP_TRY(hipMalloc((void **)&c->rbx, m));
+    HIP_TRY(hipMalloc((void **)&c->rby, m));
+    HIP_TRY(hipMemcpy(c->ru, u, m * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->rbx, bx, m, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->rby, by, m, hipMemcpyHostToDevice));
+    c->src.ru = c->ru, c->src.rbx = c->rbx, c->src.rby = c->rby, c->src.per_env = per_env;
+    return CRL_OK;
+}
+
+int crl_kernel_timing(crl_ctx *c, int enable) {
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    c->timing = enable != 0;
+    return CRL_OK;
+}
+
+int crl_kernel_time_ms(crl_ctx *c, int which, double *total_ms, int64_t *launches) {
+    if (!c || which < 0 || which > 1) return fail(CRL_EINVAL, "bad argument");
+    for (auto &p : c->ev[which]) {
+        HIP_TRY(hipEventSynchronize(p.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        c->ev_ms[which] += ms, c->ev_n[which]++;
+        hipEventDestroy(p.a), hipEventDestroy(p.b);
+    }
+    c->ev[which].clear();
+    if (total_ms) *total_ms = c->ev_ms[which];
+    if (launches) *launches = c->ev_n[which];
+    c->ev_ms[which] = 0, c->ev_n[which] = 0;
+    return CRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,371 @@
+"""HIP vector-env backend behind the reference's VecEnv protocol.
+
+Mirrors, for cPongDouble-v0, what ``DummyVecEnv([make_env_a2c_atari(...)]*N)`` does in the
+reference (competitive_rl/utils/dummy_vec_env.py:10-133, base_vec_env.py:63-252,
+atari_wrappers.py:40-53) -- same method names, argument meaning, return structure and
+error behaviour -- but one ``step`` is two HIP kernel launches over all N envs, and the
+returned arrays are PyTorch-ROCm tensors that live in HBM.
+
+PyTorch is plumbing here (device memory, stream handle, torch.distributed); the
+compute is libcrl_hip.so (include/crl.h) reached through ctypes.  No CPU fallback.
+"""
+import ctypes as C
+from abc import ABC, abstractmethod
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import spaces
+
+CHEAT_CODES = 999  # pong/base_pong_env.py:9
+
+
+class VecEnv(ABC):
+    """The reference's abstract vectorised env (utils/base_vec_env.py:63-252)."""
+
+    metadata = {"render.modes": ["human", "rgb_array"]}
+
+    def __init__(self, num_envs, observation_space, action_space):
+        self.num_envs = num_envs
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def step_async(self, actions):
+        pass
+
+    @abstractmethod
+    def step_wait(self):
+        pass
+
+    @abstractmethod
+    def close(self):
+        pass
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def _get_indices(self, indices):
+        if indices is None:
+            indices = range(self.num_envs)
+        elif isinstance(indices, int):
+            indices = [indices]
+        return indices
+
+
+class LazyInfos:
+    """``infos`` of one step without building N dicts (65 536 Python dicts per step would
+    cost more than the simulation).  Behaves like the reference's list of dicts:
+    ``infos[i]`` -> ``{"real_reward": [l, r], "num_steps": k}`` plus
+    ``"terminal_observation"`` on the step that ended env i's episode
+    (atari_wrappers.py:179-180, dummy_vec_env.py:55-57).  Host copies happen on first use.
+    """
+
+    def __init__(self, env, wrapped, done, real_reward, num_steps):
+        self._env, self._wrapped = env, wrapped
+        self._done_dev, self._rr_dev, self._ns_dev = done, real_reward, num_steps
+        self._host = None
+
+    def __len__(self):
+        return self._env.num_envs
+
+    def _sync(self):
+        if self._host is None:
+            self._host = (self._done_dev.cpu().numpy(), self._rr_dev.cpu().numpy(), self._ns_dev.cpu().numpy())
+        return self._host
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        done, rr, ns = self._sync()
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        d = {}
+        if self._wrapped:
+            d["real_reward"] = [float(rr[i, 0]), float(rr[i, 1])]
+            d["num_steps"] = int(ns[i])
+        if done[i]:
+            d["terminal_observation"] = self._env.terminal_observation([i])[0]
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def copy(self):
+        return self
+
+
+class _EnvHandle:
+    """What ``DummyVecEnv.envs[i]`` offers to the reference's scripts (vis.py:30-31,
+    test/test_pong.py:13): close() and render()."""
+
+    def __init__(self, venv, idx):
+        self._venv, self._idx = venv, idx
+        self.observation_space = venv.observation_space
+        self.action_space = venv.action_space
+
+    def close(self):
+        return None
+
+    def render(self, mode="rgb_array", **_):
+        return self._venv.get_images()[self._idx]
+
+    def seed(self, seed=None):
+        return None
+
+
+class HipPongVecEnv(VecEnv):
+    """N cPongDouble-v0 envs stepped on one MI355X.
+
+    mode="wrapped": make_env_a2c_atari semantics -- obs tuple of two (N, K, R, R) tensors
+    (K = frame_stack planes, 1 by default as in the reference where cPongDouble forbids
+    FrameStack, make_envs.py:105-106), rewards (N, 2) float32 in {-1,0,1}, dones (N, 2)
+    bool (DummyVecEnv) or (N,) (dones="subproc").
+    mode="raw": the unwrapped env under a DummyVecEnv -- obs tuple of two
+    (N, 210, 160, 3) uint8 tensors, 1 step = 1 frame.
+    Observations are views into a double buffer: valid until the next-but-one step().
+    """
+
+    def __init__(self, num_envs, seed=0, mode="wrapped", resized_dim=84, frame_stack=1, device=None,
+                 env_id_base=0, output="torch", obs_dtype="uint8", dones="dummy"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipPongVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        assert mode in ("wrapped", "raw") and output in ("torch", "numpy") and dones in ("dummy", "subproc")
+        assert obs_dtype in ("uint8", "float32")
+        self._L = N.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.mode, self.R, self.K = mode, int(resized_dim), int(frame_stack)
+        self.output, self.obs_dtype, self.dones_kind = output, obs_dtype, dones
+        self.closed = False
+        opts = N.CrlOpts(env_kind=N.CRL_ENV_PONG_DOUBLE,
+                         obs_mode=N.CRL_OBS_GRAY_RESIZED if mode == "wrapped" else N.CRL_OBS_RAW_RGB,
+                         resized_dim=self.R if mode == "wrapped" else 0, frame_stack=self.K if mode == "wrapped" else 1,
+                         num_envs=int(num_envs), env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1),
+                         device=self.device.index or 0, reserved=0)
+        self._atlas = N.load_score_atlas()
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self._L.crl_create(C.byref(opts), self._atlas.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self._h = h
+        n = int(num_envs)
+        if mode == "wrapped":
+            self._obs_shape = (n, 2, self.K, self.R, self.R)
+            box = spaces.Box(0, 255, (self.K, self.R, self.R), dtype=np.float32)
+        else:
+            self._obs_shape = (n, 2, 210, 160, 3)
+            box = spaces.Box(0, 255, (210, 160, 3), dtype=np.float32)
+        VecEnv.__init__(self, n, spaces.Tuple([box, box]), spaces.Tuple([spaces.Discrete(3), spaces.Discrete(3)]))
+        dev = self.device
+        self._obs = [torch.empty(self._obs_shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._flip = 0
+        self._rew = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+        self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        self._actions = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        self.envs = _EnvList(self)
+        self.waiting = False
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _format_obs(self, buf):
+        o0, o1 = buf[:, 0], buf[:, 1]
+        if self.obs_dtype == "float32":  # DummyVecEnv's buffer dtype (Box default)
+            o0, o1 = o0.float(), o1.float()
+        if self.output == "numpy":
+            return o0.cpu().numpy(), o1.cpu().numpy()
+        return o0, o1
+
+    def _check_open(self):
+        if self.closed:
+            raise RuntimeError("VecEnv is closed")
+
+    # ------------------------------------------------------------------ VecEnv protocol
+    def seed(self, seed=None):
+        """Env i gets seed + i (dummy_vec_env.py:65-69): here the counter-based serve
+        sampler is keyed by (seed, global env id), which is the same partition."""
+        self._check_open()
+        N.check(self._L.crl_seed(self._h, int(seed or 0) & (2 ** 64 - 1)))
+        return [None] * self.num_envs
+
+    def reset(self):
+        self._check_open()
+        buf = self._obs[self._flip]
+        self._flip ^= 1
+        N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
+        return self._format_obs(buf)
+
+    def step_async(self, actions):
+        self._check_open()
+        if isinstance(actions, torch.Tensor):
+            a = actions.to(device=self.device, dtype=torch.int32)
+        else:
+            a = torch.as_tensor(np.asarray(actions), dtype=torch.int32).to(self.device)
+        if a.shape != (self.num_envs, 2):
+            raise AssertionError(f"actions must have shape ({self.num_envs}, 2), got {tuple(a.shape)}")
+        self._actions = a.contiguous()
+        self.waiting = True
+
+    def step_wait(self):
+        self._check_open()
+        buf = self._obs[self._flip]
+        self._flip ^= 1
+        N.check(self._L.crl_step(self._h, C.c_void_p(self._actions.data_ptr()), C.c_void_p(buf.data_ptr()),
+                                 C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+        self.waiting = False
+        done = self._done.bool()
+        if self.dones_kind == "dummy":  # scalar done broadcast over the 2 agents (dummy_vec_env.py:39-40)
+            done_out = done[:, None].expand(-1, 2)
+        else:
+            done_out = done
+        rr = torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device)
+        ns = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        N.check(self._L.crl_copy_info(self._h, C.c_void_p(rr.data_ptr()), C.c_void_p(ns.data_ptr()), self._stream()))
+        infos = LazyInfos(self, self.mode == "wrapped", self._done.clone(), rr, ns)
+        rew = self._rew.clone()
+        if self.output == "numpy":
+            return self._format_obs(buf), rew.cpu().numpy(), done_out.cpu().numpy().copy(), infos
+        return self._format_obs(buf), rew, done_out.clone(), infos
+
+    def close(self):
+        if self.closed:
+            return
+        self.closed = True
+        torch.cuda.synchronize(self.device)
+        self._L.crl_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self.envs[i], attr_name) for i in self._get_indices(indices)]
+
+    def set_attr(self, attr_name, value, indices=None):
+        for i in self._get_indices(indices):
+            setattr(self.envs[i], attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return [getattr(self.envs[i], method_name)(*args, **kwargs) for i in self._get_indices(indices)]
+
+    def get_images(self, *args, **kwargs):
+        """Raw RGB view of agent 0 for every env (render(mode='rgb_array'))."""
+        st = self.get_state()
+        frames = np.zeros(self.num_envs, N.FRAME_DT)
+        for k in ("ball_x", "ball_y", "bat_l_y", "bat_r_y", "score_l", "score_r"):
+            frames[k] = st[k]
+        return list(self.render_frames(frames)[:, 0].cpu().numpy())
+
+    def render(self, mode="rgb_array", *args, **kwargs):
+        imgs = self.get_images()
+        if mode == "rgb_array":
+            return imgs[0] if self.num_envs == 1 else np.stack(imgs)
+        raise NotImplementedError("only mode='rgb_array' is available on the GPU backend")
+
+    # ------------------------------------------------------------------ extras (parity tests, checkpoint)
+    def terminal_observation(self, env_indices):
+        """Observation the episode of each listed env ended on (its most recent done step)."""
+        idx = np.ascontiguousarray(env_indices, np.int64)
+        shape = (len(idx), 2, 210, 160, 3) if self.mode == "raw" else (len(idx), 2, self.R, self.R)
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        N.check(self._L.crl_terminal_observation(self._h, idx.ctypes.data_as(C.c_void_p), len(idx),
+                                                 C.c_void_p(out.data_ptr()), self._stream()))
+        res = []
+        for k in range(len(idx)):
+            if self.mode == "raw":
+                pair = (out[k, 0], out[k, 1])
+            else:
+                pair = (out[k, 0][None], out[k, 1][None])  # (1, R, R) each, WrapPyTorch layout
+            if self.output == "numpy":
+                pair = tuple(p.cpu().numpy() for p in pair)
+            res.append(pair)
+        return res
+
+    def get_state(self):
+        st = np.zeros(self.num_envs, N.STATE_DT)
+        N.check(self._L.crl_get_state(self._h, st.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()))
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, N.STATE_DT)
+        assert len(st) == self.num_envs
+        N.check(self._L.crl_set_state(self._h, st.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()))
+
+    state_dict = get_state
+    load_state_dict = set_state
+
+    def set_replay(self, u, bx, by):
+        """Replay mode of the serve sampler: arrays [N, per_env]."""
+        if u is None:
+            N.check(self._L.crl_set_replay(self._h, None, None, None, 0))
+            return
+        u = np.ascontiguousarray(u, np.float64).reshape(self.num_envs, -1)
+        bx = np.ascontiguousarray(bx, np.uint8).reshape(self.num_envs, -1)
+        by = np.ascontiguousarray(by, np.uint8).reshape(self.num_envs, -1)
+        N.check(self._L.crl_set_replay(self._h, u.ctypes.data_as(C.c_void_p), bx.ctypes.data_as(C.c_void_p),
+                                       by.ctypes.data_as(C.c_void_p), u.shape[1]))
+
+    def render_frames(self, frames):
+        """Raw (count, 2, 210, 160, 3) render of explicit frame descriptors (raw mode only)."""
+        frames = np.ascontiguousarray(frames, N.FRAME_DT)
+        out = torch.empty((len(frames), 2, 210, 160, 3), dtype=torch.uint8, device=self.device)
+        if self.mode != "raw":
+            tmp = HipPongVecEnv(1, mode="raw", device=self.device)
+            try:
+                return tmp.render_frames(frames)
+            finally:
+                tmp.close()
+        N.check(self._L.crl_render_raw(self._h, frames.ctypes.data_as(C.c_void_p), len(frames),
+                                       C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def step_device(self, actions_i32, render=True):
+        """Hot-loop entry for training/bench code: `actions_i32` is an int32 (N, 2) tensor
+        already on the device; returns device tensors, no host work, no clones, no sync."""
+        buf = self._obs[self._flip]
+        self._flip ^= 1
+        N.check(self._L.crl_step(self._h, C.c_void_p(actions_i32.data_ptr()),
+                                 C.c_void_p(buf.data_ptr()) if render else None,
+                                 C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+        return buf, self._rew, self._done
+
+    def kernel_timing(self, enable=True):
+        N.check(self._L.crl_kernel_timing(self._h, int(enable)))
+
+    def kernel_time_ms(self, which):
+        ms, cnt = C.c_double(), C.c_int64()
+        N.check(self._L.crl_kernel_time_ms(self._h, which, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+
+class _EnvList:
+    def __init__(self, venv):
+        self._venv = venv
+
+    def __len__(self):
+        return self._venv.num_envs
+
+    def __getitem__(self, i):
+        if not -len(self) <= i < len(self):
+            raise IndexError(i)
+        return _EnvHandle(self._venv, i % len(self))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))

@@ -127,6 +127,9 @@ int crl_step(crl_ctx *ctx, const int32_t *actions_dev, uint8_t *obs_dev, float *
  * atari_wrappers.py:175-181) as device arrays valid until the next step:
  * real_reward f32 (N,2), num_steps i32 (N). */
 int crl_info(crl_ctx *ctx, const float **real_reward_dev, const int32_t **num_steps_dev);
+/* Same data copied (device to device, on `stream`) into caller-owned arrays; either
+ * destination may be NULL. */
+int crl_copy_info(crl_ctx *ctx, float *real_reward_out_dev, int32_t *num_steps_out_dev, void *stream);
 
 /* info[i]["terminal_observation"] (dummy_vec_env.py:55-57), produced lazily: renders,
  * for `count` env indices (host array), the observation the episode ended on at the

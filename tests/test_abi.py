@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads and exports exactly
+what include/crl.h declares.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "crl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(crl_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from competitive_rl_amd import _native as N
+    from competitive_rl_amd.build import build
+
+    build()
+    lib = ctypes.CDLL(N.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in crl.h but not exported"
+    assert sorted(N.SYMBOLS) == names, "ctypes binding and header disagree"
+    lib.crl_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.crl_version()
+
+
+def test_state_struct_layout_matches_header():
+    from competitive_rl_amd import _native as N
+    from oracle import pong_oracle as po
+
+    assert N.STATE_DT.itemsize == 120 and N.FRAME_DT.itemsize == 8
+    assert N.STATE_DT == po.STATE_DT
+    assert po.lib().pong_oracle_state_size() == 120
+    assert ctypes.sizeof(N.CrlOpts) == 48
+
+
+def test_create_rejects_bad_arguments_without_gpu():
+    from competitive_rl_amd import _native as N
+
+    L = N.load()
+    h = ctypes.c_void_p()
+    assert L.crl_create(None, None, ctypes.byref(h)) == -1
+    assert b"null" in L.crl_last_error()
+    atlas = N.load_score_atlas()
+    o = N.CrlOpts(env_kind=7, obs_mode=0, resized_dim=0, frame_stack=1, num_envs=4, env_id_base=0, seed=0, device=0)
+    assert L.crl_create(ctypes.byref(o), atlas.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == -1
+    assert b"env_kind" in L.crl_last_error()
+    o.env_kind, o.num_envs = 1, 0
+    assert L.crl_create(ctypes.byref(o), atlas.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == -1
+    o.num_envs, o.obs_mode, o.resized_dim, o.frame_stack = 4, 1, 85, 1
+    assert L.crl_create(ctypes.byref(o), atlas.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == -1
+    assert L.crl_step(None, None, None, None, None, None) == -1
+
+
+def test_product_has_no_oracle_dependency():
+    """The product package must not import or link the oracle."""
+    pkg = os.path.join(ROOT, "competitive_rl_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in txt.lower() or fn == "gen_score_atlas.py", f"{fn} mentions the oracle"
+
+
+def test_env_without_gpu_fails_loudly():
+    import pytest
+    import torch
+
+    import competitive_rl_amd as crl
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        crl.make_envs("cPongDouble-v0", num_envs=2, frame_stack=None, log_dir=None)
