@@ -236,14 +236,14 @@ def test_full_size_raw_properties():
     # zero-sum rewards
     assert bool((rew.sum(dim=1) == 0).all())
     # determinism: same seed, same actions -> same bytes (checksum of checksums)
-    ck1 = int(buf.view(torch.int32).sum(dtype=torch.int64))
+    ck1 = int(buf.reshape(-1).view(torch.int32).sum(dtype=torch.int64))
     env2 = crl.HipPongVecEnv(n, seed=0, mode="raw")
     env2.reset()
     g = torch.Generator(device="cuda").manual_seed(0)
     for t in range(40):
         a = torch.randint(0, 3, (n, 2), generator=g, device="cuda", dtype=torch.int32)
         buf2, _, _ = env2.step_device(a)
-    assert int(buf2.view(torch.int32).sum(dtype=torch.int64)) == ck1
+    assert int(buf2.reshape(-1).view(torch.int32).sum(dtype=torch.int64)) == ck1
     st1, st2 = env.get_state(), env2.get_state()
     assert_state_equal(st1, st2, ctx="determinism")
     env.close(), env2.close()

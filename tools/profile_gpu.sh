@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes for
+# one bench workload.  Usage: tools/profile_gpu.sh <workload> <tag>
+# Outputs under gpurun_out/prof_<tag>/ ; summaries are later copied into profiles/.
+set -u
+WL=${1:-raw}; TAG=${2:-r01_$WL}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
+cd $REPO
+python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
+# keep only small files for the merge back
+find $OUT -name '*.csv' -size +4M -delete
