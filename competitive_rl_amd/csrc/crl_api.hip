@@ -19,7 +19,8 @@ void launch_pong_gray_templates(const GrayParams &p, const uint8_t *x_first, con
                                 hipStream_t st);
 void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int zero_row0, int zero_row1,
                                 const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
-                                const uint8_t *y_last, int band_chunks, hipStream_t st);
+                                const uint8_t *y_last, int band_chunks, const uint8_t *tab_blob, const GrayTabOfs &tofs,
+                                hipStream_t st);
 }  // namespace crl
 
 using namespace crl;
@@ -86,6 +87,8 @@ struct crl_ctx {
     int32_t *xofs = nullptr, *yofs = nullptr, *xsi = nullptr, *ysi = nullptr;
     float *xalpha = nullptr, *yalpha = nullptr;
     int band_rows = 0, band_chunks = 0, zero_row0 = 0, zero_row1 = 0;
+    uint8_t *tab_blob = nullptr;
+    GrayTabOfs tofs{};
     // replay
     double *ru = nullptr;
     uint8_t *rbx = nullptr, *rby = nullptr;
@@ -148,6 +151,51 @@ static int setup_gray(crl_ctx *c) {
         if (yf[i] == 255) return fail(CRL_ESTATE, "source row %d feeds no output row", i);
     c->band_rows = band_rows;
     c->band_chunks = (band_rows * R + 15) / 16;
+    // dense tables for the LDS-resident fast evaluator
+    {
+        GrayTabOfs o{};
+        std::vector<uint8_t> blob;
+        auto put = [&](const void *src, size_t bytes) {
+            size_t at = (blob.size() + 15) & ~size_t(15);
+            blob.resize(at + bytes);
+            memcpy(blob.data() + at, src, bytes);
+            return (int)at;
+        };
+        bool ok = true;
+        int max_taps = 0;
+        auto dense = [&](const AreaTab &t, std::vector<float> &a, std::vector<uint8_t> &s0, std::vector<uint8_t> &cnt) {
+            a.assign((size_t)5 * R, 0.f), s0.assign(R, 0), cnt.assign(R, 0);
+            for (int d = 0; d < R; d++) {
+                const int k0 = t.ofs[d], k1 = t.ofs[d + 1];
+                if (k1 - k0 > 5 || k1 <= k0) { ok = false; continue; }
+                s0[d] = (uint8_t)t.si[k0], cnt[d] = (uint8_t)(k1 - k0);
+                max_taps = std::max(max_taps, k1 - k0);
+                for (int k = k0; k < k1; k++) {
+                    if (t.si[k] != t.si[k0] + (k - k0)) ok = false;
+                    a[(size_t)(k - k0) * R + d] = t.alpha[k];
+                }
+            }
+        };
+        std::vector<float> xa, ya;
+        std::vector<uint8_t> xs0, xn, ys0, yn;
+        dense(xt, xa, xs0, xn), dense(yt, ya, ys0, yn);
+        // court rectangles touch output rows >= y_first[TOP]; their taps above the court must be ink-free
+        for (int d = yf[CRL_PONG_TOP]; d < R; d++)
+            for (int k = yt.ofs[d]; k < yt.ofs[d + 1]; k++)
+                if (yt.si[k] < CRL_PONG_TOP && yt.si[k] < c->ink_row1) ok = false;
+        o.xa = put(xa.data(), xa.size() * 4), o.ya = put(ya.data(), ya.size() * 4);
+        o.xs0 = put(xs0.data(), R), o.xn = put(xn.data(), R), o.ys0 = put(ys0.data(), R), o.yn = put(yn.data(), R);
+        o.xf = put(xf.data(), xf.size()), o.xl = put(xl.data(), xl.size());
+        o.yf = put(yf.data(), yf.size()), o.yl = put(yl.data(), yl.size());
+        blob.resize((blob.size() + 15) & ~size_t(15));
+        o.total = (int)blob.size();
+        o.fast_ok = ok ? 1 : 0;
+        o.max_taps = max_taps;
+        if (o.total > 6144) return fail(CRL_ESTATE, "tap tables (%d B) exceed the LDS budget", o.total);
+        int rc2 = dev_upload(c, &c->tab_blob, blob);
+        if (rc2) return rc2;
+        c->tofs = o;
+    }
     const int chunks = (R * R + 15) / 16;
     int rc;
     if ((rc = dev_upload(c, &c->xofs, xt.ofs))) return rc;
@@ -161,7 +209,7 @@ static int setup_gray(crl_ctx *c) {
     if ((rc = dev_upload(c, &c->y_first, yf))) return rc;
     if ((rc = dev_upload(c, &c->y_last, yl))) return rc;
     if ((rc = dev_upload(c, &c->atlas_gray, c->atlas_host))) return rc;
-    if ((rc = dev_alloc(c, &c->band, (size_t)484 * 2 * c->band_chunks * 16))) return rc;
+    if ((rc = dev_alloc(c, &c->band, (size_t)3 * 484 * 2 * c->band_chunks * 16))) return rc;
     if ((rc = dev_alloc(c, &c->rest, (size_t)chunks * 16))) return rc;
     HIP_TRY(hipMemset(c->rest, 0, (size_t)chunks * 16));
     GrayParams p{};
@@ -282,7 +330,7 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = obs_dev;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
-                                   c->band_chunks, st);
+                                   c->band_chunks, c->tab_blob, c->tofs, st);
     }
     end_timed(c, 1, st);
     HIP_TRY(hipGetLastError());
@@ -351,7 +399,7 @@ static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = out_dev;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
-                                   c->band_chunks, st);
+                                   c->band_chunks, c->tab_blob, c->tofs, st);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));

@@ -204,7 +204,14 @@ void launch_pong_dynamics(const PongSoA &s, const ServeSrc &src, const int32_t *
 void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *atlas_rgb, int ink_row0, int ink_row1,
                             uint8_t *obs, hipStream_t st);
 
-struct AreaTabs;  // pong_raster_gray.hip
+// Byte offsets of the dense INTER_AREA tables inside the blob the gray kernel stages into
+// LDS: xa/ya = float[5][R] weights (tap k of output index d at [k*R + d]); xs0/xn, ys0/yn =
+// u8[R] first source index and tap count; xf/xl = u8[160], yf/yl = u8[210] first/last
+// output index fed by a source col/row.  fast_ok: every tap of an output row that a court
+// rectangle can touch lies in a source row without score ink.
+struct GrayTabOfs {
+    int xa, ya, xs0, xn, ys0, yn, xf, xl, yf, yl, total, fast_ok, max_taps;
+};
 struct GrayParams {
     const uint64_t *ring;    // [8][n] frame pairs of the 4 stack planes; plane 3 = newest (K=1 draws only it)
     int64_t n;

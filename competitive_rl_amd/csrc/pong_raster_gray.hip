@@ -20,6 +20,8 @@
 // planes are never read back from HBM: traffic = K*R*R*2 bytes of stores per env-step.
 // LDS ordering inside a tile needs no workgroup barrier: one wave owns the tile and LDS
 // operations of a wave complete in issue order.
+#include <stdlib.h>
+
 #include "pong_device.h"
 
 namespace crl {
@@ -70,20 +72,31 @@ struct GrayGeom {
     int zero_row0, zero_row1;          // output rows [zero_row0, zero_row1) of the template are all 0
     const uint8_t *x_first, *x_last;   // [160] first/last output col fed by a source col
     const uint8_t *y_first, *y_last;   // [210]
+    const uint8_t *tab_blob;           // dense tap tables + first/last maps, staged into LDS per workgroup
+    GrayTabOfs t;
+    int debug;                         // ablation switches for profiling builds (0 in production)
 };
 
 // Builds the templates with the exact evaluator (ball and bats moved off-screen), so the
 // fast path is consistent with the per-pixel definition by construction.
 __global__ __launch_bounds__(256) void pong_gray_template_kernel(GrayCtx g, GrayGeom q, uint8_t *band, uint8_t *rest) {
+    // band[((variant * 484 + sp) * 2 + view) * bb + idx]: top rows of the empty court for
+    // variant 0: both kept frames show score pair sp; 1: the second shows (sl+1, sr);
+    // 2: the second shows (sl, sr+1) -- a point scored between the two max-pooled frames.
     const int R = q.R, bb = q.band_chunks * 16;
-    const int total_band = 484 * 2 * bb;
+    const int per_variant = 484 * 2 * bb, total_band = 3 * per_variant;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Frame e;
     e.x = -100, e.y = -100, e.bl = 250, e.br = 250;
     if (i < total_band) {
-        const int sp = i / (2 * bb), rem = i - sp * 2 * bb, view = rem / bb, idx = rem - view * bb;
+        const int variant = i / per_variant, i2 = i - variant * per_variant;
+        const int sp = i2 / (2 * bb), rem = i2 - sp * 2 * bb, view = rem / bb, idx = rem - view * bb;
         e.sl = sp / 22, e.sr = sp - e.sl * 22;
-        band[i] = idx < R * R ? eval_pixel(g, e, e, view, idx / R, idx % R) : 0;
+        Frame e2 = e;
+        if (variant == 1) e2.sl += 1;
+        if (variant == 2) e2.sr += 1;
+        const bool valid = e2.sl < 22 && e2.sr < 22 && idx < R * R;
+        band[i] = valid ? eval_pixel(g, e, e2, view, idx / R, idx % R) : 0;
     } else if (i < total_band + R * R) {
         const int idx = i - total_band;
         e.sl = 0, e.sr = 0;
@@ -106,10 +119,81 @@ __device__ inline Box rect_box(const GrayGeom &q, int c0, int c1, int r0, int r1
 }
 
 static constexpr int kTileLds = 7168;  // >= 84*84, multiple of 16
+static constexpr int kTabLds = 6144;   // dense tap tables + first/last maps (4.6 KB at R = 84)
+static constexpr int kMaxTaps = 5;
+
+// Rectangles of the two kept frames in VIEW coordinates (agent 1 sees the court mirrored,
+// so its left-hand bat is the physical right bat).  A blank frame has its rows at -1000.
+struct Rects {
+    int ax, ay, bx, by;      // balls of frame a / b
+    int la, lb, ra, rb;      // y of the view-left bat in a / b, view-right bat in a / b
+};
+
+// Exact INTER_AREA value of one output pixel whose footprint lies in source rows that hold
+// no score ink (rows >= ink_row1): those rows are white bands or court rectangles, so the
+// source pixel is a few interval tests instead of a table lookup.  Same f32 operation
+// order as eval_pixel.
+template <int MAXT>
+__device__ inline uint8_t eval_fast(const uint8_t *__restrict__ tabs, const GrayTabOfs &o, int R, const Rects &q, int dy,
+                                    int dx) {
+    const float *xa = reinterpret_cast<const float *>(tabs + o.xa), *ya = reinterpret_cast<const float *>(tabs + o.ya);
+    const int sx0 = tabs[o.xs0 + dx], nx = tabs[o.xn + dx], sy0 = tabs[o.ys0 + dy], ny = tabs[o.yn + dy];
+    float p[MAXT];
+    unsigned xb[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; k++) {
+        const int c = sx0 + k;
+        p[k] = 255.f * xa[k * R + dx];
+        const unsigned m = ((unsigned)(c - q.ax) < (unsigned)CRL_PONG_BALL ? 1u : 0u) |
+                           ((unsigned)(c - q.bx) < (unsigned)CRL_PONG_BALL ? 2u : 0u) |
+                           ((unsigned)(c - CRL_PONG_BATL_X) < (unsigned)CRL_PONG_BAT_W ? 4u : 0u) |
+                           ((unsigned)(c - CRL_PONG_BATR_X) < (unsigned)CRL_PONG_BAT_W ? 8u : 0u);
+        xb[k] = k < nx ? m : 0u;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXT; j++) {
+        if (j < ny) {
+            const int r = sy0 + j;
+            const bool white = r < CRL_PONG_TOP || r >= CRL_PONG_BOTTOM;
+            unsigned yb = ((unsigned)(r - q.ay) < (unsigned)CRL_PONG_BALL ? 1u : 0u) |
+                          ((unsigned)(r - q.by) < (unsigned)CRL_PONG_BALL ? 2u : 0u) |
+                          (((unsigned)(r - q.la) < (unsigned)CRL_PONG_BAT_H || (unsigned)(r - q.lb) < (unsigned)CRL_PONG_BAT_H) ? 4u : 0u) |
+                          (((unsigned)(r - q.ra) < (unsigned)CRL_PONG_BAT_H || (unsigned)(r - q.rb) < (unsigned)CRL_PONG_BAT_H) ? 8u : 0u);
+            float buf = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXT; k++) {
+                const bool on = k < nx && (white || (xb[k] & yb) != 0u);
+                buf = on ? buf + p[k] : buf;
+            }
+            const float t = ya[j * R + dy] * buf;
+            sum = (j == 0) ? t : sum + t;
+        }
+    }
+    const int v = (int)rintf(sum);
+    return (uint8_t)min(max(v, 0), 255);
+}
+
+__device__ inline Box rect_box_lds(const uint8_t *__restrict__ tabs, const GrayTabOfs &o, int c0, int c1, int r0, int r1) {
+    c0 = max(c0, 0), c1 = min(c1, CRL_PONG_W), r0 = max(r0, 0), r1 = min(r1, CRL_PONG_H);
+    Box b = {0, 0, 0, 0};
+    if (c0 >= c1 || r0 >= r1) return b;
+    b.x0 = tabs[o.xf + c0], b.y0 = tabs[o.yf + r0];
+    b.w = tabs[o.xl + c1 - 1] - b.x0 + 1, b.h = tabs[o.yl + r1 - 1] - b.y0 + 1;
+    return b;
+}
 
 __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                GrayGeom q, uint8_t *__restrict__ obs) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][kTileLds];
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
+    // stage the constant tap tables once per workgroup (L2-resident source)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(q.tab_blob);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs);
+        for (int i = threadIdx.x; i < (q.t.total >> 4); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int tiles_per_env = 2 * q.K;
@@ -138,45 +222,66 @@ __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *_
     }
     // fast path needs one score pair for the whole plane (a point scored between the two
     // kept frames puts two different texts under the max)
-    const bool slow = blank_a || blank_b || fa.sl != fb.sl || fa.sr != fb.sr;
+    // The score rows come pre-resized from the band table when the two kept frames show
+    // the same score pair, or pairs one point apart (a point scored between the two
+    // max-pooled frames puts two texts under the max).  Anything else (only reachable
+    // through set_state or the never-written initial buffers) is evaluated per pixel.
+    bool slow = blank_a || blank_b;
+    int variant = 0, sp = fa.sl * 22 + fa.sr;
+    if (!slow && (fa.sl != fb.sl || fa.sr != fb.sr)) {
+        const int spb = fb.sl * 22 + fb.sr;
+        if (fb.sl == fa.sl + 1 && fb.sr == fa.sr) variant = 1;
+        else if (fb.sl == fa.sl && fb.sr == fa.sr + 1) variant = 2;
+        else if (fa.sl == fb.sl + 1 && fa.sr == fb.sr) variant = 1, sp = spb;
+        else if (fa.sl == fb.sl && fa.sr == fb.sr + 1) variant = 2, sp = spb;
+        else slow = true;
+    }
+    if (q.debug & 4) slow = false;
 
     // ---- 1. fill
     const int bb = q.band_chunks;
     const uint4 *__restrict__ band4 =
-        reinterpret_cast<const uint4 *>(q.band) + (int64_t)((slow ? 0 : (fa.sl * 22 + fa.sr)) * 2 + view) * bb;
+        reinterpret_cast<const uint4 *>(q.band) + (int64_t)((slow ? 0 : (variant * 484 + sp)) * 2 + view) * bb;
     const uint4 *__restrict__ rest4 = reinterpret_cast<const uint4 *>(q.rest);
     const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;  // chunks fully inside zero rows
     for (int c = lane; c < chunks; c += 64) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < bb) v = band4[c];
-        else if (c < zc0 || c >= zc1) v = rest4[c];
+        if (!(q.debug & 2)) {
+            if (c < bb) v = band4[c];
+            else if (c < zc0 || c >= zc1) v = rest4[c];
+        }
         tl4[c] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     // ---- 2. patch: boxes of the six rectangles in view coordinates
+    const bool m = view == 1;
+    Rects rc;
+    rc.ax = blank_a ? -1000 : (m ? CRL_PONG_W - fa.x - CRL_PONG_BALL : fa.x), rc.ay = blank_a ? -1000 : fa.y;
+    rc.bx = blank_b ? -1000 : (m ? CRL_PONG_W - fb.x - CRL_PONG_BALL : fb.x), rc.by = blank_b ? -1000 : fb.y;
+    rc.la = blank_a ? -1000 : (m ? fa.br : fa.bl), rc.ra = blank_a ? -1000 : (m ? fa.bl : fa.br);
+    rc.lb = blank_b ? -1000 : (m ? fb.br : fb.bl), rc.rb = blank_b ? -1000 : (m ? fb.bl : fb.br);
     Box bx[6];
     {
-        const bool m = view == 1;
-        const int bax0 = m ? CRL_PONG_W - fa.x - CRL_PONG_BALL : fa.x, bbx0 = m ? CRL_PONG_W - fb.x - CRL_PONG_BALL : fb.x;
-        const int lx = m ? CRL_PONG_BATR_X : CRL_PONG_BATL_X, rx = m ? CRL_PONG_BATL_X : CRL_PONG_BATR_X;
         const Box none = {0, 0, 0, 0};
-        bx[0] = blank_a ? none : rect_box(q, bax0, bax0 + CRL_PONG_BALL, max(fa.y, CRL_PONG_TOP), min(fa.y + CRL_PONG_BALL, CRL_PONG_BOTTOM));
-        bx[1] = blank_a ? none : rect_box(q, lx, lx + CRL_PONG_BAT_W, fa.bl, fa.bl + CRL_PONG_BAT_H);
-        bx[2] = blank_a ? none : rect_box(q, rx, rx + CRL_PONG_BAT_W, fa.br, fa.br + CRL_PONG_BAT_H);
-        const bool same_ball = !blank_a && fa.x == fb.x && fa.y == fb.y;
-        bx[3] = (blank_b || same_ball) ? none : rect_box(q, bbx0, bbx0 + CRL_PONG_BALL, max(fb.y, CRL_PONG_TOP), min(fb.y + CRL_PONG_BALL, CRL_PONG_BOTTOM));
-        bx[4] = (blank_b || (!blank_a && fa.bl == fb.bl)) ? none : rect_box(q, lx, lx + CRL_PONG_BAT_W, fb.bl, fb.bl + CRL_PONG_BAT_H);
-        bx[5] = (blank_b || (!blank_a && fa.br == fb.br)) ? none : rect_box(q, rx, rx + CRL_PONG_BAT_W, fb.br, fb.br + CRL_PONG_BAT_H);
+        bx[0] = blank_a ? none : rect_box_lds(tabs, q.t, rc.ax, rc.ax + CRL_PONG_BALL, max(rc.ay, CRL_PONG_TOP), min(rc.ay + CRL_PONG_BALL, CRL_PONG_BOTTOM));
+        bx[1] = blank_a ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.la, rc.la + CRL_PONG_BAT_H);
+        bx[2] = blank_a ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.ra, rc.ra + CRL_PONG_BAT_H);
+        const bool same_ball = rc.ax == rc.bx && rc.ay == rc.by;
+        bx[3] = (blank_b || same_ball) ? none : rect_box_lds(tabs, q.t, rc.bx, rc.bx + CRL_PONG_BALL, max(rc.by, CRL_PONG_TOP), min(rc.by + CRL_PONG_BALL, CRL_PONG_BOTTOM));
+        bx[4] = (blank_b || rc.la == rc.lb) ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.lb, rc.lb + CRL_PONG_BAT_H);
+        bx[5] = (blank_b || rc.ra == rc.rb) ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.rb, rc.rb + CRL_PONG_BAT_H);
     }
     int pre[7];
     pre[0] = slow ? q.band_rows * R : 0;  // slow path: evaluate every pixel of the score rows
 #pragma unroll
     for (int i = 0; i < 6; i++) pre[i + 1] = pre[i] + bx[i].w * bx[i].h;
-    const int total = pre[6];
+    const int total = (q.debug & 1) ? 0 : pre[6];
+    const bool fast_ok = q.t.fast_ok != 0;
     for (int p = lane; p < total; p += 64) {
         int dy, dx;
-        if (p < pre[0]) {
+        const bool band_px = p < pre[0];
+        if (band_px) {
             dy = p / R, dx = p - dy * R;
         } else {
             int i = 0;
@@ -191,7 +296,10 @@ __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *_
             const int yy = o / w;
             dy = y0 + yy, dx = x0 + (o - yy * w);
         }
-        tl[dy * R + dx] = eval_pixel(g, fa, fb, view, dy, dx);
+        uint8_t v;
+        if (band_px || !fast_ok) v = eval_pixel(g, fa, fb, view, dy, dx);
+        else v = q.t.max_taps <= 3 ? eval_fast<3>(tabs, q.t, R, rc, dy, dx) : eval_fast<5>(tabs, q.t, R, rc, dy, dx);
+        tl[dy * R + dx] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
@@ -210,19 +318,25 @@ void launch_pong_gray_templates(const GrayParams &p, const uint8_t *x_first, con
     GrayCtx g = {p.atlas_gray, p.xofs, p.yofs, p.xsi, p.ysi, p.xalpha, p.yalpha};
     GrayGeom q = {};
     q.R = p.R, q.K = p.K, q.band_rows = band_rows, q.band_chunks = band_chunks;
-    const int total = 484 * 2 * band_chunks * 16 + p.R * p.R;
+    const int total = 3 * 484 * 2 * band_chunks * 16 + p.R * p.R;
     hipLaunchKernelGGL(pong_gray_template_kernel, dim3((total + 255) / 256), dim3(256), 0, st, g, q, band, rest);
 }
 
 void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int zero_row0, int zero_row1,
                                 const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
-                                const uint8_t *y_last, int band_chunks, hipStream_t st) {
+                                const uint8_t *y_last, int band_chunks, const uint8_t *tab_blob, const GrayTabOfs &tofs,
+                                hipStream_t st) {
     if (p.n <= 0) return;
     GrayCtx g = {p.atlas_gray, p.xofs, p.yofs, p.xsi, p.ysi, p.xalpha, p.yalpha};
     GrayGeom q;
     q.R = p.R, q.K = p.K, q.band_rows = p.band_rows, q.band_chunks = band_chunks;
     q.band = p.band, q.rest = rest, q.zero_row0 = zero_row0, q.zero_row1 = zero_row1;
     q.x_first = x_first, q.x_last = x_last, q.y_first = y_first, q.y_last = y_last;
+    q.tab_blob = tab_blob, q.t = tofs;
+    {
+        static const int dbg = getenv("CRL_GRAY_DEBUG") ? atoi(getenv("CRL_GRAY_DEBUG")) : 0;
+        q.debug = dbg;
+    }
     const int64_t tiles = p.n * 2 * p.K;
     hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
                        p.obs);
