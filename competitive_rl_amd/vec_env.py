@@ -140,7 +140,7 @@ class HipPongVecEnv(VecEnv):
     """
 
     def __init__(self, num_envs, seed=0, mode="wrapped", resized_dim=84, frame_stack=1, device=None,
-                 env_id_base=0, output="torch", obs_dtype="uint8", dones="dummy"):
+                 env_id_base=0, output="torch", obs_dtype="uint8", dones="dummy", score_atlas=None):
         if not torch.cuda.is_available():
             raise RuntimeError("HipPongVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -156,7 +156,8 @@ class HipPongVecEnv(VecEnv):
                          resized_dim=self.R if mode == "wrapped" else 0, frame_stack=self.K if mode == "wrapped" else 1,
                          num_envs=int(num_envs), env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1),
                          device=self.device.index or 0, reserved=0)
-        self._atlas = N.load_score_atlas()
+        self._atlas = N.load_score_atlas() if score_atlas is None else np.ascontiguousarray(score_atlas, np.uint8)
+        assert self._atlas.size == N.ATLAS_BYTES
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             N.check(self._L.crl_create(C.byref(opts), self._atlas.ctypes.data_as(C.c_void_p), C.byref(h)))

@@ -303,3 +303,39 @@ def test_make_envs_api_surface():
     with pytest.raises(AssertionError):
         crl.make_envs("cPongDouble-v0", num_envs=2, log_dir=None)  # frame_stack default 4 is rejected
     sub.close()
+
+
+def test_reference_wrapper_golden_through_hip():
+    """BASELINE config #1 recorded from the reference's wrappers + DummyVecEnv
+    (tests/golden/pong_wrapped.npz), replayed on the GPU: rewards, dones, infos, obs,
+    terminal observations."""
+    _need_gpu()
+    import os
+
+    import competitive_rl_amd as crl
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pong_wrapped.npz"))
+    N, R = g["acts"].shape[1], int(g["resized_dim"])
+    blank = np.full((22, 22, 34, 160), 255, np.uint8)  # golden frames carry no score text
+    env = crl.HipPongVecEnv(N, mode="wrapped", resized_dim=R, frame_stack=1, score_atlas=blank, output="numpy",
+                            obs_dtype="float32")
+    env.set_replay(g["draw_u"], g["draw_bx"], g["draw_by"])
+    o = env.reset()
+    assert o[0].dtype == np.float32 and o[0].shape == (N, 1, R, R)
+    assert np.array_equal(np.stack([o[0][:, 0], o[1][:, 0]], 1), g["obs0"])
+    term = {(int(t), int(i)): k for k, (t, i) in enumerate(zip(g["term_t"], g["term_i"]))}
+    seen = 0
+    for t in range(len(g["acts"])):
+        o, r, d, info = env.step(g["acts"][t])
+        assert np.array_equal(r, g["rew"][t]) and np.array_equal(d, g["done"][t]), t
+        assert np.array_equal(np.stack([o[0][:, 0], o[1][:, 0]], 1), g["obs"][t]), t
+        if t % 50 == 0 or d.any():
+            for i in range(N):
+                assert info[i]["real_reward"] == g["real_reward"][t, i].tolist()
+                assert info[i]["num_steps"] == int(g["num_steps"][t, i])
+                if d[i, 0]:
+                    to = info[i]["terminal_observation"]
+                    assert np.array_equal(np.stack([to[0][0], to[1][0]]), g["term_obs"][term[(t, i)]])
+                    seen += 1
+    assert seen == len(g["term_t"])
+    env.close()

@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank steps ITS shard (here with the CPU oracle
+standing in for the per-GPU kernels -- the sharding / gather layer is backend-agnostic) and
+the all-gather must reproduce one unsharded batch bit for bit: RNG is keyed by global env id."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from competitive_rl_amd import _native
+    from competitive_rl_amd.sharding import all_gather_step, shard_of
+    from oracle import pong_oracle as po
+
+    atlas = _native.load_score_atlas()
+    sh = shard_of(total, world, rank)
+    env = po.PongOracle(sh.count, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=21, env_id_base=sh.base)
+    acts = np.random.RandomState(5).randint(0, 3, (steps, total, 2)).astype(np.int32)
+    env.reset()
+    outs = []
+    for t in range(steps):
+        obs, rew, done = env.step(acts[t, sh.base:sh.base + sh.count])
+        g = all_gather_step((torch.from_numpy(obs.copy()), torch.from_numpy(rew.copy()), torch.from_numpy(done.copy())))
+        outs.append([x.numpy().copy() for x in g])
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gathered.npz"), obs=np.stack([o[0] for o in outs]),
+                 rew=np.stack([o[1] for o in outs]), done=np.stack([o[2] for o in outs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_of_partitions_exactly():
+    from competitive_rl_amd.sharding import shard_of
+
+    for total, world in [(65536, 8), (524288, 8), (10, 3), (7, 7), (5, 8)]:
+        spans = [shard_of(total, world, r) for r in range(world)]
+        assert spans[0].base == 0 and sum(s.count for s in spans) == total
+        for a, b in zip(spans, spans[1:]):
+            assert a.base + a.count == b.base
+    with pytest.raises(ValueError):
+        shard_of(8, 2, 2)
+
+
+def test_two_rank_gather_equals_unsharded(tmp_path, atlas):
+    from oracle import pong_oracle as po
+
+    total, steps, world = 16, 150, 2
+    port = _free_port()
+    mp.start_processes(_worker, args=(world, port, total, steps, str(tmp_path)), nprocs=world, join=True,
+                       start_method="spawn")
+    got = np.load(tmp_path / "gathered.npz")
+    env = po.PongOracle(total, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=21)
+    acts = np.random.RandomState(5).randint(0, 3, (steps, total, 2)).astype(np.int32)
+    env.reset()
+    for t in range(steps):
+        obs, rew, done = env.step(acts[t])
+        assert np.array_equal(got["obs"][t], obs), t
+        assert np.array_equal(got["rew"][t], rew) and np.array_equal(got["done"][t], done), t
+    assert got["rew"].any()
