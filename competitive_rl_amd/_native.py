@@ -8,15 +8,17 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libcrl_hip.so")
 
-CRL_ENV_PONG_DOUBLE = 1
+CRL_ENV_PONG_DOUBLE, CRL_ENV_CAR_DOUBLE = 1, 2
+CAR_MAX_TILES = 512
 CRL_OBS_RAW_RGB, CRL_OBS_GRAY_RESIZED = 0, 1
 PONG_FRAME_BYTES = 210 * 160 * 3
 ATLAS_BYTES = 22 * 22 * 34 * 160
 
 # every symbol include/crl.h declares (tests check the library exports all of them)
-SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "crl_info", "crl_copy_info",
+SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "crl_render", "crl_info", "crl_copy_info",
            "crl_terminal_observation", "crl_get_state", "crl_set_state", "crl_set_replay", "crl_render_raw",
-           "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version"]
+           "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version",
+           "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_set_replay"]
 
 FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
                      ("score_l", "u1"), ("score_r", "u1")])
@@ -26,6 +28,16 @@ STATE_DT = np.dtype([
     ("num_rounds", "<i4"), ("num_steps", "<i4"), ("serve_ctr", "<u4"), ("wrap_steps", "<i4"),
     ("keep", FRAME_DT, (2,)), ("hist", FRAME_DT, (3, 2)),
 ])
+
+
+CAR_BODY_DT = np.dtype([(k, "<f4") for k in ("cx", "cy", "a", "vx", "vy", "w")])
+CAR_STATE_DT = np.dtype([
+    ("hull", CAR_BODY_DT), ("wheel", CAR_BODY_DT, (4,)), ("imp", "<f4", (4, 3)), ("motor_imp", "<f4", (4,)),
+    ("motor_speed", "<f4", (4,)), ("limit_state", "<i4", (4,)), ("gas", "<f8", (4,)), ("omega", "<f8", (4,)), ("phase", "<f8", (4,)),
+    ("reward", "<f8"), ("prev_reward", "<f8"), ("tile_visited_count", "<i4"), ("last_block", "<i4"), ("done", "<i4"),
+    ("step_count", "<i4"), ("first_step", "<i4"), ("pad", "<i4"),
+    ("wheel_tiles", "<u4", (4, CAR_MAX_TILES // 32)), ("visited", "<u4", (CAR_MAX_TILES // 32,))], align=True)
+CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4")], align=True)
 
 
 class CrlOpts(C.Structure):
@@ -59,6 +71,7 @@ def load():
     L.crl_reset.argtypes = [vp, vp, vp]
     L.crl_step.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crl_info.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.crl_render.argtypes = [vp, vp, vp]
     L.crl_copy_info.argtypes = [vp, vp, vp, vp]
     L.crl_terminal_observation.argtypes = [vp, vp, i64, vp, vp]
     L.crl_get_state.argtypes = [vp, vp, i64, i64, vp]
@@ -69,6 +82,11 @@ def load():
     L.crl_obs_bytes_per_env.restype = i64
     L.crl_kernel_timing.argtypes = [vp, i32]
     L.crl_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.crl_car_get_state.argtypes = [vp, vp, i64, i64, vp]
+    L.crl_car_set_state.argtypes = [vp, vp, i64, i64, vp]
+    L.crl_car_get_track.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    L.crl_car_set_track.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp]
+    L.crl_car_set_replay.argtypes = [vp, vp, vp, i64]
     L.crl_last_error.restype = C.c_char_p
     L.crl_version.restype = C.c_char_p
     for name in SYMBOLS:

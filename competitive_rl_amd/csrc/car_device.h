@@ -1,0 +1,107 @@
+// car_device.h -- device-side types shared by the cCarRacingDouble kernels (gfx950).
+//
+// What is restated (reference paths relative to competitive_rl/car_racing/):
+//   wheel model ................ Car.step / gas / brake / steer        car_dynamics.py:131-234
+//   step bookkeeping ........... CarRacing.step, process_action       car_racing_multi_players.py:527-620
+//   tile rule .................. FrictionDetector._contact                                    :111-153
+//   track ...................... CarRacing._create_track, reset                      :262-452, :454-525
+//   rigid bodies + joints ...... b2World.Step call site :600.  box2d-py ~=2.3.5 (setup.py:14) is a
+//        third-party dependency, absent from the reference tree: Box2D 2.3's published
+//        b2Island::Solve / b2RevoluteJoint / b2PolygonShape::ComputeMass are restated in f32.
+//        Car-car contacts are not modelled (DESIGN.md "CarRacing: deviations").
+//
+// Layout: every per-car quantity is an SoA array indexed by car instance ci = car * N + env,
+// so lane <-> car instance and all state loads/stores are coalesced; per-env track data is
+// [tile][env] so a wave walking tile t reads 64 consecutive envs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/crl.h"
+
+namespace crl {
+
+static constexpr int kCarMaxTiles = CRL_CAR_MAX_TILES;  // 512
+static constexpr int kWheelSlots = 6;                   // tiles one wheel can touch at once
+
+// constants of car_racing_multi_players.py:54-88 and car_dynamics.py:17-51
+#define CAR_SCALE 6.0
+#define CAR_TRACK_RAD (900 / CAR_SCALE)
+#define CAR_PLAYFIELD (2000 / CAR_SCALE)
+#define CAR_FPS 50
+#define CAR_TRACK_DETAIL_STEP (21 / CAR_SCALE)
+#define CAR_TRACK_TURN_RATE 0.31
+#define CAR_TRACK_WIDTH (40 / CAR_SCALE)
+#define CAR_BORDER (8 / CAR_SCALE)
+#define CAR_SIZE 0.02
+#define CAR_ENGINE_POWER (100000000 * CAR_SIZE * CAR_SIZE)
+#define CAR_WHEEL_MOI (4000 * CAR_SIZE * CAR_SIZE)
+#define CAR_FRICTION_LIMIT (1000000 * CAR_SIZE * CAR_SIZE)
+#define CAR_WHEEL_R 27
+#define CAR_WHEEL_W 14
+
+struct CarConsts {  // body constants computed on the host the way b2Body::ResetMassData does
+    float hull_poly[4][8][2];
+    int hull_n[4];
+    float wheel_poly[4][2];
+    float hull_inv_mass, hull_inv_I, hull_lc[2];
+    float wheel_inv_mass, wheel_inv_I;
+    float anchor[4][2];
+};
+
+struct CarSoA {
+    int64_t n;  // envs; M = 2n car instances
+    // ---- per car instance [..][M]
+    float *body;        // [30][M]: hull (cx,cy,a,vx,vy,w), wheel 0..3 likewise
+    float *jimp;        // [12][M]: revolute joint impulse (x,y,z) x 4
+    float *jmotor;      // [4][M]  motor impulse
+    float *jspeed;      // [4][M]  motor speed (kept: a done car's joints keep their last target)
+    int32_t *jlimit;    // [4][M]  limit state
+    double *wgas, *womega, *wphase;  // [4][M] wheel attributes (python floats)
+    int16_t *wtiles;    // [4][kWheelSlots][M] tiles each wheel touches (-1 = empty)
+    uint32_t *visited;  // [16][M] tile.road_visited bits
+    double *reward, *prev_reward;  // [M]
+    int32_t *visited_count, *last_block, *done, *step_count, *first_step;  // [M]
+    // ---- per env [..][n]
+    int32_t *elapsed;   // gym TimeLimit._elapsed_steps
+    uint32_t *episode;  // resets so far (RNG counter)
+    int32_t *ntiles;
+    float4 *tile_aabb;  // [512][n]
+    float *tile_poly;   // [512][10][n]  CCW float32 (b2PolygonShape)
+    float *border_poly; // [512][8][n]
+    uint8_t *border;    // [512][n]  0 none, 1 white, 2 red
+    float *start_pose;  // [3][n]    track[0] beta, x, y (birth place)
+    double *track_scratch;  // [512][4][n] the current lap (alpha, beta, x, y), f64
+};
+
+struct V2 {
+    float x, y;
+};
+__host__ __device__ inline V2 mk(float x, float y) { V2 r = {x, y}; return r; }
+__host__ __device__ inline V2 operator+(V2 a, V2 b) { return mk(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline V2 operator-(V2 a, V2 b) { return mk(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline V2 operator*(float s, V2 a) { return mk(s * a.x, s * a.y); }
+__host__ __device__ inline float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+__host__ __device__ inline float cross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
+__host__ __device__ inline V2 scross(float s, V2 a) { return mk(-s * a.y, s * a.x); }
+__host__ __device__ inline V2 rotv(float s, float c, V2 v) { return mk(c * v.x - s * v.y, s * v.x + c * v.y); }
+
+struct Body {
+    float cx, cy, a, vx, vy, w;
+};
+
+struct CarTrackSrc {  // where reset draws come from
+    uint64_t seed;
+    int64_t env_id_base;
+    const double *ru;        // replay: [n][attempts][24] uniforms, or nullptr (Philox)
+    const uint8_t *rshuffle; // replay: [n][attempts] birth-place swap bit
+    int64_t attempts;
+};
+
+void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
+                      hipStream_t st);
+void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, hipStream_t st);
+void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st);
+void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st);
+
+}  // namespace crl

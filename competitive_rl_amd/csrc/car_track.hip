@@ -1,0 +1,256 @@
+// car_track.hip -- CarRacing.reset on the GPU: procedural track + car placement, one lane per env.
+//
+// Restates CarRacing._create_track / reset (reference car_racing/car_racing_multi_players.py
+// :262-452, :454-525) and Car.__init__ (car_dynamics.py:55-129).  The walk that lays the track
+// is f64 with sin/cos/atan2; it keeps no 2500-point scratch list: pass 1 finds the two
+// start-line crossings that delimit the lap, pass 2 replays the same deterministic walk and
+// emits only the lap's points.  Runs at reset and for envs whose episode just ended, so its
+// cost is amortised over ~1000 steps.
+#include "car_device.h"
+
+namespace crl {
+
+__device__ inline void philox4x32_10c(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+}
+
+struct Checkpoints {
+    double a[12], x[12], y[12];
+    double start_alpha;
+};
+
+struct Walk {  // state of the track-laying walk
+    double x, y, beta;
+    long dest_i;
+    int laps, visited_other_side;
+};
+
+__device__ inline double sgnd(double v) { return (double)((v > 0) - (v < 0)); }
+
+// one iteration of the walk; returns the appended point
+__device__ inline void walk_step(const Checkpoints &cp, Walk &w, double out[4]) {
+    const double PI = 3.141592653589793;
+    double alpha = atan2(w.y, w.x);
+    if (w.visited_other_side && alpha > 0) w.laps++, w.visited_other_side = 0;
+    if (alpha < 0) w.visited_other_side = 1, alpha += 2 * PI;
+    double dest_x = 0, dest_y = 0;
+    for (;;) {
+        bool failed = true;
+        for (;;) {
+            const int k = (int)(w.dest_i % 12);
+            dest_x = cp.x[k], dest_y = cp.y[k];
+            if (alpha <= cp.a[k]) { failed = false; break; }
+            w.dest_i++;
+            if (w.dest_i % 12 == 0) break;
+        }
+        if (!failed) break;
+        alpha -= 2 * PI;
+    }
+    const double r1x = cos(w.beta), r1y = sin(w.beta), p1x = -r1y, p1y = r1x;
+    const double dest_dx = dest_x - w.x, dest_dy = dest_y - w.y;
+    double proj = r1x * dest_dx + r1y * dest_dy;
+    while (w.beta - alpha > 1.5 * PI) w.beta -= 2 * PI;
+    while (w.beta - alpha < -1.5 * PI) w.beta += 2 * PI;
+    const double prev_beta = w.beta;
+    proj *= CAR_SCALE;
+    if (proj > 0.3) w.beta -= fmin(CAR_TRACK_TURN_RATE, fabs(0.001 * proj));
+    if (proj < -0.3) w.beta += fmin(CAR_TRACK_TURN_RATE, fabs(0.001 * proj));
+    w.x += p1x * CAR_TRACK_DETAIL_STEP;
+    w.y += p1y * CAR_TRACK_DETAIL_STEP;
+    out[0] = alpha, out[1] = prev_beta * 0.5 + w.beta * 0.5, out[2] = w.x, out[3] = w.y;
+}
+
+__device__ inline void walk_init(Walk &w) {
+    w.x = 1.5 * CAR_TRACK_RAD, w.y = 0, w.beta = 0, w.dest_i = 0, w.laps = 0, w.visited_other_side = 0;
+}
+
+// Lays one track attempt into `trk` (global scratch [512][4] per env, stride n).  Returns n or 0.
+__device__ int create_track(const double u[24], double *__restrict__ trk, int64_t stride) {
+    const double PI = 3.141592653589793;
+    Checkpoints cp;
+    cp.start_alpha = 0;
+    for (int c = 0; c < 12; c++) {
+        const double noise = 0 + (2 * PI * 1 / 12 - 0) * u[2 * c];
+        double alpha = 2 * PI * c / 12 + noise;
+        double rad = CAR_TRACK_RAD / 3 + (CAR_TRACK_RAD - CAR_TRACK_RAD / 3) * u[2 * c + 1];
+        if (c == 0) alpha = 0, rad = 1.5 * CAR_TRACK_RAD;
+        if (c == 11) alpha = 2 * PI * c / 12, cp.start_alpha = 2 * PI * (-0.5) / 12, rad = 1.5 * CAR_TRACK_RAD;
+        cp.a[c] = alpha, cp.x[c] = rad * cos(alpha), cp.y[c] = rad * sin(alpha);
+    }
+    // pass 1: total length and the last two start-line crossings
+    Walk w;
+    walk_init(w);
+    int n = 0, cross_last = -1, cross_prev = -1, no_freeze = 2500;
+    double prev_alpha = 0;
+    for (;;) {
+        double p[4];
+        walk_step(cp, w, p);
+        if (n > 0 && p[0] > cp.start_alpha && prev_alpha <= cp.start_alpha) cross_prev = cross_last, cross_last = n;
+        prev_alpha = p[0];
+        n++;
+        if (w.laps > 4) break;
+        if (--no_freeze == 0) break;
+    }
+    // the reference scans i = n-1 .. 1 and fails at i == 0 before testing it
+    const int i2 = cross_last, i1 = cross_prev;
+    if (i2 < 1 || i1 < 1) return 0;
+    const int len = (i2 - 1) - i1;
+    if (len <= 0 || len > kCarMaxTiles) return 0;
+    // pass 2: replay and keep points i1 .. i2-2
+    walk_init(w);
+    for (int i = 0; i < i2 - 1; i++) {
+        double p[4];
+        walk_step(cp, w, p);
+        if (i >= i1) {
+            const int k = i - i1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) trk[((int64_t)k * 4 + q) * stride] = p[q];
+        }
+    }
+    const double fb = trk[1 * stride], fpx = cos(fb), fpy = sin(fb);
+    const double a = fpx * (trk[2 * stride] - trk[((int64_t)(len - 1) * 4 + 2) * stride]);
+    const double b = fpy * (trk[3 * stride] - trk[((int64_t)(len - 1) * 4 + 3) * stride]);
+    if (sqrt(a * a + b * b) > CAR_TRACK_DETAIL_STEP) return 0;
+    return len;
+}
+
+__device__ inline void store_poly_ccw(const double (*v)[2], int nv, float *dst, int64_t stride, float *aabb) {
+    double area = 0;
+    for (int i = 0; i < nv; i++) {
+        const int j = (i + 1) % nv;
+        area += v[i][0] * v[j][1] - v[j][0] * v[i][1];
+    }
+    float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+    for (int i = 0; i < nv; i++) {
+        const int k = area > 0 ? i : nv - 1 - i;
+        const float x = (float)v[k][0], y = (float)v[k][1];
+        dst[(2 * i) * stride] = x, dst[(2 * i + 1) * stride] = y;
+        x0 = fminf(x0, x), y0 = fminf(y0, y), x1 = fmaxf(x1, x), y1 = fmaxf(y1, y);
+    }
+    if (aabb) aabb[0] = x0, aabb[1] = y0, aabb[2] = x1, aabb[3] = y1;
+}
+
+// Builds tiles / borders from the lap in `trk` and places both cars.  swap = np.random.shuffle
+// outcome for the two birth places (crmp:508-512).
+__device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const double *trk, int len, int swap) {
+    const int64_t n = s.n, M = 2 * n;
+    auto T = [&](int i, int q) { return trk[((int64_t)i * 4 + q) * n]; };
+    s.ntiles[env] = len;
+    // red-white border on hard turns: 4 consecutive same-sign turns, then dilated backwards IN
+    // PLACE exactly like the reference loop (crmp:384-396; wrap-around entries chain)
+    for (int i = 0; i < len; i++) {
+        bool good = true;
+        double oneside = 0;
+        for (int neg = 0; neg < 4; neg++) {
+            const double b1 = T(((i - neg) % len + len) % len, 1), b2 = T(((i - neg - 1) % len + len) % len, 1);
+            good = good && fabs(b1 - b2) > CAR_TRACK_TURN_RATE * 0.2;
+            oneside += sgnd(b1 - b2);
+        }
+        good = good && fabs(oneside) == 4;
+        s.border[(int64_t)i * n + env] = good ? 1 : 0;
+    }
+    for (int i = 0; i < len; i++)
+        if (s.border[(int64_t)i * n + env])
+            for (int neg = 0; neg < 4; neg++) s.border[(int64_t)(((i - neg) % len + len) % len) * n + env] = 1;
+    for (int i = len - 1; i >= 0; i--) {
+        const int j = ((i - 1) % len + len) % len;
+        const double b1 = T(i, 1), x1 = T(i, 2), y1 = T(i, 3), b2 = T(j, 1), x2 = T(j, 2), y2 = T(j, 3);
+        const double PI = 3.141592653589793;
+        const double v[5][2] = {
+            {x1 - CAR_TRACK_WIDTH * cos(b1), y1 - CAR_TRACK_WIDTH * sin(b1)},
+            {x1 - CAR_TRACK_WIDTH / 2 * cos(b1 - PI / 2), y1 - CAR_TRACK_WIDTH / 2 * sin(b1 - PI / 2)},
+            {x1 + CAR_TRACK_WIDTH * cos(b1), y1 + CAR_TRACK_WIDTH * sin(b1)},
+            {x2 + CAR_TRACK_WIDTH * cos(b2), y2 + CAR_TRACK_WIDTH * sin(b2)},
+            {x2 - CAR_TRACK_WIDTH * cos(b2), y2 - CAR_TRACK_WIDTH * sin(b2)},
+        };
+        float bb[4];
+        store_poly_ccw(v, 5, s.tile_poly + (int64_t)i * 10 * n + env, n, bb);
+        s.tile_aabb[(int64_t)i * n + env] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        if (s.border[(int64_t)i * n + env]) {
+            const double side = sgnd(b2 - b1);
+            const double bp[4][2] = {
+                {x1 + side * CAR_TRACK_WIDTH * cos(b1), y1 + side * CAR_TRACK_WIDTH * sin(b1)},
+                {x1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * cos(b1), y1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * sin(b1)},
+                {x2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * cos(b2), y2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * sin(b2)},
+                {x2 + side * CAR_TRACK_WIDTH * cos(b2), y2 + side * CAR_TRACK_WIDTH * sin(b2)},
+            };
+            store_poly_ccw(bp, 4, s.border_poly + (int64_t)i * 8 * n + env, n, nullptr);
+            s.border[(int64_t)i * n + env] = (i % 2 == 0) ? 1 : 2;  // white / red
+        }
+    }
+    const double ia = T(0, 1), ix = T(0, 2), iy = T(0, 3);
+    s.start_pose[0 * n + env] = (float)ia, s.start_pose[1 * n + env] = (float)ix, s.start_pose[2 * n + env] = (float)iy;
+    for (int car = 0; car < 2; car++) {
+        const int64_t ci = car * n + env;
+        const int birth = car == 0 ? (swap ? 1 : 0) : (swap ? 0 : 1);
+        const double x0 = ix - (birth % 2) * 5, y0 = iy - floor(birth / 2.0) * 10;
+        const float a = (float)ia, sa = sinf(a), ca = cosf(a);
+        const V2 com = mk((float)x0, (float)y0) + rotv(sa, ca, mk(K.hull_lc[0], K.hull_lc[1]));
+        float *b = s.body + ci;
+        for (int k = 0; k < 30; k++) b[k * M] = 0.f;
+        b[0 * M] = com.x, b[1 * M] = com.y, b[2 * M] = a;
+        const double wpos[4][2] = {{-55, +80}, {+55, +80}, {-55, -82}, {+55, -82}};
+        for (int w = 0; w < 4; w++) {
+            b[(6 + 6 * w + 0) * M] = (float)(x0 + wpos[w][0] * CAR_SIZE);
+            b[(6 + 6 * w + 1) * M] = (float)(y0 + wpos[w][1] * CAR_SIZE);
+            b[(6 + 6 * w + 2) * M] = a;
+            s.jmotor[w * M + ci] = 0.f, s.jspeed[w * M + ci] = 0.f, s.jlimit[w * M + ci] = 0;
+            for (int q = 0; q < 3; q++) s.jimp[(3 * w + q) * M + ci] = 0.f;
+            s.wgas[w * M + ci] = 0.0, s.womega[w * M + ci] = 0.0, s.wphase[w * M + ci] = 0.0;
+            for (int q = 0; q < kWheelSlots; q++) s.wtiles[(w * kWheelSlots + q) * M + ci] = -1;
+        }
+        for (int q = 0; q < 16; q++) s.visited[q * M + ci] = 0u;
+        s.reward[ci] = 0.0, s.prev_reward[ci] = 0.0;
+        s.visited_count[ci] = 0, s.last_block[ci] = -1, s.done[ci] = 0, s.step_count[ci] = 0, s.first_step[ci] = 1;
+    }
+    s.elapsed[env] = 0;
+}
+
+__global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, CarTrackSrc src, int only_done,
+                                                       const uint8_t *__restrict__ done_env) {
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= s.n) return;
+    if (only_done && !done_env[env]) return;
+    const uint32_t episode = s.episode[env];
+    s.episode[env] = episode + 1;
+    double *trk = s.track_scratch + env;  // [512][4][n]
+    int len = 0, swap = 0;
+    for (int attempt = 0; attempt < 256 && len == 0; attempt++) {
+        double u[24];
+        if (src.attempts > 0) {
+            const int64_t a = ((int64_t)episode * 16 + attempt) % src.attempts;
+            for (int k = 0; k < 24; k++) u[k] = src.ru[(env * src.attempts + a) * 24 + k];
+            swap = src.rshuffle[env * src.attempts + a];
+        } else {
+            const uint64_t gid = (uint64_t)(src.env_id_base + env);
+            for (int k = 0; k < 13; k++) {
+                uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (episode << 12) | ((uint32_t)attempt << 4) | (uint32_t)k,
+                                 0x43415253u /* "CARS" */};
+                philox4x32_10c(c, (uint32_t)src.seed, (uint32_t)(src.seed >> 32));
+                if (k < 12) {
+                    u[2 * k] = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);
+                    u[2 * k + 1] = (double)((((uint64_t)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0);
+                } else {
+                    swap = c[0] & 1;
+                }
+            }
+        }
+        len = create_track(u, trk, s.n);
+    }
+    finish_reset(s, K, env, trk, len, swap);
+}
+
+void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(car_reset_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k, src, only_done ? 1 : 0,
+                       done_env);
+}
+
+}  // namespace crl

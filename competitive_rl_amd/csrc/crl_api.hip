@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "crl_internal.h"
 #include "pong_device.h"
 
 namespace crl {
@@ -27,7 +28,7 @@ using namespace crl;
 
 static thread_local std::string g_err;
 
-static int fail(int code, const char *fmt, ...) {
+int crl_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -36,6 +37,7 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+#define fail crl_fail
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -68,9 +70,6 @@ static AreaTab area_table(int ssize, int dsize) {
     return t;
 }
 
-struct EventPair {
-    hipEvent_t a, b;
-};
 
 struct crl_ctx {
     crl_opts o;
@@ -92,12 +91,9 @@ struct crl_ctx {
     // replay
     double *ru = nullptr;
     uint8_t *rbx = nullptr, *rby = nullptr;
-    // timing
-    bool timing = false;
-    std::vector<EventPair> ev[2];
-    double ev_ms[2] = {0, 0};
-    int64_t ev_n[2] = {0, 0};
+    crl_timer tm;
     std::vector<uint8_t> atlas_host;
+    crl_car_ctx *car = nullptr;  // set for CRL_ENV_CAR_DOUBLE contexts (everything above unused then)
 };
 
 template <class T>
@@ -119,17 +115,19 @@ static int dev_upload(crl_ctx *c, T **p, const std::vector<T> &v, size_t pad_to 
     return CRL_OK;
 }
 
-static void begin_timed(crl_ctx *c, int which, hipStream_t st) {
-    if (!c->timing) return;
-    EventPair p;
+void crl_timer_begin(crl_timer *t, int which, hipStream_t st) {
+    if (!t || !t->on) return;
+    crl_event_pair p;
     hipEventCreate(&p.a), hipEventCreate(&p.b);
     hipEventRecord(p.a, st);
-    c->ev[which].push_back(p);
+    t->ev[which].push_back(p);
 }
-static void end_timed(crl_ctx *c, int which, hipStream_t st) {
-    if (!c->timing) return;
-    hipEventRecord(c->ev[which].back().b, st);
+void crl_timer_end(crl_timer *t, int which, hipStream_t st) {
+    if (!t || !t->on) return;
+    hipEventRecord(t->ev[which].back().b, st);
 }
+static void begin_timed(crl_ctx *c, int which, hipStream_t st) { crl_timer_begin(&c->tm, which, st); }
+static void end_timed(crl_ctx *c, int which, hipStream_t st) { crl_timer_end(&c->tm, which, st); }
 
 static int setup_gray(crl_ctx *c) {
     const int R = c->o.resized_dim;
@@ -245,8 +243,21 @@ const char *crl_version(void) { return "crl-hip 0.1 (gfx950)"; }
 
 int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out) {
     if (!opts || !out || !score_atlas_host) return fail(CRL_EINVAL, "null argument");
-    if (opts->env_kind != CRL_ENV_PONG_DOUBLE) return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
+    if (opts->env_kind != CRL_ENV_PONG_DOUBLE && opts->env_kind != CRL_ENV_CAR_DOUBLE)
+        return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
     if (opts->num_envs <= 0) return fail(CRL_EINVAL, "num_envs must be positive");
+    if (opts->env_kind == CRL_ENV_CAR_DOUBLE) {
+        int nd = 0;
+        HIP_TRY(hipGetDeviceCount(&nd));
+        if (opts->device < 0 || opts->device >= nd) return fail(CRL_EINVAL, "device %d of %d", opts->device, nd);
+        HIP_TRY(hipSetDevice(opts->device));
+        crl_ctx *cc = new crl_ctx();
+        cc->o = *opts, cc->n = opts->num_envs;
+        int rc = crl_car_create(opts, &cc->car);
+        if (rc) { delete cc; return rc; }
+        *out = cc;
+        return CRL_OK;
+    }
     if (opts->obs_mode == CRL_OBS_GRAY_RESIZED) {
         if (opts->resized_dim < 8 || opts->resized_dim > 84 || (opts->resized_dim * opts->resized_dim) % 4)
             return fail(CRL_EINVAL, "resized_dim %d unsupported (8..84, R*R %% 4 == 0)", opts->resized_dim);
@@ -306,14 +317,16 @@ void crl_destroy(crl_ctx *c) {
     if (!c) return;
     hipSetDevice(c->o.device);
     hipDeviceSynchronize();
+    if (c->car) crl_car_destroy(c->car);
     for (void *p : c->allocs) hipFree(p);
     for (int w = 0; w < 2; w++)
-        for (auto &p : c->ev[w]) hipEventDestroy(p.a), hipEventDestroy(p.b);
+        for (auto &p : c->tm.ev[w]) hipEventDestroy(p.a), hipEventDestroy(p.b);
     delete c;
 }
 
 int crl_seed(crl_ctx *c, uint64_t seed) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
+    if (c->car) crl_car_seed(c->car, seed);
     c->src.seed = seed;
     return CRL_OK;
 }
@@ -340,14 +353,24 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
 int crl_reset(crl_ctx *c, uint8_t *obs_dev, void *stream) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
     hipStream_t st = (hipStream_t)stream;
+    if (c->car) return crl_car_reset(c->car, obs_dev, st);
     launch_pong_reset(c->s, c->src, c->n, st);
     HIP_TRY(hipGetLastError());
     return draw_obs(c, obs_dev, st);
 }
 
-int crl_step(crl_ctx *c, const int32_t *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, void *stream) {
-    if (!c || !actions_dev) return fail(CRL_EINVAL, "null ctx/actions");
+int crl_render(crl_ctx *c, uint8_t *obs_dev, void *stream) {
+    if (!c || !obs_dev) return fail(CRL_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
+    if (c->car) return crl_car_render(c->car, obs_dev, st);
+    return draw_obs(c, obs_dev, st);
+}
+
+int crl_step(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, void *stream) {
+    if (!c || !actions_void) return fail(CRL_EINVAL, "null ctx/actions");
+    hipStream_t st = (hipStream_t)stream;
+    if (c->car) return crl_car_step(c->car, (const float *)actions_void, obs_dev, rew_dev, done_dev, st, &c->tm);
+    const int32_t *actions_dev = (const int32_t *)actions_void;
     begin_timed(c, 0, st);
     launch_pong_dynamics(c->s, c->src, actions_dev, c->n, c->o.obs_mode == CRL_OBS_GRAY_RESIZED, rew_dev, done_dev, st);
     end_timed(c, 0, st);
@@ -357,6 +380,7 @@ int crl_step(crl_ctx *c, const int32_t *actions_dev, uint8_t *obs_dev, float *re
 
 int crl_info(crl_ctx *c, const float **real_reward_dev, const int32_t **num_steps_dev) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
+    if (c->car) return fail(CRL_ESTATE, "crl_info is a Pong entry point");
     if (real_reward_dev) *real_reward_dev = c->s.real_reward;
     if (num_steps_dev) *num_steps_dev = c->s.num_steps;
     return CRL_OK;
@@ -364,6 +388,7 @@ int crl_info(crl_ctx *c, const float **real_reward_dev, const int32_t **num_step
 
 int crl_copy_info(crl_ctx *c, float *rr_out, int32_t *ns_out, void *stream) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
+    if (c->car) return fail(CRL_ESTATE, "crl_copy_info is a Pong entry point");
     hipStream_t st = (hipStream_t)stream;
     if (rr_out) HIP_TRY(hipMemcpyAsync(rr_out, c->s.real_reward, (size_t)c->n * 8, hipMemcpyDeviceToDevice, st));
     if (ns_out) HIP_TRY(hipMemcpyAsync(ns_out, c->s.num_steps, (size_t)c->n * 4, hipMemcpyDeviceToDevice, st));
@@ -372,6 +397,7 @@ int crl_copy_info(crl_ctx *c, float *rr_out, int32_t *ns_out, void *stream) {
 
 int64_t crl_obs_bytes_per_env(const crl_ctx *c) {
     if (!c) return 0;
+    if (c->car) return crl_car_obs_bytes(c->car);
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) return 2 * (int64_t)CRL_PONG_FRAME_BYTES;
     return 2 * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim;
 }
@@ -409,6 +435,7 @@ static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::
 
 int crl_terminal_observation(crl_ctx *c, const int64_t *env_idx_host, int64_t count, uint8_t *out_dev, void *stream) {
     if (!c || (count > 0 && (!env_idx_host || !out_dev))) return fail(CRL_EINVAL, "null argument");
+    if (c->car) return fail(CRL_ESTATE, "terminal observations are not kept for CarRacing contexts");
     hipStream_t st = (hipStream_t)stream;
     std::vector<uint64_t> all((size_t)2 * c->n);
     HIP_TRY(hipMemcpyAsync(all.data(), c->s.term_frames, all.size() * 8, hipMemcpyDeviceToHost, st));
@@ -424,6 +451,7 @@ int crl_terminal_observation(crl_ctx *c, const int64_t *env_idx_host, int64_t co
 
 int crl_render_raw(crl_ctx *c, const crl_pong_frame *frames_host, int64_t count, uint8_t *out_dev, void *stream) {
     if (!c || !frames_host || !out_dev) return fail(CRL_EINVAL, "null argument");
+    if (c->car) return fail(CRL_ESTATE, "crl_render_raw is a Pong entry point");
     if (c->o.obs_mode != CRL_OBS_RAW_RGB) return fail(CRL_ESTATE, "crl_render_raw needs a RAW_RGB context");
     std::vector<uint64_t> f(count);
     memcpy(f.data(), frames_host, (size_t)count * 8);
@@ -460,6 +488,7 @@ extern "C" {
 
 int crl_get_state(crl_ctx *c, crl_pong_env_state *out, int64_t first, int64_t count, void *stream) {
     if (!c || !out || first < 0 || count < 0 || first + count > c->n) return fail(CRL_EINVAL, "bad range");
+    if (c->car) return fail(CRL_ESTATE, "use crl_car_get_state for CarRacing contexts");
     hipStream_t st = (hipStream_t)stream;
     std::vector<double> sx, sy;
     std::vector<int32_t> bx, by, bl, br, sl, sr, ro, stp, ws;
@@ -490,6 +519,7 @@ int crl_get_state(crl_ctx *c, crl_pong_env_state *out, int64_t first, int64_t co
 
 int crl_set_state(crl_ctx *c, const crl_pong_env_state *in, int64_t first, int64_t count, void *stream) {
     if (!c || !in || first < 0 || count < 0 || first + count > c->n) return fail(CRL_EINVAL, "bad range");
+    if (c->car) return fail(CRL_ESTATE, "use crl_car_set_state for CarRacing contexts");
     hipStream_t st = (hipStream_t)stream;
     std::vector<double> sx(count), sy(count);
     std::vector<int32_t> bx(count), by(count), bl(count), br(count), sl(count), sr(count), ro(count), stp(count), ws(count);
@@ -525,6 +555,7 @@ int crl_set_state(crl_ctx *c, const crl_pong_env_state *in, int64_t first, int64
 
 int crl_set_replay(crl_ctx *c, const double *u, const uint8_t *bx, const uint8_t *by, int64_t per_env) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
+    if (c->car) return fail(CRL_ESTATE, "use crl_car_set_replay for CarRacing contexts");
     HIP_TRY(hipDeviceSynchronize());
     if (c->ru) hipFree(c->ru), hipFree(c->rbx), hipFree(c->rby), c->ru = nullptr, c->rbx = c->rby = nullptr;
     c->src.ru = nullptr, c->src.rbx = c->src.rby = nullptr, c->src.per_env = 0;
@@ -543,24 +574,48 @@ int crl_set_replay(crl_ctx *c, const double *u, const uint8_t *bx, const uint8_t
 
 int crl_kernel_timing(crl_ctx *c, int enable) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
-    c->timing = enable != 0;
+    c->tm.on = enable != 0;
     return CRL_OK;
 }
 
 int crl_kernel_time_ms(crl_ctx *c, int which, double *total_ms, int64_t *launches) {
     if (!c || which < 0 || which > 1) return fail(CRL_EINVAL, "bad argument");
-    for (auto &p : c->ev[which]) {
+    crl_timer &t = c->tm;
+    for (auto &p : t.ev[which]) {
         HIP_TRY(hipEventSynchronize(p.b));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
-        c->ev_ms[which] += ms, c->ev_n[which]++;
+        t.ms[which] += ms, t.cnt[which]++;
         hipEventDestroy(p.a), hipEventDestroy(p.b);
     }
-    c->ev[which].clear();
-    if (total_ms) *total_ms = c->ev_ms[which];
-    if (launches) *launches = c->ev_n[which];
-    c->ev_ms[which] = 0, c->ev_n[which] = 0;
+    t.ev[which].clear();
+    if (total_ms) *total_ms = t.ms[which];
+    if (launches) *launches = t.cnt[which];
+    t.ms[which] = 0, t.cnt[which] = 0;
     return CRL_OK;
+}
+
+int crl_car_get_state(crl_ctx *c, crl_car_env_state *out, int64_t first, int64_t count, void *stream) {
+    if (!c || !c->car || !out) return fail(CRL_EINVAL, "not a CarRacing context / null argument");
+    return crl_car_get_state_impl(c->car, out, first, count, (hipStream_t)stream);
+}
+int crl_car_set_state(crl_ctx *c, const crl_car_env_state *in, int64_t first, int64_t count, void *stream) {
+    if (!c || !c->car || !in) return fail(CRL_EINVAL, "not a CarRacing context / null argument");
+    return crl_car_set_state_impl(c->car, in, first, count, (hipStream_t)stream);
+}
+int crl_car_get_track(crl_ctx *c, int64_t env, int32_t *n, float *tile_poly, float *border_poly, uint8_t *border,
+                      float *start_pose, void *stream) {
+    if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
+    return crl_car_get_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
+}
+int crl_car_set_track(crl_ctx *c, int64_t env, int32_t n, const float *tile_poly, const float *border_poly, const uint8_t *border,
+                      const float *start_pose, void *stream) {
+    if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
+    return crl_car_set_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
+}
+int crl_car_set_replay(crl_ctx *c, const double *u, const uint8_t *swap, int64_t attempts) {
+    if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
+    return crl_car_set_replay_impl(c->car, u, swap, attempts);
 }
 
 }  // extern "C"

@@ -1,0 +1,351 @@
+// crl_car_api.hip -- host side of the cCarRacingDouble context (C ABI of include/crl.h).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "car_device.h"
+#include "crl_internal.h"
+
+using namespace crl;
+
+struct crl_car_ctx {
+    crl_opts o;
+    int64_t n;
+    CarSoA s{};
+    CarConsts K{};
+    CarTrackSrc src{};
+    std::vector<void *> allocs;
+    uint8_t *done_car = nullptr, *done_env = nullptr;
+    float *rew_tmp = nullptr;
+    double *ru = nullptr;
+    uint8_t *rshuffle = nullptr;
+};
+
+// ---- body constants, the Box2D way (b2PolygonShape::ComputeMass, b2Body::ResetMassData), float32
+static void poly_mass(const V2 *vs, int n, float density, float *mass, V2 *center, float *I) {
+    V2 c = mk(0, 0), s = mk(0, 0);
+    float area = 0, in = 0;
+    for (int i = 0; i < n; i++) s = s + vs[i];
+    s = (1.0f / n) * s;
+    const float k_inv3 = 1.0f / 3.0f;
+    for (int i = 0; i < n; i++) {
+        const V2 e1 = vs[i] - s, e2 = vs[i + 1 < n ? i + 1 : 0] - s;
+        const float D = cross(e1, e2), ta = 0.5f * D;
+        area += ta;
+        c = c + (ta * k_inv3) * (e1 + e2);
+        const float intx2 = e1.x * e1.x + e2.x * e1.x + e2.x * e2.x, inty2 = e1.y * e1.y + e2.y * e1.y + e2.y * e2.y;
+        in += (0.25f * k_inv3 * D) * (intx2 + inty2);
+    }
+    *mass = density * area;
+    c = (1.0f / area) * c;
+    *center = c + s;
+    *I = density * in;
+    *I += *mass * (dot(*center, *center) - dot(c, c));
+}
+
+static int ccw(const double (*src)[2], int n, double scale, float (*dst)[2]) {
+    double area = 0;
+    for (int i = 0; i < n; i++) {
+        const int j = (i + 1) % n;
+        area += src[i][0] * src[j][1] - src[j][0] * src[i][1];
+    }
+    for (int i = 0; i < n; i++) {
+        const int k = area > 0 ? i : n - 1 - i;
+        dst[i][0] = (float)(src[k][0] * scale), dst[i][1] = (float)(src[k][1] * scale);
+    }
+    return n;
+}
+
+static void make_consts(CarConsts &K) {
+    static const double H1[4][2] = {{-60, 130}, {60, 130}, {60, 110}, {-60, 110}};
+    static const double H2[4][2] = {{-15, 120}, {15, 120}, {20, 20}, {-20, 20}};
+    static const double H3[8][2] = {{25, 20}, {50, -10}, {50, -40}, {20, -90}, {-20, -90}, {-50, -40}, {-50, -10}, {-25, 20}};
+    static const double H4[4][2] = {{-50, -120}, {50, -120}, {50, -90}, {-50, -90}};
+    static const double WP[4][2] = {{-CAR_WHEEL_W, +CAR_WHEEL_R}, {+CAR_WHEEL_W, +CAR_WHEEL_R}, {+CAR_WHEEL_W, -CAR_WHEEL_R}, {-CAR_WHEEL_W, -CAR_WHEEL_R}};
+    static const double WPOS[4][2] = {{-55, +80}, {+55, +80}, {-55, -82}, {+55, -82}};
+    const double(*polys[4])[2] = {H1, H2, H3, H4};
+    const int cnt[4] = {4, 4, 8, 4};
+    float mass = 0, I = 0;
+    V2 lc = mk(0, 0);
+    memset(&K, 0, sizeof(K));
+    for (int f = 0; f < 4; f++) {
+        K.hull_n[f] = ccw(polys[f], cnt[f], CAR_SIZE, K.hull_poly[f]);
+        float m, i;
+        V2 c;
+        poly_mass(reinterpret_cast<const V2 *>(K.hull_poly[f]), cnt[f], 1.0f, &m, &c, &i);
+        mass += m, lc = lc + m * c, I += i;
+    }
+    K.hull_inv_mass = 1.0f / mass;
+    lc = K.hull_inv_mass * lc;
+    K.hull_lc[0] = lc.x, K.hull_lc[1] = lc.y;
+    I -= mass * dot(lc, lc);
+    K.hull_inv_I = 1.0f / I;
+    ccw(WP, 4, CAR_SIZE, K.wheel_poly);
+    float m, i;
+    V2 c;
+    poly_mass(reinterpret_cast<const V2 *>(K.wheel_poly), 4, 0.1f, &m, &c, &i);
+    i -= m * dot(c, c);
+    K.wheel_inv_mass = 1.0f / m, K.wheel_inv_I = 1.0f / i;
+    for (int w = 0; w < 4; w++) K.anchor[w][0] = (float)(WPOS[w][0] * CAR_SIZE), K.anchor[w][1] = (float)(WPOS[w][1] * CAR_SIZE);
+}
+
+template <class T>
+static int calloc_dev(crl_car_ctx *c, T **p, size_t count) {
+    void *q = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    if (hipMalloc(&q, bytes) != hipSuccess) return crl_fail(CRL_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    if (hipMemset(q, 0, bytes) != hipSuccess) return crl_fail(CRL_EHIP, "hipMemset failed");
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return CRL_OK;
+}
+
+int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
+    crl_car_ctx *c = new crl_car_ctx();
+    c->o = *opts;
+    const int64_t n = c->n = opts->num_envs, M = 2 * n;
+    CarSoA &s = c->s;
+    s.n = n;
+    int rc = 0;
+#define A(f, cnt) if (!rc) rc = calloc_dev(c, &s.f, (size_t)(cnt))
+    A(body, 30 * M); A(jimp, 12 * M); A(jmotor, 4 * M); A(jspeed, 4 * M); A(jlimit, 4 * M);
+    A(wgas, 4 * M); A(womega, 4 * M); A(wphase, 4 * M); A(wtiles, 4 * kWheelSlots * M); A(visited, 16 * M);
+    A(reward, M); A(prev_reward, M); A(visited_count, M); A(last_block, M); A(done, M); A(step_count, M); A(first_step, M);
+    A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
+    A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
+    A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
+#undef A
+    if (!rc) rc = calloc_dev(c, &c->done_car, 2 * n);
+    if (!rc) rc = calloc_dev(c, &c->done_env, n);
+    if (!rc) rc = calloc_dev(c, &c->rew_tmp, 2 * n);
+    if (rc) { crl_car_destroy(c); return rc; }
+    make_consts(c->K);
+    c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
+    *out = c;
+    return CRL_OK;
+}
+
+void crl_car_destroy(crl_car_ctx *c) {
+    if (!c) return;
+    hipDeviceSynchronize();
+    for (void *p : c->allocs) hipFree(p);
+    if (c->ru) hipFree(c->ru);
+    if (c->rshuffle) hipFree(c->rshuffle);
+    delete c;
+}
+
+void crl_car_seed(crl_car_ctx *c, uint64_t seed) { c->src.seed = seed; }
+int64_t crl_car_obs_bytes(const crl_car_ctx *) { return 2 * CRL_CAR_OBS * CRL_CAR_OBS; }
+
+int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
+    launch_car_reset(c->s, c->K, c->src, false, nullptr, st);
+    if (obs_dev) launch_car_raster(c->s, c->K, obs_dev, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return crl_fail(CRL_EHIP, "car reset: %s", hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
+    launch_car_raster(c->s, c->K, obs_dev, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return crl_fail(CRL_EHIP, "car render: %s", hipGetErrorString(e));
+    return CRL_OK;
+}
+
+// VecEnv.step over make_car_racing_double envs (car_racing/register.py:43-53): CarRacing.step,
+// TimeLimit, FlattenMultiAgentObservation's any-done, then auto-reset of finished envs.
+int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
+                 crl_timer *tm) {
+    crl_timer_begin(tm, 0, st);
+    launch_car_step(c->s, c->K, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, st);
+    launch_car_post(c->s, c->done_car, c->done_env, 1000, st);
+    launch_car_reset(c->s, c->K, c->src, true, c->done_env, st);
+    crl_timer_end(tm, 0, st);
+    if (done_dev) hipMemcpyAsync(done_dev, c->done_env, c->n, hipMemcpyDeviceToDevice, st);
+    if (obs_dev) {
+        crl_timer_begin(tm, 1, st);
+        launch_car_raster(c->s, c->K, obs_dev, st);
+        crl_timer_end(tm, 1, st);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return crl_fail(CRL_EHIP, "car step: %s", hipGetErrorString(e));
+    return CRL_OK;
+}
+
+// ---- state exchange
+template <class T>
+static std::vector<T> pull(const T *dev, size_t count, hipStream_t st) {
+    std::vector<T> v(count);
+    hipMemcpyAsync(v.data(), dev, count * sizeof(T), hipMemcpyDeviceToHost, st);
+    return v;
+}
+
+struct HostCopy {
+    std::vector<float> body, jimp, jmotor, jspeed;
+    std::vector<int32_t> jlimit, visited_count, last_block, done, step_count, first_step, elapsed;
+    std::vector<double> wgas, womega, wphase, reward, prev_reward;
+    std::vector<int16_t> wtiles;
+    std::vector<uint32_t> visited, episode;
+};
+
+static void pull_all(crl_car_ctx *c, HostCopy &h, hipStream_t st) {
+    const int64_t n = c->n, M = 2 * n;
+    const CarSoA &s = c->s;
+    h.body = pull(s.body, 30 * M, st), h.jimp = pull(s.jimp, 12 * M, st), h.jmotor = pull(s.jmotor, 4 * M, st);
+    h.jspeed = pull(s.jspeed, 4 * M, st), h.jlimit = pull(s.jlimit, 4 * M, st);
+    h.wgas = pull(s.wgas, 4 * M, st), h.womega = pull(s.womega, 4 * M, st), h.wphase = pull(s.wphase, 4 * M, st);
+    h.wtiles = pull(s.wtiles, 4 * kWheelSlots * M, st), h.visited = pull(s.visited, 16 * M, st);
+    h.reward = pull(s.reward, M, st), h.prev_reward = pull(s.prev_reward, M, st);
+    h.visited_count = pull(s.visited_count, M, st), h.last_block = pull(s.last_block, M, st), h.done = pull(s.done, M, st);
+    h.step_count = pull(s.step_count, M, st), h.first_step = pull(s.first_step, M, st);
+    h.elapsed = pull(s.elapsed, n, st), h.episode = pull(s.episode, n, st);
+    hipStreamSynchronize(st);
+}
+
+template <class T>
+static void push(const std::vector<T> &v, T *dev, hipStream_t st) {
+    hipMemcpyAsync(dev, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st);
+}
+
+int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first, int64_t count, hipStream_t st) {
+    if (first < 0 || count < 0 || first + count > c->n) return crl_fail(CRL_EINVAL, "bad range");
+    HostCopy h;
+    pull_all(c, h, st);
+    const int64_t n = c->n, M = 2 * n;
+    for (int64_t e = 0; e < count; e++) {
+        crl_car_env_state &o = out[e];
+        memset(&o, 0, sizeof(o));
+        const int64_t env = first + e;
+        for (int car = 0; car < 2; car++) {
+            const int64_t ci = car * n + env;
+            crl_car_state &q = o.car[car];
+            crl_car_body *bodies[5] = {&q.hull, &q.wheel[0], &q.wheel[1], &q.wheel[2], &q.wheel[3]};
+            for (int b = 0; b < 5; b++) {
+                float *f = &bodies[b]->cx;
+                for (int k = 0; k < 6; k++) f[k] = h.body[(6 * b + k) * M + ci];
+            }
+            for (int w = 0; w < 4; w++) {
+                for (int k = 0; k < 3; k++) q.imp[w][k] = h.jimp[(3 * w + k) * M + ci];
+                q.motor_imp[w] = h.jmotor[w * M + ci], q.motor_speed[w] = h.jspeed[w * M + ci], q.limit_state[w] = h.jlimit[w * M + ci];
+                q.gas[w] = h.wgas[w * M + ci], q.omega[w] = h.womega[w * M + ci], q.phase[w] = h.wphase[w * M + ci];
+                for (int k = 0; k < kWheelSlots; k++) {
+                    const int t = h.wtiles[(w * kWheelSlots + k) * M + ci];
+                    if (t >= 0) q.wheel_tiles[w][t >> 5] |= 1u << (t & 31);
+                }
+            }
+            for (int k = 0; k < 16; k++) q.visited[k] = h.visited[k * M + ci];
+            q.reward = h.reward[ci], q.prev_reward = h.prev_reward[ci];
+            q.tile_visited_count = h.visited_count[ci], q.last_block = h.last_block[ci], q.done = h.done[ci];
+            q.step_count = h.step_count[ci], q.first_step = h.first_step[ci];
+        }
+        o.elapsed = h.elapsed[env], o.episode = h.episode[env];
+    }
+    return CRL_OK;
+}
+
+int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t first, int64_t count, hipStream_t st) {
+    if (first < 0 || count < 0 || first + count > c->n) return crl_fail(CRL_EINVAL, "bad range");
+    HostCopy h;
+    pull_all(c, h, st);
+    const int64_t n = c->n, M = 2 * n;
+    for (int64_t e = 0; e < count; e++) {
+        const crl_car_env_state &o = in[e];
+        const int64_t env = first + e;
+        for (int car = 0; car < 2; car++) {
+            const int64_t ci = car * n + env;
+            const crl_car_state &q = o.car[car];
+            const crl_car_body *bodies[5] = {&q.hull, &q.wheel[0], &q.wheel[1], &q.wheel[2], &q.wheel[3]};
+            for (int b = 0; b < 5; b++) {
+                const float *f = &bodies[b]->cx;
+                for (int k = 0; k < 6; k++) h.body[(6 * b + k) * M + ci] = f[k];
+            }
+            for (int w = 0; w < 4; w++) {
+                for (int k = 0; k < 3; k++) h.jimp[(3 * w + k) * M + ci] = q.imp[w][k];
+                h.jmotor[w * M + ci] = q.motor_imp[w], h.jspeed[w * M + ci] = q.motor_speed[w], h.jlimit[w * M + ci] = q.limit_state[w];
+                h.wgas[w * M + ci] = q.gas[w], h.womega[w * M + ci] = q.omega[w], h.wphase[w * M + ci] = q.phase[w];
+                int slot = 0;
+                for (int k = 0; k < kWheelSlots; k++) h.wtiles[(w * kWheelSlots + k) * M + ci] = -1;
+                for (int t = 0; t < kCarMaxTiles; t++)
+                    if ((q.wheel_tiles[w][t >> 5] >> (t & 31)) & 1) {
+                        if (slot >= kWheelSlots) return crl_fail(CRL_EINVAL, "wheel touches more than %d tiles", kWheelSlots);
+                        h.wtiles[(w * kWheelSlots + slot++) * M + ci] = (int16_t)t;
+                    }
+            }
+            for (int k = 0; k < 16; k++) h.visited[k * M + ci] = q.visited[k];
+            h.reward[ci] = q.reward, h.prev_reward[ci] = q.prev_reward;
+            h.visited_count[ci] = q.tile_visited_count, h.last_block[ci] = q.last_block, h.done[ci] = q.done;
+            h.step_count[ci] = q.step_count, h.first_step[ci] = q.first_step;
+        }
+        h.elapsed[env] = o.elapsed, h.episode[env] = o.episode;
+    }
+    const CarSoA &s = c->s;
+    push(h.body, s.body, st), push(h.jimp, s.jimp, st), push(h.jmotor, s.jmotor, st), push(h.jspeed, s.jspeed, st);
+    push(h.jlimit, s.jlimit, st), push(h.wgas, s.wgas, st), push(h.womega, s.womega, st), push(h.wphase, s.wphase, st);
+    push(h.wtiles, s.wtiles, st), push(h.visited, s.visited, st), push(h.reward, s.reward, st), push(h.prev_reward, s.prev_reward, st);
+    push(h.visited_count, s.visited_count, st), push(h.last_block, s.last_block, st), push(h.done, s.done, st);
+    push(h.step_count, s.step_count, st), push(h.first_step, s.first_step, st), push(h.elapsed, s.elapsed, st), push(h.episode, s.episode, st);
+    hipStreamSynchronize(st);
+    return CRL_OK;
+}
+
+int crl_car_get_track_impl(crl_car_ctx *c, int64_t env, int32_t *n_out, float *tile_poly, float *border_poly, uint8_t *border,
+                           float *start_pose, hipStream_t st) {
+    if (env < 0 || env >= c->n) return crl_fail(CRL_EINVAL, "env out of range");
+    const int64_t n = c->n;
+    int32_t nt = 0;
+    hipMemcpyAsync(&nt, c->s.ntiles + env, 4, hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    if (n_out) *n_out = nt;
+    // strided gathers: one 2-D copy per array
+    if (tile_poly) hipMemcpy2DAsync(tile_poly, 4, c->s.tile_poly + env, n * 4, 4, (size_t)nt * 10, hipMemcpyDeviceToHost, st);
+    if (border_poly) hipMemcpy2DAsync(border_poly, 4, c->s.border_poly + env, n * 4, 4, (size_t)nt * 8, hipMemcpyDeviceToHost, st);
+    if (border) hipMemcpy2DAsync(border, 1, c->s.border + env, n, 1, (size_t)nt, hipMemcpyDeviceToHost, st);
+    if (start_pose) hipMemcpy2DAsync(start_pose, 4, c->s.start_pose + env, n * 4, 4, 3, hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return crl_fail(CRL_EHIP, "get_track: %s", hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const float *tile_poly, const float *border_poly,
+                           const uint8_t *border, const float *start_pose, hipStream_t st) {
+    if (env < 0 || env >= c->n || nt <= 0 || nt > kCarMaxTiles || !tile_poly) return crl_fail(CRL_EINVAL, "bad track");
+    const int64_t n = c->n;
+    std::vector<float4> aabb(nt);
+    for (int t = 0; t < nt; t++) {
+        float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+        for (int k = 0; k < 5; k++) {
+            const float x = tile_poly[t * 10 + 2 * k], y = tile_poly[t * 10 + 2 * k + 1];
+            x0 = fminf(x0, x), y0 = fminf(y0, y), x1 = fmaxf(x1, x), y1 = fmaxf(y1, y);
+        }
+        aabb[t] = make_float4(x0, y0, x1, y1);
+    }
+    hipMemcpyAsync(c->s.ntiles + env, &nt, 4, hipMemcpyHostToDevice, st);
+    hipMemcpy2DAsync(c->s.tile_poly + env, n * 4, tile_poly, 4, 4, (size_t)nt * 10, hipMemcpyHostToDevice, st);
+    hipMemcpy2DAsync(c->s.tile_aabb + env, n * 16, aabb.data(), 16, 16, (size_t)nt, hipMemcpyHostToDevice, st);
+    if (border_poly) hipMemcpy2DAsync(c->s.border_poly + env, n * 4, border_poly, 4, 4, (size_t)nt * 8, hipMemcpyHostToDevice, st);
+    if (border) hipMemcpy2DAsync(c->s.border + env, n, border, 1, 1, (size_t)nt, hipMemcpyHostToDevice, st);
+    if (start_pose) hipMemcpy2DAsync(c->s.start_pose + env, n * 4, start_pose, 4, 4, 3, hipMemcpyHostToDevice, st);
+    hipStreamSynchronize(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return crl_fail(CRL_EHIP, "set_track: %s", hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_car_set_replay_impl(crl_car_ctx *c, const double *u, const uint8_t *swap, int64_t attempts) {
+    hipDeviceSynchronize();
+    if (c->ru) hipFree(c->ru), c->ru = nullptr;
+    if (c->rshuffle) hipFree(c->rshuffle), c->rshuffle = nullptr;
+    c->src.ru = nullptr, c->src.rshuffle = nullptr, c->src.attempts = 0;
+    if (attempts <= 0) return CRL_OK;
+    if (!u || !swap) return crl_fail(CRL_EINVAL, "null replay arrays");
+    const size_t m = (size_t)c->n * attempts;
+    if (hipMalloc((void **)&c->ru, m * 24 * 8) != hipSuccess || hipMalloc((void **)&c->rshuffle, m) != hipSuccess)
+        return crl_fail(CRL_ENOMEM, "replay alloc");
+    hipMemcpy(c->ru, u, m * 24 * 8, hipMemcpyHostToDevice);
+    hipMemcpy(c->rshuffle, swap, m, hipMemcpyHostToDevice);
+    c->src.ru = c->ru, c->src.rshuffle = c->rshuffle, c->src.attempts = attempts;
+    return CRL_OK;
+}

@@ -1,0 +1,41 @@
+// crl_internal.h -- shared between the per-env-kind host files of libcrl_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/crl.h"
+
+int crl_fail(int code, const char *fmt, ...);
+
+struct crl_event_pair {
+    hipEvent_t a, b;
+};
+
+// hipEvent brackets around the kernels of a step, on the launch stream (crl_kernel_timing)
+struct crl_timer {
+    bool on = false;
+    std::vector<crl_event_pair> ev[2];
+    double ms[2] = {0, 0};
+    int64_t cnt[2] = {0, 0};
+};
+void crl_timer_begin(crl_timer *t, int which, hipStream_t st);
+void crl_timer_end(crl_timer *t, int which, hipStream_t st);
+
+struct crl_car_ctx;
+int crl_car_create(const crl_opts *opts, crl_car_ctx **out);
+void crl_car_destroy(crl_car_ctx *c);
+void crl_car_seed(crl_car_ctx *c, uint64_t seed);
+int64_t crl_car_obs_bytes(const crl_car_ctx *c);
+int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st);
+int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st);
+int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
+                 crl_timer *tm);
+int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first, int64_t count, hipStream_t st);
+int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t first, int64_t count, hipStream_t st);
+int crl_car_get_track_impl(crl_car_ctx *c, int64_t env, int32_t *n_out, float *tile_poly, float *border_poly, uint8_t *border,
+                           float *start_pose, hipStream_t st);
+int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const float *tile_poly, const float *border_poly,
+                           const uint8_t *border, const float *start_pose, hipStream_t st);
+int crl_car_set_replay_impl(crl_car_ctx *c, const double *u, const uint8_t *swap, int64_t attempts);

@@ -7,10 +7,11 @@ keyword-only arguments select GPU-side options.
 import os
 
 from .vec_env import HipPongVecEnv
+from .vec_env_car import HipCarVecEnv
 
 __all__ = ["make_envs"]
 
-_HIP_IDS = ("cPongDouble-v0",)
+_HIP_IDS = ("cPongDouble-v0", "cCarRacingDouble-v0")
 
 
 def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronous=False, resized_dim=42,
@@ -39,6 +40,11 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
             f"{env_id!r} is not served by the HIP backend yet (available: {_HIP_IDS})")
     if log_dir:
         os.makedirs(log_dir, exist_ok=True)
+    if env_id == "cCarRacingDouble-v0":
+        if frame_stack is not None:
+            raise NotImplementedError("MultipleFrameStack is not fused yet: pass frame_stack=None")
+        return HipCarVecEnv(num_envs, seed=seed, device=device, env_id_base=env_id_base, output=output,
+                            dones="subproc" if asynchronous else "dummy", action_repeat=action_repeat)
     if env_id == "cPongDouble-v0":
         assert frame_stack is None
     return HipPongVecEnv(num_envs, seed=seed, mode="wrapped", resized_dim=resized_dim, frame_stack=stack_planes,

@@ -1,0 +1,202 @@
+"""HIP vector env for cCarRacingDouble-v0 behind the reference's VecEnv protocol.
+
+Mirrors ``DummyVecEnv([make_car_racing_double(seed, i, frame_stack, action_repeat)] * N)``
+(reference competitive_rl/car_racing/register.py:43-53, utils/atari_wrappers.py:308-334,
+utils/dummy_vec_env.py:10-133): observation (N, 2, 96, 96) uint8 (both agents' 96x96 gray views on
+the channel axis, WrapPyTorch layout), actions (N, 2, 2) floats in [-1, 1], reward = agent 0's
+(N, 1), done = any agent done or the 1000-step TimeLimit (N, 1); per-agent rewards and step
+counts in ``infos``.  Auto-reset lays a fresh procedural track on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import spaces
+from .vec_env import VecEnv, _EnvList
+
+
+class CarLazyInfos:
+    """``infos[i]`` -> ``{0: {"num_steps": k, "reward": r0}, 1: {...}}`` (crmp:618-620,
+    atari_wrappers.py:327-328) without building N dicts per step."""
+
+    def __init__(self, n, rew, steps):
+        self._n, self._rew_dev, self._steps_dev, self._host = n, rew, steps, None
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if self._host is None:
+            self._host = (self._rew_dev.cpu().numpy(), self._steps_dev.cpu().numpy())
+        r, st = self._host
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return {k: {"num_steps": int(st[i]), "reward": float(r[i, k])} for k in range(2)}
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+    def copy(self):
+        return self
+
+
+class HipCarVecEnv(VecEnv):
+    def __init__(self, num_envs, seed=0, device=None, env_id_base=0, output="torch", dones="dummy", action_repeat=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipCarVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        if action_repeat not in (None, 1):
+            raise NotImplementedError("action_repeat > 1 is not built yet")
+        assert output in ("torch", "numpy") and dones in ("dummy", "subproc")
+        self._L = N.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.output, self.dones_kind, self.closed = output, dones, False
+        opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE, obs_mode=0, resized_dim=0, frame_stack=1, num_envs=int(num_envs),
+                         env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0, reserved=0)
+        h = C.c_void_p()
+        dummy = np.zeros(16, np.uint8)  # crl_create's atlas argument is only used by Pong contexts
+        with torch.cuda.device(self.device):
+            N.check(self._L.crl_create(C.byref(opts), dummy.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self._h = h
+        n = int(num_envs)
+        obs_space = spaces.Box(0, 255, (2, 96, 96), dtype=np.uint8)
+        act_space = spaces.Box(-1, 1, (2, 2), dtype=np.float32)
+        VecEnv.__init__(self, n, obs_space, act_space)
+        dev = self.device
+        self._obs = [torch.empty((n, 2, 96, 96), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._flip = 0
+        self._rew = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+        self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        self._actions = torch.zeros((n, 2, 2), dtype=torch.float32, device=dev)
+        self._steps = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.envs = _EnvList(self)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_open(self):
+        if self.closed:
+            raise RuntimeError("VecEnv is closed")
+
+    def seed(self, seed=None):
+        self._check_open()
+        N.check(self._L.crl_seed(self._h, int(seed or 0) & (2 ** 64 - 1)))
+        return [None] * self.num_envs
+
+    def _out(self, t):
+        return t.cpu().numpy() if self.output == "numpy" else t
+
+    def reset(self):
+        self._check_open()
+        buf = self._obs[self._flip]
+        self._flip ^= 1
+        N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
+        self._steps.zero_()
+        return self._out(buf)
+
+    def step_async(self, actions):
+        self._check_open()
+        if isinstance(actions, torch.Tensor):
+            a = actions.to(device=self.device, dtype=torch.float32)
+        else:
+            a = torch.as_tensor(np.asarray(actions, dtype=np.float32)).to(self.device)
+        if tuple(a.shape) != (self.num_envs, 2, 2):
+            raise AssertionError(f"actions must have shape ({self.num_envs}, 2, 2), got {tuple(a.shape)}")
+        self._actions = a.contiguous()
+
+    def step_device(self, actions_f32, render=True):
+        """Hot-loop entry: float32 (N, 2, 2) device tensor in, device tensors out, no sync."""
+        buf = self._obs[self._flip]
+        self._flip ^= 1
+        N.check(self._L.crl_step(self._h, C.c_void_p(actions_f32.data_ptr()), C.c_void_p(buf.data_ptr()) if render else None,
+                                 C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+        return buf, self._rew, self._done
+
+    def step_wait(self):
+        self._check_open()
+        buf, rew, done = self.step_device(self._actions)
+        self._steps += 1
+        infos = CarLazyInfos(self.num_envs, rew.clone(), self._steps.clone())
+        self._steps.mul_((~done.bool()).to(torch.int32))
+        r0 = rew[:, :1].clone()
+        d = done.bool()
+        d = d[:, None].clone() if self.dones_kind == "dummy" else d.clone()
+        if self.dones_kind == "subproc":
+            r0 = r0[:, 0]
+        return self._out(buf), self._out(r0), self._out(d), infos
+
+    def close(self):
+        if self.closed:
+            return
+        self.closed = True
+        torch.cuda.synchronize(self.device)
+        self._L.crl_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_images(self, *a, **k):
+        return list(self._obs[self._flip ^ 1][:, 0].cpu().numpy())
+
+    # ---- parity / checkpoint helpers
+    def get_state(self):
+        st = np.zeros(self.num_envs, N.CAR_ENV_STATE_DT)
+        N.check(self._L.crl_car_get_state(self._h, st.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()))
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, N.CAR_ENV_STATE_DT)
+        N.check(self._L.crl_car_set_state(self._h, st.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()))
+
+    state_dict, load_state_dict = get_state, set_state
+
+    def get_track(self, env):
+        n = C.c_int32()
+        tiles = np.zeros((N.CAR_MAX_TILES, 5, 2), np.float32)
+        bpoly = np.zeros((N.CAR_MAX_TILES, 4, 2), np.float32)
+        border = np.zeros(N.CAR_MAX_TILES, np.uint8)
+        pose = np.zeros(3, np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        N.check(self._L.crl_car_get_track(self._h, int(env), C.byref(n), p(tiles), p(bpoly), p(border), p(pose), self._stream()))
+        k = n.value
+        return dict(n=k, tile_poly=tiles[:k], border_poly=bpoly[:k], border=border[:k], start_pose=pose)
+
+    def set_track(self, env, tile_poly, border_poly, border, start_pose):
+        tile_poly = np.ascontiguousarray(tile_poly, np.float32)
+        border_poly = np.ascontiguousarray(border_poly, np.float32)
+        border = np.ascontiguousarray(border, np.uint8)
+        start_pose = np.ascontiguousarray(start_pose, np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        N.check(self._L.crl_car_set_track(self._h, int(env), len(tile_poly), p(tile_poly), p(border_poly), p(border), p(start_pose),
+                                          self._stream()))
+
+    def set_replay(self, u, swap):
+        """u: [N, attempts, 24] uniforms of _create_track attempts; swap: [N, attempts] birth-place bits."""
+        if u is None:
+            N.check(self._L.crl_car_set_replay(self._h, None, None, 0))
+            return
+        u = np.ascontiguousarray(u, np.float64).reshape(self.num_envs, -1, 24)
+        swap = np.ascontiguousarray(swap, np.uint8).reshape(self.num_envs, -1)
+        N.check(self._L.crl_car_set_replay(self._h, u.ctypes.data_as(C.c_void_p), swap.ctypes.data_as(C.c_void_p), u.shape[1]))
+
+    def render_current(self):
+        """Re-draw the current state without stepping (after set_state / set_track)."""
+        buf = torch.empty((self.num_envs, 2, 96, 96), dtype=torch.uint8, device=self.device)
+        N.check(self._L.crl_render(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
+        return buf
+
+    def kernel_timing(self, enable=True):
+        N.check(self._L.crl_kernel_timing(self._h, int(enable)))
+
+    def kernel_time_ms(self, which):
+        ms, cnt = C.c_double(), C.c_int64()
+        N.check(self._L.crl_kernel_time_ms(self._h, which, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

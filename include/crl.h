@@ -45,7 +45,11 @@ extern "C" {
 
 enum { CRL_OK = 0, CRL_EINVAL = -1, CRL_EHIP = -2, CRL_ENOMEM = -3, CRL_ESTATE = -4 };
 
-enum crl_env_kind { CRL_ENV_PONG_DOUBLE = 1 /* cPongDouble-v0 */ };
+enum crl_env_kind { CRL_ENV_PONG_DOUBLE = 1 /* cPongDouble-v0 */, CRL_ENV_CAR_DOUBLE = 2 /* cCarRacingDouble-v0 */ };
+
+/* ---- cCarRacingDouble-v0 (car_racing/car_racing_multi_players.py:54-88) */
+#define CRL_CAR_MAX_TILES 512 /* tiles of one track (reference tracks: 230-380) */
+#define CRL_CAR_OBS 96        /* STATE_W = STATE_H = 96 */
 
 enum crl_obs_mode {
     /* raw env: obs (N,2,210,160,3) u8, 1 step = 1 frame
@@ -116,11 +120,12 @@ int crl_seed(crl_ctx *ctx, uint64_t seed);
 int crl_reset(crl_ctx *ctx, uint8_t *obs_dev, void *stream);
 
 /* VecEnv.step(actions) = step_async + step_wait (base_vec_env.py:178-187,
- * dummy_vec_env.py:48-63) with auto-reset.  actions_dev: int32 (N,2), each 0/1/2 or
- * 999.  obs_dev: per obs_mode.  rew_dev: f32 (N,2) (raw: game reward; wrapped:
+ * dummy_vec_env.py:48-63) with auto-reset.  actions_dev: Pong int32 (N,2), each 0/1/2 or
+ * 999; CarRacing float32 (N,2,2) = per car (steer, gas-or-brake) in [-1,1]; CarRacing obs is
+ * (N,2,96,96) u8, rew (N,2) per-car step rewards, done (N) = any car done or TimeLimit.  obs_dev: per obs_mode.  rew_dev: f32 (N,2) (raw: game reward; wrapped:
  * np.sign of the 4-frame sum).  done_dev: u8 (N).  Any output pointer may be NULL
  * to skip that output (obs_dev NULL = dynamics only). */
-int crl_step(crl_ctx *ctx, const int32_t *actions_dev, uint8_t *obs_dev, float *rew_dev,
+int crl_step(crl_ctx *ctx, const void *actions_dev, uint8_t *obs_dev, float *rew_dev,
              uint8_t *done_dev, void *stream);
 
 /* info[i]["real_reward"], info[i]["num_steps"] (ClipRewardEnv.step,
@@ -156,6 +161,10 @@ int crl_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *bx_host,
 int crl_render_raw(crl_ctx *ctx, const crl_pong_frame *frames_host, int64_t count,
                    uint8_t *out_dev, void *stream);
 
+/* Re-draws the CURRENT state into obs_dev without stepping (after crl_set_state /
+ * crl_car_set_state, or for VecEnv.render): same layout as crl_step's obs_dev. */
+int crl_render(crl_ctx *ctx, uint8_t *obs_dev, void *stream);
+
 /* Bytes of one env's observation in the context's obs_mode. */
 int64_t crl_obs_bytes_per_env(const crl_ctx *ctx);
 
@@ -164,6 +173,40 @@ int64_t crl_obs_bytes_per_env(const crl_ctx *ctx);
  * crl_kernel_time_ms() synchronises and returns total ms and launch count. */
 int crl_kernel_timing(crl_ctx *ctx, int enable);
 int crl_kernel_time_ms(crl_ctx *ctx, int which, double *total_ms, int64_t *launches);
+
+/* ---- cCarRacingDouble state exchange (parity tests, checkpoint) ---------------------- */
+typedef struct crl_car_body { /* b2Body: centre of mass, angle, velocities */
+    float cx, cy, a, vx, vy, w;
+} crl_car_body;
+
+typedef struct crl_car_state {   /* one car: Car (car_dynamics.py:55-129) + its env bookkeeping */
+    crl_car_body hull, wheel[4];
+    float imp[4][3], motor_imp[4], motor_speed[4]; /* revolute joints hull<->wheel          */
+    int32_t limit_state[4];
+    double gas[4], omega[4], phase[4];             /* wheel attributes                       */
+    double reward, prev_reward;                    /* CarRacing.rewards / prev_rewards       */
+    int32_t tile_visited_count, last_block, done, step_count, first_step, pad;
+    uint32_t wheel_tiles[4][CRL_CAR_MAX_TILES / 32]; /* w.tiles as bit sets                  */
+    uint32_t visited[CRL_CAR_MAX_TILES / 32];        /* tile.road_visited[car]               */
+} crl_car_state;
+
+typedef struct crl_car_env_state {
+    crl_car_state car[2];
+    int32_t elapsed;  /* gym TimeLimit._elapsed_steps */
+    uint32_t episode; /* resets so far                */
+} crl_car_env_state;
+
+int crl_car_get_state(crl_ctx *ctx, crl_car_env_state *state_host, int64_t first, int64_t count, void *stream);
+int crl_car_set_state(crl_ctx *ctx, const crl_car_env_state *state_host, int64_t first, int64_t count, void *stream);
+/* Track of env `env`: n tiles; tile_poly float32 [n][5][2] (counter-clockwise), border_poly
+ * float32 [n][4][2], border u8 [n] (0 none, 1 white, 2 red), start_pose = track[0] (beta, x, y). */
+int crl_car_get_track(crl_ctx *ctx, int64_t env, int32_t *n, float *tile_poly, float *border_poly, uint8_t *border,
+                      float *start_pose, void *stream);
+int crl_car_set_track(crl_ctx *ctx, int64_t env, int32_t n, const float *tile_poly, const float *border_poly,
+                      const uint8_t *border, const float *start_pose, void *stream);
+/* Replay mode for CarRacing.reset's randomness: per env `attempts` rows of 24 uniforms (the
+ * np_random.uniform draws of one _create_track attempt) and one birth-place swap bit each. */
+int crl_car_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *swap_host, int64_t attempts);
 
 const char *crl_last_error(void);
 const char *crl_version(void);

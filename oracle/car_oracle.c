@@ -1,0 +1,832 @@
+/*
+ * car_oracle.c -- CPU restatement of the reference's cCarRacingDouble step path.
+ *
+ * TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+ *
+ * Pinning status (DESIGN.md "Oracle"):
+ *   - track generation, wheel model, action mapping, tile-visit reward rule: PINNED to the
+ *     reference's own Python via tests/golden/car_{track,wheels,rules}.npz.
+ *   - b2World.Step (rigid bodies, revolute joints, sensor overlap): box2d-py ~=2.3.5 is a
+ *     third-party dependency that is neither vendored nor installable; its published
+ *     algorithm (Box2D 2.3 b2Island::Solve / b2RevoluteJoint / b2PolygonShape::ComputeMass)
+ *     is restated here in float32.  PARITY UNPINNED.  Car-car contacts are NOT modelled.
+ *   - observation raster: analytic (no 10000x10000 pygame map), PARITY UNPINNED.
+ *
+ * Citations: car_racing/car_racing_multi_players.py = "crmp", car_racing/car_dynamics.py = "cd".
+ * Build: -O2 -ffp-contract=off (f64 parts are CPython arithmetic, f32 parts Box2D's).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "car_oracle.h"
+
+/* ---- constants (crmp:54-88, cd:17-51) */
+#define SCALE 6.0
+#define TRACK_RAD (900 / SCALE)
+#define PLAYFIELD (2000 / SCALE)
+#define FPS 50
+#define TRACK_DETAIL_STEP (21 / SCALE)
+#define TRACK_TURN_RATE 0.31
+#define TRACK_WIDTH (40 / SCALE)
+#define BORDER (8 / SCALE)
+#define BORDER_MIN_COUNT 4
+#define SIZE 0.02
+#define ENGINE_POWER (100000000 * SIZE * SIZE)
+#define WHEEL_MOMENT_OF_INERTIA (4000 * SIZE * SIZE)
+#define FRICTION_LIMIT (1000000 * SIZE * SIZE)
+#define WHEEL_R 27
+#define WHEEL_W 14
+
+static const double WHEELPOS[4][2] = {{-55, +80}, {+55, +80}, {-55, -82}, {+55, -82}};
+static const double HULL1[4][2] = {{-60, 130}, {60, 130}, {60, 110}, {-60, 110}};
+static const double HULL2[4][2] = {{-15, 120}, {15, 120}, {20, 20}, {-20, 20}};
+static const double HULL3[8][2] = {{25, 20}, {50, -10}, {50, -40}, {20, -90}, {-20, -90}, {-50, -40}, {-50, -10}, {-25, 20}};
+static const double HULL4[4][2] = {{-50, -120}, {50, -120}, {50, -90}, {-50, -90}};
+
+/* ------------------------------------------------------------------ track (crmp:262-452) */
+static double sgn(double v) { return (v > 0) - (v < 0); }
+
+int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
+    const int CHECKPOINTS = 12;
+    double cp[12][3];
+    double start_alpha = 0;
+    int ui = 0;
+    for (int c = 0; c < CHECKPOINTS; c++) {
+        double noise = 0 + (2 * M_PI * 1 / CHECKPOINTS - 0) * u[ui++];
+        double alpha = 2 * M_PI * c / CHECKPOINTS + noise;
+        double rad = TRACK_RAD / 3 + (TRACK_RAD - TRACK_RAD / 3) * u[ui++];
+        if (c == 0) alpha = 0, rad = 1.5 * TRACK_RAD;
+        if (c == CHECKPOINTS - 1) {
+            alpha = 2 * M_PI * c / CHECKPOINTS;
+            start_alpha = 2 * M_PI * (-0.5) / CHECKPOINTS;
+            rad = 1.5 * TRACK_RAD;
+        }
+        cp[c][0] = alpha, cp[c][1] = rad * cos(alpha), cp[c][2] = rad * sin(alpha);
+    }
+    static __thread double tr[2600][4];
+    double x = 1.5 * TRACK_RAD, y = 0, beta = 0;
+    long dest_i = 0;
+    int laps = 0, n = 0, no_freeze = 2500, visited_other_side = 0;
+    for (;;) {
+        double alpha = atan2(y, x);
+        if (visited_other_side && alpha > 0) laps++, visited_other_side = 0;
+        if (alpha < 0) visited_other_side = 1, alpha += 2 * M_PI;
+        double dest_alpha, dest_x, dest_y;
+        for (;;) {
+            int failed = 1;
+            for (;;) {
+                dest_alpha = cp[dest_i % CHECKPOINTS][0], dest_x = cp[dest_i % CHECKPOINTS][1], dest_y = cp[dest_i % CHECKPOINTS][2];
+                if (alpha <= dest_alpha) { failed = 0; break; }
+                dest_i++;
+                if (dest_i % CHECKPOINTS == 0) break;
+            }
+            if (!failed) break;
+            alpha -= 2 * M_PI;
+        }
+        double r1x = cos(beta), r1y = sin(beta), p1x = -r1y, p1y = r1x;
+        double dest_dx = dest_x - x, dest_dy = dest_y - y;
+        double proj = r1x * dest_dx + r1y * dest_dy;
+        while (beta - alpha > 1.5 * M_PI) beta -= 2 * M_PI;
+        while (beta - alpha < -1.5 * M_PI) beta += 2 * M_PI;
+        double prev_beta = beta;
+        proj *= SCALE;
+        if (proj > 0.3) beta -= fmin(TRACK_TURN_RATE, fabs(0.001 * proj));
+        if (proj < -0.3) beta += fmin(TRACK_TURN_RATE, fabs(0.001 * proj));
+        x += p1x * TRACK_DETAIL_STEP;
+        y += p1y * TRACK_DETAIL_STEP;
+        tr[n][0] = alpha, tr[n][1] = prev_beta * 0.5 + beta * 0.5, tr[n][2] = x, tr[n][3] = y;
+        n++;
+        if (laps > 4) break;
+        if (--no_freeze == 0) break;
+    }
+    int i1 = -1, i2 = -1, i = n;
+    for (;;) {
+        i--;
+        if (i == 0) return 0;
+        int pass = tr[i][0] > start_alpha && tr[i - 1][0] <= start_alpha;
+        if (pass && i2 == -1) i2 = i;
+        else if (pass && i1 == -1) { i1 = i; break; }
+    }
+    int len = (i2 - 1) - i1;
+    if (len <= 0 || len > CAR_MAX_TILES) return 0;
+    double(*t)[4] = &tr[i1];
+    double fb = t[0][1], fpx = cos(fb), fpy = sin(fb);
+    double a = fpx * (t[0][2] - t[len - 1][2]), b = fpy * (t[0][3] - t[len - 1][3]);
+    double glued = sqrt(a * a + b * b);
+    if (glued > TRACK_DETAIL_STEP) return 0;
+    out->n = len;
+    for (int k = 0; k < len; k++) memcpy(out->track[k], t[k], sizeof(double) * 4);
+    /* red-white border on hard turns */
+    uint8_t border[CAR_MAX_TILES];
+    for (int k = 0; k < len; k++) {
+        int good = 1;
+        double oneside = 0;
+        for (int neg = 0; neg < BORDER_MIN_COUNT; neg++) {
+            double b1 = t[((k - neg - 0) % len + len) % len][1], b2 = t[((k - neg - 1) % len + len) % len][1];
+            good &= fabs(b1 - b2) > TRACK_TURN_RATE * 0.2;
+            oneside += sgn(b1 - b2);
+        }
+        good &= fabs(oneside) == BORDER_MIN_COUNT;
+        border[k] = (uint8_t)good;
+    }
+    for (int k = 0; k < len; k++)
+        for (int neg = 0; neg < BORDER_MIN_COUNT; neg++) border[((k - neg) % len + len) % len] |= border[k];
+    /* tiles: i = len-1 .. 0 between track[i] and track[i-1] */
+    for (int k = len - 1; k >= 0; k--) {
+        const double *p1 = t[k], *p2 = t[((k - 1) % len + len) % len];
+        double b1 = p1[1], x1 = p1[2], y1 = p1[3], b2 = p2[1], x2 = p2[2], y2 = p2[3];
+        double v[5][2] = {
+            {x1 - TRACK_WIDTH * cos(b1), y1 - TRACK_WIDTH * sin(b1)},
+            {x1 - TRACK_WIDTH / 2 * cos(b1 - M_PI / 2), y1 - TRACK_WIDTH / 2 * sin(b1 - M_PI / 2)},
+            {x1 + TRACK_WIDTH * cos(b1), y1 + TRACK_WIDTH * sin(b1)},
+            {x2 + TRACK_WIDTH * cos(b2), y2 + TRACK_WIDTH * sin(b2)},
+            {x2 - TRACK_WIDTH * cos(b2), y2 - TRACK_WIDTH * sin(b2)},
+        };
+        memcpy(out->tile[k], v, sizeof(v));
+        out->border[k] = border[k];
+        if (border[k]) {
+            double side = sgn(b2 - b1);
+            double bp[4][2] = {
+                {x1 + side * TRACK_WIDTH * cos(b1), y1 + side * TRACK_WIDTH * sin(b1)},
+                {x1 + side * (TRACK_WIDTH + BORDER) * cos(b1), y1 + side * (TRACK_WIDTH + BORDER) * sin(b1)},
+                {x2 + side * (TRACK_WIDTH + BORDER) * cos(b2), y2 + side * (TRACK_WIDTH + BORDER) * sin(b2)},
+                {x2 + side * TRACK_WIDTH * cos(b2), y2 + side * TRACK_WIDTH * sin(b2)},
+            };
+            memcpy(out->border_poly[k], bp, sizeof(bp));
+        } else {
+            memset(out->border_poly[k], 0, sizeof(out->border_poly[k]));
+        }
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------ Box2D 2.3 pieces (float32) */
+typedef struct { float x, y; } v2;
+static inline v2 V(float x, float y) { v2 r = {x, y}; return r; }
+static inline v2 vadd(v2 a, v2 b) { return V(a.x + b.x, a.y + b.y); }
+static inline v2 vsub(v2 a, v2 b) { return V(a.x - b.x, a.y - b.y); }
+static inline v2 vmul(float s, v2 a) { return V(s * a.x, s * a.y); }
+static inline float vdot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+static inline float vcross(v2 a, v2 b) { return a.x * b.y - a.y * b.x; }
+static inline v2 scross(float s, v2 a) { return V(-s * a.y, s * a.x); } /* b2Cross(float, vec) */
+static inline v2 rot(float s, float c, v2 v) { return V(c * v.x - s * v.y, s * v.x + c * v.y); }
+
+/* b2PolygonShape::ComputeMass: mass, centroid, inertia about the shape origin */
+static void poly_mass(const v2 *vs, int n, float density, float *mass, v2 *center, float *I) {
+    v2 c = V(0, 0), s = V(0, 0);
+    float area = 0, in = 0;
+    for (int i = 0; i < n; i++) s = vadd(s, vs[i]);
+    s = vmul(1.0f / n, s);
+    const float k_inv3 = 1.0f / 3.0f;
+    for (int i = 0; i < n; i++) {
+        v2 e1 = vsub(vs[i], s), e2 = vsub(vs[i + 1 < n ? i + 1 : 0], s);
+        float D = vcross(e1, e2), ta = 0.5f * D;
+        area += ta;
+        c = vadd(c, vmul(ta * k_inv3, vadd(e1, e2)));
+        float intx2 = e1.x * e1.x + e2.x * e1.x + e2.x * e2.x, inty2 = e1.y * e1.y + e2.y * e1.y + e2.y * e2.y;
+        in += (0.25f * k_inv3 * D) * (intx2 + inty2);
+    }
+    *mass = density * area;
+    c = vmul(1.0f / area, c);
+    *center = vadd(c, s);
+    *I = density * in;
+    *I += *mass * (vdot(*center, *center) - vdot(c, c));
+}
+
+/* b2PolygonShape::Set orders vertices counter-clockwise (convex hull); the car polygons
+ * are convex, so reversing a clockwise list is the same hull. */
+static int make_ccw(const double (*src)[2], int n, double scale, v2 *dst) {
+    double area = 0;
+    for (int i = 0; i < n; i++) {
+        int j = (i + 1) % n;
+        area += src[i][0] * src[j][1] - src[j][0] * src[i][1];
+    }
+    for (int i = 0; i < n; i++) {
+        int k = area > 0 ? i : n - 1 - i;
+        dst[i] = V((float)(src[k][0] * scale), (float)(src[k][1] * scale));
+    }
+    return n;
+}
+
+static car_consts K;
+static int K_ready = 0;
+
+const car_consts *car_oracle_consts(void) {
+    if (K_ready) return &K;
+    /* hull: 4 fixtures, density 1 (cd:61-71); b2Body::ResetMassData */
+    const double(*polys[4])[2] = {HULL1, HULL2, HULL3, HULL4};
+    const int cnt[4] = {4, 4, 8, 4};
+    float mass = 0, I = 0;
+    v2 lc = V(0, 0);
+    for (int f = 0; f < 4; f++) {
+        K.hull_n[f] = make_ccw(polys[f], cnt[f], SIZE, (v2 *)K.hull_poly[f]);
+        float m, i;
+        v2 c;
+        poly_mass((v2 *)K.hull_poly[f], cnt[f], 1.0f, &m, &c, &i);
+        mass += m, lc = vadd(lc, vmul(m, c)), I += i;
+    }
+    K.hull_mass = mass, K.hull_inv_mass = 1.0f / mass;
+    lc = vmul(K.hull_inv_mass, lc);
+    K.hull_lc[0] = lc.x, K.hull_lc[1] = lc.y;
+    I -= mass * vdot(lc, lc);
+    K.hull_I = I, K.hull_inv_I = 1.0f / I;
+    /* wheel: box (+-14, +-27) * SIZE, density 0.1 (cd:83-97) */
+    const double wp[4][2] = {{-WHEEL_W, +WHEEL_R}, {+WHEEL_W, +WHEEL_R}, {+WHEEL_W, -WHEEL_R}, {-WHEEL_W, -WHEEL_R}};
+    make_ccw(wp, 4, SIZE, (v2 *)K.wheel_poly);
+    float m, i;
+    v2 c;
+    poly_mass((v2 *)K.wheel_poly, 4, 0.1f, &m, &c, &i);
+    i -= m * vdot(c, c);
+    K.wheel_mass = m, K.wheel_inv_mass = 1.0f / m, K.wheel_I = i, K.wheel_inv_I = 1.0f / i;
+    for (int w = 0; w < 4; w++) K.anchor[w][0] = (float)(WHEELPOS[w][0] * SIZE), K.anchor[w][1] = (float)(WHEELPOS[w][1] * SIZE);
+    K_ready = 1;
+    return &K;
+}
+
+/* b2Body state <-> transform: xf.q = b2Rot(a); xf.p = c - q * localCenter */
+static void body_xf(const car_body *b, v2 lc, float *s, float *c, v2 *p) {
+    *s = sinf(b->a), *c = cosf(b->a);
+    *p = vsub(V(b->cx, b->cy), rot(*s, *c, lc));
+}
+
+/* Car.__init__ (cd:55-129): hull + 4 wheels at the birth place, all at init_angle */
+void car_oracle_place(car_state *car, double init_angle, double init_x, double init_y, int birth_place_index) {
+    car_oracle_consts();
+    memset(car, 0, sizeof(*car));
+    init_x -= birth_place_index % 2 * 5;
+    init_y -= floor(birth_place_index / 2.0) * 10;
+    float a = (float)init_angle, s = sinf(a), c = cosf(a);
+    v2 p = V((float)init_x, (float)init_y);
+    v2 com = vadd(p, rot(s, c, V(K.hull_lc[0], K.hull_lc[1])));
+    car->hull.cx = com.x, car->hull.cy = com.y, car->hull.a = a;
+    for (int w = 0; w < 4; w++) {
+        /* position=(init_x + wx*SIZE, init_y + wy*SIZE): NOT rotated by init_angle (cd:86) */
+        car->wheel[w].cx = (float)(init_x + WHEELPOS[w][0] * SIZE), car->wheel[w].cy = (float)(init_y + WHEELPOS[w][1] * SIZE);
+        car->wheel[w].a = a;
+    }
+}
+
+/* CarRacing.process_action (crmp:527-540) */
+void car_oracle_process_action(const double a[2], double out[3]) {
+    double a0 = fmax(fmin(a[0], 1), -1), a1 = fmax(fmin(a[1], 1), -1), a2;
+    if (a1 > 0) a2 = 0;
+    else a2 = a1, a1 = 0;
+    out[0] = a0, out[1] = fabs(a1), out[2] = fabs(a2);
+}
+
+/* Car.steer / gas / brake (cd:131-157) */
+void car_oracle_controls(car_state *car, double steer, double gas, double brake) {
+    car->steer[0] = car->steer[1] = steer;
+    gas = gas < 0 ? 0 : gas > 1 ? 1 : gas;
+    for (int w = 2; w < 4; w++) {
+        double diff = gas - car->gas[w];
+        if (diff > 0.1) diff = 0.1;
+        car->gas[w] += diff;
+    }
+    for (int w = 0; w < 4; w++) car->brake[w] = brake;
+}
+
+/* Car.step (cd:159-234), one wheel.  Inputs that the reference reads back from Box2D are
+ * float32 values widened to double; outputs motorSpeed / force narrow to float32. */
+void car_oracle_wheel(double dt, double steer, double gas, double brake, double joint_angle, double q_sin, double q_cos,
+                      double vx, double vy, int on_road, double *omega, double *phase, double *motor_speed, double force[2]) {
+    double d = steer - joint_angle;
+    *motor_speed = sgn(d) * fmin(50.0 * fabs(d), 3.0);
+    double friction_limit = FRICTION_LIMIT * 0.6;
+    if (on_road) friction_limit = fmax(friction_limit, FRICTION_LIMIT * 1.0);
+    float s = (float)q_sin, c = (float)q_cos; /* the wheel body's b2Rot (xf.q) */
+    /* GetWorldVector((0,1)) / ((1,0)) = b2Mul(q, v) in float32 */
+    double forw[2] = {(double)(c * 0.0f - s * 1.0f), (double)(s * 0.0f + c * 1.0f)};
+    double side[2] = {(double)(c * 1.0f - s * 0.0f), (double)(s * 1.0f + c * 0.0f)};
+    double vf = forw[0] * vx + forw[1] * vy, vs = side[0] * vx + side[1] * vy;
+    double om = *omega;
+    om += dt * ENGINE_POWER * gas / WHEEL_MOMENT_OF_INERTIA / (fabs(om) + 5.0);
+    if (brake >= 0.9) om = 0;
+    else if (brake > 0) {
+        double dir = -sgn(om), val = 15 * brake;
+        if (fabs(val) > fabs(om)) val = fabs(om);
+        om += dir * val;
+    }
+    *phase += om * dt;
+    double wheel_rad = 1.0 * WHEEL_R * SIZE;
+    double vr = om * wheel_rad, f_force = -vf + vr, p_force = -vs;
+    f_force *= 205000 * SIZE * SIZE, p_force *= 205000 * SIZE * SIZE;
+    double fo = sqrt(f_force * f_force + p_force * p_force);
+    if (fabs(fo) > friction_limit) {
+        f_force /= fo, p_force /= fo;
+        fo = friction_limit;
+        f_force *= fo, p_force *= fo;
+    }
+    om -= dt * f_force * wheel_rad / WHEEL_MOMENT_OF_INERTIA;
+    *omega = om;
+    force[0] = p_force * side[0] + f_force * forw[0], force[1] = p_force * side[1] + f_force * forw[1];
+}
+
+/* ---- convex polygon distance (what b2TestOverlap's GJK distance decides for sensors) */
+static float seg_seg_dist2(v2 p1, v2 q1, v2 p2, v2 q2) {
+    v2 d1 = vsub(q1, p1), d2 = vsub(q2, p2), r = vsub(p1, p2);
+    float a = vdot(d1, d1), e = vdot(d2, d2), f = vdot(d2, r), s, t;
+    const float EPS = 1e-12f;
+    if (a <= EPS && e <= EPS) return vdot(r, r);
+    if (a <= EPS) s = 0, t = fminf(fmaxf(f / e, 0), 1);
+    else {
+        float c = vdot(d1, r);
+        if (e <= EPS) t = 0, s = fminf(fmaxf(-c / a, 0), 1);
+        else {
+            float b = vdot(d1, d2), den = a * e - b * b;
+            s = den != 0 ? fminf(fmaxf((b * f - c * e) / den, 0), 1) : 0;
+            t = (b * s + f) / e;
+            if (t < 0) t = 0, s = fminf(fmaxf(-c / a, 0), 1);
+            else if (t > 1) t = 1, s = fminf(fmaxf((b - c) / a, 0), 1);
+        }
+    }
+    v2 c1 = vadd(p1, vmul(s, d1)), c2 = vadd(p2, vmul(t, d2)), d = vsub(c1, c2);
+    return vdot(d, d);
+}
+
+static int point_in_convex(v2 p, const v2 *poly, int n) { /* CCW polygon */
+    for (int i = 0; i < n; i++) {
+        v2 a = poly[i], b = poly[i + 1 < n ? i + 1 : 0];
+        if (vcross(vsub(b, a), vsub(p, a)) < 0) return 0;
+    }
+    return 1;
+}
+
+/* squared distance between two convex CCW polygons (0 when they intersect) */
+static float poly_dist2(const v2 *A, int nA, const v2 *B, int nB) {
+    if (point_in_convex(A[0], B, nB) || point_in_convex(B[0], A, nA)) return 0;
+    float best = 3.4e38f;
+    for (int i = 0; i < nA; i++)
+        for (int j = 0; j < nB; j++) {
+            float d = seg_seg_dist2(A[i], A[i + 1 < nA ? i + 1 : 0], B[j], B[j + 1 < nB ? j + 1 : 0]);
+            if (d < best) best = d;
+        }
+    return best;
+}
+
+/* ---- revolute joint (b2RevoluteJoint, bodyA = hull, bodyB = wheel) */
+enum { LIM_INACTIVE = 0, LIM_LOWER = 1, LIM_UPPER = 2 };
+#define LINEAR_SLOP 0.005f
+#define ANGULAR_SLOP (2.0f / 180.0f * 3.14159265359f)
+#define MAX_ANGULAR_CORRECTION (8.0f / 180.0f * 3.14159265359f)
+#define MAX_TRANSLATION 2.0f
+#define MAX_ROTATION (0.5f * 3.14159265359f)
+#define LOWER_ANGLE (-0.4f)
+#define UPPER_ANGLE (+0.4f)
+#define MAX_MOTOR_TORQUE ((float)(180 * 900 * SIZE * SIZE))
+
+typedef struct {
+    v2 rA, rB;
+    float m[3][3]; /* m[col][row]: ex = m[0], ey = m[1], ez = m[2] */
+    float motorMass;
+} joint_tmp;
+
+static v2 solve22(const float m[3][3], v2 b) {
+    float a11 = m[0][0], a12 = m[1][0], a21 = m[0][1], a22 = m[1][1];
+    float det = a11 * a22 - a12 * a21;
+    if (det != 0.0f) det = 1.0f / det;
+    return V(det * (a22 * b.x - a12 * b.y), det * (a11 * b.y - a21 * b.x));
+}
+
+static void solve33(const float m[3][3], const float b[3], float x[3]) {
+    const float *ex = m[0], *ey = m[1], *ez = m[2];
+    float cyz[3] = {ey[1] * ez[2] - ey[2] * ez[1], ey[2] * ez[0] - ey[0] * ez[2], ey[0] * ez[1] - ey[1] * ez[0]};
+    float det = ex[0] * cyz[0] + ex[1] * cyz[1] + ex[2] * cyz[2];
+    if (det != 0.0f) det = 1.0f / det;
+    float cbz[3] = {b[1] * ez[2] - b[2] * ez[1], b[2] * ez[0] - b[0] * ez[2], b[0] * ez[1] - b[1] * ez[0]};
+    float cyb[3] = {ey[1] * b[2] - ey[2] * b[1], ey[2] * b[0] - ey[0] * b[2], ey[0] * b[1] - ey[1] * b[0]};
+    x[0] = det * (b[0] * cyz[0] + b[1] * cyz[1] + b[2] * cyz[2]);
+    x[1] = det * (ex[0] * cbz[0] + ex[1] * cbz[1] + ex[2] * cbz[2]);
+    x[2] = det * (ex[0] * cyb[0] + ex[1] * cyb[1] + ex[2] * cyb[2]);
+}
+
+/* b2Island::Solve for one car: bodies [hull, w0..w3], joints solved in the order j3, j2, j1, j0
+ * (island build order of b2World::Solve for bodies created hull, w0, w1, w2, w3). */
+static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters, int pos_iters) {
+    const float mA = K.hull_inv_mass, iA = K.hull_inv_I, mB = K.wheel_inv_mass, iB = K.wheel_inv_I;
+    car_body *H = &car->hull;
+    /* integrate velocities: v += h * invMass * F (no gravity, no damping, no torque) */
+    H->vx += h * (mA * H->fx), H->vy += h * (mA * H->fy);
+    for (int w = 0; w < 4; w++) car->wheel[w].vx += h * (mB * car->wheel[w].fx), car->wheel[w].vy += h * (mB * car->wheel[w].fy);
+    joint_tmp jt[4];
+    v2 lcA = V(K.hull_lc[0], K.hull_lc[1]);
+    /* InitVelocityConstraints */
+    for (int q = 0; q < 4; q++) {
+        int w = 3 - q;
+        car_body *B = &car->wheel[w];
+        joint_tmp *j = &jt[w];
+        float sA = sinf(H->a), cA = cosf(H->a);
+        j->rA = rot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA));
+        j->rB = V(0, 0); /* rot(qB, localAnchorB - localCenterB) = 0 */
+        v2 rA = j->rA, rB = j->rB;
+        j->m[0][0] = mA + mB + rA.y * rA.y * iA + rB.y * rB.y * iB;
+        j->m[1][0] = -rA.y * rA.x * iA - rB.y * rB.x * iB;
+        j->m[2][0] = -rA.y * iA - rB.y * iB;
+        j->m[0][1] = j->m[1][0];
+        j->m[1][1] = mA + mB + rA.x * rA.x * iA + rB.x * rB.x * iB;
+        j->m[2][1] = rA.x * iA + rB.x * iB;
+        j->m[0][2] = j->m[2][0], j->m[1][2] = j->m[2][1], j->m[2][2] = iA + iB;
+        j->motorMass = iA + iB;
+        if (j->motorMass > 0.0f) j->motorMass = 1.0f / j->motorMass;
+        float ja = B->a - H->a - 0.0f;
+        if (ja <= LOWER_ANGLE) {
+            if (car->limit_state[w] != LIM_LOWER) car->imp[w][2] = 0;
+            car->limit_state[w] = LIM_LOWER;
+        } else if (ja >= UPPER_ANGLE) {
+            if (car->limit_state[w] != LIM_UPPER) car->imp[w][2] = 0;
+            car->limit_state[w] = LIM_UPPER;
+        } else {
+            car->limit_state[w] = LIM_INACTIVE, car->imp[w][2] = 0;
+        }
+        /* warm start */
+        car->imp[w][0] *= dt_ratio, car->imp[w][1] *= dt_ratio, car->imp[w][2] *= dt_ratio, car->motor_imp[w] *= dt_ratio;
+        v2 P = V(car->imp[w][0], car->imp[w][1]);
+        H->vx -= mA * P.x, H->vy -= mA * P.y;
+        H->w -= iA * (vcross(rA, P) + car->motor_imp[w] + car->imp[w][2]);
+        B->vx += mB * P.x, B->vy += mB * P.y;
+        B->w += iB * (vcross(rB, P) + car->motor_imp[w] + car->imp[w][2]);
+    }
+    /* velocity iterations */
+    for (int it = 0; it < vel_iters; it++)
+        for (int q = 0; q < 4; q++) {
+            int w = 3 - q;
+            car_body *B = &car->wheel[w];
+            joint_tmp *j = &jt[w];
+            v2 rA = j->rA, rB = j->rB;
+            { /* motor */
+                float Cdot = B->w - H->w - car->motor_speed[w];
+                float impulse = -j->motorMass * Cdot, old = car->motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
+                float ni = old + impulse;
+                ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
+                car->motor_imp[w] = ni;
+                impulse = ni - old;
+                H->w -= iA * impulse, B->w += iB * impulse;
+            }
+            v2 vA = V(H->vx, H->vy), vB = V(B->vx, B->vy);
+            if (car->limit_state[w] != LIM_INACTIVE) {
+                v2 Cdot1 = vsub(vsub(vadd(vB, scross(B->w, rB)), vA), scross(H->w, rA));
+                float Cdot2 = B->w - H->w;
+                float b[3] = {Cdot1.x, Cdot1.y, Cdot2}, imp[3];
+                solve33(j->m, b, imp);
+                imp[0] = -imp[0], imp[1] = -imp[1], imp[2] = -imp[2];
+                float newI = car->imp[w][2] + imp[2];
+                int lower = car->limit_state[w] == LIM_LOWER;
+                if (lower ? newI < 0.0f : newI > 0.0f) {
+                    v2 rhs = vadd(vmul(-1.0f, Cdot1), vmul(car->imp[w][2], V(j->m[2][0], j->m[2][1])));
+                    v2 red = solve22(j->m, rhs);
+                    imp[0] = red.x, imp[1] = red.y, imp[2] = -car->imp[w][2];
+                    car->imp[w][0] += red.x, car->imp[w][1] += red.y, car->imp[w][2] = 0;
+                } else {
+                    car->imp[w][0] += imp[0], car->imp[w][1] += imp[1], car->imp[w][2] += imp[2];
+                }
+                v2 P = V(imp[0], imp[1]);
+                H->vx -= mA * P.x, H->vy -= mA * P.y, H->w -= iA * (vcross(rA, P) + imp[2]);
+                B->vx += mB * P.x, B->vy += mB * P.y, B->w += iB * (vcross(rB, P) + imp[2]);
+            } else {
+                v2 Cdot = vsub(vsub(vadd(vB, scross(B->w, rB)), vA), scross(H->w, rA));
+                v2 imp = solve22(j->m, vmul(-1.0f, Cdot));
+                car->imp[w][0] += imp.x, car->imp[w][1] += imp.y;
+                H->vx -= mA * imp.x, H->vy -= mA * imp.y, H->w -= iA * vcross(rA, imp);
+                B->vx += mB * imp.x, B->vy += mB * imp.y, B->w += iB * vcross(rB, imp);
+            }
+        }
+    /* integrate positions (with the translation / rotation clamps) */
+    car_body *all[5] = {H, &car->wheel[0], &car->wheel[1], &car->wheel[2], &car->wheel[3]};
+    for (int k = 0; k < 5; k++) {
+        car_body *b = all[k];
+        v2 tr = V(h * b->vx, h * b->vy);
+        if (vdot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) {
+            float ratio = MAX_TRANSLATION / sqrtf(vdot(tr, tr));
+            b->vx *= ratio, b->vy *= ratio;
+        }
+        float ro = h * b->w;
+        if (ro * ro > MAX_ROTATION * MAX_ROTATION) b->w *= MAX_ROTATION / fabsf(ro);
+        b->cx += h * b->vx, b->cy += h * b->vy, b->a += h * b->w;
+    }
+    /* position iterations */
+    for (int it = 0; it < pos_iters; it++) {
+        int ok = 1;
+        for (int q = 0; q < 4; q++) {
+            int w = 3 - q;
+            car_body *B = &car->wheel[w];
+            float angErr = 0;
+            if (car->limit_state[w] != LIM_INACTIVE) {
+                float angle = B->a - H->a - 0.0f, C, li;
+                float mm = iA + iB;
+                if (mm > 0.0f) mm = 1.0f / mm;
+                if (car->limit_state[w] == LIM_LOWER) {
+                    C = angle - LOWER_ANGLE, angErr = -C;
+                    C = fminf(fmaxf(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION), 0.0f);
+                } else {
+                    C = angle - UPPER_ANGLE, angErr = C;
+                    C = fminf(fmaxf(C - ANGULAR_SLOP, 0.0f), MAX_ANGULAR_CORRECTION);
+                }
+                li = -mm * C;
+                H->a -= iA * li, B->a += iB * li;
+            }
+            float sA = sinf(H->a), cA = cosf(H->a);
+            v2 rA = rot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA)), rB = V(0, 0);
+            v2 C = vsub(vsub(vadd(V(B->cx, B->cy), rB), V(H->cx, H->cy)), rA);
+            float posErr = sqrtf(vdot(C, C));
+            float k[3][3];
+            k[0][0] = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
+            k[0][1] = -iA * rA.x * rA.y - iB * rB.x * rB.y;
+            k[1][0] = k[0][1];
+            k[1][1] = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+            v2 imp = vmul(-1.0f, solve22(k, C));
+            H->cx -= mA * imp.x, H->cy -= mA * imp.y, H->a -= iA * vcross(rA, imp);
+            B->cx += mB * imp.x, B->cy += mB * imp.y, B->a += iB * vcross(rB, imp);
+            ok &= posErr <= LINEAR_SLOP && angErr <= ANGULAR_SLOP;
+        }
+        if (ok) break;
+    }
+    /* ClearForces */
+    H->fx = H->fy = 0;
+    for (int w = 0; w < 4; w++) car->wheel[w].fx = car->wheel[w].fy = 0;
+}
+
+/* ------------------------------------------------------------------ env */
+static void tiles_to_f32(car_env *e) {
+    for (int t = 0; t < e->trk.n; t++) {
+        /* b2PolygonShape::Set -> CCW hull; the 5-gon is convex */
+        v2 tmp[5];
+        make_ccw(e->trk.tile[t], 5, 1.0, tmp);
+        float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+        for (int k = 0; k < 5; k++) {
+            e->tile32[t][k][0] = tmp[k].x, e->tile32[t][k][1] = tmp[k].y;
+            x0 = fminf(x0, tmp[k].x), y0 = fminf(y0, tmp[k].y), x1 = fmaxf(x1, tmp[k].x), y1 = fmaxf(y1, tmp[k].y);
+        }
+        e->tile_aabb[t][0] = x0, e->tile_aabb[t][1] = y0, e->tile_aabb[t][2] = x1, e->tile_aabb[t][3] = y1;
+    }
+}
+
+/* CarRacing.reset (crmp:454-525) with an explicit draw stream: `u` holds 24 uniforms per
+ * track attempt (attempts are consumed until one succeeds), `shuffle_swap` is the outcome
+ * of np.random.shuffle on [0, 1] (1 = swapped).  Returns the number of attempts used, or
+ * -1 when max_attempts were exhausted. */
+int car_oracle_reset(car_env *e, const double *u, int max_attempts, int shuffle_swap) {
+    car_oracle_consts();
+    int att = 0, ok = 0;
+    while (att < max_attempts && !ok) ok = car_oracle_create_track(u + 24 * att++, &e->trk);
+    if (!ok) return -1;
+    tiles_to_f32(e);
+    int birth[2] = {shuffle_swap ? 1 : 0, shuffle_swap ? 0 : 1};
+    for (int k = 0; k < 2; k++) {
+        car_oracle_place(&e->car[k], e->trk.track[0][1], e->trk.track[0][2], e->trk.track[0][3], birth[k]);
+        e->reward[k] = e->prev_reward[k] = 0, e->tile_visited_count[k] = 0, e->done[k] = 0, e->last_block[k] = -1;
+    }
+    memset(e->visited, 0, sizeof(e->visited));
+    memset(e->wheel_tiles, 0, sizeof(e->wheel_tiles));
+    e->t = 0, e->step_count = 0, e->inv_dt0 = 0.0f;
+    return att;
+}
+
+static void wheel_world_poly(const car_body *b, v2 *out) {
+    float s = sinf(b->a), c = cosf(b->a);
+    for (int k = 0; k < 4; k++) out[k] = vadd(rot(s, c, V(K.wheel_poly[k][0], K.wheel_poly[k][1])), V(b->cx, b->cy));
+}
+
+/* FrictionDetector._contact (crmp:111-153) driven by sensor overlap at the transforms the
+ * step starts from (b2ContactManager::Collide before the island solve). */
+/* One Begin/EndContact between wheel w of car c and tile t (crmp:111-153). */
+void car_oracle_contact_event(car_env *e, int c, int w, int t, int begin) {
+    if (begin) {
+        e->wheel_tiles[c][w][t >> 5] |= 1u << (t & 31);
+        if (!((e->visited[c][t >> 5] >> (t & 31)) & 1)) {
+            int last_blk = e->last_block[c] < 0 ? 0 : e->last_block[c];
+            if (t - last_blk < 50) {
+                e->last_block[c] = t;
+                e->reward[c] += 1000.0 / e->trk.n;
+            } /* else: the reference raises (self.verbose missing on the listener, crmp:146); no reward */
+            e->visited[c][t >> 5] |= 1u << (t & 31);
+            e->tile_visited_count[c] += 1;
+        }
+    } else {
+        e->wheel_tiles[c][w][t >> 5] &= ~(1u << (t & 31));
+    }
+}
+
+static void collide(car_env *e) {
+    const float R2 = (0.02f + 10.0f * 1.1920929e-07f);
+    for (int c = 0; c < 2; c++) {
+        v2 wp[4][4];
+        float bb4[4][4];
+        for (int w = 0; w < 4; w++) {
+            wheel_world_poly(&e->car[c].wheel[w], wp[w]);
+            float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+            for (int k = 0; k < 4; k++)
+                x0 = fminf(x0, wp[w][k].x), y0 = fminf(y0, wp[w][k].y), x1 = fmaxf(x1, wp[w][k].x), y1 = fmaxf(y1, wp[w][k].y);
+            bb4[w][0] = x0, bb4[w][1] = y0, bb4[w][2] = x1, bb4[w][3] = y1;
+        }
+        /* events are raised tile-major (tile 0..n-1, wheels 0..3 within a tile); Box2D's own
+         * order is its contact-list order, which is not reproducible here */
+        for (int t = 0; t < e->trk.n; t++)
+            for (int w = 0; w < 4; w++) {
+                int was = (e->wheel_tiles[c][w][t >> 5] >> (t & 31)) & 1, now = 0;
+                const float *bb = e->tile_aabb[t];
+                if (!(bb4[w][0] > bb[2] + 0.05f || bb4[w][2] < bb[0] - 0.05f || bb4[w][1] > bb[3] + 0.05f || bb4[w][3] < bb[1] - 0.05f)) {
+                    float d2 = poly_dist2(wp[w], 4, (const v2 *)e->tile32[t], 5);
+                    now = d2 < R2 * R2;
+                }
+                if (now != was) car_oracle_contact_event(e, c, w, t, now);
+            }
+    }
+}
+
+int car_oracle_wheel_on_road(const car_env *e, int c, int w) {
+    for (int k = 0; k < CAR_MAX_TILES / 32; k++)
+        if (e->wheel_tiles[c][w][k]) return 1;
+    return 0;
+}
+
+/* CarRacing.step (crmp:542-620), action_repeat = 1.  actions[c] = (steer, gas/brake) or
+ * NULL for the action-less step that reset() ends with. */
+void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[2], int done[2]) {
+    const double dt = 1.0 / FPS;
+    step_reward[0] = step_reward[1] = 0.0;
+    if (actions) {
+        for (int c = 0; c < 2; c++) {
+            double a[3];
+            car_oracle_process_action(actions[c], a);
+            car_oracle_controls(&e->car[c], -a[0], a[1], a[2]);
+        }
+        for (int c = 0; c < 2; c++) {
+            if (e->done[c]) continue;
+            car_state *car = &e->car[c];
+            for (int w = 0; w < 4; w++) { /* Car.step */
+                car_body *B = &car->wheel[w];
+                double ms, f[2];
+                double ja = (double)(B->a - car->hull.a - 0.0f);
+                car_oracle_wheel(dt, car->steer[w], car->gas[w], car->brake[w], ja, (double)sinf(B->a), (double)cosf(B->a), (double)B->vx, (double)B->vy,
+                                 car_oracle_wheel_on_road(e, c, w), &car->omega[w], &car->phase[w], &ms, f);
+                car->motor_speed[w] = (float)ms;
+                B->fx += (float)f[0], B->fy += (float)f[1];
+            }
+            e->reward[c] -= 0.1 / 1;
+            step_reward[c] += e->reward[c] - e->prev_reward[c];
+            e->prev_reward[c] = e->reward[c];
+            float s, co;
+            v2 p;
+            body_xf(&car->hull, V(K.hull_lc[0], K.hull_lc[1]), &s, &co, &p);
+            if (e->tile_visited_count[c] == e->trk.n) e->done[c] = 1;
+            if (fabs((double)p.x) > PLAYFIELD || fabs((double)p.y) > PLAYFIELD) e->done[c] = 1;
+            if (e->step_count > 1000) e->done[c] = 1;
+        }
+        /* world.Step(1/FPS, 6*30, 2*30) */
+        float h = (float)dt;
+        float dt_ratio = e->inv_dt0 * h;
+        collide(e);
+        island_solve(&e->car[1], h, dt_ratio, 180, 60);
+        island_solve(&e->car[0], h, dt_ratio, 180, 60);
+        e->inv_dt0 = 1.0f / h;
+        e->t += dt;
+        e->step_count += 1;
+    }
+    done[0] = e->done[0], done[1] = e->done[1];
+}
+
+void car_oracle_hull_position(const car_env *e, int c, float out[3]) {
+    float s, co;
+    v2 p;
+    body_xf(&e->car[c].hull, V(K.hull_lc[0], K.hull_lc[1]), &s, &co, &p);
+    out[0] = p.x, out[1] = p.y, out[2] = e->car[c].hull.a;
+}
+
+int car_oracle_env_size(void) { return (int)sizeof(car_env); }
+
+/* ------------------------------------------------------------------ observation raster
+ * CarRacing.get_observation (crmp:622-634): camera_update("rgb_array") :791-804, camera_view
+ * :764-789, Car.draw_for_pygame (cd:284-298), render_indicators_for_pygame :645-670, then luma
+ * 0.299R+0.587G+0.114B truncated to uint8.  The reference pre-rasterises a 10000x10000 map with
+ * pygame and rotates a crop of it; neither is available here, so the background is classified
+ * ANALYTICALLY at the pixel centre (point-in-polygon in world space).  Cars and indicator bars
+ * follow pygame 1.9.6's integer polygon fill rule [from memory of its draw.c].  PARITY
+ * UNPINNED; the 5-px reward text is not drawn. */
+#define G_GRASS 161
+#define G_LIGHT 176
+#define G_WHITE 255
+#define G_RED 76
+#define G_OWN 60
+#define G_OTHER 29
+#define G_BLUE 29
+#define G_ABS_REAR 44
+#define G_GREEN 149
+static const uint8_t G_ROAD[3] = {101, 103, 107};
+
+/* pygame draw_fillpoly membership test for one pixel */
+static int fillpoly_hit(const int *px, const int *py, int n, int x, int y) {
+    int miny = py[0], maxy = py[0], minx = px[0], maxx = px[0];
+    for (int i = 1; i < n; i++) {
+        if (py[i] < miny) miny = py[i];
+        if (py[i] > maxy) maxy = py[i];
+        if (px[i] < minx) minx = px[i];
+        if (px[i] > maxx) maxx = px[i];
+    }
+    if (y < miny || y > maxy) return 0;
+    if (miny == maxy) return x >= minx && x <= maxx;
+    int xs[16], k = 0;
+    for (int i = 0; i < n; i++) {
+        int ip = i ? i - 1 : n - 1;
+        int y1 = py[ip], y2 = py[i], x1, x2;
+        if (y1 < y2) x1 = px[ip], x2 = px[i];
+        else if (y1 > y2) y2 = py[ip], y1 = py[i], x2 = px[ip], x1 = px[i];
+        else continue;
+        if ((y >= y1 && y < y2) || (y == maxy && y > y1 && y <= y2)) xs[k++] = (y - y1) * (x2 - x1) / (y2 - y1) + x1;
+    }
+    for (int i = 1; i < k; i++) /* insertion sort */
+        for (int j = i; j > 0 && xs[j - 1] > xs[j]; j--) { int t = xs[j]; xs[j] = xs[j - 1]; xs[j - 1] = t; }
+    for (int i = 0; i + 1 < k; i += 2)
+        if (x >= xs[i] && x <= xs[i + 1]) return 1;
+    return 0;
+}
+
+/* pygame.draw.rect(surface, color, (x, y, w, h)) with float arguments: int-truncated, then
+ * filled as the polygon (l,t),(r,t),(r,b),(l,b) with r = x+w-1, b = y+h-1 (negative sizes
+ * therefore fill "backwards") */
+static void fill_rect(uint8_t *out, double x, double y, double w, double h, uint8_t g) {
+    int l = (int)x, t = (int)y, r = (int)x + (int)w - 1, b = (int)y + (int)h - 1;
+    int x0 = l < r ? l : r, x1 = l < r ? r : l, y0 = t < b ? t : b, y1 = t < b ? b : t;
+    for (int yy = y0 > 0 ? y0 : 0; yy <= y1 && yy < 96; yy++)
+        for (int xx = x0 > 0 ? x0 : 0; xx <= x1 && xx < 96; xx++) out[yy * 96 + xx] = g;
+}
+
+void car_oracle_render(const car_env *e, int viewer, uint8_t *out) {
+    car_oracle_consts();
+    const car_state *me = &e->car[viewer];
+    /* camera_update("rgb_array") */
+    double angle = (double)me->hull.a;
+    double vx = (double)me->hull.vx, vy = (double)me->hull.vy;
+    if (vx * vx + vy * vy > 0.5 * 0.5) angle = atan2(-vx, vy);
+    float af = (float)angle, s = sinf(af), c = cosf(af);
+    float hs, hc;
+    v2 hp;
+    body_xf(&me->hull, V(K.hull_lc[0], K.hull_lc[1]), &hs, &hc, &hp);
+    v2 off = vadd(hp, V(c * 0.0f - s * 16.0f, s * 0.0f + c * 16.0f));
+    const double obs_scale = (10 / (100 / sqrt(96.0))) * 1.8;
+    const float inv_scale = (float)(1.0 / obs_scale), scale_f = (float)obs_scale;
+    const float kf = (float)(PLAYFIELD / 20.0);
+    /* background */
+    for (int sy = 0; sy < 96; sy++)
+        for (int sx = 0; sx < 96; sx++) {
+            float dx = ((float)sx + 0.5f) - 48.0f, dy = ((float)sy + 0.5f) - 48.0f;
+            float rx = c * dx - s * dy, ry = s * dx + c * dy;
+            v2 pw = V(off.x - rx * inv_scale, off.y - ry * inv_scale);
+            float fx = floorf(pw.x / kf), fy = floorf(pw.y / kf);
+            int ix = (int)fx, iy = (int)fy;
+            int light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
+            uint8_t g = light ? G_LIGHT : G_GRASS;
+            for (int t = 0; t < e->trk.n; t++) {
+                const float *bb = e->tile_aabb[t];
+                if (e->trk.border[t]) {
+                    v2 bp[4];
+                    make_ccw(e->trk.border_poly[t], 4, 1.0, bp);
+                    if (point_in_convex(pw, bp, 4)) { g = (t % 2 == 0) ? G_WHITE : G_RED; break; }
+                }
+                if (pw.x < bb[0] || pw.x > bb[2] || pw.y < bb[1] || pw.y > bb[3]) continue;
+                if (point_in_convex(pw, (const v2 *)e->tile32[t], 5)) { g = G_ROAD[t % 3]; break; }
+            }
+            out[sy * 96 + sx] = g;
+        }
+    /* cars: car 0 then car 1; per car wheels then hull (cd:286-298) */
+    for (int k = 0; k < 2; k++) {
+        const car_state *car = &e->car[k];
+        for (int part = 0; part < 8; part++) {
+            const car_body *b = part < 4 ? &car->wheel[part] : &car->hull;
+            int nv = part < 4 ? 4 : K.hull_n[part - 4];
+            const float(*poly)[2] = part < 4 ? K.wheel_poly : K.hull_poly[part - 4];
+            float bs, bc;
+            v2 bp;
+            body_xf(b, part < 4 ? V(0, 0) : V(K.hull_lc[0], K.hull_lc[1]), &bs, &bc, &bp);
+            int px[8], py[8];
+            for (int i = 0; i < nv; i++) {
+                v2 wv = vadd(rot(bs, bc, V(poly[i][0], poly[i][1])), bp);
+                v2 d = vsub(wv, off);
+                v2 t = rot(-s, c, d); /* tmp.angle = -angle */
+                float X = (-scale_f) * t.x + 48.0f, Y = (-scale_f) * t.y + 48.0f;
+                px[i] = (int)X, py[i] = (int)Y;
+            }
+            uint8_t g = part < 4 ? 0 : (k == viewer ? G_OWN : G_OTHER);
+            int x0 = 95, x1 = 0, y0 = 95, y1 = 0;
+            for (int i = 0; i < nv; i++) {
+                if (px[i] < x0) x0 = px[i];
+                if (px[i] > x1) x1 = px[i];
+                if (py[i] < y0) y0 = py[i];
+                if (py[i] > y1) y1 = py[i];
+            }
+            for (int yy = y0 < 0 ? 0 : y0; yy <= y1 && yy < 96; yy++)
+                for (int xx = x0 < 0 ? 0 : x0; xx <= x1 && xx < 96; xx++)
+                    if (fillpoly_hit(px, py, nv, xx, yy)) out[yy * 96 + xx] = g;
+        }
+    }
+    /* indicators (render_indicators_for_pygame, width = height = 96) */
+    const double S = 96 / 40.0, Hh = 96 / 40.0;
+    double true_speed = sqrt(vx * vx + vy * vy);
+    fill_rect(out, 0, 96 - 4 * Hh, 96, 4 * Hh * 1000, 0);
+    fill_rect(out, 5 * S, 96 - Hh, S, Hh * (-0.02 * true_speed), G_BLUE);
+    for (int w = 0; w < 4; w++) fill_rect(out, (7 + w) * S, 96 - Hh, S, Hh * (-0.01 * me->omega[w]), w < 2 ? G_BLUE : G_ABS_REAR);
+    double ja = (double)(me->wheel[0].a - me->hull.a - 0.0f);
+    fill_rect(out, 20 * S, 96 - 2 * Hh, S * (10.0 * ja), 2 * Hh, G_GREEN);
+    fill_rect(out, 30 * S, 96 - 2 * Hh, S * (0.8 * (double)me->hull.w), 2 * Hh, G_RED);
+}

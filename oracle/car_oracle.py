@@ -1,0 +1,107 @@
+"""ctypes front-end of the CarRacing CPU oracle (oracle/car_oracle.c).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+
+import numpy as np
+
+from . import pong_oracle as _po
+
+MAX_TILES = 512
+
+TRACK_DT = np.dtype([("n", "<i4"), ("pad", "<i4"), ("track", "<f8", (MAX_TILES, 4)), ("tile", "<f8", (MAX_TILES, 5, 2)),
+                     ("border_poly", "<f8", (MAX_TILES, 4, 2)), ("border", "u1", (MAX_TILES,))])
+BODY_DT = np.dtype([(k, "<f4") for k in ("cx", "cy", "a", "vx", "vy", "w", "fx", "fy")])
+CAR_DT = np.dtype([("hull", BODY_DT), ("wheel", BODY_DT, (4,)), ("imp", "<f4", (4, 3)), ("motor_imp", "<f4", (4,)),
+                   ("motor_speed", "<f4", (4,)), ("limit_state", "<i4", (4,)), ("gas", "<f8", (4,)), ("brake", "<f8", (4,)),
+                   ("steer", "<f8", (4,)), ("phase", "<f8", (4,)), ("omega", "<f8", (4,))])
+ENV_DT = np.dtype([("trk", TRACK_DT), ("tile32", "<f4", (MAX_TILES, 5, 2)), ("tile_aabb", "<f4", (MAX_TILES, 4)),
+                   ("car", CAR_DT, (2,)), ("wheel_tiles", "<u4", (2, 4, MAX_TILES // 32)), ("visited", "<u4", (2, MAX_TILES // 32)),
+                   ("tile_visited_count", "<i4", (2,)), ("last_block", "<i4", (2,)), ("done", "<i4", (2,)),
+                   ("reward", "<f8", (2,)), ("prev_reward", "<f8", (2,)), ("t", "<f8"), ("step_count", "<i4"), ("inv_dt0", "<f4")],
+                  align=True)
+CONSTS_DT = np.dtype([("hull_poly", "<f4", (4, 8, 2)), ("hull_n", "<i4", (4,)), ("wheel_poly", "<f4", (4, 2)),
+                      ("hull_mass", "<f4"), ("hull_inv_mass", "<f4"), ("hull_I", "<f4"), ("hull_inv_I", "<f4"), ("hull_lc", "<f4", (2,)),
+                      ("wheel_mass", "<f4"), ("wheel_inv_mass", "<f4"), ("wheel_I", "<f4"), ("wheel_inv_I", "<f4"),
+                      ("anchor", "<f4", (4, 2))])
+
+_ready = False
+
+
+def lib():
+    global _ready
+    L = _po.lib()
+    if not _ready:
+        vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+        L.car_oracle_create_track.argtypes = [vp, vp]
+        L.car_oracle_create_track.restype = i32
+        L.car_oracle_consts.restype = vp
+        L.car_oracle_process_action.argtypes = [vp, vp]
+        L.car_oracle_controls.argtypes = [vp, f64, f64, f64]
+        L.car_oracle_wheel.argtypes = [f64] * 9 + [i32, vp, vp, vp, vp]
+        L.car_oracle_place.argtypes = [vp, f64, f64, f64, i32]
+        L.car_oracle_reset.argtypes = [vp, vp, i32, i32]
+        L.car_oracle_reset.restype = i32
+        L.car_oracle_step.argtypes = [vp, vp, vp, vp]
+        L.car_oracle_contact_event.argtypes = [vp, i32, i32, i32, i32]
+        L.car_oracle_hull_position.argtypes = [vp, i32, vp]
+        L.car_oracle_env_size.restype = i32
+        assert L.car_oracle_env_size() == ENV_DT.itemsize, (L.car_oracle_env_size(), ENV_DT.itemsize)
+        _ready = True
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def consts():
+    ptr = lib().car_oracle_consts()
+    return np.frombuffer((C.c_char * CONSTS_DT.itemsize).from_address(ptr), CONSTS_DT)[0]
+
+
+def create_track(u24):
+    u = np.ascontiguousarray(u24, np.float64)
+    trk = np.zeros(1, TRACK_DT)
+    ok = lib().car_oracle_create_track(_p(u), _p(trk))
+    return bool(ok), trk[0]
+
+
+def process_action(a):
+    a = np.ascontiguousarray(a, np.float64)
+    out = np.zeros(3)
+    lib().car_oracle_process_action(_p(a), _p(out))
+    return out
+
+
+def wheel(dt, steer, gas, brake, joint_angle, q_sin, q_cos, vx, vy, on_road, omega, phase):
+    om, ph, ms, f = np.array([omega], np.float64), np.array([phase], np.float64), np.zeros(1), np.zeros(2)
+    lib().car_oracle_wheel(dt, steer, gas, brake, joint_angle, q_sin, q_cos, vx, vy, int(on_road), _p(om), _p(ph), _p(ms), _p(f))
+    return om[0], ph[0], ms[0], f
+
+
+class CarEnv:
+    """One cCarRacingDouble env (2 cars)."""
+
+    def __init__(self):
+        self.buf = np.zeros(1, ENV_DT)
+        self.e = self.buf[0]
+
+    def reset(self, u, shuffle_swap=0):
+        u = np.ascontiguousarray(u, np.float64).reshape(-1)
+        return lib().car_oracle_reset(_p(self.buf), _p(u), len(u) // 24, int(shuffle_swap))
+
+    def step(self, actions):
+        rew, done = np.zeros(2), np.zeros(2, np.int32)
+        if actions is None:
+            lib().car_oracle_step(_p(self.buf), None, _p(rew), _p(done))
+        else:
+            a = np.ascontiguousarray(actions, np.float64).reshape(2, 2)
+            lib().car_oracle_step(_p(self.buf), _p(a), _p(rew), _p(done))
+        return rew, done
+
+    def contact_event(self, c, w, t, begin):
+        lib().car_oracle_contact_event(_p(self.buf), c, w, t, int(begin))
+
+    def hull_position(self, c):
+        out = np.zeros(3, np.float32)
+        lib().car_oracle_hull_position(_p(self.buf), c, _p(out))
+        return out

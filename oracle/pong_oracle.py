@@ -26,8 +26,8 @@ assert STATE_DT.itemsize == 120 and FRAME_DT.itemsize == 8
 
 
 def build(force=False):
-    src = os.path.join(HERE, "pong_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(HERE, f) for f in ("pong_oracle.c", "car_oracle.c", "car_oracle.h", "Makefile")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return LIB
 

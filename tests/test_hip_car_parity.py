@@ -1,0 +1,228 @@
+"""cCarRacingDouble: HIP path (through the C ABI) against the CPU oracle.
+
+Tolerances (BASELINE.md parity bar): float state within 1e-5 per step from identical pre-step
+state (teacher-forced) -- device sinf/cosf/atan2 are not bit-identical to glibc's; integer
+outcomes (tile visits, done, limit states) exact; free-running trajectories are chaotic and only
+checked loosely."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+
+
+def oracle_to_hip_state(envs):
+    """oracle car_env structs -> crl_car_env_state array"""
+    from competitive_rl_amd import _native as N
+
+    st = np.zeros(len(envs), N.CAR_ENV_STATE_DT)
+    for i, env in enumerate(envs):
+        e = env.e
+        for c in range(2):
+            q, o = st[i]["car"][c], e["car"][c]
+            for f in ("cx", "cy", "a", "vx", "vy", "w"):
+                q["hull"][f] = o["hull"][f]
+                q["wheel"][f] = o["wheel"][f]
+            q["imp"], q["motor_imp"], q["motor_speed"], q["limit_state"] = o["imp"], o["motor_imp"], o["motor_speed"], o["limit_state"]
+            q["gas"], q["omega"], q["phase"] = o["gas"], o["omega"], o["phase"]
+            q["reward"], q["prev_reward"] = e["reward"][c], e["prev_reward"][c]
+            q["tile_visited_count"], q["last_block"], q["done"] = e["tile_visited_count"][c], e["last_block"][c], e["done"][c]
+            q["step_count"], q["first_step"] = e["step_count"], int(e["inv_dt0"] == 0)
+            q["wheel_tiles"], q["visited"] = e["wheel_tiles"][c], e["visited"][c]
+        st[i]["elapsed"] = e["step_count"]
+    return st
+
+
+def push_tracks(hip, envs):
+    from oracle import car_oracle as co
+
+    for i, env in enumerate(envs):
+        e = env.e
+        n = int(e["trk"]["n"])
+        bp = np.zeros((n, 4, 2), np.float32)
+        border = np.zeros(n, np.uint8)
+        for t in range(n):
+            if e["trk"]["border"][t]:
+                p = e["trk"]["border_poly"][t]
+                area = sum(p[k][0] * p[(k + 1) % 4][1] - p[(k + 1) % 4][0] * p[k][1] for k in range(4))
+                bp[t] = p if area > 0 else p[::-1]
+                border[t] = 1 if t % 2 == 0 else 2
+        pose = e["trk"]["track"][0][1:4].astype(np.float32)
+        hip.set_track(i, e["tile32"][:n], bp, border, pose)
+
+
+def make_oracle_envs(n, seed0=0):
+    from oracle import car_oracle as co
+
+    g = np.load(os.path.join(G, "car_track.npz"))
+    draws = [g[f"{j}/draws"] for j in range(int(g["count"]))]
+    envs = []
+    for i in range(n):
+        u = np.concatenate([draws[(seed0 + i * 3 + k) % len(draws)] for k in range(6)])
+        e = co.CarEnv()
+        assert e.reset(u, i % 2) > 0
+        e.step(None)
+        envs.append(e)
+    return envs
+
+
+def test_track_generation_matches_oracle():
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import car_oracle as co
+
+    g = np.load(os.path.join(G, "car_track.npz"))
+    draws = [g[f"{j}/draws"] for j in range(int(g["count"]))]
+    n, A = 24, 6
+    u = np.zeros((n, A, 24))
+    swap = np.zeros((n, A), np.uint8)
+    for i in range(n):
+        for a in range(A):
+            u[i, a] = draws[(2 * i + a) % len(draws)]
+            swap[i, a] = (i + a) % 2
+    env = crl.HipCarVecEnv(n)
+    env.set_replay(u, swap)
+    obs = env.reset()
+    assert tuple(obs.shape) == (n, 2, 96, 96)
+    st = env.get_state()
+    for i in range(n):
+        o = co.CarEnv()
+        att = o.reset(u[i].reshape(-1), 0)
+        assert att > 0
+        sw = int(swap[i, att - 1])
+        o.reset(u[i].reshape(-1), sw)
+        tr = env.get_track(i)
+        nt = int(o.e["trk"]["n"])
+        assert tr["n"] == nt, i
+        assert np.allclose(tr["tile_poly"], o.e["tile32"][:nt], atol=2e-4), i
+        assert np.array_equal(tr["border"] > 0, o.e["trk"]["border"][:nt] > 0), i
+        for c in range(2):
+            for f in ("cx", "cy", "a"):
+                assert abs(float(st[i]["car"][c]["hull"][f]) - float(o.e["car"][c]["hull"][f])) < 2e-4, (i, c, f)
+    env.close()
+
+
+def test_step_teacher_forced_matches_oracle():
+    """From identical pre-step state: one step on both, compare, re-sync, repeat."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps = 12, 160
+    envs = make_oracle_envs(n)
+    hip = crl.HipCarVecEnv(n)
+    hip.reset()
+    push_tracks(hip, envs)
+    rs = np.random.RandomState(4)
+    worst = 0.0
+    visits = 0
+    for t in range(steps):
+        hip.set_state(oracle_to_hip_state(envs))
+        acts = rs.uniform(-1, 1, (n, 2, 2)).astype(np.float32)
+        if t < 60:
+            acts[:, :, 1] = np.abs(acts[:, :, 1])  # accelerate first so that tiles get visited
+        _, rew, done = hip.step_device(torch.as_tensor(acts).cuda(), render=False)
+        rew = rew.cpu().numpy()
+        hs = hip.get_state()
+        for i, e in enumerate(envs):
+            r, d = e.step(acts[i].astype(np.float64))
+            assert np.allclose(rew[i], r, atol=1e-6), (t, i, rew[i], r)
+            for c in range(2):
+                q, o = hs[i]["car"][c], e.e["car"][c]
+                for f in ("cx", "cy", "a", "vx", "vy", "w"):
+                    for got, want in ((q["hull"][f], o["hull"][f]), *zip(q["wheel"][f], o["wheel"][f])):
+                        err = abs(float(got) - float(want)) / max(1.0, abs(float(want)))
+                        worst = max(worst, err)
+                        assert err < 1e-5, (t, i, c, f, got, want)
+                assert np.allclose(q["omega"], o["omega"], rtol=1e-6, atol=1e-6), (t, i, c)
+                assert np.allclose(q["gas"], o["gas"]) and np.allclose(q["phase"], o["phase"], rtol=1e-6, atol=1e-6)
+                assert np.array_equal(q["limit_state"], o["limit_state"]), (t, i, c)
+                assert np.allclose(q["imp"], o["imp"], rtol=1e-3, atol=1e-4), (t, i, c)
+                assert int(q["tile_visited_count"]) == int(e.e["tile_visited_count"][c]), (t, i, c)
+                assert np.array_equal(q["visited"], e.e["visited"][c]) and np.array_equal(q["wheel_tiles"], e.e["wheel_tiles"][c])
+                assert int(q["last_block"]) == int(e.e["last_block"][c]) and int(q["done"]) == int(e.e["done"][c])
+                assert abs(float(q["reward"]) - float(e.e["reward"][c])) < 1e-9
+        visits = sum(int(e.e["tile_visited_count"].sum()) for e in envs)
+    assert visits > 4 * n, visits
+    print("worst relative state error", worst)
+    hip.close()
+
+
+def test_free_running_stays_close_and_render_matches():
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import car_oracle as co
+
+    L = co.lib()
+    L.car_oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    n, steps = 8, 120
+    envs = make_oracle_envs(n, seed0=11)
+    hip = crl.HipCarVecEnv(n)
+    hip.reset()
+    push_tracks(hip, envs)
+    hip.set_state(oracle_to_hip_state(envs))
+    rs = np.random.RandomState(9)
+    mism = []
+    for t in range(steps):
+        acts = np.stack([np.stack([[0.3 * np.sin(t / 15 + i), 0.8], [rs.uniform(-0.2, 0.2), 0.5]]) for i in range(n)]).astype(np.float32)
+        obs, rew, done = hip.step_device(torch.as_tensor(acts).cuda())
+        for i, e in enumerate(envs):
+            e.step(acts[i].astype(np.float64))
+        if t % 20 == 19:
+            # render parity from synchronised state
+            hip.set_state(oracle_to_hip_state(envs))
+            got = hip.render_current().cpu().numpy()
+            for i, e in enumerate(envs):
+                for v in range(2):
+                    want = np.zeros((96, 96), np.uint8)
+                    L.car_oracle_render(e.buf.ctypes.data, v, want.ctypes.data)
+                    mism.append(float((got[i, v] != want).mean()))
+    hs = hip.get_state()
+    for i, e in enumerate(envs):
+        for c in range(2):
+            dx = float(hs[i]["car"][c]["hull"]["cx"]) - float(e.e["car"][c]["hull"]["cx"])
+            dy = float(hs[i]["car"][c]["hull"]["cy"]) - float(e.e["car"][c]["hull"]["cy"])
+            assert np.hypot(dx, dy) < 1e-2, (i, c, dx, dy)
+    print("render mismatch fractions: max", max(mism), "mean", np.mean(mism))
+    assert max(mism) < 0.005, mism
+    palette = {0, 29, 44, 60, 76, 101, 103, 107, 149, 161, 176, 255}
+    assert set(np.unique(got).tolist()) <= palette
+    hip.close()
+
+
+def test_car_api_surface_and_time_limit():
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    envs = crl.make_envs("cCarRacingDouble-v0", num_envs=6, frame_stack=None, log_dir=None, seed=3)
+    obs = envs.reset()
+    assert tuple(obs.shape) == (6, 2, 96, 96) and obs.dtype == torch.uint8
+    acts = np.zeros((6, 2, 2), np.float32)
+    acts[:, :, 1] = 0.3
+    n_done = 0
+    for t in range(1001):
+        obs, rew, done, info = envs.step(acts)
+        assert tuple(rew.shape) == (6, 1) and tuple(done.shape) == (6, 1)
+        if t == 998:
+            assert not bool(done.any())
+        n_done += int(done.sum())
+        if t == 999:  # gym TimeLimit: max_episode_steps = 1000
+            assert bool(done.all())
+            i0 = info[0]
+            assert set(i0.keys()) == {0, 1} and i0[0]["num_steps"] == 1000 and "reward" in i0[1]
+    assert n_done == 6
+    st = envs.get_state()
+    assert (st["elapsed"] == 1).all() and (st["episode"] == 2).all()
+    with pytest.raises(AssertionError):
+        envs.step(np.zeros((6, 2), np.float32))
+    envs.close()
+    envs.close()
