@@ -206,8 +206,7 @@ def test_car_api_surface_and_time_limit():
     envs = crl.make_envs("cCarRacingDouble-v0", num_envs=6, frame_stack=None, log_dir=None, seed=3)
     obs = envs.reset()
     assert tuple(obs.shape) == (6, 2, 96, 96) and obs.dtype == torch.uint8
-    acts = np.zeros((6, 2, 2), np.float32)
-    acts[:, :, 1] = 0.3
+    acts = np.zeros((6, 2, 2), np.float32)  # idle cars: only the TimeLimit can end the episode
     n_done = 0
     for t in range(1001):
         obs, rew, done, info = envs.step(acts)
