@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 # for raw = 201 600 obs + 113 state/scalars; the frame-descriptor hand-off adds 8 B each way)
 RAW_RASTER_BYTES = 2 * 100800 + 8
 FUSED_RASTER_BYTES = {84: 2 * 4 * 84 * 84 + 8 * 8}
+# CarRacing raster: obs 2*96*96 stored + ~1.6 KB body/joint state + ~4.7 KB track read (~24 900 B/env-step)
+CAR_STEP_BYTES = 24900
 HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -37,6 +39,8 @@ def cpu_baseline(workload, budget_s=12.0):
 
     cores = len(os.sched_getaffinity(0))
     atlas = _native.load_score_atlas()
+    if workload == "car":
+        return cpu_baseline_car(cores, budget_s)
     if workload == "raw":
         n = 64 * cores
         env = po.PongOracle(n, atlas, obs_mode=po.RAW, seed=0)
@@ -61,13 +65,45 @@ def cpu_baseline(workload, budget_s=12.0):
             "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c ({workload}), OpenMP over {threads} threads, {dt:.1f} s"}
 
 
+def cpu_baseline_car(cores, budget_s):
+    """Oracle CarRacing envs stepped + rendered serially on one core (scalar port)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from oracle import car_oracle as co
+
+    L = co.lib()
+    L.car_oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    rs = np.random.RandomState(0)
+    envs = []
+    for i in range(4):
+        e = co.CarEnv()
+        while e.reset(rs.random_sample(24 * 8), i % 2) < 0:
+            pass
+        e.step(None)
+        envs.append(e)
+    out = np.zeros((96, 96), np.uint8)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < budget_s:
+        for e in envs:
+            e.step(rs.uniform(-1, 1, (2, 2)))
+            for v in range(2):
+                L.car_oracle_render(e.buf.ctypes.data, v, out.ctypes.data)
+        k += 1
+    dt = time.perf_counter() - t0
+    return {"value": len(envs) * k / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{k} steps x {len(envs)} envs, oracle/car_oracle.c step + 2 renders, 1 thread, {dt:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["raw", "fused84"], default="raw")
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--workload", choices=["raw", "fused84", "car"], default="raw")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
     ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -89,8 +125,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    n = args.envs
-    if args.workload == "raw":
+    n = args.envs or (16384 if args.workload == "car" else 65536)
+    if args.workload == "car":
+        env = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=rank * n)
+        raster_bytes, kernel = CAR_STEP_BYTES, "car_raster_kernel"
+        desc = (f"cCarRacingDouble-v0 {n} envs/GPU, (N,2,96,96) u8 obs + Box2D-style car dynamics, 1 step = 1 CarRacing.step "
+                "(BASELINE config #4)")
+    elif args.workload == "raw":
         env = crl.HipPongVecEnv(n, seed=0, mode="raw", device=dev, env_id_base=rank * n)
         raster_bytes, kernel = RAW_RASTER_BYTES, "pong_raster_raw_kernel"
         desc = f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)"
@@ -102,7 +143,10 @@ def main():
                 "1 step = 4 frames (BASELINE config #3)")
     env.reset()
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = [torch.randint(0, 3, (n, 2), generator=g, device=dev, dtype=torch.int32) for _ in range(16)]
+    if args.workload == "car":
+        pool = [torch.rand((n, 2, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
+    else:
+        pool = [torch.randint(0, 3, (n, 2), generator=g, device=dev, dtype=torch.int32) for _ in range(16)]
 
     def gather(buf, rew, done):
         if world == 1 or args.gather == "none":
@@ -154,7 +198,8 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",
                        "actions": "uniform {0,1,2}, pre-generated on device", "auto_reset": True},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm" if args.workload != "car" else "hbm (reported as required; the step kernel is VALU-latency bound, DESIGN.md)",
+                         "kernel": kernel, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "bytes_per_launch": raster_bytes * n, "avg_kernel_us": ras_avg_s * 1e6,
                          "launches_timed": ras_n,

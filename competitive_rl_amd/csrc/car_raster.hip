@@ -34,7 +34,10 @@ struct CandTile {
     float bpoly[8];
     float bb[4];
     int idx, border;
+    int sx0, sx1, sy0, sy1;  // conservative screen-space box of tile + border (culling only)
 };
+
+static constexpr int kCell = 16, kCellsPerRow = 96 / kCell, kCells = kCellsPerRow * kCellsPerRow, kCellCap = 47;
 
 struct CarPoly {
     int px[8], py[8];
@@ -91,6 +94,10 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ IndRect ind[8];
     __shared__ int wave_cnt[4];
     __shared__ int n_cand;
+    __shared__ uint8_t cell_cnt[kCells];           // 255 = overflow: fall back to the full list
+    __shared__ uint8_t cell_list[kCells][kCellCap + 1];
+    __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
+    __shared__ int ind_y0;
     const int64_t n = s.n, M = 2 * n;
     const int64_t env = blockIdx.x >> 1;
     const int viewer = blockIdx.x & 1;
@@ -189,8 +196,50 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     }
     __syncthreads();
 
-    // ---- (3) pixels
+    // ---- (2b) screen-space culling structures: per candidate a conservative screen box, per
+    // 16x16-pixel cell the ORDERED list of candidates whose box meets it.  Membership itself is
+    // still decided in world space, so culling never changes a pixel.
     const int nc = n_cand;
+    for (int c = tid; c < nc; c += 256) {
+        CandTile &ct = cand[c];
+        float x0 = 1e30f, y0 = 1e30f, x1 = -1e30f, y1 = -1e30f;
+        const int nv = ct.border ? 9 : 5;
+        for (int i = 0; i < nv; i++) {
+            const float wx = i < 5 ? ct.poly[2 * i] : ct.bpoly[2 * (i - 5)], wy = i < 5 ? ct.poly[2 * i + 1] : ct.bpoly[2 * (i - 5) + 1];
+            const V2 t = rotv(-sn, cs, mk(wx, wy) - off);
+            const float X = 48.0f - scale_f * t.x, Y = 48.0f - scale_f * t.y;
+            x0 = fminf(x0, X), y0 = fminf(y0, Y), x1 = fmaxf(x1, X), y1 = fmaxf(y1, Y);
+        }
+        ct.sx0 = (int)floorf(x0 - 1.5f), ct.sx1 = (int)ceilf(x1 + 1.5f), ct.sy0 = (int)floorf(y0 - 1.5f), ct.sy1 = (int)ceilf(y1 + 1.5f);
+    }
+    if (tid < 2) {
+        int x0 = 1 << 30, y0 = 1 << 30, x1 = -(1 << 30), y1 = -(1 << 30);
+        for (int p = 0; p < 8; p++) {
+            const CarPoly &q = cars[tid * 8 + p];
+            x0 = min(x0, q.x0), y0 = min(y0, q.y0), x1 = max(x1, q.x1), y1 = max(y1, q.y1);
+        }
+        car_box[tid][0] = x0, car_box[tid][1] = x1, car_box[tid][2] = y0, car_box[tid][3] = y1;
+    }
+    if (tid == 2) {
+        int y0 = 1 << 30;
+        for (int r = 0; r < 8; r++) y0 = min(y0, ind[r].y0);
+        ind_y0 = y0;
+    }
+    __syncthreads();
+    if (tid < kCells) {
+        const int cx0 = (tid % kCellsPerRow) * kCell, cy0 = (tid / kCellsPerRow) * kCell;
+        int cnt = 0;
+        for (int c = 0; c < nc; c++) {
+            const CandTile &ct = cand[c];
+            if (ct.sx1 < cx0 || ct.sx0 > cx0 + kCell - 1 || ct.sy1 < cy0 || ct.sy0 > cy0 + kCell - 1) continue;
+            if (cnt < kCellCap) cell_list[tid][cnt] = (uint8_t)c;
+            cnt++;
+        }
+        cell_cnt[tid] = cnt <= kCellCap ? (uint8_t)cnt : 255;
+    }
+    __syncthreads();
+
+    // ---- (3) pixels
     uint32_t *__restrict__ out = reinterpret_cast<uint32_t *>(obs + ((int64_t)env * 2 + viewer) * (96 * 96));
     for (int q = tid; q < 96 * 96 / 4; q += 256) {
         const int sy = q / 24, sx0 = (q - sy * 24) * 4;
@@ -199,10 +248,12 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         for (int k = 0; k < 4; k++) {
             const int sx = sx0 + k;
             int g = -1;
-            for (int r = 7; r >= 0 && g < 0; r--)  // indicators are drawn last
-                if (sx >= ind[r].x0 && sx <= ind[r].x1 && sy >= ind[r].y0 && sy <= ind[r].y1) g = ind[r].gray;
+            if (sy >= ind_y0)
+                for (int r = 7; r >= 0 && g < 0; r--)  // indicators are drawn last
+                    if (sx >= ind[r].x0 && sx <= ind[r].x1 && sy >= ind[r].y0 && sy <= ind[r].y1) g = ind[r].gray;
             if (g < 0) {  // cars: car 1 over car 0; hull over wheels
                 for (int c = 1; c >= 0 && g < 0; c--) {
+                    if (sx < car_box[c][0] || sx > car_box[c][1] || sy < car_box[c][2] || sy > car_box[c][3]) continue;
                     for (int p = 7; p >= 0 && g < 0; p--)
                         if (fillpoly_hit(cars[c * 8 + p], sx, sy)) g = cars[c * 8 + p].gray;
                 }
@@ -214,7 +265,11 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                 const int ix = (int)floorf(wx / kf), iy = (int)floorf(wy / kf);
                 const bool light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
                 g = light ? G_LIGHT : G_GRASS;
-                for (int c = 0; c < nc; c++) {
+                const int cell = (sy >> 4) * kCellsPerRow + (sx >> 4);
+                const int ccount = cell_cnt[cell];
+                const int niter = ccount == 255 ? nc : ccount;
+                for (int ci2 = 0; ci2 < niter; ci2++) {
+                    const int c = ccount == 255 ? ci2 : cell_list[cell][ci2];
                     const CandTile &ct = cand[c];
                     if (ct.border && in_convex(ct.bpoly, 4, wx, wy)) { g = ct.border == 1 ? G_WHITE : G_RED; break; }
                     if (wx < ct.bb[0] || wx > ct.bb[2] || wy < ct.bb[1] || wy > ct.bb[3]) continue;

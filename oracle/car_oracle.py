@@ -43,6 +43,9 @@ def lib():
         L.car_oracle_step.argtypes = [vp, vp, vp, vp]
         L.car_oracle_contact_event.argtypes = [vp, i32, i32, i32, i32]
         L.car_oracle_hull_position.argtypes = [vp, i32, vp]
+        L.car_oracle_wheel_on_road.argtypes = [vp, i32, i32]
+        L.car_oracle_wheel_on_road.restype = i32
+        L.car_oracle_render.argtypes = [vp, i32, vp]
         L.car_oracle_env_size.restype = i32
         assert L.car_oracle_env_size() == ENV_DT.itemsize, (L.car_oracle_env_size(), ENV_DT.itemsize)
         _ready = True
@@ -100,6 +103,14 @@ class CarEnv:
 
     def contact_event(self, c, w, t, begin):
         lib().car_oracle_contact_event(_p(self.buf), c, w, t, int(begin))
+
+    def wheel_on_road(self, c, w):
+        return bool(lib().car_oracle_wheel_on_road(_p(self.buf), c, w))
+
+    def render(self, viewer):
+        out = np.zeros((96, 96), np.uint8)
+        lib().car_oracle_render(_p(self.buf), int(viewer), _p(out))
+        return out
 
     def hull_position(self, c):
         out = np.zeros(3, np.float32)

@@ -1,0 +1,149 @@
+"""Known-answer checks of the oracle's Box2D 2.3 restatement (the part that cannot be pinned to
+the reference because box2d-py is not installable): rigid-body integration, revolute joints
+(point constraint, limits, motor torque cap), polygon mass data, sensor overlap."""
+import numpy as np
+import pytest
+
+from oracle import car_oracle as co
+
+G = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def fresh_env(swap=0):
+    g = np.load(G + "/car_track.npz")
+    u = np.concatenate([g[f"{j}/draws"] for j in range(4)])
+    e = co.CarEnv()
+    assert e.reset(u, swap) > 0
+    e.step(None)
+    return e
+
+
+def anchor_errors(e, c):
+    k = co.consts()
+    car = e.e["car"][c]
+    h = car["hull"]
+    s, cs = np.sin(np.float64(h["a"])), np.cos(np.float64(h["a"]))
+    errs = []
+    for w in range(4):
+        an = k["anchor"][w].astype(np.float64) - k["hull_lc"].astype(np.float64)
+        ax = h["cx"] + cs * an[0] - s * an[1]
+        ay = h["cy"] + s * an[0] + cs * an[1]
+        errs.append(np.hypot(ax - car["wheel"][w]["cx"], ay - car["wheel"][w]["cy"]))
+    return np.array(errs)
+
+
+def test_polygon_mass_data_matches_closed_forms():
+    k = co.consts()
+    # wheel box 0.56 x 1.08, density 0.1: m = rho*w*h, I = m (w^2 + h^2) / 12
+    m = 0.1 * 0.56 * 1.08
+    assert abs(k["wheel_mass"] - m) < 1e-7
+    assert abs(k["wheel_I"] - m * (0.56 ** 2 + 1.08 ** 2) / 12) < 1e-7
+    # hull: sum of 4 polygons, area by shoelace in f64
+    polys = [[(-60, 130), (60, 130), (60, 110), (-60, 110)], [(-15, 120), (15, 120), (20, 20), (-20, 20)],
+             [(25, 20), (50, -10), (50, -40), (20, -90), (-20, -90), (-50, -40), (-50, -10), (-25, 20)],
+             [(-50, -120), (50, -120), (50, -90), (-50, -90)]]
+    area = 0.0
+    for p in polys:
+        p = np.array(p, float) * 0.02
+        area += abs(0.5 * np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1]))
+    assert abs(k["hull_mass"] - area) < 1e-5
+
+
+def test_car_at_rest_stays_at_rest_and_joints_hold():
+    e = fresh_env()
+    # Car.__init__ places the wheels at UN-rotated offsets (cd:86) while the joint anchors rotate
+    # with the hull, so a freshly built car first settles onto its joints; then it must stay put
+    for _ in range(30):
+        e.step([[0.0, 0.0], [0.0, 0.0]])
+    p0 = e.hull_position(0).copy()
+    for _ in range(100):
+        e.step([[0.0, 0.0], [0.0, 0.0]])
+    p1 = e.hull_position(0)
+    assert np.allclose(p0, p1, atol=1e-4)
+    for c in range(2):
+        assert anchor_errors(e, c).max() < 1e-4
+        assert abs(float(e.e["car"][c]["hull"]["w"])) < 1e-5
+
+
+def test_full_gas_accelerates_along_heading_without_tearing_the_joints():
+    e = fresh_env()
+    a0 = float(e.e["car"][0]["hull"]["a"])
+    heading = np.array([-np.sin(a0), np.cos(a0)])
+    p0 = e.hull_position(0)[:2].copy()
+    speeds = []
+    for t in range(120):
+        e.step([[0.0, 1.0], [0.0, 0.0]])
+        h = e.e["car"][0]["hull"]
+        speeds.append(float(np.hypot(h["vx"], h["vy"])))
+        assert anchor_errors(e, 0).max() < 5e-3  # b2_linearSlop = 0.005
+    d = e.hull_position(0)[:2] - p0
+    assert speeds[-1] > 60 and np.all(np.diff(speeds[5:]) > -1e-3)  # monotone acceleration
+    assert np.dot(d, heading) / np.linalg.norm(d) > 0.999          # straight along the heading
+    # momentum budget: total tyre force is capped by 4 wheels * friction limit (400 on road)
+    mass = co.consts()["hull_mass"] + 4 * co.consts()["wheel_mass"]
+    assert max(np.diff(speeds)) * 50 * mass <= 4 * 400.0 * 1.001
+
+
+def test_steering_joint_respects_limits_and_motor_speed_cap():
+    e = fresh_env()
+    angles = []
+    for t in range(60):
+        e.step([[1.0, 0.0], [-1.0, 0.0]])  # steer(-a0): car 0 targets -1 rad (beyond the -0.4 limit)
+        c0, c1 = e.e["car"][0], e.e["car"][1]
+        angles.append((float(c0["wheel"][0]["a"] - c0["hull"]["a"]), float(c1["wheel"][0]["a"] - c1["hull"]["a"])))
+    angles = np.array(angles)
+    # joint.motorSpeed = sign * min(50*|d|, 3.0) rad/s -> at most 0.06 rad per step
+    assert np.abs(np.diff(angles[:, 0])).max() <= 0.06 + 1e-4
+    assert abs(angles[-1, 0] + 0.4) < 0.04 and abs(angles[-1, 1] - 0.4) < 0.04  # parked at the +-0.4 limits (+- angular slop)
+    assert angles[:, 0].min() > -0.4 - 0.036 and angles[:, 1].max() < 0.4 + 0.036
+    # rear wheels have no steering target other than 0
+    c0 = e.e["car"][0]
+    assert abs(float(c0["wheel"][2]["a"] - c0["hull"]["a"])) < 1e-3
+    assert set(np.unique(e.e["car"][0]["limit_state"][:2]).tolist()) <= {0, 1}
+
+
+def test_sensor_overlap_drives_tile_rewards():
+    e = fresh_env()
+    n = int(e.e["trk"]["n"])
+    tot = np.zeros(2)
+    for t in range(200):
+        r, d = e.step([[0.0, 0.6], [0.0, 0.0]])
+        tot += r
+    v = int(e.e["tile_visited_count"][0])
+    assert v >= 8
+    # -0.1 per step plus 1000/n per visited tile, the last step's visits are paid one step late
+    assert abs(tot[0] - (-0.1 * 200 + 1000.0 / n * v)) <= 1000.0 / n * 3 + 1e-6
+    assert abs(tot[1] - (-0.1 * 200 + 1000.0 / n * int(e.e["tile_visited_count"][1]))) <= 1000.0 / n * 3 + 1e-6
+    # wheels of the parked car rest on the road
+    assert all(e.wheel_on_road(1, w) for w in range(4))
+
+
+def test_out_of_playfield_and_step_limit_end_the_episode():
+    e = fresh_env()
+    e.e["car"][0]["hull"]["cx"] = 400.0  # |x| > PLAYFIELD = 333.33
+    _, d = e.step([[0.0, 0.0], [0.0, 0.0]])
+    assert d[0] == 1 and d[1] == 0
+    e2 = fresh_env()
+    e2.e["step_count"] = 1001
+    _, d = e2.step([[0.0, 0.0], [0.0, 0.0]])
+    assert d.tolist() == [1, 1]
+
+
+def test_observation_raster_structure():
+    e = fresh_env()
+    for _ in range(40):
+        e.step([[0.0, 0.7], [0.0, 0.7]])
+    for viewer in range(2):
+        img = e.render(viewer)
+        assert img.shape == (96, 96)
+        assert set(np.unique(img).tolist()) <= {0, 29, 44, 60, 76, 101, 103, 107, 149, 161, 176, 255}
+        # own hull (gray 60 = trunc(0.299*204)) sits around the camera anchor: 16 units ahead of
+        # the car is the image centre, so the car is ~28 px below it
+        ys, xs = np.nonzero(img == 60)
+        assert len(ys) > 10 and 66 < ys.mean() < 86 and 40 < xs.mean() < 56
+        # indicator strip: rows 86.. are black except the bars
+        assert (img[86:, :10] == 0).all() and (img[86:] == 0).mean() > 0.8
+        # road under the car, grass somewhere
+        assert np.isin(img[:86], [101, 103, 107]).mean() > 0.1 and np.isin(img[:86], [161, 176]).mean() > 0.1
+    # the other car shows up in blue-gray 29 in at least one of the two views
+    assert (e.render(0)[:86] == 29).any() or (e.render(1)[:86] == 29).any()
