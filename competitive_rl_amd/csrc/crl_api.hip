@@ -247,6 +247,7 @@ int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **
         return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
     if (opts->num_envs <= 0) return fail(CRL_EINVAL, "num_envs must be positive");
     if (opts->env_kind == CRL_ENV_CAR_DOUBLE) {
+        if (opts->frame_stack < 0 || opts->frame_stack > 8) return fail(CRL_EINVAL, "frame_stack must be 1..8");
         int nd = 0;
         HIP_TRY(hipGetDeviceCount(&nd));
         if (opts->device < 0 || opts->device >= nd) return fail(CRL_EINVAL, "device %d of %d", opts->device, nd);

@@ -14,11 +14,13 @@ struct crl_car_ctx {
     crl_opts o;
     int64_t n;
     CarSoA s{};
-    CarConsts K{};
+    CarConsts K_{};
     CarTrackSrc src{};
     std::vector<void *> allocs;
     uint8_t *done_car = nullptr, *done_env = nullptr;
     float *rew_tmp = nullptr;
+    int K = 1;                      // MultipleFrameStack depth (1 = no stack)
+    uint8_t *frame = nullptr, *stack = nullptr;  // K > 1: newest frames, and the context's own stack
     double *ru = nullptr;
     uint8_t *rshuffle = nullptr;
 };
@@ -120,8 +122,13 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     if (!rc) rc = calloc_dev(c, &c->done_car, 2 * n);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, 2 * n);
+    c->K = opts->frame_stack < 1 ? 1 : opts->frame_stack;
+    if (c->K > 1) {
+        if (!rc) rc = calloc_dev(c, &c->frame, (size_t)2 * n * 96 * 96);
+        if (!rc) rc = calloc_dev(c, &c->stack, (size_t)2 * n * c->K * 96 * 96);
+    }
     if (rc) { crl_car_destroy(c); return rc; }
-    make_consts(c->K);
+    make_consts(c->K_);
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
     *out = c;
     return CRL_OK;
@@ -137,18 +144,29 @@ void crl_car_destroy(crl_car_ctx *c) {
 }
 
 void crl_car_seed(crl_car_ctx *c, uint64_t seed) { c->src.seed = seed; }
-int64_t crl_car_obs_bytes(const crl_car_ctx *) { return 2 * CRL_CAR_OBS * CRL_CAR_OBS; }
+int64_t crl_car_obs_bytes(const crl_car_ctx *c) { return (int64_t)2 * c->K * CRL_CAR_OBS * CRL_CAR_OBS; }
+
+// newest frames -> obs_dev, through the frame stack when K > 1
+static void draw(crl_car_ctx *c, uint8_t *obs_dev, bool fill_all, hipStream_t st) {
+    if (c->K == 1) {
+        launch_car_raster(c->s, c->K_, obs_dev, st);
+        return;
+    }
+    launch_car_raster(c->s, c->K_, c->frame, st);
+    launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, fill_all, c->K, c->n, st);
+}
 
 int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
-    launch_car_reset(c->s, c->K, c->src, false, nullptr, st);
-    if (obs_dev) launch_car_raster(c->s, c->K, obs_dev, st);
+    launch_car_reset(c->s, c->K_, c->src, false, nullptr, st);
+    if (obs_dev) draw(c, obs_dev, true, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car reset: %s", hipGetErrorString(e));
     return CRL_OK;
 }
 
 int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
-    launch_car_raster(c->s, c->K, obs_dev, st);
+    if (c->K > 1) return crl_fail(CRL_ESTATE, "crl_render on a stacked CarRacing context would advance the stack");
+    launch_car_raster(c->s, c->K_, obs_dev, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car render: %s", hipGetErrorString(e));
     return CRL_OK;
@@ -159,14 +177,14 @@ int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
 int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
                  crl_timer *tm) {
     crl_timer_begin(tm, 0, st);
-    launch_car_step(c->s, c->K, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, st);
+    launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, st);
     launch_car_post(c->s, c->done_car, c->done_env, 1000, st);
-    launch_car_reset(c->s, c->K, c->src, true, c->done_env, st);
+    launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
     crl_timer_end(tm, 0, st);
     if (done_dev) hipMemcpyAsync(done_dev, c->done_env, c->n, hipMemcpyDeviceToDevice, st);
     if (obs_dev) {
         crl_timer_begin(tm, 1, st);
-        launch_car_raster(c->s, c->K, obs_dev, st);
+        draw(c, obs_dev, false, st);
         crl_timer_end(tm, 1, st);
     }
     hipError_t e = hipGetLastError();

@@ -41,10 +41,9 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
     if log_dir:
         os.makedirs(log_dir, exist_ok=True)
     if env_id == "cCarRacingDouble-v0":
-        if frame_stack is not None:
-            raise NotImplementedError("MultipleFrameStack is not fused yet: pass frame_stack=None")
         return HipCarVecEnv(num_envs, seed=seed, device=device, env_id_base=env_id_base, output=output,
-                            dones="subproc" if asynchronous else "dummy", action_repeat=action_repeat)
+                            dones="subproc" if asynchronous else "dummy", action_repeat=action_repeat,
+                            frame_stack=frame_stack)
     if env_id == "cPongDouble-v0":
         assert frame_stack is None
     return HipPongVecEnv(num_envs, seed=seed, mode="wrapped", resized_dim=resized_dim, frame_stack=stack_planes,

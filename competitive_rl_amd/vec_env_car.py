@@ -45,7 +45,8 @@ class CarLazyInfos:
 
 
 class HipCarVecEnv(VecEnv):
-    def __init__(self, num_envs, seed=0, device=None, env_id_base=0, output="torch", dones="dummy", action_repeat=None):
+    def __init__(self, num_envs, seed=0, device=None, env_id_base=0, output="torch", dones="dummy", action_repeat=None,
+                 frame_stack=None):
         if not torch.cuda.is_available():
             raise RuntimeError("HipCarVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -55,7 +56,8 @@ class HipCarVecEnv(VecEnv):
         self._L = N.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.output, self.dones_kind, self.closed = output, dones, False
-        opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE, obs_mode=0, resized_dim=0, frame_stack=1, num_envs=int(num_envs),
+        self.K = 1 if frame_stack is None else int(frame_stack)
+        opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE, obs_mode=0, resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
                          env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0, reserved=0)
         h = C.c_void_p()
         dummy = np.zeros(16, np.uint8)  # crl_create's atlas argument is only used by Pong contexts
@@ -63,11 +65,11 @@ class HipCarVecEnv(VecEnv):
             N.check(self._L.crl_create(C.byref(opts), dummy.ctypes.data_as(C.c_void_p), C.byref(h)))
         self._h = h
         n = int(num_envs)
-        obs_space = spaces.Box(0, 255, (2, 96, 96), dtype=np.uint8)
+        obs_space = spaces.Box(0, 255, (2 * self.K, 96, 96), dtype=np.uint8)
         act_space = spaces.Box(-1, 1, (2, 2), dtype=np.float32)
         VecEnv.__init__(self, n, obs_space, act_space)
         dev = self.device
-        self._obs = [torch.empty((n, 2, 96, 96), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._obs = [torch.empty((n, 2 * self.K, 96, 96), dtype=torch.uint8, device=dev) for _ in range(2)]
         self._flip = 0
         self._rew = torch.zeros((n, 2), dtype=torch.float32, device=dev)
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)

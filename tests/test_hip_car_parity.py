@@ -225,3 +225,45 @@ def test_car_api_surface_and_time_limit():
         envs.step(np.zeros((6, 2), np.float32))
     envs.close()
     envs.close()
+
+
+def test_multiple_frame_stack_semantics():
+    """MultipleFrameStack + FlattenMultiAgentObservation (atari_wrappers.py:262-334): per agent the
+    last K frames oldest-first, agents on the channel axis; reset and auto-reset fill all K slots."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from collections import deque
+
+    n, K, steps = 5, 4, 40
+    one = crl.make_envs("cCarRacingDouble-v0", num_envs=n, frame_stack=None, log_dir=None, seed=8)
+    stk = crl.make_envs("cCarRacingDouble-v0", num_envs=n, frame_stack=K, log_dir=None, seed=8)
+    f0 = one.reset().cpu().numpy()
+    s0 = stk.reset().cpu().numpy()
+    assert s0.shape == (n, 2 * K, 96, 96) and stk.observation_space.shape == (2 * K, 96, 96)
+    dq = [[deque([f0[i, a]] * K, maxlen=K) for a in range(2)] for i in range(n)]
+    want = np.stack([np.concatenate([np.stack(dq[i][a]) for a in range(2)]) for i in range(n)])
+    assert np.array_equal(s0, want)
+    rs = np.random.RandomState(2)
+    st = one.get_state()
+    for t in range(steps):
+        acts = rs.uniform(-1, 1, (n, 2, 2)).astype(np.float32)
+        if t == 20:  # force an early episode end in env 1: car 0 leaves the playfield
+            for e in (one, stk):
+                s_ = e.get_state()
+                s_["car"][1, 0]["hull"]["cx"] = 400.0
+                e.set_state(s_)
+        f, _, d1, _ = one.step(acts)
+        s, _, d4, _ = stk.step(acts)
+        assert torch.equal(d1, d4)
+        f = f.cpu().numpy()
+        for i in range(n):
+            for a in range(2):
+                if bool(d1[i, 0]):
+                    dq[i][a] = deque([f[i, a]] * K, maxlen=K)
+                else:
+                    dq[i][a].append(f[i, a])
+        want = np.stack([np.concatenate([np.stack(dq[i][a]) for a in range(2)]) for i in range(n)])
+        assert np.array_equal(s.cpu().numpy(), want), t
+        if t == 20:
+            assert bool(d1[1, 0])
+    one.close(), stk.close()
