@@ -7,7 +7,8 @@ from .make_envs import make_envs
 from .vec_env import CHEAT_CODES, HipPongVecEnv, LazyInfos, VecEnv
 from .vec_env_car import HipCarVecEnv
 from .frame_stack import FrameStackTensor
+from .tournament import TournamentEnvWrapper
 from .sharding import ShardSpec, all_gather_step, shard_of
 
-__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "CHEAT_CODES",
+__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "CHEAT_CODES",
            "ShardSpec", "shard_of", "all_gather_step"]

@@ -8,7 +8,8 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libcrl_hip.so")
 
-CRL_ENV_PONG_DOUBLE, CRL_ENV_CAR_DOUBLE = 1, 2
+CRL_ENV_PONG_DOUBLE, CRL_ENV_CAR_DOUBLE, CRL_ENV_PONG_SINGLE = 1, 2, 3
+CRL_FLAG_STACK_REPLICATE = 1
 CAR_MAX_TILES = 512
 CRL_OBS_RAW_RGB, CRL_OBS_GRAY_RESIZED = 0, 1
 PONG_FRAME_BYTES = 210 * 160 * 3
@@ -43,7 +44,7 @@ CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("
 class CrlOpts(C.Structure):
     _fields_ = [("env_kind", C.c_int32), ("obs_mode", C.c_int32), ("resized_dim", C.c_int32),
                 ("frame_stack", C.c_int32), ("num_envs", C.c_int64), ("env_id_base", C.c_int64),
-                ("seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("seed", C.c_uint64), ("device", C.c_int32), ("flags", C.c_int32)]
 
 
 class CrlError(RuntimeError):

@@ -129,6 +129,15 @@ void crl_timer_end(crl_timer *t, int which, hipStream_t st) {
 static void begin_timed(crl_ctx *c, int which, hipStream_t st) { crl_timer_begin(&c->tm, which, st); }
 static void end_timed(crl_ctx *c, int which, hipStream_t st) { crl_timer_end(&c->tm, which, st); }
 
+static PongMode pong_mode(const crl_ctx *c) {
+    PongMode m;
+    m.wrapped = c->o.obs_mode == CRL_OBS_GRAY_RESIZED;
+    m.single = c->o.env_kind == CRL_ENV_PONG_SINGLE;
+    m.replicate = (c->o.flags & CRL_FLAG_STACK_REPLICATE) != 0;
+    return m;
+}
+static int pong_views(const crl_ctx *c) { return c->o.env_kind == CRL_ENV_PONG_SINGLE ? 1 : 2; }
+
 static int setup_gray(crl_ctx *c) {
     const int R = c->o.resized_dim;
     AreaTab xt = area_table(CRL_PONG_W, R), yt = area_table(CRL_PONG_H, R);
@@ -243,7 +252,7 @@ const char *crl_version(void) { return "crl-hip 0.1 (gfx950)"; }
 
 int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out) {
     if (!opts || !out || !score_atlas_host) return fail(CRL_EINVAL, "null argument");
-    if (opts->env_kind != CRL_ENV_PONG_DOUBLE && opts->env_kind != CRL_ENV_CAR_DOUBLE)
+    if (opts->env_kind != CRL_ENV_PONG_DOUBLE && opts->env_kind != CRL_ENV_CAR_DOUBLE && opts->env_kind != CRL_ENV_PONG_SINGLE)
         return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
     if (opts->num_envs <= 0) return fail(CRL_EINVAL, "num_envs must be positive");
     if (opts->env_kind == CRL_ENV_CAR_DOUBLE) {
@@ -336,10 +345,10 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
     if (!obs_dev) return CRL_OK;
     begin_timed(c, 1, st);
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
-        launch_pong_raster_raw(c->s.obs_frames, c->n, c->atlas_rgb, c->ink_row0, c->ink_row1, obs_dev, st);
+        launch_pong_raster_raw(c->s.obs_frames, c->n, c->atlas_rgb, c->ink_row0, c->ink_row1, obs_dev, pong_views(c), st);
     } else {
         GrayParams p{};
-        p.ring = c->s.ring, p.n = c->n, p.R = c->o.resized_dim, p.K = c->o.frame_stack;
+        p.ring = c->s.ring, p.n = c->n, p.R = c->o.resized_dim, p.K = c->o.frame_stack, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = obs_dev;
@@ -355,7 +364,7 @@ int crl_reset(crl_ctx *c, uint8_t *obs_dev, void *stream) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
     hipStream_t st = (hipStream_t)stream;
     if (c->car) return crl_car_reset(c->car, obs_dev, st);
-    launch_pong_reset(c->s, c->src, c->n, st);
+    launch_pong_reset(c->s, c->src, c->n, pong_mode(c), st);
     HIP_TRY(hipGetLastError());
     return draw_obs(c, obs_dev, st);
 }
@@ -373,7 +382,7 @@ int crl_step(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_
     if (c->car) return crl_car_step(c->car, (const float *)actions_void, obs_dev, rew_dev, done_dev, st, &c->tm);
     const int32_t *actions_dev = (const int32_t *)actions_void;
     begin_timed(c, 0, st);
-    launch_pong_dynamics(c->s, c->src, actions_dev, c->n, c->o.obs_mode == CRL_OBS_GRAY_RESIZED, rew_dev, done_dev, st);
+    launch_pong_dynamics(c->s, c->src, actions_dev, c->n, pong_mode(c), rew_dev, done_dev, st);
     end_timed(c, 0, st);
     HIP_TRY(hipGetLastError());
     return draw_obs(c, obs_dev, st);
@@ -399,8 +408,8 @@ int crl_copy_info(crl_ctx *c, float *rr_out, int32_t *ns_out, void *stream) {
 int64_t crl_obs_bytes_per_env(const crl_ctx *c) {
     if (!c) return 0;
     if (c->car) return crl_car_obs_bytes(c->car);
-    if (c->o.obs_mode == CRL_OBS_RAW_RGB) return 2 * (int64_t)CRL_PONG_FRAME_BYTES;
-    return 2 * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim;
+    if (c->o.obs_mode == CRL_OBS_RAW_RGB) return pong_views(c) * (int64_t)CRL_PONG_FRAME_BYTES;
+    return pong_views(c) * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim;
 }
 
 // Renders `count` frame pairs (host) through a temporary context-less launch.
@@ -412,7 +421,7 @@ static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::
     HIP_TRY(hipMalloc((void **)&tmp, (size_t)8 * m * 8));
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
         HIP_TRY(hipMemcpyAsync(tmp, f0.data(), m * 8, hipMemcpyHostToDevice, st));
-        launch_pong_raster_raw(tmp, m, c->atlas_rgb, c->ink_row0, c->ink_row1, out_dev, st);
+        launch_pong_raster_raw(tmp, m, c->atlas_rgb, c->ink_row0, c->ink_row1, out_dev, pong_views(c), st);
     } else {
         // single-plane ring: only plane 3 is drawn with K = 1
         std::vector<uint64_t> ring((size_t)8 * m, kBlankFrame);
@@ -421,7 +430,7 @@ static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::
         HIP_TRY(hipMemcpyAsync(tmp, ring.data(), ring.size() * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));  // `ring` is a local
         GrayParams p{};
-        p.ring = tmp, p.n = m, p.R = c->o.resized_dim, p.K = 1;
+        p.ring = tmp, p.n = m, p.R = c->o.resized_dim, p.K = 1, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = out_dev;

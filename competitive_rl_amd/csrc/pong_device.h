@@ -198,11 +198,14 @@ __device__ inline void store_env(const PongSoA &s, int64_t i, const PongEnv &e) 
 }
 
 // launchers (defined in the .hip files, called from crl_api.hip)
-void launch_pong_reset(const PongSoA &s, const ServeSrc &src, int64_t n, hipStream_t st);
-void launch_pong_dynamics(const PongSoA &s, const ServeSrc &src, const int32_t *actions, int64_t n, bool wrapped,
+struct PongMode {
+    bool wrapped, single, replicate;  // MaxAndSkip path; cPong-v0 (AutoBat on the right); FrameStack fill
+};
+void launch_pong_reset(const PongSoA &s, const ServeSrc &src, int64_t n, PongMode mode, hipStream_t st);
+void launch_pong_dynamics(const PongSoA &s, const ServeSrc &src, const int32_t *actions, int64_t n, PongMode mode,
                           float *rew, uint8_t *done, hipStream_t st);
 void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *atlas_rgb, int ink_row0, int ink_row1,
-                            uint8_t *obs, hipStream_t st);
+                            uint8_t *obs, int views, hipStream_t st);
 
 // Byte offsets of the dense INTER_AREA tables inside the blob the gray kernel stages into
 // LDS: xa/ya = float[5][R] weights (tap k of output index d at [k*R + d]); xs0/xn, ys0/yn =
@@ -215,7 +218,7 @@ struct GrayTabOfs {
 struct GrayParams {
     const uint64_t *ring;    // [8][n] frame pairs of the 4 stack planes; plane 3 = newest (K=1 draws only it)
     int64_t n;
-    int R, K;
+    int R, K, views;
     const uint8_t *atlas_gray;  // [22*22][34][160]
     const uint8_t *band;        // pre-resized top band [22*22][2 views][band_rows][R]
     int band_rows;

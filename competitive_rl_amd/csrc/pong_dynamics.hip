@@ -14,7 +14,7 @@
 
 namespace crl {
 
-__global__ __launch_bounds__(256) void pong_reset_kernel(PongSoA s, ServeSrc src, int64_t n) {
+__global__ __launch_bounds__(256) void pong_reset_kernel(PongSoA s, ServeSrc src, int64_t n, int replicate) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     PongEnv e;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void pong_reset_kernel(PongSoA s, ServeSrc src
     const uint64_t f = frame_of(e);
     s.obs_frames[i] = f, s.obs_frames[n + i] = f;
     // stack after reset = [0, 0, 0, reset_obs]  (FrameStackTensor.reset + update)
-    for (int h = 0; h < 6; h++) s.ring[h * n + i] = kBlankFrame;
+    for (int h = 0; h < 6; h++) s.ring[h * n + i] = replicate ? f : kBlankFrame;
     s.ring[6 * n + i] = f, s.ring[7 * n + i] = f;
     s.real_reward[2 * i] = 0.f, s.real_reward[2 * i + 1] = 0.f;
     s.num_steps[i] = 0;
@@ -35,17 +35,21 @@ __global__ __launch_bounds__(256) void pong_reset_kernel(PongSoA s, ServeSrc src
 template <bool WRAPPED>
 __global__ __launch_bounds__(256) void pong_dynamics_kernel(PongSoA s, ServeSrc src, const int32_t *__restrict__ actions,
                                                             int64_t n, float *__restrict__ rew,
-                                                            uint8_t *__restrict__ done_out) {
+                                                            uint8_t *__restrict__ done_out, int single, int replicate) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     PongEnv e = load_env(s, i);
-    const int2 a = reinterpret_cast<const int2 *>(actions)[i];
+    // cPong-v0: one action per env, the right bat is the AutoBat = CHEAT_CODES on that side
+    const int2 a = single ? make_int2(actions[i], CRL_PONG_CHEAT) : reinterpret_cast<const int2 *>(actions)[i];
     int r_l, r_r;
     bool done;
     if (!WRAPPED) {
         done = frame_step(e, a.x, a.y, src, i, r_l, r_r);
         const float fl = (float)r_l, fr = (float)r_r;
-        if (rew) reinterpret_cast<float2 *>(rew)[i] = make_float2(fl, fr);
+        if (rew) {
+            if (single) rew[i] = fl;
+            else reinterpret_cast<float2 *>(rew)[i] = make_float2(fl, fr);
+        }
         reinterpret_cast<float2 *>(s.real_reward)[i] = make_float2(fl, fr);
         if (done) {
             const uint64_t t = frame_of(e);
@@ -74,9 +78,11 @@ __global__ __launch_bounds__(256) void pong_dynamics_kernel(PongSoA s, ServeSrc 
     int ws = s.wrap_steps[i] + 1;
     reinterpret_cast<float2 *>(s.real_reward)[i] = make_float2((float)tot_l, (float)tot_r);
     s.num_steps[i] = ws;
-    if (rew)
-        reinterpret_cast<float2 *>(rew)[i] =
-            make_float2((float)((tot_l > 0) - (tot_l < 0)), (float)((tot_r > 0) - (tot_r < 0)));
+    if (rew) {
+        const float sl = (float)((tot_l > 0) - (tot_l < 0)), sr = (float)((tot_r > 0) - (tot_r < 0));
+        if (single) rew[i] = sl;
+        else reinterpret_cast<float2 *>(rew)[i] = make_float2(sl, sr);
+    }
     if (done_out) done_out[i] = done ? 1 : 0;
     uint64_t f0 = k0, f1 = k1;
     if (done) {
@@ -95,25 +101,27 @@ __global__ __launch_bounds__(256) void pong_dynamics_kernel(PongSoA s, ServeSrc 
     // ring plane p (0 oldest .. 3 newest), slot sl: ring[(2p + sl) * n + i].
 #pragma unroll
     for (int p = 0; p < 3; p++) {
-        uint64_t a0 = done ? kBlankFrame : s.ring[(2 * (p + 1) + 0) * n + i];
-        uint64_t a1 = done ? kBlankFrame : s.ring[(2 * (p + 1) + 1) * n + i];
+        // done: FrameStackTensor zeroes the history; the FrameStack wrapper refills it with the reset frame
+        uint64_t a0 = done ? (replicate ? f0 : kBlankFrame) : s.ring[(2 * (p + 1) + 0) * n + i];
+        uint64_t a1 = done ? (replicate ? f1 : kBlankFrame) : s.ring[(2 * (p + 1) + 1) * n + i];
         s.ring[(2 * p + 0) * n + i] = a0, s.ring[(2 * p + 1) * n + i] = a1;
     }
     s.ring[6 * n + i] = f0, s.ring[7 * n + i] = f1;
     store_env(s, i, e);
 }
 
-void launch_pong_reset(const PongSoA &s, const ServeSrc &src, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(pong_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, src, n);
+void launch_pong_reset(const PongSoA &s, const ServeSrc &src, int64_t n, PongMode mode, hipStream_t st) {
+    hipLaunchKernelGGL(pong_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, src, n, mode.replicate ? 1 : 0);
 }
 
-void launch_pong_dynamics(const PongSoA &s, const ServeSrc &src, const int32_t *actions, int64_t n, bool wrapped,
+void launch_pong_dynamics(const PongSoA &s, const ServeSrc &src, const int32_t *actions, int64_t n, PongMode mode,
                           float *rew, uint8_t *done, hipStream_t st) {
     dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (wrapped)
-        hipLaunchKernelGGL(pong_dynamics_kernel<true>, grid, block, 0, st, s, src, actions, n, rew, done);
+    const int single = mode.single ? 1 : 0, rep = mode.replicate ? 1 : 0;
+    if (mode.wrapped)
+        hipLaunchKernelGGL(pong_dynamics_kernel<true>, grid, block, 0, st, s, src, actions, n, rew, done, single, rep);
     else
-        hipLaunchKernelGGL(pong_dynamics_kernel<false>, grid, block, 0, st, s, src, actions, n, rew, done);
+        hipLaunchKernelGGL(pong_dynamics_kernel<false>, grid, block, 0, st, s, src, actions, n, rew, done, single, rep);
 }
 
 }  // namespace crl

@@ -66,7 +66,7 @@ __device__ inline uint8_t eval_pixel(const GrayCtx &g, const Frame &fa, const Fr
 }
 
 struct GrayGeom {
-    int R, K, band_rows, band_chunks;  // band table holds band_chunks*16 bytes per (score pair, view)
+    int R, K, views, band_rows, band_chunks;  // band table holds band_chunks*16 bytes per (score pair, view)
     const uint8_t *band;               // [484][2][band_chunks*16]
     const uint8_t *rest;               // [R*R] score-independent template (used for bytes >= band_chunks*16)
     int zero_row0, zero_row1;          // output rows [zero_row0, zero_row1) of the template are all 0
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *_
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    const int tiles_per_env = 2 * q.K;
+    const int tiles_per_env = q.views * q.K;
     if (tile >= n * tiles_per_env) return;
     const int64_t env = tile / tiles_per_env;
     const int t = (int)(tile - env * tiles_per_env);
@@ -329,7 +329,7 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     if (p.n <= 0) return;
     GrayCtx g = {p.atlas_gray, p.xofs, p.yofs, p.xsi, p.ysi, p.xalpha, p.yalpha};
     GrayGeom q;
-    q.R = p.R, q.K = p.K, q.band_rows = p.band_rows, q.band_chunks = band_chunks;
+    q.R = p.R, q.K = p.K, q.views = p.views > 0 ? p.views : 2, q.band_rows = p.band_rows, q.band_chunks = band_chunks;
     q.band = p.band, q.rest = rest, q.zero_row0 = zero_row0, q.zero_row1 = zero_row1;
     q.x_first = x_first, q.x_last = x_last, q.y_first = y_first, q.y_last = y_last;
     q.tab_blob = tab_blob, q.t = tofs;
@@ -337,7 +337,7 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         static const int dbg = getenv("CRL_GRAY_DEBUG") ? atoi(getenv("CRL_GRAY_DEBUG")) : 0;
         q.debug = dbg;
     }
-    const int64_t tiles = p.n * 2 * p.K;
+    const int64_t tiles = p.n * q.views * p.K;
     hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
                        p.obs);
 }

@@ -38,16 +38,16 @@ __device__ inline uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
 __global__ __launch_bounds__(256) void pong_raster_raw_kernel(const uint64_t *__restrict__ frames,
                                                               const uint4 *__restrict__ atlas_rgb, int ink_row0,
-                                                              int ink_row1, uint4 *__restrict__ obs) {
+                                                              int ink_row1, uint4 *__restrict__ obs, int views) {
     const int64_t env = blockIdx.x;
     const uint64_t packed = frames[env];  // wave-uniform -> scalar load
     const Frame f = unpack_frame(packed);
-    uint4 *__restrict__ out = obs + env * (int64_t)(2 * kFrameChunks);
+    uint4 *__restrict__ out = obs + env * (int64_t)(views * kFrameChunks);
     const bool blank = f.sl == 255;
     const uint4 *__restrict__ band = atlas_rgb + (int64_t)((blank ? 0 : f.sl * 22 + f.sr) * CRL_PONG_TOP) * kRowChunks;
     const uint32_t bg = blank ? 0u : 0xFFFFFFFFu;
 
-    for (int q = threadIdx.x; q < 2 * kFrameChunks; q += 256) {
+    for (int q = threadIdx.x; q < views * kFrameChunks; q += 256) {
         const int view = q >= kFrameChunks;
         const int c = q - view * kFrameChunks;
         const int row = c / kRowChunks;
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(256) void pong_raster_raw_kernel(const uint64_t *__
 }
 
 void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *atlas_rgb, int ink_row0, int ink_row1,
-                            uint8_t *obs, hipStream_t st) {
+                            uint8_t *obs, int views, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(pong_raster_raw_kernel, dim3((unsigned)n), dim3(256), 0, st, frames,
-                       reinterpret_cast<const uint4 *>(atlas_rgb), ink_row0, ink_row1, reinterpret_cast<uint4 *>(obs));
+                       reinterpret_cast<const uint4 *>(atlas_rgb), ink_row0, ink_row1, reinterpret_cast<uint4 *>(obs), views);
 }
 
 }  // namespace crl

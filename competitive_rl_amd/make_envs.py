@@ -11,7 +11,7 @@ from .vec_env_car import HipCarVecEnv
 
 __all__ = ["make_envs"]
 
-_HIP_IDS = ("cPongDouble-v0", "cCarRacingDouble-v0")
+_HIP_IDS = ("cPongDouble-v0", "cPong-v0", "cPongTournament-v0", "cCarRacingDouble-v0")
 
 
 def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronous=False, resized_dim=42,
@@ -38,8 +38,19 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
     if env_id not in _HIP_IDS:
         raise NotImplementedError(
             f"{env_id!r} is not served by the HIP backend yet (available: {_HIP_IDS})")
+    if env_id == "cPongTournament-v0":  # make_envs.py:93-96
+        from .tournament import TournamentEnvWrapper
+
+        envs = make_envs("cPongDouble-v0", seed, log_dir, num_envs, asynchronous, resized_dim, None, backend=backend,
+                         device=device, output=output, obs_dtype=obs_dtype, env_id_base=env_id_base)
+        return TournamentEnvWrapper(envs, num_envs)
     if log_dir:
         os.makedirs(log_dir, exist_ok=True)
+    if env_id == "cPong-v0":  # make_env_a2c_atari + FrameStack(frame_stack) (atari_wrappers.py:40-53)
+        k = 1 if frame_stack is None else int(frame_stack)
+        return HipPongVecEnv(num_envs, seed=seed, mode="wrapped", resized_dim=resized_dim, frame_stack=k, device=device,
+                             env_id_base=env_id_base, output=output, obs_dtype=obs_dtype,
+                             dones="subproc" if asynchronous else "dummy", single_player=True, stack_replicate=True)
     if env_id == "cCarRacingDouble-v0":
         return HipCarVecEnv(num_envs, seed=seed, device=device, env_id_base=env_id_base, output=output,
                             dones="subproc" if asynchronous else "dummy", action_repeat=action_repeat,

@@ -71,8 +71,8 @@ class LazyInfos:
     (atari_wrappers.py:179-180, dummy_vec_env.py:55-57).  Host copies happen on first use.
     """
 
-    def __init__(self, env, wrapped, done, real_reward, num_steps):
-        self._env, self._wrapped = env, wrapped
+    def __init__(self, env, wrapped, done, real_reward, num_steps, single=False):
+        self._env, self._wrapped, self._single = env, wrapped, single
         self._done_dev, self._rr_dev, self._ns_dev = done, real_reward, num_steps
         self._host = None
 
@@ -95,7 +95,7 @@ class LazyInfos:
             raise IndexError(i)
         d = {}
         if self._wrapped:
-            d["real_reward"] = [float(rr[i, 0]), float(rr[i, 1])]
+            d["real_reward"] = float(rr[i, 0]) if self._single else [float(rr[i, 0]), float(rr[i, 1])]
             d["num_steps"] = int(ns[i])
         if done[i]:
             d["terminal_observation"] = self._env.terminal_observation([i])[0]
@@ -140,7 +140,8 @@ class HipPongVecEnv(VecEnv):
     """
 
     def __init__(self, num_envs, seed=0, mode="wrapped", resized_dim=84, frame_stack=1, device=None,
-                 env_id_base=0, output="torch", obs_dtype="uint8", dones="dummy", score_atlas=None):
+                 env_id_base=0, output="torch", obs_dtype="uint8", dones="dummy", score_atlas=None,
+                 single_player=False, stack_replicate=False):
         if not torch.cuda.is_available():
             raise RuntimeError("HipPongVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -151,11 +152,13 @@ class HipPongVecEnv(VecEnv):
         self.mode, self.R, self.K = mode, int(resized_dim), int(frame_stack)
         self.output, self.obs_dtype, self.dones_kind = output, obs_dtype, dones
         self.closed = False
-        opts = N.CrlOpts(env_kind=N.CRL_ENV_PONG_DOUBLE,
+        self.single, self.V = bool(single_player), 1 if single_player else 2
+        self.stack_replicate = bool(stack_replicate)
+        opts = N.CrlOpts(env_kind=N.CRL_ENV_PONG_SINGLE if single_player else N.CRL_ENV_PONG_DOUBLE,
                          obs_mode=N.CRL_OBS_GRAY_RESIZED if mode == "wrapped" else N.CRL_OBS_RAW_RGB,
                          resized_dim=self.R if mode == "wrapped" else 0, frame_stack=self.K if mode == "wrapped" else 1,
                          num_envs=int(num_envs), env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1),
-                         device=self.device.index or 0, reserved=0)
+                         device=self.device.index or 0, flags=N.CRL_FLAG_STACK_REPLICATE if stack_replicate else 0)
         self._atlas = N.load_score_atlas() if score_atlas is None else np.ascontiguousarray(score_atlas, np.uint8)
         assert self._atlas.size == N.ATLAS_BYTES
         h = C.c_void_p()
@@ -164,18 +167,21 @@ class HipPongVecEnv(VecEnv):
         self._h = h
         n = int(num_envs)
         if mode == "wrapped":
-            self._obs_shape = (n, 2, self.K, self.R, self.R)
+            self._obs_shape = (n, self.V, self.K, self.R, self.R)
             box = spaces.Box(0, 255, (self.K, self.R, self.R), dtype=np.float32)
         else:
-            self._obs_shape = (n, 2, 210, 160, 3)
+            self._obs_shape = (n, self.V, 210, 160, 3)
             box = spaces.Box(0, 255, (210, 160, 3), dtype=np.float32)
-        VecEnv.__init__(self, n, spaces.Tuple([box, box]), spaces.Tuple([spaces.Discrete(3), spaces.Discrete(3)]))
+        if self.single:  # cPong-v0: Box / Discrete(3) (pong/base_pong_env.py:22-25)
+            VecEnv.__init__(self, n, box, spaces.Discrete(3))
+        else:
+            VecEnv.__init__(self, n, spaces.Tuple([box, box]), spaces.Tuple([spaces.Discrete(3), spaces.Discrete(3)]))
         dev = self.device
         self._obs = [torch.empty(self._obs_shape, dtype=torch.uint8, device=dev) for _ in range(2)]
         self._flip = 0
-        self._rew = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+        self._rew = torch.zeros((n,) if self.single else (n, 2), dtype=torch.float32, device=dev)
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
-        self._actions = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+        self._actions = torch.zeros((n,) if self.single else (n, 2), dtype=torch.int32, device=dev)
         self.envs = _EnvList(self)
         self.waiting = False
 
@@ -184,12 +190,12 @@ class HipPongVecEnv(VecEnv):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _format_obs(self, buf):
-        o0, o1 = buf[:, 0], buf[:, 1]
+        views = [buf[:, v] for v in range(self.V)]
         if self.obs_dtype == "float32":  # DummyVecEnv's buffer dtype (Box default)
-            o0, o1 = o0.float(), o1.float()
+            views = [v.float() for v in views]
         if self.output == "numpy":
-            return o0.cpu().numpy(), o1.cpu().numpy()
-        return o0, o1
+            views = [v.cpu().numpy() for v in views]
+        return views[0] if self.single else tuple(views)
 
     def _check_open(self):
         if self.closed:
@@ -216,8 +222,11 @@ class HipPongVecEnv(VecEnv):
             a = actions.to(device=self.device, dtype=torch.int32)
         else:
             a = torch.as_tensor(np.asarray(actions), dtype=torch.int32).to(self.device)
-        if a.shape != (self.num_envs, 2):
-            raise AssertionError(f"actions must have shape ({self.num_envs}, 2), got {tuple(a.shape)}")
+        want = (self.num_envs,) if self.single else (self.num_envs, 2)
+        if self.single and a.dim() == 2 and a.shape[1] == 1:
+            a = a[:, 0]
+        if tuple(a.shape) != want:
+            raise AssertionError(f"actions must have shape {want}, got {tuple(a.shape)}")
         self._actions = a.contiguous()
         self.waiting = True
 
@@ -229,15 +238,18 @@ class HipPongVecEnv(VecEnv):
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
         self.waiting = False
         done = self._done.bool()
-        if self.dones_kind == "dummy":  # scalar done broadcast over the 2 agents (dummy_vec_env.py:39-40)
-            done_out = done[:, None].expand(-1, 2)
+        if self.dones_kind == "dummy":  # scalar done broadcast over the agents (dummy_vec_env.py:39-40)
+            done_out = done[:, None].expand(-1, self.V)
         else:
             done_out = done
         rr = torch.empty((self.num_envs, 2), dtype=torch.float32, device=self.device)
         ns = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
         N.check(self._L.crl_copy_info(self._h, C.c_void_p(rr.data_ptr()), C.c_void_p(ns.data_ptr()), self._stream()))
-        infos = LazyInfos(self, self.mode == "wrapped", self._done.clone(), rr, ns)
+        infos = LazyInfos(self, self.mode == "wrapped", self._done.clone(), rr, ns, single=self.single)
         rew = self._rew.clone()
+        if self.single and self.dones_kind == "dummy":
+            rew = rew[:, None]  # buf_rews is (N, multi_agent = 1)
+        self._prev_buf = self._obs[self._flip]  # the observation before this step (still intact)
         if self.output == "numpy":
             return self._format_obs(buf), rew.cpu().numpy(), done_out.cpu().numpy().copy(), infos
         return self._format_obs(buf), rew, done_out.clone(), infos
@@ -284,19 +296,24 @@ class HipPongVecEnv(VecEnv):
     def terminal_observation(self, env_indices):
         """Observation the episode of each listed env ended on (its most recent done step)."""
         idx = np.ascontiguousarray(env_indices, np.int64)
-        shape = (len(idx), 2, 210, 160, 3) if self.mode == "raw" else (len(idx), 2, self.R, self.R)
+        shape = (len(idx), self.V, 210, 160, 3) if self.mode == "raw" else (len(idx), self.V, self.R, self.R)
         out = torch.empty(shape, dtype=torch.uint8, device=self.device)
         N.check(self._L.crl_terminal_observation(self._h, idx.ctypes.data_as(C.c_void_p), len(idx),
                                                  C.c_void_p(out.data_ptr()), self._stream()))
         res = []
         for k in range(len(idx)):
             if self.mode == "raw":
-                pair = (out[k, 0], out[k, 1])
+                pair = tuple(out[k, v] for v in range(self.V))
+            elif self.stack_replicate and self.K > 1:
+                # FrameStack wrapper: the terminal observation is the whole stack = the K-1 newest
+                # planes of the previous observation + the terminal frame (atari_wrappers.py:249-252)
+                prev = self._prev_buf[int(idx[k])]
+                pair = tuple(torch.cat([prev[v, 1:], out[k, v][None]]) for v in range(self.V))
             else:
-                pair = (out[k, 0][None], out[k, 1][None])  # (1, R, R) each, WrapPyTorch layout
+                pair = tuple(out[k, v][None] for v in range(self.V))  # (1, R, R) each, WrapPyTorch layout
             if self.output == "numpy":
                 pair = tuple(p.cpu().numpy() for p in pair)
-            res.append(pair)
+            res.append(pair[0] if self.single else pair)
         return res
 
     def get_state(self):

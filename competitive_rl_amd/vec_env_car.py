@@ -58,7 +58,7 @@ class HipCarVecEnv(VecEnv):
         self.output, self.dones_kind, self.closed = output, dones, False
         self.K = 1 if frame_stack is None else int(frame_stack)
         opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE, obs_mode=0, resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
-                         env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0, reserved=0)
+                         env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0, flags=0)
         h = C.c_void_p()
         dummy = np.zeros(16, np.uint8)  # crl_create's atlas argument is only used by Pong contexts
         with torch.cuda.device(self.device):

@@ -45,7 +45,18 @@ extern "C" {
 
 enum { CRL_OK = 0, CRL_EINVAL = -1, CRL_EHIP = -2, CRL_ENOMEM = -3, CRL_ESTATE = -4 };
 
-enum crl_env_kind { CRL_ENV_PONG_DOUBLE = 1 /* cPongDouble-v0 */, CRL_ENV_CAR_DOUBLE = 2 /* cCarRacingDouble-v0 */ };
+enum crl_env_kind {
+    CRL_ENV_PONG_DOUBLE = 1, /* cPongDouble-v0                                                    */
+    CRL_ENV_CAR_DOUBLE = 2,  /* cCarRacingDouble-v0                                               */
+    /* cPong-v0 (PongSinglePlayerEnv, pong/base_pong_env.py:16-82): the right bat is the AutoBat
+       (:445-454) = action 999 on that side; actions int32 (N), one view, obs (N,1,...) raw or
+       (N,K,R,R) wrapped, rewards f32 (N) = the left player's */
+    CRL_ENV_PONG_SINGLE = 3,
+};
+/* crl_opts.flags */
+#define CRL_FLAG_STACK_REPLICATE 1 /* FrameStack wrapper semantics (utils/atari_wrappers.py:243-247):
+                                      reset fills all K planes with the first frame, instead of
+                                      FrameStackTensor's zeroed history */
 
 /* ---- cCarRacingDouble-v0 (car_racing/car_racing_multi_players.py:54-88) */
 #define CRL_CAR_MAX_TILES 512 /* tiles of one track (reference tracks: 230-380) */
@@ -97,7 +108,7 @@ typedef struct crl_opts {
                             id so results do not depend on how envs are sharded      */
     uint64_t seed;       /* make_envs(seed=...)                                      */
     int32_t device;      /* HIP device ordinal                                       */
-    int32_t reserved;
+    int32_t flags;       /* CRL_FLAG_*                                                  */
 } crl_opts;
 
 typedef struct crl_ctx crl_ctx;

@@ -46,6 +46,7 @@ def lib():
         L.pong_oracle_destroy.argtypes = [vp]
         L.pong_oracle_set_threads.argtypes = [vp, i32]
         L.pong_oracle_seed.argtypes = [vp, u64]
+        L.pong_oracle_set_mode.argtypes = [vp, i32, i32]
         L.pong_oracle_set_replay.argtypes = [vp, vp, vp, vp, i64]
         L.pong_oracle_state.restype = vp
         L.pong_oracle_state.argtypes = [vp]
@@ -98,15 +99,18 @@ def render_gray(fa, fb, atlas, view, R):
 class PongOracle:
     """Batch of cPongDouble envs with VecEnv.step/reset semantics (auto-reset)."""
 
-    def __init__(self, num_envs, atlas, obs_mode=RAW, resized_dim=84, frame_stack=1, seed=0, env_id_base=0):
+    def __init__(self, num_envs, atlas, obs_mode=RAW, resized_dim=84, frame_stack=1, seed=0, env_id_base=0,
+                 single=False, replicate=False):
         self.n, self.mode, self.R, self.K = int(num_envs), obs_mode, int(resized_dim), int(frame_stack)
         self.atlas = np.ascontiguousarray(atlas, np.uint8)
         assert self.atlas.size == 22 * 22 * 34 * 160
         self.h = lib().pong_oracle_create(self.n, obs_mode, self.R, self.K, seed, env_id_base, _p(self.atlas))
         self._replay = None
-        shape = (self.n, 2, 210, 160, 3) if obs_mode == RAW else (self.n, 2, self.K, self.R, self.R)
+        self.single, self.V = bool(single), 1 if single else 2
+        lib().pong_oracle_set_mode(self.h, int(single), int(replicate))
+        shape = (self.n, self.V, 210, 160, 3) if obs_mode == RAW else (self.n, self.V, self.K, self.R, self.R)
         self.obs = np.zeros(shape, np.uint8)
-        self.rew = np.zeros((self.n, 2), np.float32)
+        self.rew = np.zeros((self.n,) if single else (self.n, 2), np.float32)
         self.done = np.zeros((self.n,), np.uint8)
 
     def close(self):
@@ -157,12 +161,12 @@ class PongOracle:
         return self.obs
 
     def step(self, actions, render=True):
-        a = np.ascontiguousarray(actions, np.int32).reshape(self.n, 2)
+        a = np.ascontiguousarray(actions, np.int32).reshape((self.n,) if self.single else (self.n, 2))
         lib().pong_oracle_step(self.h, _p(a), _p(self.obs) if render else None, _p(self.rew), _p(self.done))
         return self.obs, self.rew, self.done
 
     def terminal_observation(self, i):
-        shape = (2, 210, 160, 3) if self.mode == RAW else (2, self.R, self.R)
+        shape = (self.V, 210, 160, 3) if self.mode == RAW else (self.V, self.R, self.R)
         out = np.empty(shape, np.uint8)
         lib().pong_oracle_terminal_observation(self.h, int(i), _p(out))
         return out

@@ -166,6 +166,65 @@ def main():
     print("steps", T, "envs", N, "dones", int(dones[:, :, 0].sum()), "points", int((real != 0).any(-1).sum()),
           "terminal obs", len(term_t), "draws/env", nd.tolist())
 
+    # ---------------------------------------------------------------- cPong-v0 (single player, FrameStack 4)
+    N1, T1, K = 3, 700, 4
+    router1 = Router(N1, 900)
+    pong.random = router1
+
+    def thunk1(i):
+        inner = aw.make_env_a2c_atari("cPong-v0", 0, i, None, R, K)
+
+        def f():
+            router1.cur = i
+
+            class Tag1(gym.Wrapper):
+                def step(self, a):
+                    router1.cur = i
+                    return self.env.step(a)
+
+                def reset(self, **kw):
+                    router1.cur = i
+                    return self.env.reset(**kw)
+
+            return Tag1(inner())
+
+        return f
+
+    venv1 = dv.DummyVecEnv([thunk1(i) for i in range(N1)])
+    for s_ in router1.streams:
+        s_.u.clear(), s_.bx.clear(), s_.by.clear()
+    o0 = venv1.reset()
+    assert o0.shape == (N1, K, R, R)
+    acts1 = np.random.RandomState(3).randint(0, 3, (T1, N1))
+    rew1 = np.zeros((T1, N1, 1), np.float32)
+    done1 = np.zeros((T1, N1, 1), bool)
+    real1 = np.zeros((T1, N1), np.float32)
+    ns1 = np.zeros((T1, N1), np.int32)
+    obs1 = np.zeros((T1, N1, K, R, R), np.uint8)
+    tt, ti, to = [], [], []
+    for t in range(T1):
+        o, r, d, info = venv1.step(acts1[t])
+        assert r.shape == (N1, 1) and d.shape == (N1, 1)
+        rew1[t], done1[t] = r, d
+        assert np.array_equal(o, np.round(o))
+        obs1[t] = o.astype(np.uint8)
+        for i in range(N1):
+            real1[t, i] = info[i]["real_reward"]
+            ns1[t, i] = info[i]["num_steps"]
+            if "terminal_observation" in info[i]:
+                tt.append(t), ti.append(i), to.append(np.asarray(info[i]["terminal_observation"]).astype(np.uint8))
+    L1 = max(len(s_.u) for s_ in router1.streams)
+    du1 = np.zeros((N1, L1)), np.zeros((N1, L1), np.uint8), np.zeros((N1, L1), np.uint8)
+    nd1 = np.array([len(s_.u) for s_ in router1.streams])
+    for i, s_ in enumerate(router1.streams):
+        du1[0][i, :nd1[i]], du1[1][i, :nd1[i]], du1[2][i, :nd1[i]] = s_.u, s_.bx, s_.by
+    np.savez_compressed(
+        os.path.join(HERE, "pong_single_wrapped.npz"), acts=acts1.astype(np.int32), rew=rew1, done=done1, real_reward=real1,
+        num_steps=ns1, obs=obs1, obs0=o0.astype(np.uint8), term_t=np.array(tt), term_i=np.array(ti),
+        term_obs=np.stack(to) if to else np.zeros((0, K, R, R), np.uint8), draw_u=du1[0], draw_bx=du1[1], draw_by=du1[2],
+        ndraws=nd1, resized_dim=R, frame_stack=K)
+    print("single: steps", T1, "envs", N1, "dones", int(done1.sum()), "terminal obs", len(tt), "draws/env", nd1.tolist())
+
 
 if __name__ == "__main__":
     main()

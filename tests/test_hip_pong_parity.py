@@ -339,3 +339,57 @@ def test_reference_wrapper_golden_through_hip():
                     seen += 1
     assert seen == len(g["term_t"])
     env.close()
+
+
+def test_single_player_golden_and_tournament_shapes():
+    """cPong-v0 (PongSinglePlayerEnv + FrameStack 4) recorded from the reference, replayed on the
+    GPU; then the make_envs.py:121-170 self-test: cPong-v0 and cPongTournament-v0 agree on shapes."""
+    _need_gpu()
+    import os
+
+    import competitive_rl_amd as crl
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pong_single_wrapped.npz"))
+    N, R, K = g["acts"].shape[1], int(g["resized_dim"]), int(g["frame_stack"])
+    blank = np.full((22, 22, 34, 160), 255, np.uint8)
+    env = crl.HipPongVecEnv(N, mode="wrapped", resized_dim=R, frame_stack=K, score_atlas=blank, output="numpy",
+                            single_player=True, stack_replicate=True)
+    env.set_replay(g["draw_u"], g["draw_bx"], g["draw_by"])
+    o = env.reset()
+    assert o.shape == (N, K, R, R) and np.array_equal(o, g["obs0"])
+    term = {(int(t), int(i)): k for k, (t, i) in enumerate(zip(g["term_t"], g["term_i"]))}
+    seen = 0
+    for t in range(len(g["acts"])):
+        o, r, d, info = env.step(g["acts"][t])
+        assert r.shape == (N, 1) and d.shape == (N, 1)
+        assert np.array_equal(r, g["rew"][t]) and np.array_equal(d, g["done"][t]), t
+        assert np.array_equal(o, g["obs"][t]), t
+        for i in np.nonzero(d[:, 0])[0]:
+            inf = info[int(i)]
+            assert inf["real_reward"] == float(g["real_reward"][t, i]) and inf["num_steps"] == int(g["num_steps"][t, i])
+            assert np.array_equal(inf["terminal_observation"], g["term_obs"][term[(t, int(i))]])
+            seen += 1
+    assert seen == len(g["term_t"])
+    env.close()
+
+    envs = crl.make_envs("cPong-v0", num_envs=3, log_dir=None, asynchronous=False)
+    tour = crl.make_envs("cPongTournament-v0", num_envs=3, log_dir=None, asynchronous=False)
+    assert tuple(envs.reset().shape) == (3, 4, 42, 42)  # frame_stack = 4 default
+    assert tuple(tour.reset().shape) == (3, 1, 42, 42)
+    o1, r1, d1, _ = envs.step([0, 1, 0])
+    o2, r2, d2, _ = tour.step([0, 1, 0])
+    assert tuple(r1.shape) == tuple(r2.shape) == (3, 1) and tuple(d1.shape) == tuple(d2.shape) == (3, 1)
+    assert envs.action_space.n == 3 and tour.action_space.n == 3
+    # RULE_BASED opponent == the AutoBat of cPong-v0: same game when stacks are ignored
+    e1 = crl.make_envs("cPong-v0", num_envs=5, log_dir=None, frame_stack=None, seed=4)
+    e2 = crl.make_envs("cPongTournament-v0", num_envs=5, log_dir=None, seed=4)
+    a, b = e1.reset(), e2.reset()
+    assert torch.equal(a, b)
+    rs = np.random.RandomState(0)
+    for t in range(150):
+        act = rs.randint(0, 3, 5)
+        a, ra, da, _ = e1.step(act)
+        b, rb, db, _ = e2.step(act)
+        assert torch.equal(a, b) and torch.equal(ra, rb) and torch.equal(da, db)
+    for e in (envs, tour, e1, e2):
+        e.close()

@@ -49,3 +49,32 @@ def test_f32_area_resize_equals_exact_rational_on_pong_frames(g):
     assert g["obs"].shape[2:] == (2, 42, 42)
     levels = np.unique(g["obs"])
     assert levels.size > 4  # fractional coverage levels are present, not just 0/255
+
+
+def test_single_player_framestack_matches_reference():
+    """cPong-v0: PongSinglePlayerEnv (AutoBat opponent) + MaxAndSkip + WarpFrame + ClipReward +
+    FrameStack(4) + WrapPyTorch under the reference's DummyVecEnv (pong_single_wrapped.npz)."""
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "pong_single_wrapped.npz"))
+    N, R, K = g["acts"].shape[1], int(g["resized_dim"]), int(g["frame_stack"])
+    env = po.PongOracle(N, blank_atlas(), obs_mode=po.GRAY, resized_dim=R, frame_stack=K, single=True, replicate=True)
+    env.set_replay(g["draw_u"], g["draw_bx"], g["draw_by"])
+    obs = env.reset()
+    assert obs.shape == (N, 1, K, R, R)
+    assert np.array_equal(obs[:, 0], g["obs0"])
+    term = {(int(t), int(i)): k for k, (t, i) in enumerate(zip(g["term_t"], g["term_i"]))}
+    prev = obs[:, 0].copy()
+    seen = 0
+    for t in range(len(g["acts"])):
+        obs, rew, done = env.step(g["acts"][t])
+        assert np.array_equal(rew, g["rew"][t][:, 0]), t
+        assert np.array_equal(done.astype(bool), g["done"][t][:, 0]), t
+        assert np.array_equal(env.real_reward[:, 0], g["real_reward"][t]), t
+        assert np.array_equal(env.num_steps, g["num_steps"][t]), t
+        assert np.array_equal(obs[:, 0], g["obs"][t]), t
+        for i in np.nonzero(done)[0]:
+            want = g["term_obs"][term[(t, int(i))]]  # FrameStack: (K, R, R) = 3 older planes + the terminal one
+            assert np.array_equal(env.terminal_observation(int(i))[0], want[-1])
+            assert np.array_equal(prev[i, 1:], want[:-1])
+            seen += 1
+        prev = obs[:, 0].copy()
+    assert seen == len(g["term_t"]) >= 5
