@@ -8,7 +8,7 @@ import numpy as np
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libcrl_hip.so")
 
-CRL_ENV_PONG_DOUBLE, CRL_ENV_CAR_DOUBLE, CRL_ENV_PONG_SINGLE = 1, 2, 3
+CRL_ENV_PONG_DOUBLE, CRL_ENV_CAR_DOUBLE, CRL_ENV_PONG_SINGLE, CRL_ENV_CAR_SINGLE = 1, 2, 3, 4
 CRL_FLAG_STACK_REPLICATE = 1
 CAR_MAX_TILES = 512
 CRL_OBS_RAW_RGB, CRL_OBS_GRAY_RESIZED = 0, 1

@@ -50,7 +50,8 @@ struct CarConsts {  // body constants computed on the host the way b2Body::Reset
 };
 
 struct CarSoA {
-    int64_t n;  // envs; M = 2n car instances
+    int64_t n;  // envs
+    int players; // cars per env: 2 = cCarRacingDouble-v0, 1 = cCarRacing-v0; M = players * n car instances
     // ---- per car instance [..][M]
     float *body;        // [30][M]: hull (cx,cy,a,vx,vy,w), wheel 0..3 likewise
     float *jimp;        // [12][M]: revolute joint impulse (x,y,z) x 4
@@ -104,6 +105,6 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st);
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st);
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
-                      hipStream_t st);
+                      int players, hipStream_t st);
 
 }  // namespace crl

@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ uint8_t cell_list[kCells][kCellCap + 1];
     __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
     __shared__ int ind_y0;
-    const int64_t n = s.n, M = 2 * n;
-    const int64_t env = blockIdx.x >> 1;
-    const int viewer = blockIdx.x & 1;
+    const int64_t n = s.n, M = (int64_t)s.players * n;
+    const int64_t env = blockIdx.x / s.players;
+    const int viewer = blockIdx.x - env * s.players;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t me = viewer * n + env;
 
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     }
 
     // ---- (2) car polygons (threads 0..15) and indicator rectangles (threads 16..23)
-    if (tid < 16) {
+    if (tid < 8 * s.players) {
         const int k = tid >> 3, part = tid & 7;  // car k; parts 0..3 wheels, 4..7 hull fixtures
         const int64_t ci = k * n + env;
         const int o = part < 4 ? 6 + 6 * part : 0;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         }
         q.gray = part < 4 ? 0 : (k == viewer ? G_OWN : G_OTHER);
         cars[tid] = q;
-    } else if (tid < 24) {
+    } else if (tid >= 16 && tid < 24) {
         const int r = tid - 16;
         const double S = 96 / 40.0, Hh = 96 / 40.0;
         IndRect q;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         }
         ct.sx0 = (int)floorf(x0 - 1.5f), ct.sx1 = (int)ceilf(x1 + 1.5f), ct.sy0 = (int)floorf(y0 - 1.5f), ct.sy1 = (int)ceilf(y1 + 1.5f);
     }
-    if (tid < 2) {
+    if (tid < s.players) {
         int x0 = 1 << 30, y0 = 1 << 30, x1 = -(1 << 30), y1 = -(1 << 30);
         for (int p = 0; p < 8; p++) {
             const CarPoly &q = cars[tid * 8 + p];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         }
         car_box[tid][0] = x0, car_box[tid][1] = x1, car_box[tid][2] = y0, car_box[tid][3] = y1;
     }
-    if (tid == 2) {
+    if (tid == 32) {
         int y0 = 1 << 30;
         for (int r = 0; r < 8; r++) y0 = min(y0, ind[r].y0);
         ind_y0 = y0;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __syncthreads();
 
     // ---- (3) pixels
-    uint32_t *__restrict__ out = reinterpret_cast<uint32_t *>(obs + ((int64_t)env * 2 + viewer) * (96 * 96));
+    uint32_t *__restrict__ out = reinterpret_cast<uint32_t *>(obs + ((int64_t)env * s.players + viewer) * (96 * 96));
     for (int q = tid; q < 96 * 96 / 4; q += 256) {
         const int sy = q / 24, sx0 = (q - sy * 24) * 4;
         uint32_t word = 0;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                 for (int r = 7; r >= 0 && g < 0; r--)  // indicators are drawn last
                     if (sx >= ind[r].x0 && sx <= ind[r].x1 && sy >= ind[r].y0 && sy <= ind[r].y1) g = ind[r].gray;
             if (g < 0) {  // cars: car 1 over car 0; hull over wheels
-                for (int c = 1; c >= 0 && g < 0; c--) {
+                for (int c = s.players - 1; c >= 0 && g < 0; c--) {
                     if (sx < car_box[c][0] || sx > car_box[c][1] || sy < car_box[c][2] || sy > car_box[c][3]) continue;
                     for (int p = 7; p >= 0 && g < 0; p--)
                         if (fillpoly_hit(cars[c * 8 + p], sx, sy)) g = cars[c * 8 + p].gray;
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
 // writes K planes into the context's own stack and the caller's obs tensor.
 __global__ __launch_bounds__(256) void car_stack_kernel(const uint4 *__restrict__ frame, uint4 *__restrict__ stack,
                                                         uint4 *__restrict__ obs, const uint8_t *__restrict__ fill_env,
-                                                        int fill_all, int K, int64_t n) {
+                                                        int fill_all, int K, int64_t n, int players) {
     const int64_t tile = blockIdx.x;  // (env, agent)
-    const int64_t env = tile >> 1;
+    const int64_t env = tile / players;
     const bool fill = fill_all || fill_env[env];
     const int chunks = 96 * 96 / 16;
     const uint4 *f = frame + tile * chunks;
@@ -308,13 +308,13 @@ __global__ __launch_bounds__(256) void car_stack_kernel(const uint4 *__restrict_
 }
 
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
-                      hipStream_t st) {
-    hipLaunchKernelGGL(car_stack_kernel, dim3((unsigned)(2 * n)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(frame),
-                       reinterpret_cast<uint4 *>(stack), reinterpret_cast<uint4 *>(obs), fill_env, fill_all ? 1 : 0, K, n);
+                      int players, hipStream_t st) {
+    hipLaunchKernelGGL(car_stack_kernel, dim3((unsigned)(players * n)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(frame),
+                       reinterpret_cast<uint4 *>(stack), reinterpret_cast<uint4 *>(obs), fill_env, fill_all ? 1 : 0, K, n, players);
 }
 
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st) {
-    hipLaunchKernelGGL(car_raster_kernel, dim3((unsigned)(2 * s.n)), dim3(256), 0, st, s, k, obs);
+    hipLaunchKernelGGL(car_raster_kernel, dim3((unsigned)(s.players * s.n)), dim3(256), 0, st, s, k, obs);
 }
 
 }  // namespace crl

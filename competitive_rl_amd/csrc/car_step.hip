@@ -92,7 +92,7 @@ __device__ inline float poly_dist2(const V2 (&A)[4], const V2 (&B)[5]) {
 
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
                                                       float *__restrict__ rew_out, uint8_t *__restrict__ done_car) {
-    const int64_t M = 2 * s.n;
+    const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= M) return;
     const int car = ci >= s.n ? 1 : 0;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     const int ntiles = s.ntiles[env];
 
     // ---- CarRacing.step: controls for every car, done or not (crmp:549-556)
-    const float2 act = reinterpret_cast<const float2 *>(actions)[env * 2 + car];
+    const float2 act = reinterpret_cast<const float2 *>(actions)[env * s.players + car];
     double a0 = fmax(fmin((double)act.x, 1.0), -1.0), a1 = fmax(fmin((double)act.y, 1.0), -1.0), a2;
     if (a1 > 0) a2 = 0;
     else a2 = a1, a1 = 0;
@@ -430,8 +430,8 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     s.reward[ci] = reward, s.prev_reward[ci] = prev_reward;
     s.visited_count[ci] = visited_count, s.last_block[ci] = last_block, s.done[ci] = done;
     s.step_count[ci] = step_count, s.first_step[ci] = 0;
-    if (rew_out) rew_out[env * 2 + car] = (float)step_reward;
-    if (done_car) done_car[env * 2 + car] = (uint8_t)done;
+    if (rew_out) rew_out[env * s.players + car] = (float)step_reward;
+    if (done_car) done_car[env * s.players + car] = (uint8_t)done;
 }
 
 // Env-level bookkeeping after the physics: gym TimeLimit (max_episode_steps = 1000,
@@ -441,13 +441,14 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     const int el = s.elapsed[env] + 1;
-    const bool d = done_car[2 * env] || done_car[2 * env + 1] || el >= max_episode_steps;
+    bool d = el >= max_episode_steps;
+    for (int c = 0; c < s.players; c++) d = d || done_car[s.players * env + c];
     s.elapsed[env] = el;
     done_env[env] = d ? 1 : 0;
 }
 
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, hipStream_t st) {
-    const int64_t M = 2 * s.n;
+    const int64_t M = (int64_t)s.players * s.n;
     hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car);
 }
 

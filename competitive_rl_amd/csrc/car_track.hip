@@ -140,7 +140,7 @@ __device__ inline void store_poly_ccw(const double (*v)[2], int nv, float *dst, 
 // Builds tiles / borders from the lap in `trk` and places both cars.  swap = np.random.shuffle
 // outcome for the two birth places (crmp:508-512).
 __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const double *trk, int len, int swap) {
-    const int64_t n = s.n, M = 2 * n;
+    const int64_t n = s.n, M = (int64_t)s.players * n;
     auto T = [&](int i, int q) { return trk[((int64_t)i * 4 + q) * n]; };
     s.ntiles[env] = len;
     // red-white border on hard turns: 4 consecutive same-sign turns, then dilated backwards IN
@@ -187,9 +187,10 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
     }
     const double ia = T(0, 1), ix = T(0, 2), iy = T(0, 3);
     s.start_pose[0 * n + env] = (float)ia, s.start_pose[1 * n + env] = (float)ix, s.start_pose[2 * n + env] = (float)iy;
-    for (int car = 0; car < 2; car++) {
+    for (int car = 0; car < s.players; car++) {
         const int64_t ci = car * n + env;
-        const int birth = car == 0 ? (swap ? 1 : 0) : (swap ? 0 : 1);
+        // np.random.shuffle(arange(num_player)): one car always gets birth place 0
+        const int birth = s.players == 1 ? 0 : (car == 0 ? (swap ? 1 : 0) : (swap ? 0 : 1));
         const double x0 = ix - (birth % 2) * 5, y0 = iy - floor(birth / 2.0) * 10;
         const float a = (float)ia, sa = sinf(a), ca = cosf(a);
         const V2 com = mk((float)x0, (float)y0) + rotv(sa, ca, mk(K.hull_lc[0], K.hull_lc[1]));

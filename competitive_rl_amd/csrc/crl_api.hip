@@ -252,10 +252,11 @@ const char *crl_version(void) { return "crl-hip 0.1 (gfx950)"; }
 
 int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out) {
     if (!opts || !out || !score_atlas_host) return fail(CRL_EINVAL, "null argument");
-    if (opts->env_kind != CRL_ENV_PONG_DOUBLE && opts->env_kind != CRL_ENV_CAR_DOUBLE && opts->env_kind != CRL_ENV_PONG_SINGLE)
+    if (opts->env_kind != CRL_ENV_PONG_DOUBLE && opts->env_kind != CRL_ENV_CAR_DOUBLE && opts->env_kind != CRL_ENV_PONG_SINGLE &&
+        opts->env_kind != CRL_ENV_CAR_SINGLE)
         return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
     if (opts->num_envs <= 0) return fail(CRL_EINVAL, "num_envs must be positive");
-    if (opts->env_kind == CRL_ENV_CAR_DOUBLE) {
+    if (opts->env_kind == CRL_ENV_CAR_DOUBLE || opts->env_kind == CRL_ENV_CAR_SINGLE) {
         if (opts->frame_stack < 0 || opts->frame_stack > 8) return fail(CRL_EINVAL, "frame_stack must be 1..8");
         int nd = 0;
         HIP_TRY(hipGetDeviceCount(&nd));

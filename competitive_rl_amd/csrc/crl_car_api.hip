@@ -107,9 +107,10 @@ static int calloc_dev(crl_car_ctx *c, T **p, size_t count) {
 int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     crl_car_ctx *c = new crl_car_ctx();
     c->o = *opts;
-    const int64_t n = c->n = opts->num_envs, M = 2 * n;
+    const int players = opts->env_kind == CRL_ENV_CAR_SINGLE ? 1 : 2;
+    const int64_t n = c->n = opts->num_envs, M = (int64_t)players * n;
     CarSoA &s = c->s;
-    s.n = n;
+    s.n = n, s.players = players;
     int rc = 0;
 #define A(f, cnt) if (!rc) rc = calloc_dev(c, &s.f, (size_t)(cnt))
     A(body, 30 * M); A(jimp, 12 * M); A(jmotor, 4 * M); A(jspeed, 4 * M); A(jlimit, 4 * M);
@@ -119,13 +120,13 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
 #undef A
-    if (!rc) rc = calloc_dev(c, &c->done_car, 2 * n);
+    if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
-    if (!rc) rc = calloc_dev(c, &c->rew_tmp, 2 * n);
+    if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     c->K = opts->frame_stack < 1 ? 1 : opts->frame_stack;
     if (c->K > 1) {
-        if (!rc) rc = calloc_dev(c, &c->frame, (size_t)2 * n * 96 * 96);
-        if (!rc) rc = calloc_dev(c, &c->stack, (size_t)2 * n * c->K * 96 * 96);
+        if (!rc) rc = calloc_dev(c, &c->frame, (size_t)M * 96 * 96);
+        if (!rc) rc = calloc_dev(c, &c->stack, (size_t)M * c->K * 96 * 96);
     }
     if (rc) { crl_car_destroy(c); return rc; }
     make_consts(c->K_);
@@ -144,7 +145,7 @@ void crl_car_destroy(crl_car_ctx *c) {
 }
 
 void crl_car_seed(crl_car_ctx *c, uint64_t seed) { c->src.seed = seed; }
-int64_t crl_car_obs_bytes(const crl_car_ctx *c) { return (int64_t)2 * c->K * CRL_CAR_OBS * CRL_CAR_OBS; }
+int64_t crl_car_obs_bytes(const crl_car_ctx *c) { return (int64_t)c->s.players * c->K * CRL_CAR_OBS * CRL_CAR_OBS; }
 
 // newest frames -> obs_dev, through the frame stack when K > 1
 static void draw(crl_car_ctx *c, uint8_t *obs_dev, bool fill_all, hipStream_t st) {
@@ -153,7 +154,7 @@ static void draw(crl_car_ctx *c, uint8_t *obs_dev, bool fill_all, hipStream_t st
         return;
     }
     launch_car_raster(c->s, c->K_, c->frame, st);
-    launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, fill_all, c->K, c->n, st);
+    launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, fill_all, c->K, c->n, c->s.players, st);
 }
 
 int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
@@ -209,7 +210,7 @@ struct HostCopy {
 };
 
 static void pull_all(crl_car_ctx *c, HostCopy &h, hipStream_t st) {
-    const int64_t n = c->n, M = 2 * n;
+    const int64_t n = c->n, M = (int64_t)c->s.players * n;
     const CarSoA &s = c->s;
     h.body = pull(s.body, 30 * M, st), h.jimp = pull(s.jimp, 12 * M, st), h.jmotor = pull(s.jmotor, 4 * M, st);
     h.jspeed = pull(s.jspeed, 4 * M, st), h.jlimit = pull(s.jlimit, 4 * M, st);
@@ -231,12 +232,12 @@ int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first
     if (first < 0 || count < 0 || first + count > c->n) return crl_fail(CRL_EINVAL, "bad range");
     HostCopy h;
     pull_all(c, h, st);
-    const int64_t n = c->n, M = 2 * n;
+    const int64_t n = c->n, M = (int64_t)c->s.players * n;
     for (int64_t e = 0; e < count; e++) {
         crl_car_env_state &o = out[e];
         memset(&o, 0, sizeof(o));
         const int64_t env = first + e;
-        for (int car = 0; car < 2; car++) {
+        for (int car = 0; car < c->s.players; car++) {
             const int64_t ci = car * n + env;
             crl_car_state &q = o.car[car];
             crl_car_body *bodies[5] = {&q.hull, &q.wheel[0], &q.wheel[1], &q.wheel[2], &q.wheel[3]};
@@ -267,11 +268,11 @@ int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t 
     if (first < 0 || count < 0 || first + count > c->n) return crl_fail(CRL_EINVAL, "bad range");
     HostCopy h;
     pull_all(c, h, st);
-    const int64_t n = c->n, M = 2 * n;
+    const int64_t n = c->n, M = (int64_t)c->s.players * n;
     for (int64_t e = 0; e < count; e++) {
         const crl_car_env_state &o = in[e];
         const int64_t env = first + e;
-        for (int car = 0; car < 2; car++) {
+        for (int car = 0; car < c->s.players; car++) {
             const int64_t ci = car * n + env;
             const crl_car_state &q = o.car[car];
             const crl_car_body *bodies[5] = {&q.hull, &q.wheel[0], &q.wheel[1], &q.wheel[2], &q.wheel[3]};

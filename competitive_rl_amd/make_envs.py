@@ -11,7 +11,7 @@ from .vec_env_car import HipCarVecEnv
 
 __all__ = ["make_envs"]
 
-_HIP_IDS = ("cPongDouble-v0", "cPong-v0", "cPongTournament-v0", "cCarRacingDouble-v0")
+_HIP_IDS = ("cPongDouble-v0", "cPong-v0", "cPongTournament-v0", "cCarRacingDouble-v0", "cCarRacing-v0")
 
 
 def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronous=False, resized_dim=42,
@@ -51,6 +51,10 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
         return HipPongVecEnv(num_envs, seed=seed, mode="wrapped", resized_dim=resized_dim, frame_stack=k, device=device,
                              env_id_base=env_id_base, output=output, obs_dtype=obs_dtype,
                              dones="subproc" if asynchronous else "dummy", single_player=True, stack_replicate=True)
+    if env_id == "cCarRacing-v0":  # make_car_racing (car_racing/register.py:29-40): FrameStack, one car
+        return HipCarVecEnv(num_envs, seed=seed, device=device, env_id_base=env_id_base, output=output,
+                            dones="subproc" if asynchronous else "dummy", action_repeat=action_repeat,
+                            frame_stack=frame_stack, players=1)
     if env_id == "cCarRacingDouble-v0":
         return HipCarVecEnv(num_envs, seed=seed, device=device, env_id_base=env_id_base, output=output,
                             dones="subproc" if asynchronous else "dummy", action_repeat=action_repeat,

@@ -35,6 +35,8 @@ class CarLazyInfos:
             i += self._n
         if not 0 <= i < self._n:
             raise IndexError(i)
+        if r.shape[1] == 1:  # cCarRacing-v0: info = {"num_steps": k} (crmp:616)
+            return {"num_steps": int(st[i])}
         return {k: {"num_steps": int(st[i]), "reward": float(r[i, k])} for k in range(2)}
 
     def __iter__(self):
@@ -46,7 +48,7 @@ class CarLazyInfos:
 
 class HipCarVecEnv(VecEnv):
     def __init__(self, num_envs, seed=0, device=None, env_id_base=0, output="torch", dones="dummy", action_repeat=None,
-                 frame_stack=None):
+                 frame_stack=None, players=2):
         if not torch.cuda.is_available():
             raise RuntimeError("HipCarVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -57,7 +59,9 @@ class HipCarVecEnv(VecEnv):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.output, self.dones_kind, self.closed = output, dones, False
         self.K = 1 if frame_stack is None else int(frame_stack)
-        opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE, obs_mode=0, resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
+        assert players in (1, 2)
+        self.P = int(players)  # 2 = cCarRacingDouble-v0, 1 = cCarRacing-v0
+        opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE if players == 2 else N.CRL_ENV_CAR_SINGLE, obs_mode=0, resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
                          env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0, flags=0)
         h = C.c_void_p()
         dummy = np.zeros(16, np.uint8)  # crl_create's atlas argument is only used by Pong contexts
@@ -65,15 +69,15 @@ class HipCarVecEnv(VecEnv):
             N.check(self._L.crl_create(C.byref(opts), dummy.ctypes.data_as(C.c_void_p), C.byref(h)))
         self._h = h
         n = int(num_envs)
-        obs_space = spaces.Box(0, 255, (2 * self.K, 96, 96), dtype=np.uint8)
-        act_space = spaces.Box(-1, 1, (2, 2), dtype=np.float32)
+        obs_space = spaces.Box(0, 255, (self.P * self.K, 96, 96), dtype=np.uint8)
+        act_space = spaces.Box(-1, 1, (2, 2) if self.P == 2 else (2,), dtype=np.float32)
         VecEnv.__init__(self, n, obs_space, act_space)
         dev = self.device
-        self._obs = [torch.empty((n, 2 * self.K, 96, 96), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._obs = [torch.empty((n, self.P * self.K, 96, 96), dtype=torch.uint8, device=dev) for _ in range(2)]
         self._flip = 0
-        self._rew = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+        self._rew = torch.zeros((n, self.P), dtype=torch.float32, device=dev)
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
-        self._actions = torch.zeros((n, 2, 2), dtype=torch.float32, device=dev)
+        self._actions = torch.zeros((n, self.P, 2), dtype=torch.float32, device=dev)
         self._steps = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.envs = _EnvList(self)
 
@@ -106,8 +110,10 @@ class HipCarVecEnv(VecEnv):
             a = actions.to(device=self.device, dtype=torch.float32)
         else:
             a = torch.as_tensor(np.asarray(actions, dtype=np.float32)).to(self.device)
-        if tuple(a.shape) != (self.num_envs, 2, 2):
-            raise AssertionError(f"actions must have shape ({self.num_envs}, 2, 2), got {tuple(a.shape)}")
+        if self.P == 1 and tuple(a.shape) == (self.num_envs, 2):
+            a = a[:, None, :]
+        if tuple(a.shape) != (self.num_envs, self.P, 2):
+            raise AssertionError(f"actions must have shape ({self.num_envs}, {self.P}, 2), got {tuple(a.shape)}")
         self._actions = a.contiguous()
 
     def step_device(self, actions_f32, render=True):

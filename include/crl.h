@@ -52,6 +52,9 @@ enum crl_env_kind {
        (:445-454) = action 999 on that side; actions int32 (N), one view, obs (N,1,...) raw or
        (N,K,R,R) wrapped, rewards f32 (N) = the left player's */
     CRL_ENV_PONG_SINGLE = 3,
+    /* cCarRacing-v0: CarRacing(num_player=1) (car_racing/register.py:11-17, 29-40): one car,
+       actions f32 (N,1,2), obs (N,K,96,96), rewards f32 (N,1) */
+    CRL_ENV_CAR_SINGLE = 4,
 };
 /* crl_opts.flags */
 #define CRL_FLAG_STACK_REPLICATE 1 /* FrameStack wrapper semantics (utils/atari_wrappers.py:243-247):

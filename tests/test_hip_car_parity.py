@@ -267,3 +267,36 @@ def test_multiple_frame_stack_semantics():
         if t == 20:
             assert bool(d1[1, 0])
     one.close(), stk.close()
+
+
+def test_single_car_env_matches_car0_of_double():
+    """cCarRacing-v0 (CarRacing(num_player=1), car_racing/register.py:11-17,29-40): same kernels
+    with one car instance per env.  Car 0 of a Double env with birth place 0 runs the same physics."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 6
+    rs = np.random.RandomState(5)
+    u = rs.random_sample((n, 8, 24))
+    swap = np.zeros((n, 8), np.uint8)
+    one = crl.make_envs("cCarRacing-v0", num_envs=n, frame_stack=4, log_dir=None)
+    two = crl.make_envs("cCarRacingDouble-v0", num_envs=n, frame_stack=None, log_dir=None)
+    one.set_replay(u, swap), two.set_replay(u, swap)
+    o1, o2 = one.reset(), two.reset()
+    assert tuple(o1.shape) == (n, 4, 96, 96) and one.action_space.shape == (2,)
+    assert bool((o1[:, 0] == o1[:, 3]).all())  # FrameStack.reset: 4 copies
+    for t in range(60):
+        a = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+        a[:, 1] = abs(a[:, 1])
+        a2 = np.stack([a, np.zeros_like(a)], 1)
+        o1, r1, d1, i1 = one.step(a)
+        o2, r2, d2, i2 = two.step(a2)
+        assert tuple(r1.shape) == (n, 1) and tuple(d1.shape) == (n, 1) and set(i1[0].keys()) == {"num_steps"}
+        assert torch.allclose(r1, r2)
+    s1, s2 = one.get_state(), two.get_state()
+    for f in ("cx", "cy", "a", "vx", "vy", "w"):
+        assert np.allclose(s1["car"][:, 0]["hull"][f], s2["car"][:, 0]["hull"][f], rtol=1e-6, atol=1e-6)
+    # the single-car view has no blue opponent; its newest plane equals car 0's view wherever car 1 is not drawn
+    new1, new2 = o1[:, 3].cpu().numpy(), o2[:, 0].cpu().numpy()
+    assert ((new1 != new2).mean(axis=(1, 2)) < 0.02).all() and not (new1[:, :86] == 29).any()
+    one.close(), two.close()
