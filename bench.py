@@ -41,6 +41,8 @@ def cpu_baseline(workload, budget_s=12.0):
     atlas = _native.load_score_atlas()
     if workload == "car":
         return cpu_baseline_car(cores, budget_s)
+    if workload == "fused84_newest":
+        workload = "fused84"
     if workload == "raw":
         n = 64 * cores
         env = po.PongOracle(n, atlas, obs_mode=po.RAW, seed=0)
@@ -102,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["raw", "fused84", "car"], default="raw")
+    ap.add_argument("--workload", choices=["raw", "fused84", "fused84_newest", "car"], default="raw")
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
     ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -135,6 +137,12 @@ def main():
         env = crl.HipPongVecEnv(n, seed=0, mode="raw", device=dev, env_id_base=rank * n)
         raster_bytes, kernel = RAW_RASTER_BYTES, "pong_raster_raw_kernel"
         desc = f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)"
+    elif args.workload == "fused84_newest":
+        # variant of config #3: only the newest plane is written, the consumer keeps the stack
+        env = crl.HipPongVecEnv(n, seed=0, mode="wrapped", resized_dim=84, frame_stack=1, device=dev, env_id_base=rank * n)
+        raster_bytes, kernel = 2 * 84 * 84 + 16, "pong_raster_gray_kernel"
+        desc = (f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA, newest plane only (N,2,1,84,84) u8, "
+                "1 step = 4 frames (variant of BASELINE config #3)")
     else:
         env = crl.HipPongVecEnv(n, seed=0, mode="wrapped", resized_dim=84, frame_stack=4, device=dev,
                                 env_id_base=rank * n)
