@@ -72,6 +72,11 @@ struct CarSoA {
     float *border_poly; // [512][8][n]
     uint8_t *border;    // [512][n]  0 none, 1 white, 2 red
     float *start_pose;  // [3][n]    track[0] beta, x, y (birth place)
+    // env-major copies of the same track for the raster (one workgroup walks ONE env's tiles)
+    float4 *tile_aabb_em;  // [n][512]
+    float *tile_poly_em;   // [n][512][10]
+    float *border_poly_em; // [n][512][8]
+    uint8_t *border_em;    // [n][512]
     double *track_scratch;  // [512][4][n] the current lap (alpha, beta, x, y), f64
 };
 

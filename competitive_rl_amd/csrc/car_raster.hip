@@ -11,13 +11,17 @@
 //
 // Per workgroup: (1) the tiles whose AABB meets the camera's view box are compacted IN ORDER
 // into LDS (draw order matters: lower tile index is drawn later and wins), (2) the 16 car
-// polygons and 8 indicator rectangles are projected once into LDS, (3) each thread resolves
-// 4 consecutive pixels per iteration and stores one dword: 1 KiB contiguous per wave store.
+// polygons and 8 indicator rectangles are projected once into LDS, (3) the background is
+// resolved 4 pixels per thread into an LDS tile, cars and indicator bars are patched over their
+// bounding boxes only (one lane per pixel), and the tile is streamed out 16 B per lane.
+#include <stdlib.h>
+
 #include "car_device.h"
 
 namespace crl {
 
-static constexpr int kMaxCand = 160;
+static constexpr int kMaxCand = 128;
+static constexpr int kRankCap = 2048;  // pixels of one car's screen box handled by the patch pass
 
 #define G_GRASS 161
 #define G_LIGHT 176
@@ -30,14 +34,24 @@ static constexpr int kMaxCand = 160;
 #define G_GREEN 149
 
 struct CandTile {
-    float poly[10];
-    float bpoly[8];
-    float bb[4];
+    float4 edge[5];   // tile edges (ax, ay, bx-ax, by-ay), counter-clockwise
+    float4 bedge[4];  // border quad edges, same form
+    float4 bb;        // world AABB of the tile polygon
+    float4 bb_all;    // world AABB of tile + border
     int idx, border;
     int sx0, sx1, sy0, sy1;  // conservative screen-space box of tile + border (culling only)
 };
 
-static constexpr int kCell = 16, kCellsPerRow = 96 / kCell, kCells = kCellsPerRow * kCellsPerRow, kCellCap = 47;
+// inside test against precomputed edges: (bx-ax)*(y-ay) - (by-ay)*(x-ax) >= 0 for every edge
+__device__ inline bool in_edges(const float4 *e, int nv, float x, float y) {
+    for (int i = 0; i < nv; i++) {
+        const float4 q = e[i];
+        if ((q.z * (y - q.y) - q.w * (x - q.x)) < 0) return false;
+    }
+    return true;
+}
+
+static constexpr int kCell = 8, kCellShift = 3, kCellsPerRow = 96 / kCell, kCells = kCellsPerRow * kCellsPerRow, kCellCap = 23;
 
 struct CarPoly {
     int px[8], py[8];
@@ -49,13 +63,12 @@ struct IndRect {
 };
 
 __device__ inline bool in_convex(const float *poly, int nv, float x, float y) {
-    bool in = true;
     for (int i = 0; i < nv; i++) {
         const int j = i + 1 < nv ? i + 1 : 0;
         const float ax = poly[2 * i], ay = poly[2 * i + 1], bx = poly[2 * j], by = poly[2 * j + 1];
-        in = in && !(((bx - ax) * (y - ay) - (by - ay) * (x - ax)) < 0);
+        if (((bx - ax) * (y - ay) - (by - ay) * (x - ax)) < 0) return false;
     }
-    return in;
+    return true;
 }
 
 // pygame draw_fillpoly membership of pixel (x, y)
@@ -88,7 +101,7 @@ __device__ inline IndRect make_rect(double x, double y, double w, double h, int 
     return q;
 }
 
-__global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs) {
+__global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg) {
     __shared__ CandTile cand[kMaxCand];
     __shared__ CarPoly cars[16];
     __shared__ IndRect ind[8];
@@ -98,6 +111,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ uint8_t cell_list[kCells][kCellCap + 1];
     __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
     __shared__ int ind_y0;
+    __shared__ __attribute__((aligned(16))) uint32_t tile32[96 * 96 / 4];
     const int64_t n = s.n, M = (int64_t)s.players * n;
     const int64_t env = blockIdx.x / s.players;
     const int viewer = blockIdx.x - env * s.players;
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         bool keep = false;
         float4 bb = make_float4(0, 0, 0, 0);
         if (t < ntiles) {
-            bb = s.tile_aabb[(int64_t)t * n + env];
+            bb = s.tile_aabb_em[env * kCarMaxTiles + t];
             keep = !(bb.x > off.x + vr || bb.z < off.x - vr || bb.y > off.y + vr || bb.w < off.y - vr);
         }
         const unsigned long long m = __ballot(keep);
@@ -139,11 +153,24 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         slot += __popcll(m & ((1ull << lane) - 1ull));
         if (keep && slot < kMaxCand) {
             CandTile &c = cand[slot];
-            for (int k = 0; k < 10; k++) c.poly[k] = s.tile_poly[((int64_t)t * 10 + k) * n + env];
-            c.bb[0] = bb.x, c.bb[1] = bb.y, c.bb[2] = bb.z, c.bb[3] = bb.w;
-            c.idx = t, c.border = s.border[(int64_t)t * n + env];
-            if (c.border)
-                for (int k = 0; k < 8; k++) c.bpoly[k] = s.border_poly[((int64_t)t * 8 + k) * n + env];
+            float pv[10], bv[8];
+            for (int k = 0; k < 10; k++) pv[k] = s.tile_poly_em[(env * kCarMaxTiles + t) * 10 + k];
+            for (int i = 0; i < 5; i++) {
+                const int j = i + 1 < 5 ? i + 1 : 0;
+                c.edge[i] = make_float4(pv[2 * i], pv[2 * i + 1], pv[2 * j] - pv[2 * i], pv[2 * j + 1] - pv[2 * i + 1]);
+            }
+            c.bb = bb, c.bb_all = bb;
+            c.idx = t, c.border = s.border_em[env * kCarMaxTiles + t];
+            if (c.border) {
+                float x0 = bb.x, y0 = bb.y, x1 = bb.z, y1 = bb.w;
+                for (int k = 0; k < 8; k++) bv[k] = s.border_poly_em[(env * kCarMaxTiles + t) * 8 + k];
+                for (int i = 0; i < 4; i++) {
+                    const int j = i + 1 < 4 ? i + 1 : 0;
+                    c.bedge[i] = make_float4(bv[2 * i], bv[2 * i + 1], bv[2 * j] - bv[2 * i], bv[2 * j + 1] - bv[2 * i + 1]);
+                    x0 = fminf(x0, bv[2 * i]), y0 = fminf(y0, bv[2 * i + 1]), x1 = fmaxf(x1, bv[2 * i]), y1 = fmaxf(y1, bv[2 * i + 1]);
+                }
+                c.bb_all = make_float4(x0, y0, x1, y1);
+            }
         }
         __syncthreads();
         if (tid == 0) n_cand = min(kMaxCand, n_cand + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __syncthreads();
 
     // ---- (2b) screen-space culling structures: per candidate a conservative screen box, per
-    // 16x16-pixel cell the ORDERED list of candidates whose box meets it.  Membership itself is
+    // 8x8-pixel cell the ORDERED list of candidates whose box meets it.  Membership itself is
     // still decided in world space, so culling never changes a pixel.
     const int nc = n_cand;
     for (int c = tid; c < nc; c += 256) {
@@ -205,7 +232,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         float x0 = 1e30f, y0 = 1e30f, x1 = -1e30f, y1 = -1e30f;
         const int nv = ct.border ? 9 : 5;
         for (int i = 0; i < nv; i++) {
-            const float wx = i < 5 ? ct.poly[2 * i] : ct.bpoly[2 * (i - 5)], wy = i < 5 ? ct.poly[2 * i + 1] : ct.bpoly[2 * (i - 5) + 1];
+            const float wx = i < 5 ? ct.edge[i].x : ct.bedge[i - 5].x, wy = i < 5 ? ct.edge[i].y : ct.bedge[i - 5].y;
             const V2 t = rotv(-sn, cs, mk(wx, wy) - off);
             const float X = 48.0f - scale_f * t.x, Y = 48.0f - scale_f * t.y;
             x0 = fminf(x0, X), y0 = fminf(y0, Y), x1 = fmaxf(x1, X), y1 = fmaxf(y1, Y);
@@ -239,47 +266,100 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     }
     __syncthreads();
 
-    // ---- (3) pixels
-    uint32_t *__restrict__ out = reinterpret_cast<uint32_t *>(obs + ((int64_t)env * s.players + viewer) * (96 * 96));
+    // ---- (3a) background into the LDS tile: 4 consecutive pixels per thread-iteration share one
+    // culling cell, so every candidate's edges are read from LDS once per 4 pixels
     for (int q = tid; q < 96 * 96 / 4; q += 256) {
         const int sy = q / 24, sx0 = (q - sy * 24) * 4;
-        uint32_t word = 0;
-#pragma unroll 1
+        float wx[4], wy[4];
+        int g[4];
+        float ax0 = 3.4e38f, ay0 = 3.4e38f, ax1 = -3.4e38f, ay1 = -3.4e38f;
+#pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int sx = sx0 + k;
-            int g = -1;
-            if (sy >= ind_y0)
-                for (int r = 7; r >= 0 && g < 0; r--)  // indicators are drawn last
-                    if (sx >= ind[r].x0 && sx <= ind[r].x1 && sy >= ind[r].y0 && sy <= ind[r].y1) g = ind[r].gray;
-            if (g < 0) {  // cars: car 1 over car 0; hull over wheels
-                for (int c = s.players - 1; c >= 0 && g < 0; c--) {
-                    if (sx < car_box[c][0] || sx > car_box[c][1] || sy < car_box[c][2] || sy > car_box[c][3]) continue;
-                    for (int p = 7; p >= 0 && g < 0; p--)
-                        if (fillpoly_hit(cars[c * 8 + p], sx, sy)) g = cars[c * 8 + p].gray;
-                }
-            }
-            if (g < 0) {
-                const float dx = ((float)sx + 0.5f) - 48.0f, dy = ((float)sy + 0.5f) - 48.0f;
-                const float rx = cs * dx - sn * dy, ry = sn * dx + cs * dy;
-                const float wx = off.x - rx * inv_scale, wy = off.y - ry * inv_scale;
-                const int ix = (int)floorf(wx / kf), iy = (int)floorf(wy / kf);
-                const bool light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
-                g = light ? G_LIGHT : G_GRASS;
-                const int cell = (sy >> 4) * kCellsPerRow + (sx >> 4);
-                const int ccount = cell_cnt[cell];
-                const int niter = ccount == 255 ? nc : ccount;
-                for (int ci2 = 0; ci2 < niter; ci2++) {
-                    const int c = ccount == 255 ? ci2 : cell_list[cell][ci2];
-                    const CandTile &ct = cand[c];
-                    if (ct.border && in_convex(ct.bpoly, 4, wx, wy)) { g = ct.border == 1 ? G_WHITE : G_RED; break; }
-                    if (wx < ct.bb[0] || wx > ct.bb[2] || wy < ct.bb[1] || wy > ct.bb[3]) continue;
-                    if (in_convex(ct.poly, 5, wx, wy)) { g = ct.idx % 3 == 0 ? 101 : (ct.idx % 3 == 1 ? 103 : 107); break; }
-                }
-            }
-            word |= (uint32_t)g << (8 * k);
+            const float dx = ((float)(sx0 + k) + 0.5f) - 48.0f, dy = ((float)sy + 0.5f) - 48.0f;
+            const float rx = cs * dx - sn * dy, ry = sn * dx + cs * dy;
+            wx[k] = off.x - rx * inv_scale, wy[k] = off.y - ry * inv_scale;
+            const int ix = (int)floorf(wx[k] / kf), iy = (int)floorf(wy[k] / kf);
+            const bool light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
+            g[k] = light ? G_LIGHT : G_GRASS;
+            ax0 = fminf(ax0, wx[k]), ay0 = fminf(ay0, wy[k]), ax1 = fmaxf(ax1, wx[k]), ay1 = fmaxf(ay1, wy[k]);
         }
-        out[q] = word;
+        unsigned open = 0xFu;  // pixels not yet covered by a (later-drawn) polygon
+        const int cell = (sy >> kCellShift) * kCellsPerRow + (sx0 >> kCellShift);
+        const int ccount = cell_cnt[cell];
+        const int niter = (dbg & 2) ? 0 : (ccount == 255 ? nc : ccount);
+        for (int ci2 = 0; ci2 < niter && open; ci2++) {
+            const int c = ccount == 255 ? ci2 : cell_list[cell][ci2];
+            const CandTile &ct = cand[c];
+            const float4 ba = ct.bb_all;
+            if (ax0 > ba.z || ax1 < ba.x || ay0 > ba.w || ay1 < ba.y) continue;
+            if (ct.border) {
+                const int bg = ct.border == 1 ? G_WHITE : G_RED;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((open >> k & 1u) && in_edges(ct.bedge, 4, wx[k], wy[k])) g[k] = bg, open &= ~(1u << k);
+            }
+            const float4 bb = ct.bb;
+            const int rg = ct.idx % 3 == 0 ? 101 : (ct.idx % 3 == 1 ? 103 : 107);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!(open >> k & 1u)) continue;
+                if (wx[k] < bb.x || wx[k] > bb.z || wy[k] < bb.y || wy[k] > bb.w) continue;
+                if (in_edges(ct.edge, 5, wx[k], wy[k])) g[k] = rg, open &= ~(1u << k);
+            }
+        }
+        tile32[q] = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
     }
+    __syncthreads();
+    uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile32);
+
+    // ---- (3b) cars: one work item per (car polygon, pixel of that polygon's box), all 256 lanes
+    // busy; draw order (car 0 wheels, hull, then car 1) is resolved by an LDS atomicMax on
+    // (draw rank << 8 | gray) per pixel, then written over the background.
+    if (!(dbg & 1)) {
+        uint32_t *rank = reinterpret_cast<uint32_t *>(cand);  // candidates are dead after (3a): reuse as [96*96/.. ] scratch
+        for (int c = 0; c < s.players; c++) {
+            const int x0 = max(car_box[c][0], 0), x1 = min(car_box[c][1], 95), y0 = max(car_box[c][2], 0), y1 = min(car_box[c][3], 95);
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            if (w <= 0 || h <= 0 || w * h > kRankCap) continue;  // (a car never spans more than ~20x20 px)
+            for (int p = tid; p < w * h; p += 256) rank[p] = 0u;
+            __syncthreads();
+            for (int item = tid; item < 8 * w * h; item += 256) {
+                const int part = item / (w * h), p = item - part * (w * h);
+                const int yy = p / w, sx = x0 + (p - yy * w), sy = y0 + yy;
+                const CarPoly &cp = cars[c * 8 + part];
+                if (fillpoly_hit(cp, sx, sy)) atomicMax(&rank[p], ((uint32_t)(part + 1) << 8) | (uint32_t)cp.gray);
+            }
+            __syncthreads();
+            for (int p = tid; p < w * h; p += 256) {
+                const uint32_t r = rank[p];
+                if (r) {
+                    const int yy = p / w;
+                    tile8[(y0 + yy) * 96 + x0 + (p - yy * w)] = (uint8_t)(r & 255u);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- (3c) indicator strip: drawn last; later rectangles win
+    {
+        const int y0 = max(ind_y0, 0);
+        const int npx = (96 - y0) * 96;
+        for (int p = tid; p < npx && !(dbg & 4); p += 256) {
+            const int yy = p / 96, sx = p - yy * 96, sy = y0 + yy;
+            for (int r = 7; r >= 0; r--)
+                if (sx >= ind[r].x0 && sx <= ind[r].x1 && sy >= ind[r].y0 && sy <= ind[r].y1) {
+                    tile8[sy * 96 + sx] = (uint8_t)ind[r].gray;
+                    break;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- (3d) stream the tile out: 16 B per lane, 1 KiB contiguous per wave store
+    uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + ((int64_t)env * s.players + viewer) * (96 * 96));
+    const uint4 *tile4 = reinterpret_cast<const uint4 *>(tile32);
+    for (int q = tid; q < 96 * 96 / 16; q += 256) out[q] = tile4[q];
 }
 
 // MultipleFrameStack + FlattenMultiAgentObservation + WrapPyTorch (reference
@@ -314,7 +394,8 @@ void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const 
 }
 
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st) {
-    hipLaunchKernelGGL(car_raster_kernel, dim3((unsigned)(s.players * s.n)), dim3(256), 0, st, s, k, obs);
+    static const int dbg = getenv("CRL_CAR_DEBUG") ? atoi(getenv("CRL_CAR_DEBUG")) : 0;
+    hipLaunchKernelGGL(car_raster_kernel, dim3((unsigned)(s.players * s.n)), dim3(256), 0, st, s, k, obs, dbg);
 }
 
 }  // namespace crl

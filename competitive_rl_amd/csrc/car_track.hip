@@ -173,6 +173,8 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         float bb[4];
         store_poly_ccw(v, 5, s.tile_poly + (int64_t)i * 10 * n + env, n, bb);
         s.tile_aabb[(int64_t)i * n + env] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        s.tile_aabb_em[env * kCarMaxTiles + i] = make_float4(bb[0], bb[1], bb[2], bb[3]);
+        for (int q = 0; q < 10; q++) s.tile_poly_em[(env * kCarMaxTiles + i) * 10 + q] = s.tile_poly[((int64_t)i * 10 + q) * n + env];
         if (s.border[(int64_t)i * n + env]) {
             const double side = sgnd(b2 - b1);
             const double bp[4][2] = {
@@ -183,7 +185,9 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
             };
             store_poly_ccw(bp, 4, s.border_poly + (int64_t)i * 8 * n + env, n, nullptr);
             s.border[(int64_t)i * n + env] = (i % 2 == 0) ? 1 : 2;  // white / red
+            for (int q = 0; q < 8; q++) s.border_poly_em[(env * kCarMaxTiles + i) * 8 + q] = s.border_poly[((int64_t)i * 8 + q) * n + env];
         }
+        s.border_em[env * kCarMaxTiles + i] = s.border[(int64_t)i * n + env];
     }
     const double ia = T(0, 1), ix = T(0, 2), iy = T(0, 3);
     s.start_pose[0 * n + env] = (float)ia, s.start_pose[1 * n + env] = (float)ix, s.start_pose[2 * n + env] = (float)iy;

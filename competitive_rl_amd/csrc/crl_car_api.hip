@@ -119,6 +119,8 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
+    A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
+    A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
 #undef A
     if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
@@ -347,6 +349,11 @@ int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const float 
     if (border_poly) hipMemcpy2DAsync(c->s.border_poly + env, n * 4, border_poly, 4, 4, (size_t)nt * 8, hipMemcpyHostToDevice, st);
     if (border) hipMemcpy2DAsync(c->s.border + env, n, border, 1, 1, (size_t)nt, hipMemcpyHostToDevice, st);
     if (start_pose) hipMemcpy2DAsync(c->s.start_pose + env, n * 4, start_pose, 4, 4, 3, hipMemcpyHostToDevice, st);
+    // env-major copies read by the raster
+    hipMemcpyAsync(c->s.tile_poly_em + env * kCarMaxTiles * 10, tile_poly, (size_t)nt * 40, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(c->s.tile_aabb_em + env * kCarMaxTiles, aabb.data(), (size_t)nt * 16, hipMemcpyHostToDevice, st);
+    if (border_poly) hipMemcpyAsync(c->s.border_poly_em + env * kCarMaxTiles * 8, border_poly, (size_t)nt * 32, hipMemcpyHostToDevice, st);
+    if (border) hipMemcpyAsync(c->s.border_em + env * kCarMaxTiles, border, (size_t)nt, hipMemcpyHostToDevice, st);
     hipStreamSynchronize(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "set_track: %s", hipGetErrorString(e));
