@@ -38,7 +38,11 @@ CAR_STATE_DT = np.dtype([
     ("reward", "<f8"), ("prev_reward", "<f8"), ("tile_visited_count", "<i4"), ("last_block", "<i4"), ("done", "<i4"),
     ("step_count", "<i4"), ("first_step", "<i4"), ("pad", "<i4"),
     ("wheel_tiles", "<u4", (4, CAR_MAX_TILES // 32)), ("visited", "<u4", (CAR_MAX_TILES // 32,))], align=True)
-CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4")], align=True)
+CAR_CONTACT_DT = np.dtype([("pair", "<i4"), ("count", "<i4"), ("type", "<i4"), ("ln", "<f4", (2,)), ("lp", "<f4", (2,)),
+                           ("pt", "<f4", (2, 2)), ("id", "<u4", (2,)), ("nimp", "<f4", (2,)), ("timp", "<f4", (2,))])
+CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4"), ("n_contact", "<i4"), ("pad", "<i4"),
+                             ("contact", CAR_CONTACT_DT, (16,))], align=True)
+CRL_FLAG_CAR_NO_CONTACTS = 2
 
 
 class CrlOpts(C.Structure):

@@ -1,0 +1,409 @@
+// car_contact.hip -- the two cars of an env solved as ONE Box2D island when they can touch.
+//
+// One lane per env, active only where car_step_kernel flagged the env as coupled (oriented boxes
+// overlap).  Restates, in float32, Box2D 2.3's b2CollidePolygons (reference-face clipping, <= 2
+// manifold points, contact ids for warm starting) and b2ContactSolver (friction then normal with
+// the 2-point block solver; Baumgarte position correction) around the same joint phases as the
+// single-car island (car_solver.h).  Third-party algorithm, absent from the reference tree
+// (box2d-py ~=2.3.5): parity unpinned; the CPU checker restates the same algorithm.
+//
+// A = a fixture of car 0, B = a fixture of car 1 (fixtures 0-3: hull polygons, 4-7: wheels; wheels do
+// not collide with wheels).  friction = sqrt(0.2*0.2), restitution = 0, polygonRadius = 0.01.
+#include "car_solver.h"
+
+namespace crl {
+
+struct XF {
+    float s, c;
+    V2 p;
+};
+__device__ inline V2 xmul(const XF &t, V2 v) { return rotv(t.s, t.c, v) + t.p; }
+__device__ inline V2 qmulT(const XF &t, V2 v) { return mk(t.c * v.x + t.s * v.y, -t.s * v.x + t.c * v.y); }
+__device__ inline V2 xmulT(const XF &t, V2 v) { return qmulT(t, v - t.p); }
+
+struct Shape {
+    const float (*v)[2];
+    int n;
+};
+__device__ inline Shape shape_of(const CarConsts &K, int f) {
+    Shape s;
+    s.v = f < 4 ? K.hull_poly[f] : K.wheel_poly, s.n = f < 4 ? K.hull_n[f] : 4;
+    return s;
+}
+__device__ inline V2 shape_vertex(const Shape &s, int i) { return mk(s.v[i][0], s.v[i][1]); }
+__device__ inline V2 shape_normal(const Shape &s, int i) {
+    const int j = i + 1 < s.n ? i + 1 : 0;
+    const V2 e = mk(s.v[j][0] - s.v[i][0], s.v[j][1] - s.v[i][1]);
+    const V2 n = mk(e.y, -e.x);
+    const float len = sqrtf(dot(n, n));
+    return (1.0f / len) * n;
+}
+
+struct Contact {  // persisted manifold (car_device.h: kContactWords floats per contact)
+    int pair, count, type;
+    float ln[2], lp[2], pt[2][2];
+    uint32_t id[2];
+    float nimp[2], timp[2];
+};
+
+struct BRef {
+    Body *b;
+    float im, ii;
+    V2 lc;
+};
+__device__ inline BRef body_of(CarRegs &c, const CarConsts &K, int fixture) {
+    BRef r;
+    if (fixture < 4) r.b = &c.H, r.im = K.hull_inv_mass, r.ii = K.hull_inv_I, r.lc = mk(K.hull_lc[0], K.hull_lc[1]);
+    else r.b = &c.W[fixture - 4], r.im = K.wheel_inv_mass, r.ii = K.wheel_inv_I, r.lc = mk(0.f, 0.f);
+    return r;
+}
+__device__ inline XF xf_of(const BRef &r) {
+    XF t;
+    t.s = sinf(r.b->a), t.c = cosf(r.b->a);
+    t.p = mk(r.b->cx, r.b->cy) - rotv(t.s, t.c, r.lc);
+    return t;
+}
+
+__device__ inline float max_separation(int &edge, const Shape &p1, const XF &x1, const Shape &p2, const XF &x2) {
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int i = 0; i < p1.n; i++) {
+        const V2 n = rotv(x1.s, x1.c, shape_normal(p1, i)), v1 = xmul(x1, shape_vertex(p1, i));
+        float si = 3.4e38f;
+        for (int j = 0; j < p2.n; j++) {
+            const float sij = dot(n, xmul(x2, shape_vertex(p2, j)) - v1);
+            if (sij < si) si = sij;
+        }
+        if (si > best) best = si, bi = i;
+    }
+    edge = bi;
+    return best;
+}
+
+struct ClipV {
+    V2 v;
+    uint32_t id;
+};
+__device__ inline uint32_t mkid(uint32_t ia, uint32_t ib, uint32_t ta, uint32_t tb) { return ia | (ib << 8) | (ta << 16) | (tb << 24); }
+
+__device__ inline int clip_segment(ClipV out[2], const ClipV in[2], V2 normal, float offset, int vertexIndexA) {
+    int n = 0;
+    const float d0 = dot(normal, in[0].v) - offset, d1 = dot(normal, in[1].v) - offset;
+    if (d0 <= 0.0f) out[n++] = in[0];
+    if (d1 <= 0.0f) out[n++] = in[1];
+    if (d0 * d1 < 0.0f) {
+        const float interp = d0 / (d0 - d1);
+        out[n].v = in[0].v + interp * (in[1].v - in[0].v);
+        out[n].id = mkid((uint32_t)vertexIndexA, (in[0].id >> 8) & 255u, 0u, 1u);
+        n++;
+    }
+    return n;
+}
+
+__device__ void collide_polygons(Contact &c, const Shape &pa, const XF &xa, const Shape &pb, const XF &xb) {
+    c.count = 0;
+    const float totalRadius = 0.02f;
+    int edgeA, edgeB;
+    const float sepA = max_separation(edgeA, pa, xa, pb, xb);
+    if (sepA > totalRadius) return;
+    const float sepB = max_separation(edgeB, pb, xb, pa, xa);
+    if (sepB > totalRadius) return;
+    const bool flip = sepB > 0.98f * sepA + 0.001f;
+    const Shape &p1 = flip ? pb : pa, &p2 = flip ? pa : pb;
+    const XF &x1 = flip ? xb : xa, &x2 = flip ? xa : xb;
+    const int edge1 = flip ? edgeB : edgeA;
+    c.type = flip ? 1 : 0;
+    ClipV inc[2];
+    {
+        const V2 n1 = qmulT(x2, rotv(x1.s, x1.c, shape_normal(p1, edge1)));
+        int idx = 0;
+        float mind = 3.4e38f;
+        for (int i = 0; i < p2.n; i++) {
+            const float d = dot(n1, shape_normal(p2, i));
+            if (d < mind) mind = d, idx = i;
+        }
+        const int i1 = idx, i2 = i1 + 1 < p2.n ? i1 + 1 : 0;
+        inc[0].v = xmul(x2, shape_vertex(p2, i1)), inc[0].id = mkid((uint32_t)edge1, (uint32_t)i1, 1u, 0u);
+        inc[1].v = xmul(x2, shape_vertex(p2, i2)), inc[1].id = mkid((uint32_t)edge1, (uint32_t)i2, 1u, 0u);
+    }
+    const int iv1 = edge1, iv2 = edge1 + 1 < p1.n ? edge1 + 1 : 0;
+    V2 v11 = shape_vertex(p1, iv1), v12 = shape_vertex(p1, iv2);
+    V2 lt = v12 - v11;
+    lt = (1.0f / sqrtf(dot(lt, lt))) * lt;
+    const V2 ln = mk(lt.y, -lt.x), planePoint = 0.5f * (v11 + v12);
+    const V2 tangent = rotv(x1.s, x1.c, lt), normal = mk(tangent.y, -tangent.x);
+    v11 = xmul(x1, v11), v12 = xmul(x1, v12);
+    const float frontOffset = dot(normal, v11);
+    const float side1 = -dot(tangent, v11) + totalRadius, side2 = dot(tangent, v12) + totalRadius;
+    ClipV c1[2], c2[2];
+    if (clip_segment(c1, inc, -1.0f * tangent, side1, iv1) < 2) return;
+    if (clip_segment(c2, c1, tangent, side2, iv2) < 2) return;
+    c.ln[0] = ln.x, c.ln[1] = ln.y, c.lp[0] = planePoint.x, c.lp[1] = planePoint.y;
+    int n = 0;
+    for (int i = 0; i < 2; i++) {
+        const float sep = dot(normal, c2[i].v) - frontOffset;
+        if (sep <= totalRadius) {
+            const V2 lpt = xmulT(x2, c2[i].v);
+            c.pt[n][0] = lpt.x, c.pt[n][1] = lpt.y;
+            uint32_t id = c2[i].id;
+            if (flip) id = mkid((id >> 8) & 255u, id & 255u, (id >> 24) & 255u, (id >> 16) & 255u);
+            c.id[n] = id;
+            n++;
+        }
+    }
+    c.count = n;
+}
+
+struct ContactVC {
+    V2 normal, rA[2], rB[2];
+    float nmass[2], tmass[2], K[2][2], invK[2][2];
+    int count;
+};
+
+__device__ inline void world_manifold(const Contact &c, const XF &xa, const XF &xb, V2 &normal, V2 pts[2]) {
+    const float rA = 0.01f, rB = 0.01f;
+    if (c.type == 0) {
+        const V2 n = rotv(xa.s, xa.c, mk(c.ln[0], c.ln[1])), plane = xmul(xa, mk(c.lp[0], c.lp[1]));
+        for (int i = 0; i < c.count; i++) {
+            const V2 clip = xmul(xb, mk(c.pt[i][0], c.pt[i][1]));
+            const V2 cA = clip + (rA - dot(clip - plane, n)) * n, cB = clip - rB * n;
+            pts[i] = 0.5f * (cA + cB);
+        }
+        normal = n;
+    } else {
+        const V2 n = rotv(xb.s, xb.c, mk(c.ln[0], c.ln[1])), plane = xmul(xb, mk(c.lp[0], c.lp[1]));
+        for (int i = 0; i < c.count; i++) {
+            const V2 clip = xmul(xa, mk(c.pt[i][0], c.pt[i][1]));
+            const V2 cB = clip + (rB - dot(clip - plane, n)) * n, cA = clip - rA * n;
+            pts[i] = 0.5f * (cA + cB);
+        }
+        normal = -1.0f * n;
+    }
+}
+
+__device__ inline V2 bvel(const Body &b) { return mk(b.vx, b.vy); }
+__device__ inline void apply_imp(const BRef &A, const BRef &B, V2 rA, V2 rB, V2 P) {
+    A.b->vx -= A.im * P.x, A.b->vy -= A.im * P.y, A.b->w -= A.ii * cross(rA, P);
+    B.b->vx += B.im * P.x, B.b->vy += B.im * P.y, B.b->w += B.ii * cross(rB, P);
+}
+__device__ inline V2 rel_vel(const BRef &A, const BRef &B, V2 rA, V2 rB) {
+    return ((bvel(*B.b) + scross(B.b->w, rB)) - bvel(*A.b)) - scross(A.b->w, rA);
+}
+
+__global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) {
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= s.n || !s.coupled[env]) return;
+    const int64_t M = 2 * s.n;
+    CarRegs car[2];
+    for (int k = 0; k < 2; k++) {
+        const int64_t ci = k * s.n + env;
+        load_car(s, M, ci, car[k]);
+        for (int w = 0; w < 4; w++) car[k].fx[w] = s.wforce[(2 * w + 0) * M + ci], car[k].fy[w] = s.wforce[(2 * w + 1) * M + ci];
+    }
+    const int first_step = s.first_step[env];
+    const float h = (float)(1.0 / CAR_FPS);
+    const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
+
+    // ---- Collide: manifolds of the 48 fixture pairs, impulses carried over by contact id
+    Contact ct[kMaxContacts];
+    int nc = 0;
+    {
+        float *old = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
+        const int n_old = s.n_contact[env];
+        for (int fa = 0; fa < 8; fa++)
+            for (int fb = 0; fb < 8; fb++) {
+                if (fa >= 4 && fb >= 4) continue;
+                const BRef A = body_of(car[0], K, fa), B = body_of(car[1], K, fb);
+                Contact c;
+                c.pair = fa * 8 + fb, c.type = 0;
+                for (int i = 0; i < 2; i++) c.nimp[i] = c.timp[i] = 0.f, c.id[i] = 0u, c.pt[i][0] = c.pt[i][1] = 0.f;
+                c.ln[0] = c.ln[1] = c.lp[0] = c.lp[1] = 0.f;
+                collide_polygons(c, shape_of(K, fa), xf_of(A), shape_of(K, fb), xf_of(B));
+                if (c.count == 0 || nc >= kMaxContacts) continue;
+                for (int k = 0; k < n_old; k++) {
+                    const float *o = old + k * kContactWords;
+                    if (__float_as_int(o[0]) != c.pair) continue;
+                    const int ocount = __float_as_int(o[1]);
+                    for (int i = 0; i < c.count; i++)
+                        for (int j = 0; j < ocount; j++)
+                            if (__float_as_uint(o[11 + j]) == c.id[i]) c.nimp[i] = o[13 + j], c.timp[i] = o[15 + j];
+                }
+                ct[nc++] = c;
+            }
+    }
+
+    if (nc == 0) {
+        // boxes overlap but nothing touches: two independent islands, as in the per-car kernel
+        island_solve(car[1], K, h, dt_ratio);
+        island_solve(car[0], K, h, dt_ratio);
+    } else {
+        JointTmp jt[2];
+        ContactVC vc[kMaxContacts];
+        isl_integrate_vel(car[1], K, h), isl_integrate_vel(car[0], K, h);
+        // b2ContactSolver::InitializeVelocityConstraints, then WarmStart
+        for (int k = 0; k < nc; k++) {
+            Contact &c = ct[k];
+            ContactVC &q = vc[k];
+            const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
+            q.count = c.count;
+            const float mA = A.im, iA = A.ii, mB = B.im, iB = B.ii;
+            V2 pts[2];
+            world_manifold(c, xf_of(A), xf_of(B), q.normal, pts);
+            const V2 cA = mk(A.b->cx, A.b->cy), cB = mk(B.b->cx, B.b->cy), tangent = mk(q.normal.y, -q.normal.x);
+            for (int j = 0; j < c.count; j++) {
+                c.nimp[j] *= dt_ratio, c.timp[j] *= dt_ratio;
+                q.rA[j] = pts[j] - cA, q.rB[j] = pts[j] - cB;
+                const float rnA = cross(q.rA[j], q.normal), rnB = cross(q.rB[j], q.normal);
+                const float kN = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+                q.nmass[j] = kN > 0.0f ? 1.0f / kN : 0.0f;
+                const float rtA = cross(q.rA[j], tangent), rtB = cross(q.rB[j], tangent);
+                const float kT = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+                q.tmass[j] = kT > 0.0f ? 1.0f / kT : 0.0f;
+            }
+            if (q.count == 2) {
+                const float rn1A = cross(q.rA[0], q.normal), rn1B = cross(q.rB[0], q.normal);
+                const float rn2A = cross(q.rA[1], q.normal), rn2B = cross(q.rB[1], q.normal);
+                const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B, k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+                const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+                if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+                    q.K[0][0] = k11, q.K[0][1] = k12, q.K[1][0] = k12, q.K[1][1] = k22;
+                    float det = k11 * k22 - k12 * k12;
+                    if (det != 0.0f) det = 1.0f / det;
+                    q.invK[0][0] = det * k22, q.invK[1][0] = -det * k12, q.invK[0][1] = -det * k12, q.invK[1][1] = det * k11;
+                } else {
+                    q.count = 1;
+                }
+            }
+        }
+        for (int k = 0; k < nc; k++) {
+            const Contact &c = ct[k];
+            const ContactVC &q = vc[k];
+            const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
+            const V2 tangent = mk(q.normal.y, -q.normal.x);
+            for (int j = 0; j < q.count; j++) {
+                const V2 P = c.nimp[j] * q.normal + c.timp[j] * tangent;
+                A.b->w -= A.ii * cross(q.rA[j], P), A.b->vx -= A.im * P.x, A.b->vy -= A.im * P.y;
+                B.b->w += B.ii * cross(q.rB[j], P), B.b->vx += B.im * P.x, B.b->vy += B.im * P.y;
+            }
+        }
+        isl_joints_init(car[1], jt[1], K, dt_ratio), isl_joints_init(car[0], jt[0], K, dt_ratio);
+        const float friction = sqrtf(0.2f * 0.2f);
+#pragma unroll 1
+        for (int it = 0; it < 180; it++) {
+            isl_joints_vel(car[1], jt[1], K, h), isl_joints_vel(car[0], jt[0], K, h);
+            for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolveVelocityConstraints
+                Contact &c = ct[k];
+                ContactVC &q = vc[k];
+                const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
+                const V2 normal = q.normal, tangent = mk(normal.y, -normal.x);
+                for (int j = 0; j < q.count; j++) {
+                    const float vt = dot(rel_vel(A, B, q.rA[j], q.rB[j]), tangent);
+                    float lambda = q.tmass[j] * (-vt);
+                    const float maxF = friction * c.nimp[j];
+                    float ni = c.timp[j] + lambda;
+                    ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
+                    lambda = ni - c.timp[j], c.timp[j] = ni;
+                    apply_imp(A, B, q.rA[j], q.rB[j], lambda * tangent);
+                }
+                if (q.count == 1) {
+                    const float vn = dot(rel_vel(A, B, q.rA[0], q.rB[0]), normal);
+                    float lambda = -q.nmass[0] * (vn - 0.0f);
+                    const float ni = fmaxf(c.nimp[0] + lambda, 0.0f);
+                    lambda = ni - c.nimp[0], c.nimp[0] = ni;
+                    apply_imp(A, B, q.rA[0], q.rB[0], lambda * normal);
+                } else if (q.count == 2) {
+                    const V2 a = mk(c.nimp[0], c.nimp[1]);
+                    float vn1 = dot(rel_vel(A, B, q.rA[0], q.rB[0]), normal), vn2 = dot(rel_vel(A, B, q.rA[1], q.rB[1]), normal);
+                    V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
+                    b = b - mk(q.K[0][0] * a.x + q.K[1][0] * a.y, q.K[0][1] * a.x + q.K[1][1] * a.y);
+                    V2 x = mk(-(q.invK[0][0] * b.x + q.invK[1][0] * b.y), -(q.invK[0][1] * b.x + q.invK[1][1] * b.y));
+                    bool solved = x.x >= 0.0f && x.y >= 0.0f;
+                    if (!solved) {
+                        x = mk(-q.nmass[0] * b.x, 0.0f);
+                        vn2 = q.K[0][1] * x.x + b.y;
+                        solved = x.x >= 0.0f && vn2 >= 0.0f;
+                    }
+                    if (!solved) {
+                        x = mk(0.0f, -q.nmass[1] * b.y);
+                        vn1 = q.K[1][0] * x.y + b.x;
+                        solved = x.y >= 0.0f && vn1 >= 0.0f;
+                    }
+                    if (!solved) {
+                        x = mk(0.0f, 0.0f);
+                        solved = b.x >= 0.0f && b.y >= 0.0f;
+                    }
+                    if (solved) {
+                        const V2 d = x - a;
+                        const V2 P1 = d.x * normal, P2 = d.y * normal;
+                        A.b->vx -= A.im * (P1.x + P2.x), A.b->vy -= A.im * (P1.y + P2.y);
+                        A.b->w -= A.ii * (cross(q.rA[0], P1) + cross(q.rA[1], P2));
+                        B.b->vx += B.im * (P1.x + P2.x), B.b->vy += B.im * (P1.y + P2.y);
+                        B.b->w += B.ii * (cross(q.rB[0], P1) + cross(q.rB[1], P2));
+                        c.nimp[0] = x.x, c.nimp[1] = x.y;
+                    }
+                }
+            }
+        }
+        isl_integrate_pos(car[1], h), isl_integrate_pos(car[0], h);
+#pragma unroll 1
+        for (int it = 0; it < 60; it++) {
+            float minSep = 0.0f;
+            for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolvePositionConstraints
+                const Contact &c = ct[k];
+                const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
+                for (int j = 0; j < c.count; j++) {
+                    const XF xa = xf_of(A), xb = xf_of(B);
+                    V2 normal, point;
+                    float sep;
+                    if (c.type == 0) {
+                        normal = rotv(xa.s, xa.c, mk(c.ln[0], c.ln[1]));
+                        const V2 plane = xmul(xa, mk(c.lp[0], c.lp[1])), clip = xmul(xb, mk(c.pt[j][0], c.pt[j][1]));
+                        sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
+                    } else {
+                        normal = rotv(xb.s, xb.c, mk(c.ln[0], c.ln[1]));
+                        const V2 plane = xmul(xb, mk(c.lp[0], c.lp[1])), clip = xmul(xa, mk(c.pt[j][0], c.pt[j][1]));
+                        sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
+                        normal = -1.0f * normal;
+                    }
+                    const V2 rA = point - mk(A.b->cx, A.b->cy), rB = point - mk(B.b->cx, B.b->cy);
+                    if (sep < minSep) minSep = sep;
+                    const float C = fminf(fmaxf(0.2f * (sep + LINEAR_SLOP), -0.2f), 0.0f);
+                    const float rnA = cross(rA, normal), rnB = cross(rB, normal);
+                    const float Kn = A.im + B.im + A.ii * rnA * rnA + B.ii * rnB * rnB;
+                    const float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
+                    const V2 P = impulse * normal;
+                    A.b->cx -= A.im * P.x, A.b->cy -= A.im * P.y, A.b->a -= A.ii * cross(rA, P);
+                    B.b->cx += B.im * P.x, B.b->cy += B.im * P.y, B.b->a += B.ii * cross(rB, P);
+                }
+            }
+            const bool cok = minSep >= -3.0f * LINEAR_SLOP;
+            const bool j1 = isl_joints_pos(car[1], K), j0 = isl_joints_pos(car[0], K);
+            if (cok && j1 && j0) break;
+        }
+    }
+
+    // ---- store bodies, joints and the manifolds with their impulses
+    for (int k = 0; k < 2; k++) {
+        const int64_t ci = k * s.n + env;
+        store_car(s, M, ci, car[k]);
+        s.first_step[ci] = 0;
+    }
+    s.n_contact[env] = nc;
+    float *out = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
+    for (int k = 0; k < nc; k++) {
+        float *o = out + k * kContactWords;
+        const Contact &c = ct[k];
+        o[0] = __int_as_float(c.pair), o[1] = __int_as_float(c.count), o[2] = __int_as_float(c.type);
+        o[3] = c.ln[0], o[4] = c.ln[1], o[5] = c.lp[0], o[6] = c.lp[1];
+        o[7] = c.pt[0][0], o[8] = c.pt[0][1], o[9] = c.pt[1][0], o[10] = c.pt[1][1];
+        o[11] = __uint_as_float(c.id[0]), o[12] = __uint_as_float(c.id[1]);
+        o[13] = c.nimp[0], o[14] = c.nimp[1], o[15] = c.timp[0], o[16] = c.timp[1];
+    }
+}
+
+void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st) {
+    if (s.players != 2 || !s.contacts_enabled) return;
+    hipLaunchKernelGGL(car_coupled_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k);
+}
+
+}  // namespace crl

@@ -23,6 +23,7 @@ namespace crl {
 
 static constexpr int kCarMaxTiles = CRL_CAR_MAX_TILES;  // 512
 static constexpr int kWheelSlots = 6;                   // tiles one wheel can touch at once
+static constexpr int kMaxContacts = 16, kContactWords = 20;
 
 // constants of car_racing_multi_players.py:54-88 and car_dynamics.py:17-51
 #define CAR_SCALE 6.0
@@ -78,6 +79,12 @@ struct CarSoA {
     float *border_poly_em; // [n][512][8]
     uint8_t *border_em;    // [n][512]
     double *track_scratch;  // [512][4][n] the current lap (alpha, beta, x, y), f64
+    // ---- car-car contacts (players == 2)
+    int contacts_enabled;
+    float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
+    int32_t *coupled;       // [n] 1 = the two cars are solved together this step
+    int32_t *n_contact;     // [n] touching car-car contacts carried to the next step (warm start)
+    float *contact;         // [n][16][kContactWords] persisted manifolds + impulses
 };
 
 struct V2 {
@@ -96,6 +103,26 @@ struct Body {
     float cx, cy, a, vx, vy, w;
 };
 
+// Conservative "could these two cars touch" test on the hull poses: oriented boxes that contain
+// hull + steered wheels (half extents 1.75 x 2.75 about the hull origin, + margin), separating
+// axis test.  Symmetric in its arguments' roles, evaluated identically by both lanes of an env.
+__host__ __device__ inline bool cars_near(const CarConsts &K, float x0, float y0, float a0, float x1, float y1, float a1) {
+    const float ex = 1.75f + 0.2f, ey = 2.75f + 0.2f;
+    const float s0 = sinf(a0), c0 = cosf(a0), s1 = sinf(a1), c1 = cosf(a1);
+    // box centres = hull origins (body origin = centre of mass - R * localCenter)
+    const float ox0 = x0 - (c0 * K.hull_lc[0] - s0 * K.hull_lc[1]), oy0 = y0 - (s0 * K.hull_lc[0] + c0 * K.hull_lc[1]);
+    const float ox1 = x1 - (c1 * K.hull_lc[0] - s1 * K.hull_lc[1]), oy1 = y1 - (s1 * K.hull_lc[0] + c1 * K.hull_lc[1]);
+    const float dx = ox1 - ox0, dy = oy1 - oy0;
+    const float ax[4][2] = {{c0, s0}, {-s0, c0}, {c1, s1}, {-s1, c1}};
+    for (int i = 0; i < 4; i++) {
+        const float ux = ax[i][0], uy = ax[i][1];
+        const float r0 = ex * fabsf(c0 * ux + s0 * uy) + ey * fabsf(-s0 * ux + c0 * uy);
+        const float r1 = ex * fabsf(c1 * ux + s1 * uy) + ey * fabsf(-s1 * ux + c1 * uy);
+        if (fabsf(dx * ux + dy * uy) > r0 + r1) return false;
+    }
+    return true;
+}
+
 struct CarTrackSrc {  // where reset draws come from
     uint64_t seed;
     int64_t env_id_base;
@@ -107,6 +134,7 @@ struct CarTrackSrc {  // where reset draws come from
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st);
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, hipStream_t st);
+void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st);
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st);
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,

@@ -1,0 +1,251 @@
+// car_solver.h -- Box2D 2.3 island solve for one car (hull + 4 wheels, 4 revolute joints), split
+// into its phases so that the per-car kernel and the coupled (car-car contact) kernel share it.
+// Restated from b2Island::Solve / b2RevoluteJoint (third-party box2d-py ~=2.3.5; see car_device.h).
+#pragma once
+#include "car_device.h"
+
+namespace crl {
+
+#define LINEAR_SLOP 0.005f
+#define ANGULAR_SLOP (2.0f / 180.0f * 3.14159265359f)
+#define MAX_ANGULAR_CORRECTION (8.0f / 180.0f * 3.14159265359f)
+#define MAX_TRANSLATION 2.0f
+#define MAX_ROTATION (0.5f * 3.14159265359f)
+#define LOWER_ANGLE (-0.4f)
+#define UPPER_ANGLE (+0.4f)
+#define MAX_MOTOR_TORQUE ((float)(180 * 900 * CAR_SIZE * CAR_SIZE))
+enum { LIM_INACTIVE = 0, LIM_LOWER = 1, LIM_UPPER = 2 };
+
+struct M33 {  // columns ex, ey, ez as in b2Mat33
+    float ex[3], ey[3], ez[3];
+};
+
+__device__ inline V2 solve22(const M33 &m, V2 b) {
+    const float a11 = m.ex[0], a12 = m.ey[0], a21 = m.ex[1], a22 = m.ey[1];
+    float det = a11 * a22 - a12 * a21;
+    if (det != 0.0f) det = 1.0f / det;
+    return mk(det * (a22 * b.x - a12 * b.y), det * (a11 * b.y - a21 * b.x));
+}
+
+__device__ inline void solve33(const M33 &m, const float b[3], float x[3]) {
+    const float *ex = m.ex, *ey = m.ey, *ez = m.ez;
+    const float cyz[3] = {ey[1] * ez[2] - ey[2] * ez[1], ey[2] * ez[0] - ey[0] * ez[2], ey[0] * ez[1] - ey[1] * ez[0]};
+    float det = ex[0] * cyz[0] + ex[1] * cyz[1] + ex[2] * cyz[2];
+    if (det != 0.0f) det = 1.0f / det;
+    const float cbz[3] = {b[1] * ez[2] - b[2] * ez[1], b[2] * ez[0] - b[0] * ez[2], b[0] * ez[1] - b[1] * ez[0]};
+    const float cyb[3] = {ey[1] * b[2] - ey[2] * b[1], ey[2] * b[0] - ey[0] * b[2], ey[0] * b[1] - ey[1] * b[0]};
+    x[0] = det * (b[0] * cyz[0] + b[1] * cyz[1] + b[2] * cyz[2]);
+    x[1] = det * (ex[0] * cbz[0] + ex[1] * cbz[1] + ex[2] * cbz[2]);
+    x[2] = det * (ex[0] * cyb[0] + ex[1] * cyb[1] + ex[2] * cyb[2]);
+}
+
+// One car's solver state while it lives in registers.
+struct CarRegs {
+    Body H, W[4];
+    float imp[4][3], motor_imp[4], motor_speed[4];
+    int lim[4];
+    float fx[4], fy[4];  // tyre forces applied to the wheels this step
+};
+
+struct JointTmp {
+    V2 rA[4];
+    M33 mass[4];
+    float motorMass;
+};
+
+#define ISL_CONSTS                                                                                                     \
+    const float mA = K.hull_inv_mass, iA = K.hull_inv_I, mB = K.wheel_inv_mass, iB = K.wheel_inv_I;                   \
+    const V2 lcA = mk(K.hull_lc[0], K.hull_lc[1]);                                                                     \
+    (void)mA, (void)iA, (void)mB, (void)iB, (void)lcA
+
+// integrate velocities (the hull carries no applied force; the wheels carry the tyre forces)
+__device__ inline void isl_integrate_vel(CarRegs &c, const CarConsts &K, float h) {
+    const float mB = K.wheel_inv_mass;
+#pragma unroll
+    for (int w = 0; w < 4; w++) c.W[w].vx += h * (mB * c.fx[w]), c.W[w].vy += h * (mB * c.fy[w]);
+}
+
+// b2RevoluteJoint::InitVelocityConstraints + warm start, joints in island order j3, j2, j1, j0
+__device__ inline void isl_joints_init(CarRegs &c, JointTmp &j, const CarConsts &K, float dt_ratio) {
+    ISL_CONSTS;
+    j.motorMass = iA + iB;
+    if (j.motorMass > 0.0f) j.motorMass = 1.0f / j.motorMass;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = 3 - q;
+        const float sA = sinf(c.H.a), cA = cosf(c.H.a);
+        j.rA[w] = rotv(sA, cA, mk(K.anchor[w][0], K.anchor[w][1]) - lcA);
+        const V2 r = j.rA[w];
+        M33 &m = j.mass[w];
+        m.ex[0] = mA + mB + r.y * r.y * iA + 0.0f * 0.0f * iB;
+        m.ey[0] = -r.y * r.x * iA - 0.0f * 0.0f * iB;
+        m.ez[0] = -r.y * iA - 0.0f * iB;
+        m.ex[1] = m.ey[0];
+        m.ey[1] = mA + mB + r.x * r.x * iA + 0.0f * 0.0f * iB;
+        m.ez[1] = r.x * iA + 0.0f * iB;
+        m.ex[2] = m.ez[0], m.ey[2] = m.ez[1], m.ez[2] = iA + iB;
+        const float ja = c.W[w].a - c.H.a - 0.0f;
+        if (ja <= LOWER_ANGLE) {
+            if (c.lim[w] != LIM_LOWER) c.imp[w][2] = 0;
+            c.lim[w] = LIM_LOWER;
+        } else if (ja >= UPPER_ANGLE) {
+            if (c.lim[w] != LIM_UPPER) c.imp[w][2] = 0;
+            c.lim[w] = LIM_UPPER;
+        } else {
+            c.lim[w] = LIM_INACTIVE, c.imp[w][2] = 0;
+        }
+        c.imp[w][0] *= dt_ratio, c.imp[w][1] *= dt_ratio, c.imp[w][2] *= dt_ratio, c.motor_imp[w] *= dt_ratio;
+        const V2 P = mk(c.imp[w][0], c.imp[w][1]);
+        c.H.vx -= mA * P.x, c.H.vy -= mA * P.y;
+        c.H.w -= iA * (cross(r, P) + c.motor_imp[w] + c.imp[w][2]);
+        c.W[w].vx += mB * P.x, c.W[w].vy += mB * P.y;
+        c.W[w].w += iB * (cross(mk(0.f, 0.f), P) + c.motor_imp[w] + c.imp[w][2]);
+    }
+}
+
+// one velocity iteration over the 4 joints (motor, then limit / point constraint)
+__device__ inline void isl_joints_vel(CarRegs &c, const JointTmp &j, const CarConsts &K, float h) {
+    ISL_CONSTS;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = 3 - q;
+        const V2 r = j.rA[w], rB = mk(0.f, 0.f);
+        {  // motor
+            const float Cdot = c.W[w].w - c.H.w - c.motor_speed[w];
+            float impulse = -j.motorMass * Cdot;
+            const float old = c.motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
+            float ni = old + impulse;
+            ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
+            c.motor_imp[w] = ni;
+            impulse = ni - old;
+            c.H.w -= iA * impulse, c.W[w].w += iB * impulse;
+        }
+        const V2 vA = mk(c.H.vx, c.H.vy), vB = mk(c.W[w].vx, c.W[w].vy);
+        if (c.lim[w] != LIM_INACTIVE) {
+            const V2 Cdot1 = ((vB + scross(c.W[w].w, rB)) - vA) - scross(c.H.w, r);
+            const float Cdot2 = c.W[w].w - c.H.w;
+            const float b[3] = {Cdot1.x, Cdot1.y, Cdot2};
+            float im[3];
+            solve33(j.mass[w], b, im);
+            im[0] = -im[0], im[1] = -im[1], im[2] = -im[2];
+            const float newI = c.imp[w][2] + im[2];
+            const bool lower = c.lim[w] == LIM_LOWER;
+            if (lower ? newI < 0.0f : newI > 0.0f) {
+                const V2 rhs = (-1.0f * Cdot1) + c.imp[w][2] * mk(j.mass[w].ez[0], j.mass[w].ez[1]);
+                const V2 red = solve22(j.mass[w], rhs);
+                im[0] = red.x, im[1] = red.y, im[2] = -c.imp[w][2];
+                c.imp[w][0] += red.x, c.imp[w][1] += red.y, c.imp[w][2] = 0;
+            } else {
+                c.imp[w][0] += im[0], c.imp[w][1] += im[1], c.imp[w][2] += im[2];
+            }
+            const V2 P = mk(im[0], im[1]);
+            c.H.vx -= mA * P.x, c.H.vy -= mA * P.y, c.H.w -= iA * (cross(r, P) + im[2]);
+            c.W[w].vx += mB * P.x, c.W[w].vy += mB * P.y, c.W[w].w += iB * (cross(rB, P) + im[2]);
+        } else {
+            const V2 Cdot = ((vB + scross(c.W[w].w, rB)) - vA) - scross(c.H.w, r);
+            const V2 im = solve22(j.mass[w], -1.0f * Cdot);
+            c.imp[w][0] += im.x, c.imp[w][1] += im.y;
+            c.H.vx -= mA * im.x, c.H.vy -= mA * im.y, c.H.w -= iA * cross(r, im);
+            c.W[w].vx += mB * im.x, c.W[w].vy += mB * im.y, c.W[w].w += iB * cross(rB, im);
+        }
+    }
+}
+
+__device__ inline void integrate_body(Body &b, float h) {
+    const V2 tr = mk(h * b.vx, h * b.vy);
+    if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) {
+        const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr));
+        b.vx *= ratio, b.vy *= ratio;
+    }
+    const float ro = h * b.w;
+    if (ro * ro > MAX_ROTATION * MAX_ROTATION) b.w *= MAX_ROTATION / fabsf(ro);
+    b.cx += h * b.vx, b.cy += h * b.vy, b.a += h * b.w;
+}
+
+__device__ inline void isl_integrate_pos(CarRegs &c, float h) {
+    integrate_body(c.H, h);
+#pragma unroll
+    for (int w = 0; w < 4; w++) integrate_body(c.W[w], h);
+}
+
+// one position iteration over the 4 joints; true when all are within slop
+__device__ inline bool isl_joints_pos(CarRegs &c, const CarConsts &K) {
+    ISL_CONSTS;
+    float motorMass = iA + iB;
+    if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = 3 - q;
+        float angErr = 0;
+        if (c.lim[w] != LIM_INACTIVE) {
+            const float angle = c.W[w].a - c.H.a - 0.0f;
+            float C;
+            if (c.lim[w] == LIM_LOWER) {
+                C = angle - LOWER_ANGLE, angErr = -C;
+                C = fminf(fmaxf(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION), 0.0f);
+            } else {
+                C = angle - UPPER_ANGLE, angErr = C;
+                C = fminf(fmaxf(C - ANGULAR_SLOP, 0.0f), MAX_ANGULAR_CORRECTION);
+            }
+            const float li = -motorMass * C;
+            c.H.a -= iA * li, c.W[w].a += iB * li;
+        }
+        const float sA = sinf(c.H.a), cA = cosf(c.H.a);
+        const V2 r = rotv(sA, cA, mk(K.anchor[w][0], K.anchor[w][1]) - lcA), rB = mk(0.f, 0.f);
+        const V2 C = ((mk(c.W[w].cx, c.W[w].cy) + rB) - mk(c.H.cx, c.H.cy)) - r;
+        const float posErr = sqrtf(dot(C, C));
+        M33 k;
+        k.ex[0] = mA + mB + iA * r.y * r.y + iB * rB.y * rB.y;
+        k.ex[1] = -iA * r.x * r.y - iB * rB.x * rB.y;
+        k.ey[0] = k.ex[1];
+        k.ey[1] = mA + mB + iA * r.x * r.x + iB * rB.x * rB.x;
+        const V2 im = -1.0f * solve22(k, C);
+        c.H.cx -= mA * im.x, c.H.cy -= mA * im.y, c.H.a -= iA * cross(r, im);
+        c.W[w].cx += mB * im.x, c.W[w].cy += mB * im.y, c.W[w].a += iB * cross(rB, im);
+        ok = ok && posErr <= LINEAR_SLOP && angErr <= ANGULAR_SLOP;
+    }
+    return ok;
+}
+
+// b2Island::Solve for one car on its own
+__device__ inline void island_solve(CarRegs &c, const CarConsts &K, float h, float dt_ratio) {
+    JointTmp j;
+    isl_integrate_vel(c, K, h);
+    isl_joints_init(c, j, K, dt_ratio);
+#pragma unroll 1
+    for (int it = 0; it < 180; it++) isl_joints_vel(c, j, K, h);
+    isl_integrate_pos(c, h);
+#pragma unroll 1
+    for (int it = 0; it < 60; it++)
+        if (isl_joints_pos(c, K)) break;
+}
+
+__device__ inline void load_car(const CarSoA &s, int64_t M, int64_t ci, CarRegs &c) {
+    const float *b = s.body + ci;
+    c.H.cx = b[0 * M], c.H.cy = b[1 * M], c.H.a = b[2 * M], c.H.vx = b[3 * M], c.H.vy = b[4 * M], c.H.w = b[5 * M];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int o = 6 + 6 * w;
+        c.W[w].cx = b[(o + 0) * M], c.W[w].cy = b[(o + 1) * M], c.W[w].a = b[(o + 2) * M];
+        c.W[w].vx = b[(o + 3) * M], c.W[w].vy = b[(o + 4) * M], c.W[w].w = b[(o + 5) * M];
+        c.imp[w][0] = s.jimp[(3 * w + 0) * M + ci], c.imp[w][1] = s.jimp[(3 * w + 1) * M + ci], c.imp[w][2] = s.jimp[(3 * w + 2) * M + ci];
+        c.motor_imp[w] = s.jmotor[w * M + ci], c.motor_speed[w] = s.jspeed[w * M + ci], c.lim[w] = s.jlimit[w * M + ci];
+        c.fx[w] = 0.f, c.fy[w] = 0.f;
+    }
+}
+
+__device__ inline void store_car(const CarSoA &s, int64_t M, int64_t ci, const CarRegs &c) {
+    float *b = s.body + ci;
+    b[0 * M] = c.H.cx, b[1 * M] = c.H.cy, b[2 * M] = c.H.a, b[3 * M] = c.H.vx, b[4 * M] = c.H.vy, b[5 * M] = c.H.w;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int o = 6 + 6 * w;
+        b[(o + 0) * M] = c.W[w].cx, b[(o + 1) * M] = c.W[w].cy, b[(o + 2) * M] = c.W[w].a;
+        b[(o + 3) * M] = c.W[w].vx, b[(o + 4) * M] = c.W[w].vy, b[(o + 5) * M] = c.W[w].w;
+        s.jimp[(3 * w + 0) * M + ci] = c.imp[w][0], s.jimp[(3 * w + 1) * M + ci] = c.imp[w][1], s.jimp[(3 * w + 2) * M + ci] = c.imp[w][2];
+        s.jmotor[w * M + ci] = c.motor_imp[w], s.jspeed[w * M + ci] = c.motor_speed[w], s.jlimit[w * M + ci] = c.lim[w];
+    }
+}
+
+}  // namespace crl

@@ -5,44 +5,11 @@
 // track tiles (Begin/EndContact -> tile rewards) -> island solve (180 velocity iterations over
 // 4 revolute joints, <= 60 position iterations) entirely in registers.  Bound by the sequential
 // Gauss-Seidel chain (VALU latency), not by HBM: ~1.3 KB of state per car per step.
-#include "car_device.h"
+#include "car_solver.h"
 
 namespace crl {
 
 __device__ inline double sgn(double v) { return (double)((v > 0) - (v < 0)); }
-
-#define LINEAR_SLOP 0.005f
-#define ANGULAR_SLOP (2.0f / 180.0f * 3.14159265359f)
-#define MAX_ANGULAR_CORRECTION (8.0f / 180.0f * 3.14159265359f)
-#define MAX_TRANSLATION 2.0f
-#define MAX_ROTATION (0.5f * 3.14159265359f)
-#define LOWER_ANGLE (-0.4f)
-#define UPPER_ANGLE (+0.4f)
-#define MAX_MOTOR_TORQUE ((float)(180 * 900 * CAR_SIZE * CAR_SIZE))
-enum { LIM_INACTIVE = 0, LIM_LOWER = 1, LIM_UPPER = 2 };
-
-struct M33 {  // columns ex, ey, ez as in b2Mat33
-    float ex[3], ey[3], ez[3];
-};
-
-__device__ inline V2 solve22(const M33 &m, V2 b) {
-    const float a11 = m.ex[0], a12 = m.ey[0], a21 = m.ex[1], a22 = m.ey[1];
-    float det = a11 * a22 - a12 * a21;
-    if (det != 0.0f) det = 1.0f / det;
-    return mk(det * (a22 * b.x - a12 * b.y), det * (a11 * b.y - a21 * b.x));
-}
-
-__device__ inline void solve33(const M33 &m, const float b[3], float x[3]) {
-    const float *ex = m.ex, *ey = m.ey, *ez = m.ez;
-    const float cyz[3] = {ey[1] * ez[2] - ey[2] * ez[1], ey[2] * ez[0] - ey[0] * ez[2], ey[0] * ez[1] - ey[1] * ez[0]};
-    float det = ex[0] * cyz[0] + ex[1] * cyz[1] + ex[2] * cyz[2];
-    if (det != 0.0f) det = 1.0f / det;
-    const float cbz[3] = {b[1] * ez[2] - b[2] * ez[1], b[2] * ez[0] - b[0] * ez[2], b[0] * ez[1] - b[1] * ez[0]};
-    const float cyb[3] = {ey[1] * b[2] - ey[2] * b[1], ey[2] * b[0] - ey[0] * b[2], ey[0] * b[1] - ey[1] * b[0]};
-    x[0] = det * (b[0] * cyz[0] + b[1] * cyz[1] + b[2] * cyz[2]);
-    x[1] = det * (ex[0] * cbz[0] + ex[1] * cbz[1] + ex[2] * cbz[2]);
-    x[2] = det * (ex[0] * cyb[0] + ex[1] * cyb[1] + ex[2] * cyb[2]);
-}
 
 // ---- convex polygon distance: what b2TestOverlap (GJK distance < radii) decides for sensors
 __device__ inline float seg_seg_dist2(V2 p1, V2 q1, V2 p2, V2 q2) {
@@ -110,6 +77,7 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
             Wb[w].vx = b[(o + 3) * M], Wb[w].vy = b[(o + 4) * M], Wb[w].w = b[(o + 5) * M];
         }
     }
+    const Body H0 = H;  // pre-step hull pose (the near test must be the same in both lanes)
     float imp[4][3], motor_imp[4], motor_speed[4];
     int lim[4];
     double gas[4], omega[4], phase[4];
@@ -262,149 +230,42 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         }
     }
 
-    // ---- world.Step: b2Island::Solve for this car (joints in island order j3, j2, j1, j0)
-    {
+    // ---- world.Step: b2Island::Solve.  A car whose oriented box meets the other car's is handed to
+    // the coupled kernel (car_contact.hip), which adds the car-car contact constraints; everyone
+    // else is an island of its own and is solved here.
+    CarRegs cr;
+    cr.H = H;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        cr.W[w] = Wb[w], cr.fx[w] = fx[w], cr.fy[w] = fy[w];
+        cr.imp[w][0] = imp[w][0], cr.imp[w][1] = imp[w][1], cr.imp[w][2] = imp[w][2];
+        cr.motor_imp[w] = motor_imp[w], cr.motor_speed[w] = motor_speed[w], cr.lim[w] = lim[w];
+    }
+    bool coupled = false;
+    if (s.players == 2 && s.contacts_enabled) {
+        // both lanes of an env evaluate the same symmetric test on the pre-solve hull poses
+        const int64_t c0 = env, c1 = s.n + env;
+        const float x0 = car == 0 ? H0.cx : s.body[0 * M + c0], y0 = car == 0 ? H0.cy : s.body[1 * M + c0], a0 = car == 0 ? H0.a : s.body[2 * M + c0];
+        const float x1 = car == 1 ? H0.cx : s.body[0 * M + c1], y1 = car == 1 ? H0.cy : s.body[1 * M + c1], a1 = car == 1 ? H0.a : s.body[2 * M + c1];
+        coupled = cars_near(K, x0, y0, a0, x1, y1, a1);
+    }
+    if (coupled) {
+        // keep the pre-solve bodies; pass the tyre forces and joint targets to the coupled kernel
+#pragma unroll
+        for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
+        if (car == 0) s.coupled[env] = 1;
+    } else {
         const float h = (float)(1.0 / CAR_FPS);
         const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
-        const float mA = K.hull_inv_mass, iA = K.hull_inv_I, mB = K.wheel_inv_mass, iB = K.wheel_inv_I;
-        const V2 lcA = mk(K.hull_lc[0], K.hull_lc[1]);
-        // integrate velocities (hull has no applied force; wheels carry the tyre forces)
+        island_solve(cr, K, h, dt_ratio);
+        if (car == 0 && s.players == 2) s.coupled[env] = 0, s.n_contact[env] = 0;
+    }
+    H = cr.H;
 #pragma unroll
-        for (int w = 0; w < 4; w++) Wb[w].vx += h * (mB * fx[w]), Wb[w].vy += h * (mB * fy[w]);
-        V2 rA[4];
-        M33 mass[4];
-        float motorMass = iA + iB;
-        if (motorMass > 0.0f) motorMass = 1.0f / motorMass;
-        // InitVelocityConstraints + warm start
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int w = 3 - q;
-            const float sA = sinf(H.a), cA = cosf(H.a);
-            rA[w] = rotv(sA, cA, mk(K.anchor[w][0], K.anchor[w][1]) - lcA);
-            const V2 r = rA[w];
-            M33 &m = mass[w];
-            m.ex[0] = mA + mB + r.y * r.y * iA + 0.0f * 0.0f * iB;
-            m.ey[0] = -r.y * r.x * iA - 0.0f * 0.0f * iB;
-            m.ez[0] = -r.y * iA - 0.0f * iB;
-            m.ex[1] = m.ey[0];
-            m.ey[1] = mA + mB + r.x * r.x * iA + 0.0f * 0.0f * iB;
-            m.ez[1] = r.x * iA + 0.0f * iB;
-            m.ex[2] = m.ez[0], m.ey[2] = m.ez[1], m.ez[2] = iA + iB;
-            const float ja = Wb[w].a - H.a - 0.0f;
-            if (ja <= LOWER_ANGLE) {
-                if (lim[w] != LIM_LOWER) imp[w][2] = 0;
-                lim[w] = LIM_LOWER;
-            } else if (ja >= UPPER_ANGLE) {
-                if (lim[w] != LIM_UPPER) imp[w][2] = 0;
-                lim[w] = LIM_UPPER;
-            } else {
-                lim[w] = LIM_INACTIVE, imp[w][2] = 0;
-            }
-            imp[w][0] *= dt_ratio, imp[w][1] *= dt_ratio, imp[w][2] *= dt_ratio, motor_imp[w] *= dt_ratio;
-            const V2 P = mk(imp[w][0], imp[w][1]);
-            H.vx -= mA * P.x, H.vy -= mA * P.y;
-            H.w -= iA * (cross(r, P) + motor_imp[w] + imp[w][2]);
-            Wb[w].vx += mB * P.x, Wb[w].vy += mB * P.y;
-            Wb[w].w += iB * (cross(mk(0.f, 0.f), P) + motor_imp[w] + imp[w][2]);
-        }
-        // velocity iterations
-#pragma unroll 1
-        for (int it = 0; it < 180; it++) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int w = 3 - q;
-                const V2 r = rA[w], rB = mk(0.f, 0.f);
-                {  // motor
-                    const float Cdot = Wb[w].w - H.w - motor_speed[w];
-                    float impulse = -motorMass * Cdot;
-                    const float old = motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
-                    float ni = old + impulse;
-                    ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
-                    motor_imp[w] = ni;
-                    impulse = ni - old;
-                    H.w -= iA * impulse, Wb[w].w += iB * impulse;
-                }
-                const V2 vA = mk(H.vx, H.vy), vB = mk(Wb[w].vx, Wb[w].vy);
-                if (lim[w] != LIM_INACTIVE) {
-                    const V2 Cdot1 = ((vB + scross(Wb[w].w, rB)) - vA) - scross(H.w, r);
-                    const float Cdot2 = Wb[w].w - H.w;
-                    const float b[3] = {Cdot1.x, Cdot1.y, Cdot2};
-                    float im[3];
-                    solve33(mass[w], b, im);
-                    im[0] = -im[0], im[1] = -im[1], im[2] = -im[2];
-                    const float newI = imp[w][2] + im[2];
-                    const bool lower = lim[w] == LIM_LOWER;
-                    if (lower ? newI < 0.0f : newI > 0.0f) {
-                        const V2 rhs = (-1.0f * Cdot1) + imp[w][2] * mk(mass[w].ez[0], mass[w].ez[1]);
-                        const V2 red = solve22(mass[w], rhs);
-                        im[0] = red.x, im[1] = red.y, im[2] = -imp[w][2];
-                        imp[w][0] += red.x, imp[w][1] += red.y, imp[w][2] = 0;
-                    } else {
-                        imp[w][0] += im[0], imp[w][1] += im[1], imp[w][2] += im[2];
-                    }
-                    const V2 P = mk(im[0], im[1]);
-                    H.vx -= mA * P.x, H.vy -= mA * P.y, H.w -= iA * (cross(r, P) + im[2]);
-                    Wb[w].vx += mB * P.x, Wb[w].vy += mB * P.y, Wb[w].w += iB * (cross(rB, P) + im[2]);
-                } else {
-                    const V2 Cdot = ((vB + scross(Wb[w].w, rB)) - vA) - scross(H.w, r);
-                    const V2 im = solve22(mass[w], -1.0f * Cdot);
-                    imp[w][0] += im.x, imp[w][1] += im.y;
-                    H.vx -= mA * im.x, H.vy -= mA * im.y, H.w -= iA * cross(r, im);
-                    Wb[w].vx += mB * im.x, Wb[w].vy += mB * im.y, Wb[w].w += iB * cross(rB, im);
-                }
-            }
-        }
-        // integrate positions
-        auto integrate = [&](Body &b) {
-            const V2 tr = mk(h * b.vx, h * b.vy);
-            if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) {
-                const float ratio = MAX_TRANSLATION / sqrtf(dot(tr, tr));
-                b.vx *= ratio, b.vy *= ratio;
-            }
-            const float ro = h * b.w;
-            if (ro * ro > MAX_ROTATION * MAX_ROTATION) b.w *= MAX_ROTATION / fabsf(ro);
-            b.cx += h * b.vx, b.cy += h * b.vy, b.a += h * b.w;
-        };
-        integrate(H);
-#pragma unroll
-        for (int w = 0; w < 4; w++) integrate(Wb[w]);
-        // position iterations
-#pragma unroll 1
-        for (int it = 0; it < 60; it++) {
-            bool ok = true;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int w = 3 - q;
-                float angErr = 0;
-                if (lim[w] != LIM_INACTIVE) {
-                    const float angle = Wb[w].a - H.a - 0.0f;
-                    float C;
-                    if (lim[w] == LIM_LOWER) {
-                        C = angle - LOWER_ANGLE, angErr = -C;
-                        C = fminf(fmaxf(C + ANGULAR_SLOP, -MAX_ANGULAR_CORRECTION), 0.0f);
-                    } else {
-                        C = angle - UPPER_ANGLE, angErr = C;
-                        C = fminf(fmaxf(C - ANGULAR_SLOP, 0.0f), MAX_ANGULAR_CORRECTION);
-                    }
-                    const float li = -motorMass * C;
-                    H.a -= iA * li, Wb[w].a += iB * li;
-                }
-                const float sA = sinf(H.a), cA = cosf(H.a);
-                const V2 r = rotv(sA, cA, mk(K.anchor[w][0], K.anchor[w][1]) - lcA), rB = mk(0.f, 0.f);
-                const V2 C = ((mk(Wb[w].cx, Wb[w].cy) + rB) - mk(H.cx, H.cy)) - r;
-                const float posErr = sqrtf(dot(C, C));
-                M33 k;
-                k.ex[0] = mA + mB + iA * r.y * r.y + iB * rB.y * rB.y;
-                k.ex[1] = -iA * r.x * r.y - iB * rB.x * rB.y;
-                k.ey[0] = k.ex[1];
-                k.ey[1] = mA + mB + iA * r.x * r.x + iB * rB.x * rB.x;
-                const V2 im = -1.0f * solve22(k, C);
-                H.cx -= mA * im.x, H.cy -= mA * im.y, H.a -= iA * cross(r, im);
-                Wb[w].cx += mB * im.x, Wb[w].cy += mB * im.y, Wb[w].a += iB * cross(rB, im);
-                ok = ok && posErr <= LINEAR_SLOP && angErr <= ANGULAR_SLOP;
-            }
-            if (ok) break;
-        }
+    for (int w = 0; w < 4; w++) {
+        Wb[w] = cr.W[w];
+        imp[w][0] = cr.imp[w][0], imp[w][1] = cr.imp[w][1], imp[w][2] = cr.imp[w][2];
+        motor_imp[w] = cr.motor_imp[w], lim[w] = cr.lim[w];
     }
     step_count += 1;
 
@@ -429,7 +290,8 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     }
     s.reward[ci] = reward, s.prev_reward[ci] = prev_reward;
     s.visited_count[ci] = visited_count, s.last_block[ci] = last_block, s.done[ci] = done;
-    s.step_count[ci] = step_count, s.first_step[ci] = 0;
+    s.step_count[ci] = step_count;
+    if (!coupled) s.first_step[ci] = 0;  // (the coupled kernel clears it after using it)
     if (rew_out) rew_out[env * s.players + car] = (float)step_reward;
     if (done_car) done_car[env * s.players + car] = (uint8_t)done;
 }

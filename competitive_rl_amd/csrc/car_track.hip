@@ -216,6 +216,7 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         s.visited_count[ci] = 0, s.last_block[ci] = -1, s.done[ci] = 0, s.step_count[ci] = 0, s.first_step[ci] = 1;
     }
     s.elapsed[env] = 0;
+    if (s.n_contact) s.n_contact[env] = 0, s.coupled[env] = 0;
 }
 
 __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, CarTrackSrc src, int only_done,

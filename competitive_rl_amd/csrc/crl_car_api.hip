@@ -111,6 +111,7 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     const int64_t n = c->n = opts->num_envs, M = (int64_t)players * n;
     CarSoA &s = c->s;
     s.n = n, s.players = players;
+    s.contacts_enabled = (players == 2 && !(opts->flags & CRL_FLAG_CAR_NO_CONTACTS)) ? 1 : 0;
     int rc = 0;
 #define A(f, cnt) if (!rc) rc = calloc_dev(c, &s.f, (size_t)(cnt))
     A(body, 30 * M); A(jimp, 12 * M); A(jmotor, 4 * M); A(jspeed, 4 * M); A(jlimit, 4 * M);
@@ -119,6 +120,7 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
+    A(wforce, 8 * M); A(coupled, n); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
 #undef A
@@ -181,6 +183,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
                  crl_timer *tm) {
     crl_timer_begin(tm, 0, st);
     launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, st);
+    launch_car_coupled(c->s, c->K_, st);
     launch_car_post(c->s, c->done_car, c->done_env, 1000, st);
     launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
     crl_timer_end(tm, 0, st);
@@ -209,6 +212,8 @@ struct HostCopy {
     std::vector<double> wgas, womega, wphase, reward, prev_reward;
     std::vector<int16_t> wtiles;
     std::vector<uint32_t> visited, episode;
+    std::vector<int32_t> n_contact;
+    std::vector<float> contact;
 };
 
 static void pull_all(crl_car_ctx *c, HostCopy &h, hipStream_t st) {
@@ -222,6 +227,7 @@ static void pull_all(crl_car_ctx *c, HostCopy &h, hipStream_t st) {
     h.visited_count = pull(s.visited_count, M, st), h.last_block = pull(s.last_block, M, st), h.done = pull(s.done, M, st);
     h.step_count = pull(s.step_count, M, st), h.first_step = pull(s.first_step, M, st);
     h.elapsed = pull(s.elapsed, n, st), h.episode = pull(s.episode, n, st);
+    h.n_contact = pull(s.n_contact, n, st), h.contact = pull(s.contact, (size_t)n * kMaxContacts * kContactWords, st);
     hipStreamSynchronize(st);
 }
 
@@ -262,6 +268,9 @@ int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first
             q.step_count = h.step_count[ci], q.first_step = h.first_step[ci];
         }
         o.elapsed = h.elapsed[env], o.episode = h.episode[env];
+        o.n_contact = h.n_contact[env];
+        for (int k = 0; k < o.n_contact && k < kMaxContacts; k++)
+            memcpy(&o.contact[k], &h.contact[((size_t)env * kMaxContacts + k) * kContactWords], sizeof(crl_car_contact));
     }
     return CRL_OK;
 }
@@ -300,6 +309,9 @@ int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t 
             h.step_count[ci] = q.step_count, h.first_step[ci] = q.first_step;
         }
         h.elapsed[env] = o.elapsed, h.episode[env] = o.episode;
+        h.n_contact[env] = o.n_contact;
+        for (int k = 0; k < o.n_contact && k < kMaxContacts; k++)
+            memcpy(&h.contact[((size_t)env * kMaxContacts + k) * kContactWords], &o.contact[k], sizeof(crl_car_contact));
     }
     const CarSoA &s = c->s;
     push(h.body, s.body, st), push(h.jimp, s.jimp, st), push(h.jmotor, s.jmotor, st), push(h.jspeed, s.jspeed, st);
@@ -307,6 +319,7 @@ int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t 
     push(h.wtiles, s.wtiles, st), push(h.visited, s.visited, st), push(h.reward, s.reward, st), push(h.prev_reward, s.prev_reward, st);
     push(h.visited_count, s.visited_count, st), push(h.last_block, s.last_block, st), push(h.done, s.done, st);
     push(h.step_count, s.step_count, st), push(h.first_step, s.first_step, st), push(h.elapsed, s.elapsed, st), push(h.episode, s.episode, st);
+    push(h.n_contact, s.n_contact, st), push(h.contact, s.contact, st);
     hipStreamSynchronize(st);
     return CRL_OK;
 }

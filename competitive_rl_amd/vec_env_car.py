@@ -48,7 +48,7 @@ class CarLazyInfos:
 
 class HipCarVecEnv(VecEnv):
     def __init__(self, num_envs, seed=0, device=None, env_id_base=0, output="torch", dones="dummy", action_repeat=None,
-                 frame_stack=None, players=2):
+                 frame_stack=None, players=2, car_contacts=True):
         if not torch.cuda.is_available():
             raise RuntimeError("HipCarVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -62,7 +62,8 @@ class HipCarVecEnv(VecEnv):
         assert players in (1, 2)
         self.P = int(players)  # 2 = cCarRacingDouble-v0, 1 = cCarRacing-v0
         opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE if players == 2 else N.CRL_ENV_CAR_SINGLE, obs_mode=0, resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
-                         env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0, flags=0)
+                         env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0,
+                         flags=0 if car_contacts else N.CRL_FLAG_CAR_NO_CONTACTS)
         h = C.c_void_p()
         dummy = np.zeros(16, np.uint8)  # crl_create's atlas argument is only used by Pong contexts
         with torch.cuda.device(self.device):

@@ -57,6 +57,8 @@ enum crl_env_kind {
     CRL_ENV_CAR_SINGLE = 4,
 };
 /* crl_opts.flags */
+#define CRL_FLAG_CAR_NO_CONTACTS 2  /* cCarRacingDouble: skip the car-car contact constraints (cars pass
+                                      through each other); default is to solve them */
 #define CRL_FLAG_STACK_REPLICATE 1 /* FrameStack wrapper semantics (utils/atari_wrappers.py:243-247):
                                       reset fills all K planes with the first frame, instead of
                                       FrameStackTensor's zeroed history */
@@ -204,10 +206,22 @@ typedef struct crl_car_state {   /* one car: Car (car_dynamics.py:55-129) + its 
     uint32_t visited[CRL_CAR_MAX_TILES / 32];        /* tile.road_visited[car]               */
 } crl_car_state;
 
+#define CRL_CAR_MAX_CONTACTS 16
+typedef struct crl_car_contact { /* a touching contact between a fixture of car 0 and one of car 1 */
+    int32_t pair;           /* fa * 8 + fb; fixtures 0-3 hull polygons, 4-7 wheels               */
+    int32_t count, type;    /* manifold points (1-2); 0 = face of A is the reference, 1 = of B   */
+    float ln[2], lp[2];     /* manifold local normal / point (reference body frame)              */
+    float pt[2][2];         /* manifold points (incident body frame)                             */
+    uint32_t id[2];         /* contact feature ids (warm-start key)                              */
+    float nimp[2], timp[2]; /* accumulated normal / tangent impulses                             */
+} crl_car_contact;
+
 typedef struct crl_car_env_state {
     crl_car_state car[2];
     int32_t elapsed;  /* gym TimeLimit._elapsed_steps */
     uint32_t episode; /* resets so far                */
+    int32_t n_contact, pad;
+    crl_car_contact contact[CRL_CAR_MAX_CONTACTS];
 } crl_car_env_state;
 
 int crl_car_get_state(crl_ctx *ctx, crl_car_env_state *state_host, int64_t first, int64_t count, void *stream);

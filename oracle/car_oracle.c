@@ -402,17 +402,25 @@ static void solve33(const float m[3][3], const float b[3], float x[3]) {
     x[2] = det * (ex[0] * cyb[0] + ex[1] * cyb[1] + ex[2] * cyb[2]);
 }
 
-/* b2Island::Solve for one car: bodies [hull, w0..w3], joints solved in the order j3, j2, j1, j0
- * (island build order of b2World::Solve for bodies created hull, w0, w1, w2, w3). */
-static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters, int pos_iters) {
-    const float mA = K.hull_inv_mass, iA = K.hull_inv_I, mB = K.wheel_inv_mass, iB = K.wheel_inv_I;
-    car_body *H = &car->hull;
-    /* integrate velocities: v += h * invMass * F (no gravity, no damping, no torque) */
+/* b2Island::Solve, split into its phases so that one car (the usual case) and two cars coupled by
+ * contacts run the same code.  Bodies of a car: [hull, w0..w3]; its joints are solved in the order
+ * j3, j2, j1, j0 (island build order of b2World::Solve for bodies created hull, w0, w1, w2, w3). */
+#define ISL_CONSTS \
+    const float mA = K.hull_inv_mass, iA = K.hull_inv_I, mB = K.wheel_inv_mass, iB = K.wheel_inv_I; \
+    car_body *H = &car->hull; \
+    const v2 lcA = V(K.hull_lc[0], K.hull_lc[1]); \
+    (void)mA, (void)iA, (void)mB, (void)iB, (void)H, (void)lcA
+
+/* integrate velocities: v += h * invMass * F (no gravity, no damping, no torque) */
+static void isl_integrate_vel(car_state *car, float h) {
+    ISL_CONSTS;
     H->vx += h * (mA * H->fx), H->vy += h * (mA * H->fy);
     for (int w = 0; w < 4; w++) car->wheel[w].vx += h * (mB * car->wheel[w].fx), car->wheel[w].vy += h * (mB * car->wheel[w].fy);
-    joint_tmp jt[4];
-    v2 lcA = V(K.hull_lc[0], K.hull_lc[1]);
-    /* InitVelocityConstraints */
+}
+
+/* b2RevoluteJoint::InitVelocityConstraints (+ warm start) for the 4 joints */
+static void isl_joints_init(car_state *car, joint_tmp *jt, float dt_ratio) {
+    ISL_CONSTS;
     for (int q = 0; q < 4; q++) {
         int w = 3 - q;
         car_body *B = &car->wheel[w];
@@ -448,8 +456,11 @@ static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters,
         B->vx += mB * P.x, B->vy += mB * P.y;
         B->w += iB * (vcross(rB, P) + car->motor_imp[w] + car->imp[w][2]);
     }
-    /* velocity iterations */
-    for (int it = 0; it < vel_iters; it++)
+}
+
+/* one velocity iteration: b2RevoluteJoint::SolveVelocityConstraints for the 4 joints */
+static void isl_joints_vel(car_state *car, joint_tmp *jt, float h) {
+    ISL_CONSTS;
         for (int q = 0; q < 4; q++) {
             int w = 3 - q;
             car_body *B = &car->wheel[w];
@@ -492,7 +503,11 @@ static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters,
                 B->vx += mB * imp.x, B->vy += mB * imp.y, B->w += iB * vcross(rB, imp);
             }
         }
-    /* integrate positions (with the translation / rotation clamps) */
+}
+
+/* integrate positions (with the translation / rotation clamps) */
+static void isl_integrate_pos(car_state *car, float h) {
+    ISL_CONSTS;
     car_body *all[5] = {H, &car->wheel[0], &car->wheel[1], &car->wheel[2], &car->wheel[3]};
     for (int k = 0; k < 5; k++) {
         car_body *b = all[k];
@@ -505,9 +520,12 @@ static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters,
         if (ro * ro > MAX_ROTATION * MAX_ROTATION) b->w *= MAX_ROTATION / fabsf(ro);
         b->cx += h * b->vx, b->cy += h * b->vy, b->a += h * b->w;
     }
-    /* position iterations */
-    for (int it = 0; it < pos_iters; it++) {
-        int ok = 1;
+}
+
+/* one position iteration: b2RevoluteJoint::SolvePositionConstraints for the 4 joints */
+static int isl_joints_pos(car_state *car) {
+    ISL_CONSTS;
+    int ok = 1;
         for (int q = 0; q < 4; q++) {
             int w = 3 - q;
             car_body *B = &car->wheel[w];
@@ -540,11 +558,386 @@ static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters,
             B->cx += mB * imp.x, B->cy += mB * imp.y, B->a += iB * vcross(rB, imp);
             ok &= posErr <= LINEAR_SLOP && angErr <= ANGULAR_SLOP;
         }
-        if (ok) break;
-    }
-    /* ClearForces */
-    H->fx = H->fy = 0;
+    return ok;
+}
+
+static void isl_clear_forces(car_state *car) {
+    car->hull.fx = car->hull.fy = 0;
     for (int w = 0; w < 4; w++) car->wheel[w].fx = car->wheel[w].fy = 0;
+}
+
+static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters, int pos_iters) {
+    joint_tmp jt[4];
+    isl_integrate_vel(car, h);
+    isl_joints_init(car, jt, dt_ratio);
+    for (int it = 0; it < vel_iters; it++) isl_joints_vel(car, jt, h);
+    isl_integrate_pos(car, h);
+    for (int it = 0; it < pos_iters; it++)
+        if (isl_joints_pos(car)) break;
+    isl_clear_forces(car);
+}
+
+
+/* ------------------------------------------------------------------ car-car contacts
+ * b2CollidePolygons (manifold), b2ContactSolver (velocity: friction then normal with the 2-point
+ * block solver; position: Baumgarte pseudo-impulses) restated from Box2D 2.3 [published
+ * algorithm, not available here: UNPINNED].  A = a fixture of car 0, B = a fixture of car 1
+ * (car 0's proxies are created first).  Wheels do not collide with wheels (category 0x20 / mask 1).
+ * Friction = sqrt(0.2 * 0.2), restitution = 0. */
+typedef struct { float s, c; v2 p; } xform;
+static inline v2 xmul(xform t, v2 v) { return vadd(rot(t.s, t.c, v), t.p); }
+static inline v2 qmulT(xform t, v2 v) { return V(t.c * v.x + t.s * v.y, -t.s * v.x + t.c * v.y); }
+static inline v2 xmulT(xform t, v2 v) { return qmulT(t, vsub(v, t.p)); }
+
+typedef struct { const float (*v)[2]; int n; v2 nrm[8]; } shape;
+static shape SH[8]; /* 0-3 hull polygons, 4-7 the wheel box */
+static int SH_ready = 0;
+static void shapes_init(void) {
+    if (SH_ready) return;
+    car_oracle_consts();
+    for (int f = 0; f < 8; f++) {
+        SH[f].v = f < 4 ? K.hull_poly[f] : K.wheel_poly, SH[f].n = f < 4 ? K.hull_n[f] : 4;
+        for (int i = 0; i < SH[f].n; i++) {
+            int j = i + 1 < SH[f].n ? i + 1 : 0;
+            v2 e = V(SH[f].v[j][0] - SH[f].v[i][0], SH[f].v[j][1] - SH[f].v[i][1]);
+            v2 n = V(e.y, -e.x); /* b2Cross(edge, 1) */
+            float len = sqrtf(vdot(n, n));
+            SH[f].nrm[i] = vmul(1.0f / len, n);
+        }
+    }
+    SH_ready = 1;
+}
+
+typedef struct { car_body *b; float im, ii; v2 lc; } bref;
+static bref body_of(car_env *e, int car, int fixture) {
+    bref r;
+    if (fixture < 4) r.b = &e->car[car].hull, r.im = K.hull_inv_mass, r.ii = K.hull_inv_I, r.lc = V(K.hull_lc[0], K.hull_lc[1]);
+    else r.b = &e->car[car].wheel[fixture - 4], r.im = K.wheel_inv_mass, r.ii = K.wheel_inv_I, r.lc = V(0, 0);
+    return r;
+}
+static xform xf_of(const bref *r) {
+    xform t;
+    t.s = sinf(r->b->a), t.c = cosf(r->b->a);
+    t.p = vsub(V(r->b->cx, r->b->cy), rot(t.s, t.c, r->lc));
+    return t;
+}
+
+/* b2FindMaxSeparation (exhaustive form): best edge of poly1 against poly2's vertices */
+static float max_separation(int *edge, const shape *p1, xform x1, const shape *p2, xform x2) {
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int i = 0; i < p1->n; i++) {
+        v2 n = rot(x1.s, x1.c, p1->nrm[i]), v1 = xmul(x1, V(p1->v[i][0], p1->v[i][1]));
+        float si = 3.4e38f;
+        for (int j = 0; j < p2->n; j++) {
+            float sij = vdot(n, vsub(xmul(x2, V(p2->v[j][0], p2->v[j][1])), v1));
+            if (sij < si) si = sij;
+        }
+        if (si > best) best = si, bi = i;
+    }
+    *edge = bi;
+    return best;
+}
+
+typedef struct { v2 v; uint32_t id; } clipv;
+#define MKID(ia, ib, ta, tb) ((uint32_t)(ia) | ((uint32_t)(ib) << 8) | ((uint32_t)(ta) << 16) | ((uint32_t)(tb) << 24))
+static int clip_segment(clipv out[2], const clipv in[2], v2 normal, float offset, int vertexIndexA) {
+    int n = 0;
+    float d0 = vdot(normal, in[0].v) - offset, d1 = vdot(normal, in[1].v) - offset;
+    if (d0 <= 0.0f) out[n++] = in[0];
+    if (d1 <= 0.0f) out[n++] = in[1];
+    if (d0 * d1 < 0.0f) {
+        float interp = d0 / (d0 - d1);
+        out[n].v = vadd(in[0].v, vmul(interp, vsub(in[1].v, in[0].v)));
+        out[n].id = MKID(vertexIndexA, (in[0].id >> 8) & 255u, 0 /*e_vertex*/, 1 /*e_face*/);
+        n++;
+    }
+    return n;
+}
+
+/* b2CollidePolygons -> manifold in `c` (count = 0 when not touching) */
+static void collide_polygons(car_contact *c, const shape *pa, xform xa, const shape *pb, xform xb) {
+    c->count = 0;
+    const float totalRadius = 0.02f;
+    int edgeA, edgeB;
+    float sepA = max_separation(&edgeA, pa, xa, pb, xb);
+    if (sepA > totalRadius) return;
+    float sepB = max_separation(&edgeB, pb, xb, pa, xa);
+    if (sepB > totalRadius) return;
+    const shape *p1, *p2;
+    xform x1, x2;
+    int edge1, flip;
+    if (sepB > 0.98f * sepA + 0.001f) p1 = pb, p2 = pa, x1 = xb, x2 = xa, edge1 = edgeB, c->type = 1, flip = 1;
+    else p1 = pa, p2 = pb, x1 = xa, x2 = xb, edge1 = edgeA, c->type = 0, flip = 0;
+    /* b2FindIncidentEdge */
+    clipv inc[2];
+    {
+        v2 n1 = qmulT(x2, rot(x1.s, x1.c, p1->nrm[edge1]));
+        int idx = 0;
+        float mind = 3.4e38f;
+        for (int i = 0; i < p2->n; i++) {
+            float d = vdot(n1, p2->nrm[i]);
+            if (d < mind) mind = d, idx = i;
+        }
+        int i1 = idx, i2 = i1 + 1 < p2->n ? i1 + 1 : 0;
+        inc[0].v = xmul(x2, V(p2->v[i1][0], p2->v[i1][1])), inc[0].id = MKID(edge1, i1, 1, 0);
+        inc[1].v = xmul(x2, V(p2->v[i2][0], p2->v[i2][1])), inc[1].id = MKID(edge1, i2, 1, 0);
+    }
+    int iv1 = edge1, iv2 = edge1 + 1 < p1->n ? edge1 + 1 : 0;
+    v2 v11 = V(p1->v[iv1][0], p1->v[iv1][1]), v12 = V(p1->v[iv2][0], p1->v[iv2][1]);
+    v2 lt = vsub(v12, v11);
+    lt = vmul(1.0f / sqrtf(vdot(lt, lt)), lt);
+    v2 ln = V(lt.y, -lt.x), planePoint = vmul(0.5f, vadd(v11, v12));
+    v2 tangent = rot(x1.s, x1.c, lt), normal = V(tangent.y, -tangent.x);
+    v11 = xmul(x1, v11), v12 = xmul(x1, v12);
+    float frontOffset = vdot(normal, v11);
+    float side1 = -vdot(tangent, v11) + totalRadius, side2 = vdot(tangent, v12) + totalRadius;
+    clipv c1[2], c2[2];
+    if (clip_segment(c1, inc, vmul(-1.0f, tangent), side1, iv1) < 2) return;
+    if (clip_segment(c2, c1, tangent, side2, iv2) < 2) return;
+    c->ln[0] = ln.x, c->ln[1] = ln.y, c->lp[0] = planePoint.x, c->lp[1] = planePoint.y;
+    int n = 0;
+    for (int i = 0; i < 2; i++) {
+        float sep = vdot(normal, c2[i].v) - frontOffset;
+        if (sep <= totalRadius) {
+            v2 lpt = xmulT(x2, c2[i].v);
+            c->pt[n][0] = lpt.x, c->pt[n][1] = lpt.y;
+            uint32_t id = c2[i].id;
+            if (flip) id = MKID((id >> 8) & 255u, id & 255u, (id >> 24) & 255u, (id >> 16) & 255u);
+            c->id[n] = id;
+            n++;
+        }
+    }
+    c->count = n;
+}
+
+/* b2ContactManager::Collide for the car-car pairs: new manifolds, impulses carried by id */
+static void collide_cars(car_env *e) {
+    shapes_init();
+    car_contact old[CAR_MAX_CONTACTS];
+    int n_old = e->n_contact;
+    memcpy(old, e->contact, sizeof(old));
+    e->n_contact = 0;
+    /* cheap reject: hull centres more than two car lengths apart */
+    float dx = e->car[0].hull.cx - e->car[1].hull.cx, dy = e->car[0].hull.cy - e->car[1].hull.cy;
+    if (dx * dx + dy * dy > 12.0f * 12.0f) return;
+    for (int fa = 0; fa < 8; fa++)
+        for (int fb = 0; fb < 8; fb++) {
+            if (fa >= 4 && fb >= 4) continue; /* wheel-wheel filtered out */
+            bref A = body_of(e, 0, fa), B = body_of(e, 1, fb);
+            car_contact c;
+            memset(&c, 0, sizeof(c));
+            c.pair = fa * 8 + fb;
+            collide_polygons(&c, &SH[fa], xf_of(&A), &SH[fb], xf_of(&B));
+            if (c.count == 0 || e->n_contact >= CAR_MAX_CONTACTS) continue;
+            for (int k = 0; k < n_old; k++)
+                if (old[k].pair == c.pair)
+                    for (int i = 0; i < c.count; i++)
+                        for (int j = 0; j < old[k].count; j++)
+                            if (old[k].id[j] == c.id[i]) c.nimp[i] = old[k].nimp[j], c.timp[i] = old[k].timp[j];
+            e->contact[e->n_contact++] = c;
+        }
+}
+
+typedef struct {
+    bref A, B;
+    v2 normal, rA[2], rB[2];
+    float nmass[2], tmass[2], bias[2], K[2][2], invK[2][2];
+    int count;
+} contact_vc;
+
+static void world_manifold(const car_contact *c, xform xa, xform xb, v2 *normal, v2 pts[2]) {
+    const float rA = 0.01f, rB = 0.01f;
+    if (c->type == 0) {
+        v2 n = rot(xa.s, xa.c, V(c->ln[0], c->ln[1])), plane = xmul(xa, V(c->lp[0], c->lp[1]));
+        for (int i = 0; i < c->count; i++) {
+            v2 clip = xmul(xb, V(c->pt[i][0], c->pt[i][1]));
+            v2 cA = vadd(clip, vmul(rA - vdot(vsub(clip, plane), n), n)), cB = vsub(clip, vmul(rB, n));
+            pts[i] = vmul(0.5f, vadd(cA, cB));
+        }
+        *normal = n;
+    } else {
+        v2 n = rot(xb.s, xb.c, V(c->ln[0], c->ln[1])), plane = xmul(xb, V(c->lp[0], c->lp[1]));
+        for (int i = 0; i < c->count; i++) {
+            v2 clip = xmul(xa, V(c->pt[i][0], c->pt[i][1]));
+            v2 cB = vadd(clip, vmul(rB - vdot(vsub(clip, plane), n), n)), cA = vsub(clip, vmul(rA, n));
+            pts[i] = vmul(0.5f, vadd(cA, cB));
+        }
+        *normal = vmul(-1.0f, n);
+    }
+}
+
+static inline v2 bvel(const car_body *b) { return V(b->vx, b->vy); }
+
+/* b2ContactSolver::InitializeVelocityConstraints + WarmStart */
+static void contacts_init(car_env *e, contact_vc *vc, float dt_ratio) {
+    for (int k = 0; k < e->n_contact; k++) {
+        car_contact *c = &e->contact[k];
+        contact_vc *q = &vc[k];
+        q->A = body_of(e, 0, c->pair >> 3), q->B = body_of(e, 1, c->pair & 7);
+        q->count = c->count;
+        const float mA = q->A.im, iA = q->A.ii, mB = q->B.im, iB = q->B.ii;
+        v2 pts[2];
+        world_manifold(c, xf_of(&q->A), xf_of(&q->B), &q->normal, pts);
+        v2 cA = V(q->A.b->cx, q->A.b->cy), cB = V(q->B.b->cx, q->B.b->cy);
+        v2 tangent = V(q->normal.y, -q->normal.x);
+        for (int j = 0; j < c->count; j++) {
+            c->nimp[j] *= dt_ratio, c->timp[j] *= dt_ratio;
+            q->rA[j] = vsub(pts[j], cA), q->rB[j] = vsub(pts[j], cB);
+            float rnA = vcross(q->rA[j], q->normal), rnB = vcross(q->rB[j], q->normal);
+            float kN = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+            q->nmass[j] = kN > 0.0f ? 1.0f / kN : 0.0f;
+            float rtA = vcross(q->rA[j], tangent), rtB = vcross(q->rB[j], tangent);
+            float kT = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+            q->tmass[j] = kT > 0.0f ? 1.0f / kT : 0.0f;
+            q->bias[j] = 0.0f; /* restitution 0 */
+        }
+        if (q->count == 2) {
+            float rn1A = vcross(q->rA[0], q->normal), rn1B = vcross(q->rB[0], q->normal);
+            float rn2A = vcross(q->rA[1], q->normal), rn2B = vcross(q->rB[1], q->normal);
+            float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B, k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+            float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+            if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+                q->K[0][0] = k11, q->K[0][1] = k12, q->K[1][0] = k12, q->K[1][1] = k22; /* K[col][row] */
+                float det = k11 * k22 - k12 * k12;
+                if (det != 0.0f) det = 1.0f / det;
+                q->invK[0][0] = det * k22, q->invK[1][0] = -det * k12, q->invK[0][1] = -det * k12, q->invK[1][1] = det * k11;
+            } else {
+                q->count = 1;
+            }
+        }
+    }
+    for (int k = 0; k < e->n_contact; k++) { /* WarmStart */
+        car_contact *c = &e->contact[k];
+        contact_vc *q = &vc[k];
+        v2 tangent = V(q->normal.y, -q->normal.x);
+        for (int j = 0; j < q->count; j++) {
+            v2 P = vadd(vmul(c->nimp[j], q->normal), vmul(c->timp[j], tangent));
+            q->A.b->w -= q->A.ii * vcross(q->rA[j], P), q->A.b->vx -= q->A.im * P.x, q->A.b->vy -= q->A.im * P.y;
+            q->B.b->w += q->B.ii * vcross(q->rB[j], P), q->B.b->vx += q->B.im * P.x, q->B.b->vy += q->B.im * P.y;
+        }
+    }
+}
+
+static void apply_imp(contact_vc *q, int j, v2 P) {
+    q->A.b->vx -= q->A.im * P.x, q->A.b->vy -= q->A.im * P.y, q->A.b->w -= q->A.ii * vcross(q->rA[j], P);
+    q->B.b->vx += q->B.im * P.x, q->B.b->vy += q->B.im * P.y, q->B.b->w += q->B.ii * vcross(q->rB[j], P);
+}
+static v2 rel_vel(const contact_vc *q, int j) {
+    return vsub(vsub(vadd(bvel(q->B.b), scross(q->B.b->w, q->rB[j])), bvel(q->A.b)), scross(q->A.b->w, q->rA[j]));
+}
+
+/* b2ContactSolver::SolveVelocityConstraints, one iteration */
+static void contacts_vel(car_env *e, contact_vc *vc) {
+    const float friction = sqrtf(0.2f * 0.2f);
+    for (int k = 0; k < e->n_contact; k++) {
+        car_contact *c = &e->contact[k];
+        contact_vc *q = &vc[k];
+        v2 normal = q->normal, tangent = V(normal.y, -normal.x);
+        for (int j = 0; j < q->count; j++) { /* friction first */
+            float vt = vdot(rel_vel(q, j), tangent);
+            float lambda = q->tmass[j] * (-vt), maxF = friction * c->nimp[j];
+            float ni = c->timp[j] + lambda;
+            ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
+            lambda = ni - c->timp[j], c->timp[j] = ni;
+            apply_imp(q, j, vmul(lambda, tangent));
+        }
+        if (q->count == 1) {
+            float vn = vdot(rel_vel(q, 0), normal);
+            float lambda = -q->nmass[0] * (vn - q->bias[0]);
+            float ni = fmaxf(c->nimp[0] + lambda, 0.0f);
+            lambda = ni - c->nimp[0], c->nimp[0] = ni;
+            apply_imp(q, 0, vmul(lambda, normal));
+        } else if (q->count == 2) { /* block solver */
+            v2 a = V(c->nimp[0], c->nimp[1]);
+            float vn1 = vdot(rel_vel(q, 0), normal), vn2 = vdot(rel_vel(q, 1), normal);
+            v2 b = V(vn1 - q->bias[0], vn2 - q->bias[1]);
+            b = vsub(b, V(q->K[0][0] * a.x + q->K[1][0] * a.y, q->K[0][1] * a.x + q->K[1][1] * a.y));
+            v2 x;
+            int solved = 0;
+            x = V(-(q->invK[0][0] * b.x + q->invK[1][0] * b.y), -(q->invK[0][1] * b.x + q->invK[1][1] * b.y));
+            if (x.x >= 0.0f && x.y >= 0.0f) solved = 1;
+            if (!solved) {
+                x = V(-q->nmass[0] * b.x, 0.0f);
+                vn2 = q->K[0][1] * x.x + b.y;
+                if (x.x >= 0.0f && vn2 >= 0.0f) solved = 1;
+            }
+            if (!solved) {
+                x = V(0.0f, -q->nmass[1] * b.y);
+                vn1 = q->K[1][0] * x.y + b.x;
+                if (x.y >= 0.0f && vn1 >= 0.0f) solved = 1;
+            }
+            if (!solved) {
+                x = V(0.0f, 0.0f);
+                if (b.x >= 0.0f && b.y >= 0.0f) solved = 1;
+            }
+            if (solved) {
+                v2 d = vsub(x, a);
+                v2 P1 = vmul(d.x, normal), P2 = vmul(d.y, normal);
+                q->A.b->vx -= q->A.im * (P1.x + P2.x), q->A.b->vy -= q->A.im * (P1.y + P2.y);
+                q->A.b->w -= q->A.ii * (vcross(q->rA[0], P1) + vcross(q->rA[1], P2));
+                q->B.b->vx += q->B.im * (P1.x + P2.x), q->B.b->vy += q->B.im * (P1.y + P2.y);
+                q->B.b->w += q->B.ii * (vcross(q->rB[0], P1) + vcross(q->rB[1], P2));
+                c->nimp[0] = x.x, c->nimp[1] = x.y;
+            }
+        }
+    }
+}
+
+/* b2ContactSolver::SolvePositionConstraints, one iteration; returns minSeparation >= -3*slop */
+static int contacts_pos(car_env *e) {
+    float minSep = 0.0f;
+    for (int k = 0; k < e->n_contact; k++) {
+        car_contact *c = &e->contact[k];
+        bref A = body_of(e, 0, c->pair >> 3), B = body_of(e, 1, c->pair & 7);
+        for (int j = 0; j < c->count; j++) {
+            xform xa = xf_of(&A), xb = xf_of(&B);
+            v2 normal, point;
+            float sep;
+            if (c->type == 0) {
+                normal = rot(xa.s, xa.c, V(c->ln[0], c->ln[1]));
+                v2 plane = xmul(xa, V(c->lp[0], c->lp[1])), clip = xmul(xb, V(c->pt[j][0], c->pt[j][1]));
+                sep = vdot(vsub(clip, plane), normal) - 0.01f - 0.01f, point = clip;
+            } else {
+                normal = rot(xb.s, xb.c, V(c->ln[0], c->ln[1]));
+                v2 plane = xmul(xb, V(c->lp[0], c->lp[1])), clip = xmul(xa, V(c->pt[j][0], c->pt[j][1]));
+                sep = vdot(vsub(clip, plane), normal) - 0.01f - 0.01f, point = clip;
+                normal = vmul(-1.0f, normal);
+            }
+            v2 rA = vsub(point, V(A.b->cx, A.b->cy)), rB = vsub(point, V(B.b->cx, B.b->cy));
+            if (sep < minSep) minSep = sep;
+            float C = fminf(fmaxf(0.2f * (sep + LINEAR_SLOP), -0.2f), 0.0f);
+            float rnA = vcross(rA, normal), rnB = vcross(rB, normal);
+            float Kn = A.im + B.im + A.ii * rnA * rnA + B.ii * rnB * rnB;
+            float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
+            v2 P = vmul(impulse, normal);
+            A.b->cx -= A.im * P.x, A.b->cy -= A.im * P.y, A.b->a -= A.ii * vcross(rA, P);
+            B.b->cx += B.im * P.x, B.b->cy += B.im * P.y, B.b->a += B.ii * vcross(rB, P);
+        }
+    }
+    return minSep >= -3.0f * LINEAR_SLOP;
+}
+
+/* b2Island::Solve for the two cars joined by touching contacts: contacts are initialised and
+ * warm-started before the joints; each velocity iteration solves joints (car 1, car 0) then
+ * contacts; each position iteration contacts then joints. */
+static void island_solve_coupled(car_env *e, float h, float dt_ratio, int vel_iters, int pos_iters) {
+    joint_tmp jt[2][4];
+    contact_vc vc[CAR_MAX_CONTACTS];
+    isl_integrate_vel(&e->car[1], h), isl_integrate_vel(&e->car[0], h);
+    contacts_init(e, vc, dt_ratio);
+    isl_joints_init(&e->car[1], jt[1], dt_ratio), isl_joints_init(&e->car[0], jt[0], dt_ratio);
+    for (int it = 0; it < vel_iters; it++) {
+        isl_joints_vel(&e->car[1], jt[1], h), isl_joints_vel(&e->car[0], jt[0], h);
+        contacts_vel(e, vc);
+    }
+    isl_integrate_pos(&e->car[1], h), isl_integrate_pos(&e->car[0], h);
+    for (int it = 0; it < pos_iters; it++) {
+        int cok = contacts_pos(e);
+        int j1 = isl_joints_pos(&e->car[1]), j0 = isl_joints_pos(&e->car[0]);
+        if (cok && j1 && j0) break;
+    }
+    isl_clear_forces(&e->car[1]), isl_clear_forces(&e->car[0]);
 }
 
 /* ------------------------------------------------------------------ env */
@@ -580,6 +973,7 @@ int car_oracle_reset(car_env *e, const double *u, int max_attempts, int shuffle_
     memset(e->visited, 0, sizeof(e->visited));
     memset(e->wheel_tiles, 0, sizeof(e->wheel_tiles));
     e->t = 0, e->step_count = 0, e->inv_dt0 = 0.0f;
+    e->n_contact = 0;
     return att;
 }
 
@@ -678,8 +1072,13 @@ void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[
         float h = (float)dt;
         float dt_ratio = e->inv_dt0 * h;
         collide(e);
-        island_solve(&e->car[1], h, dt_ratio, 180, 60);
-        island_solve(&e->car[0], h, dt_ratio, 180, 60);
+        if (e->contacts_enabled) collide_cars(e);
+        if (e->contacts_enabled && e->n_contact > 0) {
+            island_solve_coupled(e, h, dt_ratio, 180, 60);
+        } else {
+            island_solve(&e->car[1], h, dt_ratio, 180, 60);
+            island_solve(&e->car[0], h, dt_ratio, 180, 60);
+        }
         e->inv_dt0 = 1.0f / h;
         e->t += dt;
         e->step_count += 1;

@@ -33,6 +33,16 @@ typedef struct car_consts {
     float anchor[4][2];
 } car_consts;
 
+#define CAR_MAX_CONTACTS 16
+typedef struct car_contact { /* one touching b2Contact between a fixture of car 0 and one of car 1 */
+    int32_t pair;        /* fa * 8 + fb; fixtures 0-3 = hull polygons, 4-7 = wheels        */
+    int32_t count, type; /* manifold points (1-2); 0 = e_faceA, 1 = e_faceB                 */
+    float ln[2], lp[2];  /* manifold.localNormal / localPoint (reference body frame)       */
+    float pt[2][2];      /* manifold.points[i].localPoint (incident body frame)            */
+    uint32_t id[2];      /* b2ContactID key                                                */
+    float nimp[2], timp[2]; /* accumulated normal / tangent impulses (warm start)          */
+} car_contact;
+
 typedef struct car_env {
     car_track trk;
     float tile32[CAR_MAX_TILES][5][2]; /* CCW, float32 as b2PolygonShape stores them */
@@ -44,6 +54,8 @@ typedef struct car_env {
     double reward[2], prev_reward[2], t;
     int32_t step_count;
     float inv_dt0;
+    int32_t n_contact, contacts_enabled;
+    car_contact contact[CAR_MAX_CONTACTS];
 } car_env;
 
 int car_oracle_create_track(const double *u, car_track *out);

@@ -13,10 +13,13 @@ BODY_DT = np.dtype([(k, "<f4") for k in ("cx", "cy", "a", "vx", "vy", "w", "fx",
 CAR_DT = np.dtype([("hull", BODY_DT), ("wheel", BODY_DT, (4,)), ("imp", "<f4", (4, 3)), ("motor_imp", "<f4", (4,)),
                    ("motor_speed", "<f4", (4,)), ("limit_state", "<i4", (4,)), ("gas", "<f8", (4,)), ("brake", "<f8", (4,)),
                    ("steer", "<f8", (4,)), ("phase", "<f8", (4,)), ("omega", "<f8", (4,))])
+CONTACT_DT = np.dtype([("pair", "<i4"), ("count", "<i4"), ("type", "<i4"), ("ln", "<f4", (2,)), ("lp", "<f4", (2,)),
+                       ("pt", "<f4", (2, 2)), ("id", "<u4", (2,)), ("nimp", "<f4", (2,)), ("timp", "<f4", (2,))])
 ENV_DT = np.dtype([("trk", TRACK_DT), ("tile32", "<f4", (MAX_TILES, 5, 2)), ("tile_aabb", "<f4", (MAX_TILES, 4)),
                    ("car", CAR_DT, (2,)), ("wheel_tiles", "<u4", (2, 4, MAX_TILES // 32)), ("visited", "<u4", (2, MAX_TILES // 32)),
                    ("tile_visited_count", "<i4", (2,)), ("last_block", "<i4", (2,)), ("done", "<i4", (2,)),
-                   ("reward", "<f8", (2,)), ("prev_reward", "<f8", (2,)), ("t", "<f8"), ("step_count", "<i4"), ("inv_dt0", "<f4")],
+                   ("reward", "<f8", (2,)), ("prev_reward", "<f8", (2,)), ("t", "<f8"), ("step_count", "<i4"), ("inv_dt0", "<f4"),
+                   ("n_contact", "<i4"), ("contacts_enabled", "<i4"), ("contact", CONTACT_DT, (16,))],
                   align=True)
 CONSTS_DT = np.dtype([("hull_poly", "<f4", (4, 8, 2)), ("hull_n", "<i4", (4,)), ("wheel_poly", "<f4", (4, 2)),
                       ("hull_mass", "<f4"), ("hull_inv_mass", "<f4"), ("hull_I", "<f4"), ("hull_inv_I", "<f4"), ("hull_lc", "<f4", (2,)),

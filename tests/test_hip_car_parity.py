@@ -40,6 +40,9 @@ def oracle_to_hip_state(envs):
             q["step_count"], q["first_step"] = e["step_count"], int(e["inv_dt0"] == 0)
             q["wheel_tiles"], q["visited"] = e["wheel_tiles"][c], e["visited"][c]
         st[i]["elapsed"] = e["step_count"]
+        st[i]["n_contact"] = e["n_contact"]
+        for f in ("pair", "count", "type", "ln", "lp", "pt", "id", "nimp", "timp"):
+            st[i]["contact"][f] = e["contact"][f]
     return st
 
 
@@ -71,6 +74,7 @@ def make_oracle_envs(n, seed0=0):
         u = np.concatenate([draws[(seed0 + i * 3 + k) % len(draws)] for k in range(6)])
         e = co.CarEnv()
         assert e.reset(u, i % 2) > 0
+        e.e["contacts_enabled"] = 1
         e.step(None)
         envs.append(e)
     return envs
@@ -300,3 +304,61 @@ def test_single_car_env_matches_car0_of_double():
     new1, new2 = o1[:, 3].cpu().numpy(), o2[:, 0].cpu().numpy()
     assert ((new1 != new2).mean(axis=(1, 2)) < 0.02).all() and not (new1[:, :86] == 29).any()
     one.close(), two.close()
+
+
+def test_car_car_contacts_teacher_forced():
+    """Cars driven into each other: manifolds, warm-started impulses and the coupled island solve
+    against the oracle, re-synchronised every step (the contact solver is branchy, so the float
+    tolerance is 1e-4 here)."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps = 8, 150
+    envs = make_oracle_envs(n, seed0=20)
+    rs = np.random.RandomState(1)
+    for i, e in enumerate(envs):  # park car 1 a few units ahead of car 0, slightly off-axis / rotated
+        c0, c1 = e.e["car"][0], e.e["car"][1]
+        a = float(c0["hull"]["a"])
+        hd, lat = np.array([-np.sin(a), np.cos(a)]), np.array([np.cos(a), np.sin(a)])
+        tgt = np.array([c0["hull"]["cx"], c0["hull"]["cy"]]) + (7.0 + 0.3 * i) * hd + rs.uniform(-1.2, 1.2) * lat
+        off = tgt - np.array([c1["hull"]["cx"], c1["hull"]["cy"]])
+        c1["hull"]["cx"] += off[0]
+        c1["hull"]["cy"] += off[1]
+        for w in range(4):
+            c1["wheel"][w]["cx"] += off[0]
+            c1["wheel"][w]["cy"] += off[1]
+        for k in range(30):  # let the joints settle before the crash
+            e.step([[0.0, 0.0], [0.0, 0.0]])
+    hip = crl.HipCarVecEnv(n)
+    hip.reset()
+    push_tracks(hip, envs)
+    worst, touched, max_nc = 0.0, 0, 0
+    for t in range(steps):
+        hip.set_state(oracle_to_hip_state(envs))
+        acts = np.zeros((n, 2, 2), np.float32)
+        acts[:, 0, 1] = 1.0
+        acts[:, 0, 0] = 0.2 * np.sin(t / 11.0)
+        acts[:, 1, 1] = -0.3 if t > 90 else 0.0
+        hip.step_device(torch.as_tensor(acts).cuda(), render=False)
+        hs = hip.get_state()
+        for i, e in enumerate(envs):
+            e.step(acts[i].astype(np.float64))
+            nc = int(e.e["n_contact"])
+            assert int(hs[i]["n_contact"]) == nc, (t, i, int(hs[i]["n_contact"]), nc)
+            max_nc = max(max_nc, nc)
+            touched += nc > 0
+            for k in range(nc):
+                q, o = hs[i]["contact"][k], e.e["contact"][k]
+                assert int(q["pair"]) == int(o["pair"]) and int(q["count"]) == int(o["count"]) and int(q["type"]) == int(o["type"])
+                assert np.array_equal(q["id"][:int(o["count"])], o["id"][:int(o["count"])])
+                assert np.allclose(q["nimp"], o["nimp"], rtol=2e-3, atol=2e-3), (t, i, k, q["nimp"], o["nimp"])
+            for c in range(2):
+                q, o = hs[i]["car"][c], e.e["car"][c]
+                for f in ("cx", "cy", "a", "vx", "vy", "w"):
+                    for got, want in ((q["hull"][f], o["hull"][f]), *zip(q["wheel"][f], o["wheel"][f])):
+                        err = abs(float(got) - float(want)) / max(1.0, abs(float(want)))
+                        worst = max(worst, err)
+                        assert err < 1e-4, (t, i, c, f, got, want)
+    print("contacts: worst relative state error", worst, "env-steps with contacts", touched, "max contacts", max_nc)
+    assert touched > 50 and max_nc >= 1
+    hip.close()
