@@ -194,7 +194,12 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n || !s.coupled[env]) return;
     const int64_t M = 2 * s.n;
-    CarRegs car[2];
+    // Bodies are picked by fixture index at run time, so the solver state cannot stay in registers;
+    // it lives in LDS (one slice per lane) instead of scratch memory.
+    __shared__ CarRegs sh_car[64][2];
+    __shared__ Contact sh_ct[64][kMaxContacts];
+    __shared__ ContactVC sh_vc[64][kMaxContacts];
+    CarRegs(&car)[2] = sh_car[threadIdx.x];
     for (int k = 0; k < 2; k++) {
         const int64_t ci = k * s.n + env;
         load_car(s, M, ci, car[k]);
@@ -205,14 +210,32 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
     const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
 
     // ---- Collide: manifolds of the 48 fixture pairs, impulses carried over by contact id
-    Contact ct[kMaxContacts];
+    Contact *ct = sh_ct[threadIdx.x];
     int nc = 0;
+    // bounding circle of every fixture (world centre, radius): rejects most of the 48 pairs cheaply;
+    // circles that do not overlap cannot be within the 0.02 contact margin
+    float fcx[2][8], fcy[2][8], frad[2][8];
+    for (int k = 0; k < 2; k++)
+        for (int f = 0; f < 8; f++) {
+            const Shape sh = shape_of(K, f);
+            V2 ctr = mk(0.f, 0.f);
+            for (int i = 0; i < sh.n; i++) ctr = ctr + shape_vertex(sh, i);
+            ctr = (1.0f / sh.n) * ctr;
+            float r2 = 0.f;
+            for (int i = 0; i < sh.n; i++) r2 = fmaxf(r2, dot(shape_vertex(sh, i) - ctr, shape_vertex(sh, i) - ctr));
+            const V2 wc = xmul(xf_of(body_of(car[k], K, f)), ctr);
+            fcx[k][f] = wc.x, fcy[k][f] = wc.y, frad[k][f] = sqrtf(r2) + 0.03f;
+        }
     {
         float *old = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
         const int n_old = s.n_contact[env];
         for (int fa = 0; fa < 8; fa++)
             for (int fb = 0; fb < 8; fb++) {
                 if (fa >= 4 && fb >= 4) continue;
+                {
+                    const float dx = fcx[0][fa] - fcx[1][fb], dy = fcy[0][fa] - fcy[1][fb], rr = frad[0][fa] + frad[1][fb];
+                    if (dx * dx + dy * dy > rr * rr) continue;
+                }
                 const BRef A = body_of(car[0], K, fa), B = body_of(car[1], K, fb);
                 Contact c;
                 c.pair = fa * 8 + fb, c.type = 0;
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
         island_solve(car[0], K, h, dt_ratio);
     } else {
         JointTmp jt[2];
-        ContactVC vc[kMaxContacts];
+        ContactVC *vc = sh_vc[threadIdx.x];
         isl_integrate_vel(car[1], K, h), isl_integrate_vel(car[0], K, h);
         // b2ContactSolver::InitializeVelocityConstraints, then WarmStart
         for (int k = 0; k < nc; k++) {

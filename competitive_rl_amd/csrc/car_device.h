@@ -8,7 +8,7 @@
 //   rigid bodies + joints ...... b2World.Step call site :600.  box2d-py ~=2.3.5 (setup.py:14) is a
 //        third-party dependency, absent from the reference tree: Box2D 2.3's published
 //        b2Island::Solve / b2RevoluteJoint / b2PolygonShape::ComputeMass are restated in f32.
-//        Car-car contacts are not modelled (DESIGN.md "CarRacing: deviations").
+//        Car-car contacts: car_contact.hip (DESIGN.md "CarRacing: deviations").
 //
 // Layout: every per-car quantity is an SoA array indexed by car instance ci = car * N + env,
 // so lane <-> car instance and all state loads/stores are coalesced; per-env track data is
@@ -23,7 +23,7 @@ namespace crl {
 
 static constexpr int kCarMaxTiles = CRL_CAR_MAX_TILES;  // 512
 static constexpr int kWheelSlots = 6;                   // tiles one wheel can touch at once
-static constexpr int kMaxContacts = 16, kContactWords = 20;
+static constexpr int kMaxContacts = 8, kContactWords = 20;
 
 // constants of car_racing_multi_players.py:54-88 and car_dynamics.py:17-51
 #define CAR_SCALE 6.0

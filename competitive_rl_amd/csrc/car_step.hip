@@ -1,7 +1,7 @@
 // car_step.hip -- one cCarRacingDouble step, one lane per CAR INSTANCE (2 lanes per env).
 //
-// The two cars of an env only interact through contacts, which this build does not model,
-// so each car is an independent Box2D island: wheel model (f64) -> sensor overlap with the
+// The two cars of an env only interact through contacts; unless their oriented boxes overlap
+// (then car_contact.hip solves them together) each car is an independent Box2D island: wheel model (f64) -> sensor overlap with the
 // track tiles (Begin/EndContact -> tile rewards) -> island solve (180 velocity iterations over
 // 4 revolute joints, <= 60 position iterations) entirely in registers.  Bound by the sequential
 // Gauss-Seidel chain (VALU latency), not by HBM: ~1.3 KB of state per car per step.

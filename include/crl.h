@@ -206,7 +206,7 @@ typedef struct crl_car_state {   /* one car: Car (car_dynamics.py:55-129) + its 
     uint32_t visited[CRL_CAR_MAX_TILES / 32];        /* tile.road_visited[car]               */
 } crl_car_state;
 
-#define CRL_CAR_MAX_CONTACTS 16
+#define CRL_CAR_MAX_CONTACTS 8
 typedef struct crl_car_contact { /* a touching contact between a fixture of car 0 and one of car 1 */
     int32_t pair;           /* fa * 8 + fb; fixtures 0-3 hull polygons, 4-7 wheels               */
     int32_t count, type;    /* manifold points (1-2); 0 = face of A is the reference, 1 = of B   */

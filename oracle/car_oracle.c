@@ -9,7 +9,7 @@
  *   - b2World.Step (rigid bodies, revolute joints, sensor overlap): box2d-py ~=2.3.5 is a
  *     third-party dependency that is neither vendored nor installable; its published
  *     algorithm (Box2D 2.3 b2Island::Solve / b2RevoluteJoint / b2PolygonShape::ComputeMass)
- *     is restated here in float32.  PARITY UNPINNED.  Car-car contacts are NOT modelled.
+ *     is restated here in float32 (joints, wheel-tile sensors, car-car contacts).  PARITY UNPINNED.
  *   - observation raster: analytic (no 10000x10000 pygame map), PARITY UNPINNED.
  *
  * Citations: car_racing/car_racing_multi_players.py = "crmp", car_racing/car_dynamics.py = "cd".

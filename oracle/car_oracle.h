@@ -33,7 +33,7 @@ typedef struct car_consts {
     float anchor[4][2];
 } car_consts;
 
-#define CAR_MAX_CONTACTS 16
+#define CAR_MAX_CONTACTS 8
 typedef struct car_contact { /* one touching b2Contact between a fixture of car 0 and one of car 1 */
     int32_t pair;        /* fa * 8 + fb; fixtures 0-3 = hull polygons, 4-7 = wheels        */
     int32_t count, type; /* manifold points (1-2); 0 = e_faceA, 1 = e_faceB                 */

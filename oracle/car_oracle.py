@@ -19,7 +19,7 @@ ENV_DT = np.dtype([("trk", TRACK_DT), ("tile32", "<f4", (MAX_TILES, 5, 2)), ("ti
                    ("car", CAR_DT, (2,)), ("wheel_tiles", "<u4", (2, 4, MAX_TILES // 32)), ("visited", "<u4", (2, MAX_TILES // 32)),
                    ("tile_visited_count", "<i4", (2,)), ("last_block", "<i4", (2,)), ("done", "<i4", (2,)),
                    ("reward", "<f8", (2,)), ("prev_reward", "<f8", (2,)), ("t", "<f8"), ("step_count", "<i4"), ("inv_dt0", "<f4"),
-                   ("n_contact", "<i4"), ("contacts_enabled", "<i4"), ("contact", CONTACT_DT, (16,))],
+                   ("n_contact", "<i4"), ("contacts_enabled", "<i4"), ("contact", CONTACT_DT, (8,))],
                   align=True)
 CONSTS_DT = np.dtype([("hull_poly", "<f4", (4, 8, 2)), ("hull_n", "<i4", (4,)), ("wheel_poly", "<f4", (4, 2)),
                       ("hull_mass", "<f4"), ("hull_inv_mass", "<f4"), ("hull_I", "<f4"), ("hull_inv_I", "<f4"), ("hull_lc", "<f4", (2,)),
