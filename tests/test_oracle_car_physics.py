@@ -147,3 +147,41 @@ def test_observation_raster_structure():
         assert np.isin(img[:86], [101, 103, 107]).mean() > 0.1 and np.isin(img[:86], [161, 176]).mean() > 0.1
     # the other car shows up in blue-gray 29 in at least one of the two views
     assert (e.render(0)[:86] == 29).any() or (e.render(1)[:86] == 29).any()
+
+
+def _park_car1_ahead(e, dist):
+    c0, c1 = e.e["car"][0], e.e["car"][1]
+    a = float(c0["hull"]["a"])
+    hd = np.array([-np.sin(a), np.cos(a)])
+    off = np.array([c0["hull"]["cx"] - c1["hull"]["cx"], c0["hull"]["cy"] - c1["hull"]["cy"]]) + dist * hd
+    c1["hull"]["cx"] += off[0]
+    c1["hull"]["cy"] += off[1]
+    for w in range(4):
+        c1["wheel"][w]["cx"] += off[0]
+        c1["wheel"][w]["cy"] += off[1]
+    return hd
+
+
+@pytest.mark.parametrize("contacts", [1, 0])
+def test_rear_end_collision_pushes_instead_of_passing_through(contacts):
+    e = fresh_env()
+    e.e["contacts_enabled"] = contacts
+    hd = _park_car1_ahead(e, 8.0)
+    gaps, ncs = [], []
+    for t in range(140):
+        e.step([[0.0, 1.0], [0.0, 0.0]])
+        c0, c1 = e.e["car"][0], e.e["car"][1]
+        d = np.array([c1["hull"]["cx"] - c0["hull"]["cx"], c1["hull"]["cy"] - c0["hull"]["cy"]])
+        gaps.append(float(np.dot(d, hd)))
+        ncs.append(int(e.e["n_contact"]))
+    if contacts:
+        # hull is 5.0 long (front +2.6, rear -2.4): bumper to bumper, centres stay >= 5.0 - slop apart
+        assert min(gaps) > 5.0 - 0.03 and max(ncs) >= 1
+        v0 = np.hypot(e.e["car"][0]["hull"]["vx"], e.e["car"][0]["hull"]["vy"])
+        v1 = np.hypot(e.e["car"][1]["hull"]["vx"], e.e["car"][1]["hull"]["vy"])
+        assert v1 > 10 and abs(v0 - v1) < 0.5  # the parked car is being pushed along
+        k = int(np.argmax(np.array(ncs) > 0))
+        assert all(n > 0 for n in ncs[k + 5:])  # resting contact persists, warm-started
+        assert float(e.e["contact"][0]["nimp"].sum()) > 1.0
+    else:
+        assert min(gaps) < 3.0 and max(ncs) == 0  # without the contact solver the cars overlap
