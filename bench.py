@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the cPongDouble hot path on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raw|fused84] [--gather none|scalars|obs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raw|fused84|fused84_newest|car] [--gather none|scalars|obs]
 
 A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated,
 device-resident) random actions, auto-reset included, no host sync inside the timed loop.
@@ -200,12 +200,14 @@ def main():
         if os.path.exists(tfile):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         line = {
-            "metric": "env-steps/sec (whole node), cPongDouble 65536 envs per GPU",
+            "metric": ("env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU" if args.workload == "car"
+                       else "env-steps/sec (whole node), cPongDouble 65536 envs per GPU"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",
-                       "actions": "uniform {0,1,2}, pre-generated on device", "auto_reset": True},
+                       "actions": ("uniform [-1,1]^2 per car" if args.workload == "car" else "uniform {0,1,2}") + ", pre-generated on device",
+                       "auto_reset": True},
             "roofline": {"bound": "hbm" if args.workload != "car" else "hbm (reported as required; the step kernel is VALU-latency bound, DESIGN.md)",
                          "kernel": kernel, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
