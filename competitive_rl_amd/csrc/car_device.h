@@ -136,7 +136,7 @@ void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &sr
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st);
-void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st);
+void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr);
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
                       int players, hipStream_t st);
 

@@ -446,7 +446,17 @@ static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::
 
 int crl_terminal_observation(crl_ctx *c, const int64_t *env_idx_host, int64_t count, uint8_t *out_dev, void *stream) {
     if (!c || (count > 0 && (!env_idx_host || !out_dev))) return fail(CRL_EINVAL, "null argument");
-    if (c->car) return fail(CRL_ESTATE, "terminal observations are not kept for CarRacing contexts");
+    if (c->car) {
+        // CarRacing keeps the finished envs' last frames (players, 96, 96): gather the requested ones
+        const int64_t tile = (int64_t)crl_car_players(c->car) * 96 * 96;
+        for (int64_t k = 0; k < count; k++) {
+            const int64_t i = env_idx_host[k];
+            if (i < 0 || i >= c->n) return fail(CRL_EINVAL, "env index %lld out of range", (long long)i);
+            HIP_TRY(hipMemcpyAsync(out_dev + k * tile, crl_car_terminal_frames(c->car) + i * tile, tile, hipMemcpyDeviceToDevice,
+                                   (hipStream_t)stream));
+        }
+        return CRL_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     std::vector<uint64_t> all((size_t)2 * c->n);
     HIP_TRY(hipMemcpyAsync(all.data(), c->s.term_frames, all.size() * 8, hipMemcpyDeviceToHost, st));

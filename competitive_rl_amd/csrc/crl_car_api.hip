@@ -21,6 +21,7 @@ struct crl_car_ctx {
     float *rew_tmp = nullptr;
     int K = 1;                      // MultipleFrameStack depth (1 = no stack)
     uint8_t *frame = nullptr, *stack = nullptr;  // K > 1: newest frames, and the context's own stack
+    uint8_t *term = nullptr;  // [n][players][96][96] last frame of the episode an env just finished
     double *ru = nullptr;
     uint8_t *rshuffle = nullptr;
 };
@@ -127,6 +128,7 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
+    if (!rc) rc = calloc_dev(c, &c->term, (size_t)M * 96 * 96);
     c->K = opts->frame_stack < 1 ? 1 : opts->frame_stack;
     if (c->K > 1) {
         if (!rc) rc = calloc_dev(c, &c->frame, (size_t)M * 96 * 96);
@@ -169,6 +171,9 @@ int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
     return CRL_OK;
 }
 
+const uint8_t *crl_car_terminal_frames(const crl_car_ctx *c) { return c->term; }
+int crl_car_players(const crl_car_ctx *c) { return c->s.players; }
+
 int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
     if (c->K > 1) return crl_fail(CRL_ESTATE, "crl_render on a stacked CarRacing context would advance the stack");
     launch_car_raster(c->s, c->K_, obs_dev, st);
@@ -185,6 +190,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, st);
     launch_car_coupled(c->s, c->K_, st);
     launch_car_post(c->s, c->done_car, c->done_env, 1000, st);
+    // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
+    if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);
     launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
     crl_timer_end(tm, 0, st);
     if (done_dev) hipMemcpyAsync(done_dev, c->done_env, c->n, hipMemcpyDeviceToDevice, st);

@@ -30,6 +30,8 @@ void crl_car_seed(crl_car_ctx *c, uint64_t seed);
 int64_t crl_car_obs_bytes(const crl_car_ctx *c);
 int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st);
 int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st);
+const uint8_t *crl_car_terminal_frames(const crl_car_ctx *c);
+int crl_car_players(const crl_car_ctx *c);
 int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
                  crl_timer *tm);
 int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first, int64_t count, hipStream_t st);

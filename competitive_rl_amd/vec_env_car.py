@@ -21,23 +21,29 @@ class CarLazyInfos:
     """``infos[i]`` -> ``{0: {"num_steps": k, "reward": r0}, 1: {...}}`` (crmp:618-620,
     atari_wrappers.py:327-328) without building N dicts per step."""
 
-    def __init__(self, n, rew, steps):
+    def __init__(self, n, rew, steps, env=None, done=None):
         self._n, self._rew_dev, self._steps_dev, self._host = n, rew, steps, None
+        self._env, self._done_dev = env, done
 
     def __len__(self):
         return self._n
 
     def __getitem__(self, i):
         if self._host is None:
-            self._host = (self._rew_dev.cpu().numpy(), self._steps_dev.cpu().numpy())
-        r, st = self._host
+            self._host = (self._rew_dev.cpu().numpy(), self._steps_dev.cpu().numpy(),
+                          self._done_dev.cpu().numpy() if self._done_dev is not None else None)
+        r, st, dn = self._host
         if i < 0:
             i += self._n
         if not 0 <= i < self._n:
             raise IndexError(i)
         if r.shape[1] == 1:  # cCarRacing-v0: info = {"num_steps": k} (crmp:616)
-            return {"num_steps": int(st[i])}
-        return {k: {"num_steps": int(st[i]), "reward": float(r[i, k])} for k in range(2)}
+            d = {"num_steps": int(st[i])}
+        else:
+            d = {k: {"num_steps": int(st[i]), "reward": float(r[i, k])} for k in range(2)}
+        if dn is not None and dn[i]:
+            d["terminal_observation"] = self._env.terminal_observation([i])[0]
+        return d
 
     def __iter__(self):
         return (self[i] for i in range(self._n))
@@ -129,7 +135,8 @@ class HipCarVecEnv(VecEnv):
         self._check_open()
         buf, rew, done = self.step_device(self._actions)
         self._steps += 1
-        infos = CarLazyInfos(self.num_envs, rew.clone(), self._steps.clone())
+        self._prev_buf = self._obs[self._flip]  # observation before this step (the stack's older planes)
+        infos = CarLazyInfos(self.num_envs, rew.clone(), self._steps.clone(), env=self, done=done.clone())
         self._steps.mul_((~done.bool()).to(torch.int32))
         r0 = rew[:, :1].clone()
         d = done.bool()
@@ -154,6 +161,22 @@ class HipCarVecEnv(VecEnv):
 
     def get_images(self, *a, **k):
         return list(self._obs[self._flip ^ 1][:, 0].cpu().numpy())
+
+    def terminal_observation(self, env_indices):
+        """Observation (P*K, 96, 96) each listed env's episode ended on, at its most recent done step."""
+        idx = np.ascontiguousarray(env_indices, np.int64)
+        out = torch.empty((len(idx), self.P, 96, 96), dtype=torch.uint8, device=self.device)
+        N.check(self._L.crl_terminal_observation(self._h, idx.ctypes.data_as(C.c_void_p), len(idx), C.c_void_p(out.data_ptr()),
+                                                 self._stream()))
+        res = []
+        for k in range(len(idx)):
+            if self.K > 1:  # MultipleFrameStack / FrameStack: K-1 newest planes of the previous obs + the last frame
+                prev = self._prev_buf[int(idx[k])].view(self.P, self.K, 96, 96)
+                o = torch.cat([prev[:, 1:], out[k][:, None]], dim=1).reshape(self.P * self.K, 96, 96)
+            else:
+                o = out[k]
+            res.append(o.cpu().numpy() if self.output == "numpy" else o)
+        return res
 
     # ---- parity / checkpoint helpers
     def get_state(self):

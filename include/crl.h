@@ -155,7 +155,8 @@ int crl_copy_info(crl_ctx *ctx, float *real_reward_out_dev, int32_t *num_steps_o
 /* info[i]["terminal_observation"] (dummy_vec_env.py:55-57), produced lazily: renders,
  * for `count` env indices (host array), the observation the episode ended on at the
  * most recent step where that env was done.  out_dev: raw (count,2,210,160,3) or
- * wrapped (count,2,R,R) u8. */
+ * wrapped (count,2,R,R) u8; CarRacing (count,players,96,96) u8 = the frames drawn just before the
+ * auto-reset (with a K-stack the caller prepends the K-1 newest planes it already holds). */
 int crl_terminal_observation(crl_ctx *ctx, const int64_t *env_idx_host, int64_t count,
                              uint8_t *out_dev, void *stream);
 

@@ -222,7 +222,8 @@ def test_car_api_surface_and_time_limit():
         if t == 999:  # gym TimeLimit: max_episode_steps = 1000
             assert bool(done.all())
             i0 = info[0]
-            assert set(i0.keys()) == {0, 1} and i0[0]["num_steps"] == 1000 and "reward" in i0[1]
+            assert set(i0.keys()) == {0, 1, "terminal_observation"} and i0[0]["num_steps"] == 1000 and "reward" in i0[1]
+            assert tuple(i0["terminal_observation"].shape) == (2, 96, 96)
     assert n_done == 6
     st = envs.get_state()
     assert (st["elapsed"] == 1).all() and (st["episode"] == 2).all()
@@ -250,6 +251,7 @@ def test_multiple_frame_stack_semantics():
     assert np.array_equal(s0, want)
     rs = np.random.RandomState(2)
     st = one.get_state()
+    prev_stack = torch.as_tensor(s0).cuda()
     for t in range(steps):
         acts = rs.uniform(-1, 1, (n, 2, 2)).astype(np.float32)
         if t == 20:  # force an early episode end in env 1: car 0 leaves the playfield
@@ -257,9 +259,10 @@ def test_multiple_frame_stack_semantics():
                 s_ = e.get_state()
                 s_["car"][1, 0]["hull"]["cx"] = 400.0
                 e.set_state(s_)
-        f, _, d1, _ = one.step(acts)
-        s, _, d4, _ = stk.step(acts)
+        f, _, d1, info1 = one.step(acts)
+        s, _, d4, info4 = stk.step(acts)
         assert torch.equal(d1, d4)
+        f_t = f
         f = f.cpu().numpy()
         for i in range(n):
             for a in range(2):
@@ -271,6 +274,14 @@ def test_multiple_frame_stack_semantics():
         assert np.array_equal(s.cpu().numpy(), want), t
         if t == 20:
             assert bool(d1[1, 0])
+            # terminal_observation: the pre-reset frames, and for the stacked env the whole last stack
+            t1 = info1[1]["terminal_observation"]
+            t4 = info4[1]["terminal_observation"]
+            assert tuple(t1.shape) == (2, 96, 96) and tuple(t4.shape) == (2 * K, 96, 96)
+            assert torch.equal(t4.view(2, K, 96, 96)[:, -1], t1)
+            assert torch.equal(t4.view(2, K, 96, 96)[:, :-1], prev_stack[1].view(2, K, 96, 96)[:, 1:])
+            assert not torch.equal(t1, f_t[1])  # not the reset frame that step() returned
+        prev_stack = s.clone()
     one.close(), stk.close()
 
 
