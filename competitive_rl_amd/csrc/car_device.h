@@ -63,6 +63,7 @@ struct CarSoA {
     int16_t *wtiles;    // [4][kWheelSlots][M] tiles each wheel touches (-1 = empty)
     uint32_t *visited;  // [16][M] tile.road_visited bits
     double *reward, *prev_reward;  // [M]
+    double *step_acc;   // [M] step reward accumulated over the action repeats of the current step
     int32_t *visited_count, *last_block, *done, *step_count, *first_step;  // [M]
     // ---- per env [..][n]
     int32_t *elapsed;   // gym TimeLimit._elapsed_steps
@@ -133,7 +134,8 @@ struct CarTrackSrc {  // where reset draws come from
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st);
-void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, hipStream_t st);
+void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
+                     hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st);
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr);

@@ -58,7 +58,8 @@ __device__ inline float poly_dist2(const V2 (&A)[4], const V2 (&B)[5]) {
 }
 
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
-                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_car) {
+                                                      float *__restrict__ rew_out, uint8_t *__restrict__ done_car, int sub,
+                                                      int repeat) {
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= M) return;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     if (a1 > 0) a2 = 0;
     else a2 = a1, a1 = 0;
     const double steer_t = -a0, gas_t = fabs(a1), brake = fabs(a2);
-    {
+    if (sub == 0) {  // the controls are applied once per CarRacing.step, before the action-repeat loop
         const double g = gas_t < 0 ? 0 : gas_t > 1 ? 1 : gas_t;
 #pragma unroll
         for (int w = 2; w < 4; w++) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
             omega[w] = om;
             fx[w] += (float)(p_force * side0 + f_force * forw0), fy[w] += (float)(p_force * side1 + f_force * forw1);
         }
-        reward -= 0.1 / 1;
+        reward -= 0.1 / repeat;
         step_reward += reward - prev_reward;
         prev_reward = reward;
         const float hs = sinf(H.a), hc = cosf(H.a);
@@ -292,7 +293,12 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     s.visited_count[ci] = visited_count, s.last_block[ci] = last_block, s.done[ci] = done;
     s.step_count[ci] = step_count;
     if (!coupled) s.first_step[ci] = 0;  // (the coupled kernel clears it after using it)
-    if (rew_out) rew_out[env * s.players + car] = (float)step_reward;
+    if (rew_out) {
+        // step_rewards accumulate over the repeats in f64 (crmp:584); the running sum is kept in prev_step
+        const double acc = (sub == 0 ? 0.0 : s.step_acc[ci]) + step_reward;
+        s.step_acc[ci] = acc;
+        rew_out[env * s.players + car] = (float)acc;
+    }
     if (done_car) done_car[env * s.players + car] = (uint8_t)done;
 }
 
@@ -309,9 +315,10 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
     done_env[env] = d ? 1 : 0;
 }
 
-void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, hipStream_t st) {
+void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
+                     hipStream_t st) {
     const int64_t M = (int64_t)s.players * s.n;
-    hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car);
+    hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car, sub, repeat);
 }
 
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st) {

@@ -20,6 +20,7 @@ struct crl_car_ctx {
     uint8_t *done_car = nullptr, *done_env = nullptr;
     float *rew_tmp = nullptr;
     int K = 1;                      // MultipleFrameStack depth (1 = no stack)
+    int repeat = 1;                 // CarRacing(action_repeat=...)
     uint8_t *frame = nullptr, *stack = nullptr;  // K > 1: newest frames, and the context's own stack
     uint8_t *term = nullptr;  // [n][players][96][96] last frame of the episode an env just finished
     double *ru = nullptr;
@@ -117,7 +118,7 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
 #define A(f, cnt) if (!rc) rc = calloc_dev(c, &s.f, (size_t)(cnt))
     A(body, 30 * M); A(jimp, 12 * M); A(jmotor, 4 * M); A(jspeed, 4 * M); A(jlimit, 4 * M);
     A(wgas, 4 * M); A(womega, 4 * M); A(wphase, 4 * M); A(wtiles, 4 * kWheelSlots * M); A(visited, 16 * M);
-    A(reward, M); A(prev_reward, M); A(visited_count, M); A(last_block, M); A(done, M); A(step_count, M); A(first_step, M);
+    A(reward, M); A(prev_reward, M); A(step_acc, M); A(visited_count, M); A(last_block, M); A(done, M); A(step_count, M); A(first_step, M);
     A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
@@ -130,6 +131,7 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     if (!rc) rc = calloc_dev(c, &c->term, (size_t)M * 96 * 96);
     c->K = opts->frame_stack < 1 ? 1 : opts->frame_stack;
+    c->repeat = opts->resized_dim >= 1 ? opts->resized_dim : 1;  // CarRacing contexts carry action_repeat in resized_dim
     if (c->K > 1) {
         if (!rc) rc = calloc_dev(c, &c->frame, (size_t)M * 96 * 96);
         if (!rc) rc = calloc_dev(c, &c->stack, (size_t)M * c->K * 96 * 96);
@@ -187,8 +189,10 @@ int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
 int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
                  crl_timer *tm) {
     crl_timer_begin(tm, 0, st);
-    launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, st);
-    launch_car_coupled(c->s, c->K_, st);
+    for (int sub = 0; sub < c->repeat; sub++) {  // action repetition: Car.step + world.Step per repeat (crmp:576-603)
+        launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, sub, c->repeat, st);
+        launch_car_coupled(c->s, c->K_, st);
+    }
     launch_car_post(c->s, c->done_car, c->done_env, 1000, st);
     // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
     if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);

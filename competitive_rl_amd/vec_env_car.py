@@ -58,8 +58,8 @@ class HipCarVecEnv(VecEnv):
         if not torch.cuda.is_available():
             raise RuntimeError("HipCarVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
-        if action_repeat not in (None, 1):
-            raise NotImplementedError("action_repeat > 1 is not built yet")
+        self.action_repeat = 1 if action_repeat is None else int(action_repeat)
+        assert 1 <= self.action_repeat <= 16
         assert output in ("torch", "numpy") and dones in ("dummy", "subproc")
         self._L = N.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -67,7 +67,8 @@ class HipCarVecEnv(VecEnv):
         self.K = 1 if frame_stack is None else int(frame_stack)
         assert players in (1, 2)
         self.P = int(players)  # 2 = cCarRacingDouble-v0, 1 = cCarRacing-v0
-        opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE if players == 2 else N.CRL_ENV_CAR_SINGLE, obs_mode=0, resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
+        opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE if players == 2 else N.CRL_ENV_CAR_SINGLE, obs_mode=0,
+                         resized_dim=self.action_repeat, frame_stack=self.K, num_envs=int(num_envs),
                          env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0,
                          flags=0 if car_contacts else N.CRL_FLAG_CAR_NO_CONTACTS)
         h = C.c_void_p()

@@ -106,7 +106,8 @@ typedef struct crl_pong_env_state {
 typedef struct crl_opts {
     int32_t env_kind;    /* crl_env_kind                                             */
     int32_t obs_mode;    /* crl_obs_mode                                             */
-    int32_t resized_dim; /* R: 84 or 42 (make_envs.py:67 resized_dim); 0 for raw     */
+    int32_t resized_dim; /* Pong: R = 84 or 42 (make_envs.py:67 resized_dim), 0 for raw;
+                            CarRacing: action_repeat (0 or 1 = none)                 */
     int32_t frame_stack; /* K planes per agent in GRAY_RESIZED mode (1 or 4)         */
     int64_t num_envs;    /* envs owned by THIS context (one shard)                   */
     int64_t env_id_base; /* global id of env 0 of this shard: RNG is keyed by global

@@ -1037,7 +1037,7 @@ int car_oracle_wheel_on_road(const car_env *e, int c, int w) {
 
 /* CarRacing.step (crmp:542-620), action_repeat = 1.  actions[c] = (steer, gas/brake) or
  * NULL for the action-less step that reset() ends with. */
-void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[2], int done[2]) {
+void car_oracle_step_repeat(car_env *e, const double (*actions)[2], int repeat, double step_reward[2], int done[2]) {
     const double dt = 1.0 / FPS;
     step_reward[0] = step_reward[1] = 0.0;
     if (actions) {
@@ -1046,6 +1046,7 @@ void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[
             car_oracle_process_action(actions[c], a);
             car_oracle_controls(&e->car[c], -a[0], a[1], a[2]);
         }
+      for (int rep = 0; rep < repeat; rep++) { /* action repetition (crmp:576) */
         for (int c = 0; c < 2; c++) {
             if (e->done[c]) continue;
             car_state *car = &e->car[c];
@@ -1058,7 +1059,7 @@ void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[
                 car->motor_speed[w] = (float)ms;
                 B->fx += (float)f[0], B->fy += (float)f[1];
             }
-            e->reward[c] -= 0.1 / 1;
+            e->reward[c] -= 0.1 / repeat;
             step_reward[c] += e->reward[c] - e->prev_reward[c];
             e->prev_reward[c] = e->reward[c];
             float s, co;
@@ -1082,8 +1083,13 @@ void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[
         e->inv_dt0 = 1.0f / h;
         e->t += dt;
         e->step_count += 1;
+      }
     }
     done[0] = e->done[0], done[1] = e->done[1];
+}
+
+void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[2], int done[2]) {
+    car_oracle_step_repeat(e, actions, 1, step_reward, done);
 }
 
 void car_oracle_hull_position(const car_env *e, int c, float out[3]) {

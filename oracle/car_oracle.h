@@ -67,6 +67,7 @@ void car_oracle_wheel(double dt, double steer, double gas, double brake, double 
                       double vx, double vy, int on_road, double *omega, double *phase, double *motor_speed, double force[2]);
 int car_oracle_reset(car_env *e, const double *u, int max_attempts, int shuffle_swap);
 void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[2], int done[2]);
+void car_oracle_step_repeat(car_env *e, const double (*actions)[2], int repeat, double step_reward[2], int done[2]);
 void car_oracle_contact_event(car_env *e, int c, int w, int t, int begin);
 int car_oracle_wheel_on_road(const car_env *e, int c, int w);
 void car_oracle_hull_position(const car_env *e, int c, float out[3]);

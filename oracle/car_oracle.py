@@ -44,6 +44,7 @@ def lib():
         L.car_oracle_reset.argtypes = [vp, vp, i32, i32]
         L.car_oracle_reset.restype = i32
         L.car_oracle_step.argtypes = [vp, vp, vp, vp]
+        L.car_oracle_step_repeat.argtypes = [vp, vp, i32, vp, vp]
         L.car_oracle_contact_event.argtypes = [vp, i32, i32, i32, i32]
         L.car_oracle_hull_position.argtypes = [vp, i32, vp]
         L.car_oracle_wheel_on_road.argtypes = [vp, i32, i32]
@@ -102,6 +103,12 @@ class CarEnv:
         else:
             a = np.ascontiguousarray(actions, np.float64).reshape(2, 2)
             lib().car_oracle_step(_p(self.buf), _p(a), _p(rew), _p(done))
+        return rew, done
+
+    def step_repeat(self, actions, repeat):
+        rew, done = np.zeros(2), np.zeros(2, np.int32)
+        a = np.ascontiguousarray(actions, np.float64).reshape(2, 2)
+        lib().car_oracle_step_repeat(_p(self.buf), _p(a), int(repeat), _p(rew), _p(done))
         return rew, done
 
     def contact_event(self, c, w, t, begin):

@@ -374,3 +374,34 @@ def test_car_car_contacts_teacher_forced():
     print("contacts: worst relative state error", worst, "env-steps with contacts", touched, "max contacts", max_nc)
     assert touched > 50 and max_nc >= 1
     hip.close()
+
+
+def test_action_repeat_matches_oracle():
+    """CarRacing(action_repeat=3): controls once, then 3 x (Car.step, -0.1/3, world.Step) (crmp:576-603)."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps, rep = 6, 40, 3
+    envs = make_oracle_envs(n, seed0=31)
+    hip = crl.HipCarVecEnv(n, action_repeat=rep)
+    hip.reset()
+    push_tracks(hip, envs)
+    rs = np.random.RandomState(6)
+    for t in range(steps):
+        hip.set_state(oracle_to_hip_state(envs))
+        acts = rs.uniform(-1, 1, (n, 2, 2)).astype(np.float32)
+        acts[:, :, 1] = np.abs(acts[:, :, 1])
+        _, rew, done = hip.step_device(torch.as_tensor(acts).cuda(), render=False)
+        rew = rew.cpu().numpy()
+        hs = hip.get_state()
+        for i, e in enumerate(envs):
+            r, d = e.step_repeat(acts[i].astype(np.float64), rep)
+            assert np.allclose(rew[i], r, atol=1e-6), (t, i, rew[i], r)
+            for c in range(2):
+                q, o = hs[i]["car"][c], e.e["car"][c]
+                for f in ("cx", "cy", "a", "vx", "vy", "w"):
+                    assert abs(float(q["hull"][f]) - float(o["hull"][f])) <= 3e-5 * max(1.0, abs(float(o["hull"][f]))), (t, i, c, f)
+                assert int(q["step_count"]) == int(e.e["step_count"]) and np.allclose(q["gas"], o["gas"])
+                assert int(q["tile_visited_count"]) == int(e.e["tile_visited_count"][c])
+    assert int(envs[0].e["step_count"]) == steps * rep
+    hip.close()
