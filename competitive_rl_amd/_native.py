@@ -112,3 +112,10 @@ def load_score_atlas():
     a = np.ascontiguousarray(a, dtype=np.uint8)
     assert a.size == ATLAS_BYTES
     return a
+
+
+def load_car_text():
+    b = np.load(os.path.join(PKG, "assets", "car_reward_text.npz"))["bits"]
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    assert b.shape == (3001, 10)
+    return b

@@ -358,6 +358,18 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     }
     __syncthreads();
 
+    // ---- (3c') reward read-out "%05.0f" (white, 1-bit glyphs) blitted last at (0, 91)
+    if (s.text_bits && tid < 32 * CRL_CAR_TEXT_ROWS) {
+        const double r = s.reward[me];
+        const double rr = rint(r);  // "%.0f" rounds half to even
+        int idx = (int)rr - CRL_CAR_TEXT_RMIN;
+        if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
+        idx = min(max(idx, 0), CRL_CAR_TEXT_STRINGS - 1);
+        const int row = tid >> 5, col = tid & 31, sy = 91 + row;
+        if (sy < 96 && ((s.text_bits[idx * CRL_CAR_TEXT_ROWS + row] >> col) & 1u)) tile8[sy * 96 + col] = 255;
+    }
+    __syncthreads();
+
     // ---- (3d) stream the tile out: 16 B per lane, 1 KiB contiguous per wave store
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + ((int64_t)env * s.players + viewer) * (96 * 96));
     const uint4 *tile4 = reinterpret_cast<const uint4 *>(tile32);

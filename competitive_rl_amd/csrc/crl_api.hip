@@ -251,7 +251,9 @@ const char *crl_last_error(void) { return g_err.c_str(); }
 const char *crl_version(void) { return "crl-hip 0.1 (gfx950)"; }
 
 int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out) {
-    if (!opts || !out || !score_atlas_host) return fail(CRL_EINVAL, "null argument");
+    if (!opts || !out) return fail(CRL_EINVAL, "null argument");
+    const bool is_car = opts->env_kind == CRL_ENV_CAR_DOUBLE || opts->env_kind == CRL_ENV_CAR_SINGLE;
+    if (!score_atlas_host && !is_car) return fail(CRL_EINVAL, "null argument");
     if (opts->env_kind != CRL_ENV_PONG_DOUBLE && opts->env_kind != CRL_ENV_CAR_DOUBLE && opts->env_kind != CRL_ENV_PONG_SINGLE &&
         opts->env_kind != CRL_ENV_CAR_SINGLE)
         return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
@@ -264,7 +266,7 @@ int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **
         HIP_TRY(hipSetDevice(opts->device));
         crl_ctx *cc = new crl_ctx();
         cc->o = *opts, cc->n = opts->num_envs;
-        int rc = crl_car_create(opts, &cc->car);
+        int rc = crl_car_create(opts, reinterpret_cast<const uint32_t *>(score_atlas_host), &cc->car);
         if (rc) { delete cc; return rc; }
         *out = cc;
         return CRL_OK;

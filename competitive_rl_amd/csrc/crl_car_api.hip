@@ -106,7 +106,7 @@ static int calloc_dev(crl_car_ctx *c, T **p, size_t count) {
     return CRL_OK;
 }
 
-int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
+int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car_ctx **out) {
     crl_car_ctx *c = new crl_car_ctx();
     c->o = *opts;
     const int players = opts->env_kind == CRL_ENV_CAR_SINGLE ? 1 : 2;
@@ -138,6 +138,13 @@ int crl_car_create(const crl_opts *opts, crl_car_ctx **out) {
     }
     if (rc) { crl_car_destroy(c); return rc; }
     make_consts(c->K_);
+    if (text_bits_host) {
+        uint32_t *tb = nullptr;
+        rc = calloc_dev(c, &tb, (size_t)CRL_CAR_TEXT_STRINGS * CRL_CAR_TEXT_ROWS);
+        if (rc) { crl_car_destroy(c); return rc; }
+        hipMemcpy(tb, text_bits_host, (size_t)CRL_CAR_TEXT_STRINGS * CRL_CAR_TEXT_ROWS * 4, hipMemcpyHostToDevice);
+        c->s.text_bits = tb;
+    }
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
     *out = c;
     return CRL_OK;

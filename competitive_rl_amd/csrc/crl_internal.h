@@ -24,7 +24,7 @@ void crl_timer_begin(crl_timer *t, int which, hipStream_t st);
 void crl_timer_end(crl_timer *t, int which, hipStream_t st);
 
 struct crl_car_ctx;
-int crl_car_create(const crl_opts *opts, crl_car_ctx **out);
+int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car_ctx **out);
 void crl_car_destroy(crl_car_ctx *c);
 void crl_car_seed(crl_car_ctx *c, uint64_t seed);
 int64_t crl_car_obs_bytes(const crl_car_ctx *c);

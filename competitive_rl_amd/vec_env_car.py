@@ -72,9 +72,9 @@ class HipCarVecEnv(VecEnv):
                          env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0,
                          flags=0 if car_contacts else N.CRL_FLAG_CAR_NO_CONTACTS)
         h = C.c_void_p()
-        dummy = np.zeros(16, np.uint8)  # crl_create's atlas argument is only used by Pong contexts
+        self._text = N.load_car_text()  # reward read-out bitmaps of the indicator strip
         with torch.cuda.device(self.device):
-            N.check(self._L.crl_create(C.byref(opts), dummy.ctypes.data_as(C.c_void_p), C.byref(h)))
+            N.check(self._L.crl_create(C.byref(opts), self._text.ctypes.data_as(C.c_void_p), C.byref(h)))
         self._h = h
         n = int(num_envs)
         obs_space = spaces.Box(0, 255, (self.P * self.K, 96, 96), dtype=np.uint8)

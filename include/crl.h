@@ -66,6 +66,11 @@ enum crl_env_kind {
 /* ---- cCarRacingDouble-v0 (car_racing/car_racing_multi_players.py:54-88) */
 #define CRL_CAR_MAX_TILES 512 /* tiles of one track (reference tracks: 230-380) */
 #define CRL_CAR_OBS 96        /* STATE_W = STATE_H = 96 */
+/* reward read-out of the indicator strip: bitmaps of "%05.0f" % r for r = -999..2000 plus "-0000",
+   10 rows of 32 bits each (competitive_rl_amd/assets/car_reward_text.npz) */
+#define CRL_CAR_TEXT_STRINGS 3001
+#define CRL_CAR_TEXT_ROWS 10
+#define CRL_CAR_TEXT_RMIN (-999)
 
 enum crl_obs_mode {
     /* raw env: obs (N,2,210,160,3) u8, 1 step = 1 frame
@@ -121,7 +126,9 @@ typedef struct crl_ctx crl_ctx;
 
 /* make_envs(...) -> VecEnv construction (make_envs.py:67-118; DummyVecEnv.__init__
  * dummy_vec_env.py:26-46).  `score_atlas_host`: CRL_PONG_ATLAS_BYTES gray values of
- * the top band for every score pair (Scoreboard.draw, base_pong_env.py:474-487). */
+ * the top band for every score pair (Scoreboard.draw, base_pong_env.py:474-487).  CarRacing
+ * contexts take the reward-text bitmaps instead (uint32 [CRL_CAR_TEXT_STRINGS][CRL_CAR_TEXT_ROWS],
+ * draw_text, car_racing/pygame_rendering.py:16-18) or NULL to leave the text out. */
 int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out);
 
 /* VecEnv.close (dummy_vec_env.py:77-79; idempotent like subproc_vec_env.py:131-141) */

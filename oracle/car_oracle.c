@@ -1157,6 +1157,9 @@ static void fill_rect(uint8_t *out, double x, double y, double w, double h, uint
         for (int xx = x0 > 0 ? x0 : 0; xx <= x1 && xx < 96; xx++) out[yy * 96 + xx] = g;
 }
 
+static const uint32_t *TEXT_BITS = 0; /* [3001][10] reward read-out bitmaps, or NULL */
+void car_oracle_set_text(const uint32_t *bits) { TEXT_BITS = bits; }
+
 void car_oracle_render(const car_env *e, int viewer, uint8_t *out) {
     car_oracle_consts();
     const car_state *me = &e->car[viewer];
@@ -1234,4 +1237,14 @@ void car_oracle_render(const car_env *e, int viewer, uint8_t *out) {
     double ja = (double)(me->wheel[0].a - me->hull.a - 0.0f);
     fill_rect(out, 20 * S, 96 - 2 * Hh, S * (10.0 * ja), 2 * Hh, G_GREEN);
     fill_rect(out, 30 * S, 96 - 2 * Hh, S * (0.8 * (double)me->hull.w), 2 * Hh, G_RED);
+    /* draw_text("%05.0f" % rewards[viewer], 0.96, 91.2, 5-px font, not antialiased, white) */
+    if (TEXT_BITS) {
+        double r = e->reward[viewer], rr = rint(r);
+        int idx = (int)rr - (-999);
+        if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = 3000;
+        idx = idx < 0 ? 0 : idx > 3000 ? 3000 : idx;
+        for (int row = 0; row < 10 && 91 + row < 96; row++)
+            for (int col = 0; col < 32; col++)
+                if ((TEXT_BITS[idx * 10 + row] >> col) & 1u) out[(91 + row) * 96 + col] = 255;
+    }
 }

@@ -50,6 +50,7 @@ def lib():
         L.car_oracle_wheel_on_road.argtypes = [vp, i32, i32]
         L.car_oracle_wheel_on_road.restype = i32
         L.car_oracle_render.argtypes = [vp, i32, vp]
+        L.car_oracle_set_text.argtypes = [vp]
         L.car_oracle_env_size.restype = i32
         assert L.car_oracle_env_size() == ENV_DT.itemsize, (L.car_oracle_env_size(), ENV_DT.itemsize)
         _ready = True
@@ -58,6 +59,16 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+_text = None
+
+
+def set_text(bits):
+    """Reward read-out bitmaps u32 [3001, 10] (kept alive here); None turns the text off."""
+    global _text
+    _text = None if bits is None else np.ascontiguousarray(bits, np.uint32)
+    lib().car_oracle_set_text(None if _text is None else _p(_text))
 
 
 def consts():

@@ -167,8 +167,11 @@ def test_free_running_stays_close_and_render_matches():
     import competitive_rl_amd as crl
     from oracle import car_oracle as co
 
+    from competitive_rl_amd import _native as N
+
     L = co.lib()
     L.car_oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    co.set_text(N.load_car_text())
     n, steps = 8, 120
     envs = make_oracle_envs(n, seed0=11)
     hip = crl.HipCarVecEnv(n)
@@ -201,6 +204,8 @@ def test_free_running_stays_close_and_render_matches():
     assert max(mism) < 0.005, mism
     palette = {0, 29, 44, 60, 76, 101, 103, 107, 149, 161, 176, 255}
     assert set(np.unique(got).tolist()) <= palette
+    assert (got[:, :, 91:, :16] == 255).any()  # the reward read-out is there
+    co.set_text(None)
     hip.close()
 
 
