@@ -1108,7 +1108,7 @@ int car_oracle_env_size(void) { return (int)sizeof(car_env); }
  * pygame and rotates a crop of it; neither is available here, so the background is classified
  * ANALYTICALLY at the pixel centre (point-in-polygon in world space).  Cars and indicator bars
  * follow pygame 1.9.6's integer polygon fill rule [from memory of its draw.c].  PARITY
- * UNPINNED; the 5-px reward text is not drawn. */
+ * UNPINNED; the 5-px reward text comes from pre-baked 1-bit strings (car_oracle_set_text). */
 #define G_GRASS 161
 #define G_LIGHT 176
 #define G_WHITE 255
