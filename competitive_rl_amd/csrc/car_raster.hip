@@ -294,20 +294,36 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             const CandTile &ct = cand[c];
             const float4 ba = ct.bb_all;
             if (ax0 > ba.z || ax1 < ba.x || ay0 > ba.w || ay1 < ba.y) continue;
-            if (ct.border) {
+            if (ct.border) {  // the border quad is drawn right after its tile, so it is tested first
+                unsigned in = open;
+                for (int i = 0; i < 4 && in; i++) {
+                    const float4 e = ct.bedge[i];  // one LDS read per edge, shared by the 4 pixels
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((in >> k & 1u) && (e.z * (wy[k] - e.y) - e.w * (wx[k] - e.x)) < 0) in &= ~(1u << k);
+                }
                 const int bg = ct.border == 1 ? G_WHITE : G_RED;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if ((open >> k & 1u) && in_edges(ct.bedge, 4, wx[k], wy[k])) g[k] = bg, open &= ~(1u << k);
+                    if (in >> k & 1u) g[k] = bg;
+                open &= ~in;
             }
             const float4 bb = ct.bb;
+            unsigned in = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((open >> k & 1u) && !(wx[k] < bb.x || wx[k] > bb.z || wy[k] < bb.y || wy[k] > bb.w)) in |= 1u << k;
+            for (int i = 0; i < 5 && in; i++) {
+                const float4 e = ct.edge[i];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((in >> k & 1u) && (e.z * (wy[k] - e.y) - e.w * (wx[k] - e.x)) < 0) in &= ~(1u << k);
+            }
             const int rg = ct.idx % 3 == 0 ? 101 : (ct.idx % 3 == 1 ? 103 : 107);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (!(open >> k & 1u)) continue;
-                if (wx[k] < bb.x || wx[k] > bb.z || wy[k] < bb.y || wy[k] > bb.w) continue;
-                if (in_edges(ct.edge, 5, wx[k], wy[k])) g[k] = rg, open &= ~(1u << k);
-            }
+            for (int k = 0; k < 4; k++)
+                if (in >> k & 1u) g[k] = rg;
+            open &= ~in;
         }
         tile32[q] = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
     }
