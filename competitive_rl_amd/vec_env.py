@@ -149,6 +149,8 @@ class HipPongVecEnv(VecEnv):
         assert obs_dtype in ("uint8", "float32")
         self._L = N.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.mode, self.R, self.K = mode, int(resized_dim), int(frame_stack)
         self.output, self.obs_dtype, self.dones_kind = output, obs_dtype, dones
         self.closed = False
@@ -357,6 +359,8 @@ class HipPongVecEnv(VecEnv):
     def step_device(self, actions_i32, render=True):
         """Hot-loop entry for training/bench code: `actions_i32` is an int32 (N, 2) tensor
         already on the device; returns device tensors, no host work, no clones, no sync."""
+        if not (actions_i32.is_contiguous() and actions_i32.dtype == torch.int32 and actions_i32.device == self.device):
+            raise AssertionError("step_device needs a contiguous int32 tensor on the env's device")
         buf = self._obs[self._flip]
         self._flip ^= 1
         N.check(self._L.crl_step(self._h, C.c_void_p(actions_i32.data_ptr()),

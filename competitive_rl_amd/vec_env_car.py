@@ -63,6 +63,8 @@ class HipCarVecEnv(VecEnv):
         assert output in ("torch", "numpy") and dones in ("dummy", "subproc")
         self._L = N.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.output, self.dones_kind, self.closed = output, dones, False
         self.K = 1 if frame_stack is None else int(frame_stack)
         assert players in (1, 2)
@@ -126,6 +128,8 @@ class HipCarVecEnv(VecEnv):
 
     def step_device(self, actions_f32, render=True):
         """Hot-loop entry: float32 (N, 2, 2) device tensor in, device tensors out, no sync."""
+        if not (actions_f32.is_contiguous() and actions_f32.dtype == torch.float32 and actions_f32.device == self.device):
+            raise AssertionError("step_device needs a contiguous float32 tensor on the env's device")
         buf = self._obs[self._flip]
         self._flip ^= 1
         N.check(self._L.crl_step(self._h, C.c_void_p(actions_f32.data_ptr()), C.c_void_p(buf.data_ptr()) if render else None,

@@ -21,7 +21,7 @@ def build_states(g):
     st["num_rounds"], st["num_steps"] = inp[:, C["rounds"]], inp[:, C["steps"]]
     st["keep"]["score_l"] = 255
     st["hist"]["score_l"] = 255
-    acts = inp[:, [C["a_l"], C["a_r"]]].astype(np.int32)
+    acts = np.ascontiguousarray(inp[:, [C["a_l"], C["a_r"]]].astype(np.int32))
     return st, acts
 
 
