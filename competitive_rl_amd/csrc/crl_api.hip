@@ -199,6 +199,13 @@ static int setup_gray(crl_ctx *c) {
         o.fast_ok = ok ? 1 : 0;
         o.max_taps = max_taps;
         if (o.total > 6144) return fail(CRL_ESTATE, "tap tables (%d B) exceed the LDS budget", o.total);
+        {
+            std::vector<int32_t> b32;
+            for (auto *v : {&xf, &xl, &yf, &yl})
+                for (uint8_t e : *v) b32.push_back(e);
+            o.box32 = put(b32.data(), b32.size() * 4);
+            blob.resize((blob.size() + 15) & ~size_t(15));
+        }
         int rc2 = dev_upload(c, &c->tab_blob, blob);
         if (rc2) return rc2;
         c->tofs = o;

@@ -312,6 +312,159 @@ __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Production kernel: ONE WAVEFRONT PER (env, plane group), looping over the group's planes
+// and both views.  Compared with the tile-per-wave kernel above (kept for ablation,
+// CRL_GRAY_DEBUG=8) this
+//   * pays the HBM latency of the ring read once per env instead of once per tile (lanes
+//     0..7 fetch the eight frame words, parked in LDS) and stages the tap tables once per
+//     32 tiles instead of once per 4;
+//   * keeps everything that is uniform over the wavefront -- frame decode, score-pair
+//     classification, the six output boxes -- in scalar registers (the wave index goes
+//     through readfirstlane, the first/last maps are int32 so they come in by s_load);
+//   * issues the template loads of a tile before its box arithmetic so their L2 latency is
+//     covered, and decodes patch positions with a reciprocal instead of an integer divide.
+template <int MAXT>
+__global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
+                                                                   GrayGeom q, uint8_t *__restrict__ obs, int ppw) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][kTileLds];
+    __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
+    __shared__ uint64_t words_[4][8];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(q.tab_blob);
+        uint4 *dst = reinterpret_cast<uint4 *>(tabs);
+        for (int i = threadIdx.x; i < (q.t.total >> 4); i += 256) dst[i] = src[i];
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int K = q.K, groups = K / ppw;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const bool live = wid < n * groups;
+    const int64_t env = live ? wid / groups : 0;
+    const int p0 = (int)(wid - env * groups) * ppw;
+    if (live && lane < 8) words_[wave][lane] = ring[(int64_t)lane * n + env];
+    __syncthreads();
+    if (!live) return;
+
+    const int R = q.R, RR = R * R, chunks = (RR + 15) >> 4;
+    const bool vec16 = (RR & 15) == 0;
+    uint8_t *tl = lds[wave];
+    uint4 *tl4 = reinterpret_cast<uint4 *>(tl);
+    const int32_t *__restrict__ xf32 = reinterpret_cast<const int32_t *>(q.tab_blob + q.t.box32);
+    const int32_t *__restrict__ xl32 = xf32 + CRL_PONG_W, *__restrict__ yf32 = xl32 + CRL_PONG_W, *__restrict__ yl32 = yf32 + CRL_PONG_H;
+    const int bb = q.band_chunks;
+    const uint4 *__restrict__ rest4 = reinterpret_cast<const uint4 *>(q.rest);
+    const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;  // chunks fully inside zero rows
+    const bool fast_ok = q.t.fast_ok != 0;
+
+#pragma unroll 1
+    for (int plane = p0; plane < p0 + ppw; plane++) {
+        const int rp = 4 - K + plane;  // ring plane
+        uint64_t pa = words_[wave][2 * rp], pb = words_[wave][2 * rp + 1];
+        pa = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pa);
+        pb = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pb);
+        const Frame fa = unpack_frame(pa), fb = unpack_frame(pb);
+        const bool blank_a = fa.sl == 255, blank_b = fb.sl == 255;
+        // The score rows come pre-resized from the band table when the two kept frames show
+        // the same score pair, or pairs one point apart (a point scored between the two
+        // max-pooled frames puts two texts under the max).  Anything else (only reachable
+        // through set_state or the never-written initial buffers) is evaluated per pixel.
+        bool slow = blank_a || blank_b;
+        int variant = 0, sp = fa.sl * 22 + fa.sr;
+        if (!slow && (fa.sl != fb.sl || fa.sr != fb.sr)) {
+            const int spb = fb.sl * 22 + fb.sr;
+            if (fb.sl == fa.sl + 1 && fb.sr == fa.sr) variant = 1;
+            else if (fb.sl == fa.sl && fb.sr == fa.sr + 1) variant = 2;
+            else if (fa.sl == fb.sl + 1 && fa.sr == fb.sr) variant = 1, sp = spb;
+            else if (fa.sl == fb.sl && fa.sr == fb.sr + 1) variant = 2, sp = spb;
+            else slow = true;
+        }
+#pragma unroll 1
+        for (int view = 0; view < q.views; view++) {
+            const int64_t tile = (env * q.views + view) * K + plane;
+            uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + tile * (int64_t)RR);
+            uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(obs + tile * (int64_t)RR);
+            if (blank_a && blank_b) {  // plane erased by a done (FrameStackTensor mask)
+                if (vec16)
+                    for (int c = lane; c < chunks; c += 64) out[c] = make_uint4(0, 0, 0, 0);
+                else
+                    for (int w = lane; w < (RR >> 2); w += 64) out32[w] = 0u;
+                continue;
+            }
+            // ---- 1. fill (loads first; the scalar box arithmetic below overlaps them)
+            const uint4 *__restrict__ band4 =
+                reinterpret_cast<const uint4 *>(q.band) + (int64_t)((slow ? 0 : (variant * 484 + sp)) * 2 + view) * bb;
+            for (int c = lane; c < chunks; c += 64) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < bb) v = band4[c];
+                else if (c < zc0 || c >= zc1) v = rest4[c];
+                tl4[c] = v;
+            }
+            // ---- 2. patch: boxes of the six rectangles in view coordinates (scalar)
+            const bool m = view == 1;
+            Rects rc;
+            rc.ax = blank_a ? -1000 : (m ? CRL_PONG_W - fa.x - CRL_PONG_BALL : fa.x), rc.ay = blank_a ? -1000 : fa.y;
+            rc.bx = blank_b ? -1000 : (m ? CRL_PONG_W - fb.x - CRL_PONG_BALL : fb.x), rc.by = blank_b ? -1000 : fb.y;
+            rc.la = blank_a ? -1000 : (m ? fa.br : fa.bl), rc.ra = blank_a ? -1000 : (m ? fa.bl : fa.br);
+            rc.lb = blank_b ? -1000 : (m ? fb.br : fb.bl), rc.rb = blank_b ? -1000 : (m ? fb.bl : fb.br);
+            Box bx[6];
+            {
+                auto box = [&](bool none, int c0, int c1, int r0, int r1) {
+                    c0 = max(c0, 0), c1 = min(c1, CRL_PONG_W), r0 = max(r0, 0), r1 = min(r1, CRL_PONG_H);
+                    Box b = {0, 0, 0, 0};
+                    if (none || c0 >= c1 || r0 >= r1) return b;
+                    b.x0 = xf32[c0], b.y0 = yf32[r0];
+                    b.w = xl32[c1 - 1] - b.x0 + 1, b.h = yl32[r1 - 1] - b.y0 + 1;
+                    return b;
+                };
+                const bool same_ball = rc.ax == rc.bx && rc.ay == rc.by;
+                bx[0] = box(blank_a, rc.ax, rc.ax + CRL_PONG_BALL, max(rc.ay, CRL_PONG_TOP), min(rc.ay + CRL_PONG_BALL, CRL_PONG_BOTTOM));
+                bx[1] = box(blank_a, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.la, rc.la + CRL_PONG_BAT_H);
+                bx[2] = box(blank_a, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.ra, rc.ra + CRL_PONG_BAT_H);
+                bx[3] = box(blank_b || same_ball, rc.bx, rc.bx + CRL_PONG_BALL, max(rc.by, CRL_PONG_TOP), min(rc.by + CRL_PONG_BALL, CRL_PONG_BOTTOM));
+                bx[4] = box(blank_b || rc.la == rc.lb, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.lb, rc.lb + CRL_PONG_BAT_H);
+                bx[5] = box(blank_b || rc.ra == rc.rb, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.rb, rc.rb + CRL_PONG_BAT_H);
+            }
+            int pre[7];
+            float rw[6];
+            pre[0] = slow ? q.band_rows * R : 0;  // slow path: evaluate every pixel of the score rows
+#pragma unroll
+            for (int i = 0; i < 6; i++) pre[i + 1] = pre[i] + bx[i].w * bx[i].h, rw[i] = 1.0f / (float)max(bx[i].w, 1);
+            const int total = pre[6];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (int p = lane; p < total; p += 64) {
+                int dy, dx;
+                const bool band_px = p < pre[0];
+                if (band_px) {
+                    dy = p / R, dx = p - dy * R;
+                } else {
+                    // select the box without dynamic register indexing
+                    int x0 = bx[0].x0, y0 = bx[0].y0, w = bx[0].w, base = pre[0];
+                    float r = rw[0];
+#pragma unroll
+                    for (int k = 1; k < 6; k++)
+                        if (p >= pre[k]) x0 = bx[k].x0, y0 = bx[k].y0, w = bx[k].w, base = pre[k], r = rw[k];
+                    const int o = p - base;
+                    const int yy = (int)(((float)o + 0.5f) * r);  // o / w, exact for these sizes
+                    dy = y0 + yy, dx = x0 + (o - yy * w);
+                }
+                uint8_t v;
+                if (band_px || !fast_ok) v = eval_pixel(g, fa, fb, view, dy, dx);
+                else v = eval_fast<MAXT>(tabs, q.t, R, rc, dy, dx);
+                tl[dy * R + dx] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // ---- 3. stream the tile out
+            if (vec16) {
+                for (int c = lane; c < chunks; c += 64) out[c] = tl4[c];
+            } else {
+                const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
+                for (int w = lane; w < (RR >> 2); w += 64) out32[w] = tl32[w];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+    }
+}
+
 void launch_pong_gray_templates(const GrayParams &p, const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
                                 const uint8_t *y_last, int band_rows, int band_chunks, uint8_t *band, uint8_t *rest,
                                 hipStream_t st) {
@@ -338,8 +491,21 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         q.debug = dbg;
     }
     const int64_t tiles = p.n * q.views * p.K;
-    hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
-                       p.obs);
+    if (q.debug & 8) {
+        hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
+                           p.obs);
+        return;
+    }
+    // planes per wave: the whole stack of an env per wave once there are enough envs to fill
+    // the chip (256 CUs x 16 waves), one plane per wave below that
+    const int ppw = (p.n >= 8192 && !(q.debug & 16)) ? p.K : 1;
+    const int64_t waves = p.n * (p.K / ppw);
+    if (tofs.max_taps <= 3)
+        hipLaunchKernelGGL(pong_raster_gray_env_kernel<3>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p.ring, p.n,
+                           g, q, p.obs, ppw);
+    else
+        hipLaunchKernelGGL(pong_raster_gray_env_kernel<5>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p.ring, p.n,
+                           g, q, p.obs, ppw);
 }
 
 }  // namespace crl
