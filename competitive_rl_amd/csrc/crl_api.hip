@@ -190,10 +190,31 @@ static int setup_gray(crl_ctx *c) {
         for (int d = yf[CRL_PONG_TOP]; d < R; d++)
             for (int k = yt.ofs[d]; k < yt.ofs[d + 1]; k++)
                 if (yt.si[k] < CRL_PONG_TOP && yt.si[k] < c->ink_row1) ok = false;
-        o.xa = put(xa.data(), xa.size() * 4), o.ya = put(ya.data(), ya.size() * 4);
+        // the x weights are stored pre-multiplied by 255 (the only non-zero source value): same single f32 multiply
+        for (float &a : xa) a = 255.0f * a;
+        o.xa = o.xa255 = put(xa.data(), xa.size() * 4), o.ya = put(ya.data(), ya.size() * 4);
         o.xs0 = put(xs0.data(), R), o.xn = put(xn.data(), R), o.ys0 = put(ys0.data(), R), o.yn = put(yn.data(), R);
         o.xf = put(xf.data(), xf.size()), o.xl = put(xl.data(), xl.size());
         o.yf = put(yf.data(), yf.size()), o.yl = put(yl.data(), yl.size());
+        {
+            // separable evaluator: 255*alpha, and the static bits of the per-row / per-col words
+            // (bit 5t+2 / 5t+3: tap t lies in the left / right bat's columns; bit 5t+4: rows: tap t
+            // is a white source row, cols: tap t exists)
+            std::vector<uint32_t> rs(R, 0), cs(R, 0);
+            for (int d = 0; d < R; d++) {
+                for (int j = 0; j < yn[d] && j < 5; j++) {
+                    const int r = ys0[d] + j;
+                    if (r < CRL_PONG_TOP || r >= CRL_PONG_BOTTOM) rs[d] |= 16u << (5 * j);
+                }
+                for (int k = 0; k < xn[d] && k < 5; k++) {
+                    const int cc = xs0[d] + k;
+                    cs[d] |= 16u << (5 * k);
+                    if (cc >= CRL_PONG_BATL_X && cc < CRL_PONG_BATL_X + CRL_PONG_BAT_W) cs[d] |= 4u << (5 * k);
+                    if (cc >= CRL_PONG_BATR_X && cc < CRL_PONG_BATR_X + CRL_PONG_BAT_W) cs[d] |= 8u << (5 * k);
+                }
+            }
+            o.rowstatic = put(rs.data(), rs.size() * 4), o.colstatic = put(cs.data(), cs.size() * 4);
+        }
         blob.resize((blob.size() + 15) & ~size_t(15));
         o.total = (int)blob.size();
         o.fast_ok = ok ? 1 : 0;

@@ -214,6 +214,7 @@ void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *at
 // rectangle can touch lies in a source row without score ink.
 struct GrayTabOfs {
     int xa, ya, xs0, xn, ys0, yn, xf, xl, yf, yl, total, fast_ok, max_taps;
+    int xa255, rowstatic, colstatic;  // 255*xalpha (f32 [5][R]); static bits of row_pack / col_pack (u32 [R])
     int box32;  // byte offset (past `total`, global memory only) of int32 copies of xf|xl|yf|yl for scalar loads
 };
 struct GrayParams {

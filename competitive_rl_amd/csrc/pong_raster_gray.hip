@@ -120,7 +120,7 @@ __device__ inline Box rect_box(const GrayGeom &q, int c0, int c1, int r0, int r1
 
 static constexpr int kTileLds = 7168;  // >= 84*84, multiple of 16
 static constexpr int kTabLds = 6144;   // dense tap tables + first/last maps (4.6 KB at R = 84)
-static constexpr int kMaxTaps = 5;
+static constexpr int kMaxR = 96;       // largest resized_dim the LDS tile holds (84) rounded up
 
 // Rectangles of the two kept frames in VIEW coordinates (agent 1 sees the court mirrored,
 // so its left-hand bat is the physical right bat).  A blank frame has its rows at -1000.
@@ -143,7 +143,7 @@ __device__ inline uint8_t eval_fast(const uint8_t *__restrict__ tabs, const Gray
 #pragma unroll
     for (int k = 0; k < MAXT; k++) {
         const int c = sx0 + k;
-        p[k] = 255.f * xa[k * R + dx];
+        p[k] = xa[k * R + dx];  // table holds 255 * alpha
         const unsigned m = ((unsigned)(c - q.ax) < (unsigned)CRL_PONG_BALL ? 1u : 0u) |
                            ((unsigned)(c - q.bx) < (unsigned)CRL_PONG_BALL ? 2u : 0u) |
                            ((unsigned)(c - CRL_PONG_BATL_X) < (unsigned)CRL_PONG_BAT_W ? 4u : 0u) |
@@ -324,12 +324,75 @@ __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *_
 //     through readfirstlane, the first/last maps are int32 so they come in by s_load);
 //   * issues the template loads of a tile before its box arithmetic so their L2 latency is
 //     covered, and decodes patch positions with a reciprocal instead of an integer divide.
+// Separable form of eval_fast.  For the pixel (dy, dx) the source pixel under tap (j, k) is
+// lit iff some rectangle (ball a, ball b, view-left bat, view-right bat, white band) holds
+// both source row sy0+j and source col sx0+k.  Row membership depends only on dy and
+// column membership only on dx, so each is computed once per tile into a 5-bit-per-tap
+// word (rowpack[dy], colpack[dx]) and a pixel costs one AND per tap pair:
+//   lit(j, k) = ((rowpack >> 5j) & (colpack >> 5k) & 31) != 0.
+// Bit 0 ball a, 1 ball b, 2 left bat, 3 right bat, 4 white (rows: the row is white; cols:
+// the tap exists).  The static bits (bats' columns, white rows, tap validity) come from
+// tables built on the host.  Same f32 operation order as eval_pixel.
+template <int MAXT>
+__device__ inline uint32_t row_pack(const uint8_t *__restrict__ tabs, const GrayTabOfs &o, const Rects &q, int dy) {
+    const int sy0 = tabs[o.ys0 + dy], ny = tabs[o.yn + dy];
+    uint32_t pack = 0;
+#pragma unroll
+    for (int j = 0; j < MAXT; j++) {
+        const int r = sy0 + j;
+        const uint32_t b = ((unsigned)(r - q.ay) < (unsigned)CRL_PONG_BALL ? 1u : 0u) |
+                           ((unsigned)(r - q.by) < (unsigned)CRL_PONG_BALL ? 2u : 0u) |
+                           (((unsigned)(r - q.la) < (unsigned)CRL_PONG_BAT_H || (unsigned)(r - q.lb) < (unsigned)CRL_PONG_BAT_H) ? 4u : 0u) |
+                           (((unsigned)(r - q.ra) < (unsigned)CRL_PONG_BAT_H || (unsigned)(r - q.rb) < (unsigned)CRL_PONG_BAT_H) ? 8u : 0u);
+        pack |= b << (5 * j);
+    }
+    const uint32_t valid = (1u << (5 * ny)) - 1u;
+    return (pack & valid) | reinterpret_cast<const uint32_t *>(tabs + o.rowstatic)[dy];
+}
+
+template <int MAXT>
+__device__ inline uint32_t col_pack(const uint8_t *__restrict__ tabs, const GrayTabOfs &o, const Rects &q, int dx) {
+    const int sx0 = tabs[o.xs0 + dx], nx = tabs[o.xn + dx];
+    uint32_t pack = 0;
+#pragma unroll
+    for (int k = 0; k < MAXT; k++) {
+        const int c = sx0 + k;
+        const uint32_t b = ((unsigned)(c - q.ax) < (unsigned)CRL_PONG_BALL ? 1u : 0u) | ((unsigned)(c - q.bx) < (unsigned)CRL_PONG_BALL ? 2u : 0u);
+        pack |= b << (5 * k);
+    }
+    const uint32_t valid = (1u << (5 * nx)) - 1u;
+    return (pack & valid) | reinterpret_cast<const uint32_t *>(tabs + o.colstatic)[dx];
+}
+
+template <int MAXT>
+__device__ inline uint8_t eval_sep(const uint8_t *__restrict__ tabs, const GrayTabOfs &o, int R, uint32_t rp, uint32_t cp, int dy,
+                                   int dx) {
+    const float *xa = reinterpret_cast<const float *>(tabs + o.xa255), *ya = reinterpret_cast<const float *>(tabs + o.ya);
+    float p[MAXT];
+    uint32_t cm[MAXT];
+#pragma unroll
+    for (int k = 0; k < MAXT; k++) p[k] = xa[k * R + dx], cm[k] = (cp >> (5 * k)) & 31u;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXT; j++) {
+        const uint32_t rn = (rp >> (5 * j)) & 31u;
+        float buf = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXT; k++) buf = buf + ((rn & cm[k]) != 0u ? p[k] : 0.f);
+        const float t = ya[j * R + dy] * buf;
+        sum = (j == 0) ? t : sum + t;
+    }
+    const int v = (int)rintf(sum);
+    return (uint8_t)min(max(v, 0), 255);
+}
+
 template <int MAXT>
 __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][kTileLds];
     __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
     __shared__ uint64_t words_[4][8];
+    __shared__ uint32_t rowpack_[4][kMaxR], colpack_[4][kMaxR];
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(q.tab_blob);
         uint4 *dst = reinterpret_cast<uint4 *>(tabs);
@@ -427,9 +490,21 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             int pre[7];
             float rw[6];
             pre[0] = slow ? q.band_rows * R : 0;  // slow path: evaluate every pixel of the score rows
+            int ymin = R, ymax = 0, xmin = R, xmax = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++) pre[i + 1] = pre[i] + bx[i].w * bx[i].h, rw[i] = 1.0f / (float)max(bx[i].w, 1);
+            for (int i = 0; i < 6; i++) {
+                pre[i + 1] = pre[i] + bx[i].w * bx[i].h, rw[i] = 1.0f / (float)max(bx[i].w, 1);
+                if (bx[i].w * bx[i].h > 0) {
+                    ymin = min(ymin, bx[i].y0), ymax = max(ymax, bx[i].y0 + bx[i].h);
+                    xmin = min(xmin, bx[i].x0), xmax = max(xmax, bx[i].x0 + bx[i].w);
+                }
+            }
             const int total = pre[6];
+            uint32_t *rowpack = rowpack_[wave], *colpack = colpack_[wave];
+            if (fast_ok) {
+                for (int dy = ymin + lane; dy < ymax; dy += 64) rowpack[dy] = row_pack<MAXT>(tabs, q.t, rc, dy);
+                for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             for (int p = lane; p < total; p += 64) {
                 int dy, dx;
@@ -449,7 +524,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                 }
                 uint8_t v;
                 if (band_px || !fast_ok) v = eval_pixel(g, fa, fb, view, dy, dx);
-                else v = eval_fast<MAXT>(tabs, q.t, R, rc, dy, dx);
+                else v = eval_sep<MAXT>(tabs, q.t, R, rowpack[dy], colpack[dx], dy, dx);
                 tl[dy * R + dx] = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
