@@ -120,6 +120,7 @@ __device__ inline Box rect_box(const GrayGeom &q, int c0, int c1, int r0, int r1
 
 static constexpr int kTileLds = 7168;  // >= 84*84, multiple of 16
 static constexpr int kTabLds = 6144;   // dense tap tables + first/last maps (4.6 KB at R = 84)
+static constexpr int kTileIters = kTileLds / 16 / 64;  // 16-byte chunks per lane per tile
 static constexpr int kMaxR = 96;       // largest resized_dim the LDS tile holds (84) rounded up
 
 // Rectangles of the two kept frames in VIEW coordinates (agent 1 sees the court mirrored,
@@ -412,8 +413,6 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
     const bool vec16 = (RR & 15) == 0;
     uint8_t *tl = lds[wave];
     uint4 *tl4 = reinterpret_cast<uint4 *>(tl);
-    const int32_t *__restrict__ xf32 = reinterpret_cast<const int32_t *>(q.tab_blob + q.t.box32);
-    const int32_t *__restrict__ xl32 = xf32 + CRL_PONG_W, *__restrict__ yf32 = xl32 + CRL_PONG_W, *__restrict__ yl32 = yf32 + CRL_PONG_H;
     const int bb = q.band_chunks;
     const uint4 *__restrict__ rest4 = reinterpret_cast<const uint4 *>(q.rest);
     const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;  // chunks fully inside zero rows
@@ -453,14 +452,17 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                     for (int w = lane; w < (RR >> 2); w += 64) out32[w] = 0u;
                 continue;
             }
-            // ---- 1. fill (loads first; the scalar box arithmetic below overlaps them)
+            // ---- 1. template loads into registers (L2); the box arithmetic and the row / column
+            //         words below overlap their latency, the LDS tile is filled afterwards
             const uint4 *__restrict__ band4 =
                 reinterpret_cast<const uint4 *>(q.band) + (int64_t)((slow ? 0 : (variant * 484 + sp)) * 2 + view) * bb;
-            for (int c = lane; c < chunks; c += 64) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (c < bb) v = band4[c];
-                else if (c < zc0 || c >= zc1) v = rest4[c];
-                tl4[c] = v;
+            uint4 tv[kTileIters];
+#pragma unroll
+            for (int it = 0; it < kTileIters; it++) {
+                const int c = lane + 64 * it;
+                tv[it] = make_uint4(0, 0, 0, 0);
+                if (c < bb) tv[it] = band4[c];
+                else if (c < chunks && (c < zc0 || c >= zc1)) tv[it] = rest4[c];
             }
             // ---- 2. patch: boxes of the six rectangles in view coordinates (scalar)
             const bool m = view == 1;
@@ -472,12 +474,8 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             Box bx[6];
             {
                 auto box = [&](bool none, int c0, int c1, int r0, int r1) {
-                    c0 = max(c0, 0), c1 = min(c1, CRL_PONG_W), r0 = max(r0, 0), r1 = min(r1, CRL_PONG_H);
-                    Box b = {0, 0, 0, 0};
-                    if (none || c0 >= c1 || r0 >= r1) return b;
-                    b.x0 = xf32[c0], b.y0 = yf32[r0];
-                    b.w = xl32[c1 - 1] - b.x0 + 1, b.h = yl32[r1 - 1] - b.y0 + 1;
-                    return b;
+                    const Box b = {0, 0, 0, 0};
+                    return none ? b : rect_box_lds(tabs, q.t, c0, c1, r0, r1);
                 };
                 const bool same_ball = rc.ax == rc.bx && rc.ay == rc.by;
                 bx[0] = box(blank_a, rc.ax, rc.ax + CRL_PONG_BALL, max(rc.ay, CRL_PONG_TOP), min(rc.ay + CRL_PONG_BALL, CRL_PONG_BOTTOM));
@@ -505,6 +503,9 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                 for (int dy = ymin + lane; dy < ymax; dy += 64) rowpack[dy] = row_pack<MAXT>(tabs, q.t, rc, dy);
                 for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
             }
+#pragma unroll
+            for (int it = 0; it < kTileIters; it++)
+                if (lane + 64 * it < chunks) tl4[lane + 64 * it] = tv[it];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             for (int p = lane; p < total; p += 64) {
                 int dy, dx;
