@@ -387,7 +387,7 @@ __device__ inline uint8_t eval_sep(const uint8_t *__restrict__ tabs, const GrayT
     return (uint8_t)min(max(v, 0), 255);
 }
 
-template <int MAXT>
+template <int MAXT, bool DBG>
 __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][kTileLds];
@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
     const uint4 *__restrict__ rest4 = reinterpret_cast<const uint4 *>(q.rest);
     const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;  // chunks fully inside zero rows
     const bool fast_ok = q.t.fast_ok != 0;
+    const int dbg = DBG ? q.debug : 0;  // ablation switches (profiling instance only)
 
 #pragma unroll 1
     for (int plane = p0; plane < p0 + ppw; plane++) {
@@ -461,6 +462,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             for (int it = 0; it < kTileIters; it++) {
                 const int c = lane + 64 * it;
                 tv[it] = make_uint4(0, 0, 0, 0);
+                if (dbg & 32) continue;
                 if (c < bb) tv[it] = band4[c];
                 else if (c < chunks && (c < zc0 || c >= zc1)) tv[it] = rest4[c];
             }
@@ -497,9 +499,9 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                     xmin = min(xmin, bx[i].x0), xmax = max(xmax, bx[i].x0 + bx[i].w);
                 }
             }
-            const int total = pre[6];
+            const int total = (dbg & 1) ? 0 : pre[6];
             uint32_t *rowpack = rowpack_[wave], *colpack = colpack_[wave];
-            if (fast_ok) {
+            if (fast_ok && !(dbg & 2)) {
                 for (int dy = ymin + lane; dy < ymax; dy += 64) rowpack[dy] = row_pack<MAXT>(tabs, q.t, rc, dy);
                 for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
             }
@@ -530,7 +532,11 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             // ---- 3. stream the tile out
-            if (vec16) {
+            if (dbg & 64) {
+#pragma unroll
+                for (int it = 0; it < kTileIters; it++)
+                    if (lane + 64 * it < chunks) out[lane + 64 * it] = tv[it];
+            } else if (vec16) {
                 for (int c = lane; c < chunks; c += 64) out[c] = tl4[c];
             } else {
                 const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
@@ -576,12 +582,13 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     // the chip (256 CUs x 16 waves), one plane per wave below that
     const int ppw = (p.n >= 8192 && !(q.debug & 16)) ? p.K : 1;
     const int64_t waves = p.n * (p.K / ppw);
-    if (tofs.max_taps <= 3)
-        hipLaunchKernelGGL(pong_raster_gray_env_kernel<3>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p.ring, p.n,
-                           g, q, p.obs, ppw);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (q.debug & ~16)  // any ablation switch: the instrumented instance
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+    else if (tofs.max_taps <= 3)
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
     else
-        hipLaunchKernelGGL(pong_raster_gray_env_kernel<5>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, p.ring, p.n,
-                           g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
 }
 
 }  // namespace crl
