@@ -140,13 +140,13 @@ def main():
     elif args.workload == "fused84_newest":
         # variant of config #3: only the newest plane is written, the consumer keeps the stack
         env = crl.HipPongVecEnv(n, seed=0, mode="wrapped", resized_dim=84, frame_stack=1, device=dev, env_id_base=rank * n)
-        raster_bytes, kernel = 2 * 84 * 84 + 16, "pong_raster_gray_kernel"
+        raster_bytes, kernel = 2 * 84 * 84 + 16, "pong_raster_gray_env_kernel"
         desc = (f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA, newest plane only (N,2,1,84,84) u8, "
                 "1 step = 4 frames (variant of BASELINE config #3)")
     else:
         env = crl.HipPongVecEnv(n, seed=0, mode="wrapped", resized_dim=84, frame_stack=4, device=dev,
                                 env_id_base=rank * n)
-        raster_bytes, kernel = FUSED_RASTER_BYTES[84], "pong_raster_gray_kernel"
+        raster_bytes, kernel = FUSED_RASTER_BYTES[84], "pong_raster_gray_env_kernel"
         desc = (f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack (N,2,4,84,84) u8, "
                 "1 step = 4 frames (BASELINE config #3)")
     env.reset()

@@ -191,8 +191,12 @@ __device__ inline V2 rel_vel(const BRef &A, const BRef &B, V2 rA, V2 rB) {
 }
 
 __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) {
-    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n || !s.coupled[env]) return;
+    // dense over the compacted list of coupled envs: a workgroup holds 111 KB of LDS, so the ones
+    // past the end of the list must leave at once (the frames of the other envs are being drawn
+    // on the same CUs meanwhile)
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= *s.coupled_count) return;
+    const int64_t env = s.coupled_list[slot];
     const int64_t M = 2 * s.n;
     // Bodies are picked by fixture index at run time, so the solver state cannot stay in registers;
     // it lives in LDS (one slice per lane) instead of scratch memory.

@@ -85,6 +85,8 @@ struct CarSoA {
     int contacts_enabled;
     float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
     int32_t *coupled;       // [n] 1 = the two cars are solved together this step
+    int32_t *coupled_list;  // [n] the coupled envs of this step, compacted (any order), and
+    int32_t *coupled_count; // [1] how many: the coupled kernel launches dense wavefronts over the list
     int32_t *n_contact;     // [n] touching car-car contacts carried to the next step (warm start)
     float *contact;         // [n][16][kContactWords] persisted manifolds + impulses
 };
@@ -138,8 +140,9 @@ void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &sr
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
-void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st);
-void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr);
+void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int max_episode_steps, hipStream_t st);
+// only_env: draw env e iff only_env[e] == want; nullptr = every env
+void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
                       int players, hipStream_t st);
 

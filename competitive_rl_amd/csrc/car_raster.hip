@@ -102,7 +102,7 @@ __device__ inline IndRect make_rect(double x, double y, double w, double h, int 
 }
 
 __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
-                                                         const uint8_t *__restrict__ only_env) {
+                                                         const uint8_t *__restrict__ only_env, int want) {
     __shared__ CandTile cand[kMaxCand];
     __shared__ CarPoly cars[16];
     __shared__ IndRect ind[8];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     const int64_t n = s.n, M = (int64_t)s.players * n;
     const int64_t env = blockIdx.x / s.players;
     const int viewer = blockIdx.x - env * s.players;
-    if (only_env && !only_env[env]) return;  // terminal-observation pass: finished envs only
+    if (only_env && only_env[env] != want) return;  // env subset: finished envs / one class of the step pipeline
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t me = viewer * n + env;
 
@@ -423,9 +423,9 @@ void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const 
                        reinterpret_cast<uint4 *>(stack), reinterpret_cast<uint4 *>(obs), fill_env, fill_all ? 1 : 0, K, n, players);
 }
 
-void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env) {
+void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env, int want) {
     static const int dbg = getenv("CRL_CAR_DEBUG") ? atoi(getenv("CRL_CAR_DEBUG")) : 0;
-    hipLaunchKernelGGL(car_raster_kernel, dim3((unsigned)(s.players * s.n)), dim3(256), 0, st, s, k, obs, dbg, only_env);
+    hipLaunchKernelGGL(car_raster_kernel, dim3((unsigned)(s.players * s.n)), dim3(256), 0, st, s, k, obs, dbg, only_env, want);
 }
 
 }  // namespace crl

@@ -254,7 +254,10 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         // keep the pre-solve bodies; pass the tyre forces and joint targets to the coupled kernel
 #pragma unroll
         for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
-        if (car == 0) s.coupled[env] = 1;
+        if (car == 0) {
+            s.coupled[env] = 1;
+            s.coupled_list[atomicAdd(s.coupled_count, 1)] = (int32_t)env;
+        }
     } else {
         const float h = (float)(1.0 / CAR_FPS);
         const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
@@ -305,7 +308,8 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
 // Env-level bookkeeping after the physics: gym TimeLimit (max_episode_steps = 1000,
 // car_racing/register.py:15-26) and FlattenMultiAgentObservation's done = any (atari_wrappers.py:329-330).
 __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *__restrict__ done_car,
-                                                       uint8_t *__restrict__ done_env, int max_episode_steps) {
+                                                       uint8_t *__restrict__ done_env, uint8_t *__restrict__ slow_env,
+                                                       int max_episode_steps) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     const int el = s.elapsed[env] + 1;
@@ -313,16 +317,20 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
     for (int c = 0; c < s.players; c++) d = d || done_car[s.players * env + c];
     s.elapsed[env] = el;
     done_env[env] = d ? 1 : 0;
+    // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = after the reset
+    if (slow_env) slow_env[env] = d ? 2 : ((s.coupled && s.coupled[env]) ? 1 : 0);
 }
 
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st) {
     const int64_t M = (int64_t)s.players * s.n;
+    if (s.coupled_count) hipMemsetAsync(s.coupled_count, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car, sub, repeat);
 }
 
-void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, int max_episode_steps, hipStream_t st) {
-    hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env,
+void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int max_episode_steps,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env, slow_env,
                        max_episode_steps);
 }
 

@@ -25,6 +25,12 @@ struct crl_car_ctx {
     uint8_t *term = nullptr;  // [n][players][96][96] last frame of the episode an env just finished
     double *ru = nullptr;
     uint8_t *rshuffle = nullptr;
+    // latency-bound part of a step (coupled solve, track generation for finished envs) runs on a
+    // side stream next to the raster; slow_env = pipeline class per env (car_post_kernel)
+    uint8_t *slow_env = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_coupled = nullptr, ev_term = nullptr, ev_join = nullptr;
+    bool overlap = true;
 };
 
 // ---- body constants, the Box2D way (b2PolygonShape::ComputeMass, b2Body::ResetMassData), float32
@@ -122,12 +128,13 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
-    A(wforce, 8 * M); A(coupled, n); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
 #undef A
     if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
+    if (!rc) rc = calloc_dev(c, &c->slow_env, n);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     if (!rc) rc = calloc_dev(c, &c->term, (size_t)M * 96 * 96);
     c->K = opts->frame_stack < 1 ? 1 : opts->frame_stack;
@@ -146,6 +153,15 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         c->s.text_bits = tb;
     }
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
+    c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_coupled, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_term, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        crl_car_destroy(c);
+        return crl_fail(CRL_EHIP, "car create: side stream");
+    }
     *out = c;
     return CRL_OK;
 }
@@ -153,6 +169,11 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
 void crl_car_destroy(crl_car_ctx *c) {
     if (!c) return;
     hipDeviceSynchronize();
+    if (c->side) hipStreamDestroy(c->side);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_coupled) hipEventDestroy(c->ev_coupled);
+    if (c->ev_term) hipEventDestroy(c->ev_term);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     for (void *p : c->allocs) hipFree(p);
     if (c->ru) hipFree(c->ru);
     if (c->rshuffle) hipFree(c->rshuffle);
@@ -195,22 +216,52 @@ int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
 // TimeLimit, FlattenMultiAgentObservation's any-done, then auto-reset of finished envs.
 int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
                  crl_timer *tm) {
+    // Rewards and done flags are final after car_step_kernel (the reference evaluates them before
+    // world.Step, crmp:576-603), so the env-level bookkeeping does not wait for the coupled solve.
+    const bool fork = c->overlap && obs_dev != nullptr;
     crl_timer_begin(tm, 0, st);
     for (int sub = 0; sub < c->repeat; sub++) {  // action repetition: Car.step + world.Step per repeat (crmp:576-603)
         launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, sub, c->repeat, st);
-        launch_car_coupled(c->s, c->K_, st);
+        if (!(fork && sub == c->repeat - 1)) launch_car_coupled(c->s, c->K_, st);
     }
-    launch_car_post(c->s, c->done_car, c->done_env, 1000, st);
-    // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
-    if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);
-    launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
-    crl_timer_end(tm, 0, st);
-    if (done_dev) hipMemcpyAsync(done_dev, c->done_env, c->n, hipMemcpyDeviceToDevice, st);
-    if (obs_dev) {
+    launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, 1000, st);
+    if (!fork) {
+        // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
+        if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);
+        launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
+        crl_timer_end(tm, 0, st);
+        if (obs_dev) {
+            crl_timer_begin(tm, 1, st);
+            draw(c, obs_dev, false, st);
+            crl_timer_end(tm, 1, st);
+        }
+    } else {
+        // Two streams.  Side: the latency-bound work only a few envs need (coupled solve, then track
+        // generation for finished envs; a handful of busy lanes each).  Main: the frames, in three
+        // classes as their inputs become final -- envs that neither touch nor finished (drawn next
+        // to the coupled solve), coupled envs, finished envs (terminal frame before the reset, first
+        // frame of the new episode after it).  The classes are disjoint sets of envs.
+        uint8_t *target = c->K == 1 ? obs_dev : c->frame;
+        hipEventRecord(c->ev_fork, st);
+        hipStreamWaitEvent(c->side, c->ev_fork, 0);
+        launch_car_coupled(c->s, c->K_, c->side);
+        hipEventRecord(c->ev_coupled, c->side);
+        crl_timer_end(tm, 0, st);
         crl_timer_begin(tm, 1, st);
-        draw(c, obs_dev, false, st);
+        launch_car_raster(c->s, c->K_, target, st, c->slow_env, 0);
+        hipStreamWaitEvent(st, c->ev_coupled, 0);
+        launch_car_raster(c->s, c->K_, c->term, st, c->done_env, 1);  // info["terminal_observation"]
+        hipEventRecord(c->ev_term, st);
+        hipStreamWaitEvent(c->side, c->ev_term, 0);
+        launch_car_reset(c->s, c->K_, c->src, true, c->done_env, c->side);
+        hipEventRecord(c->ev_join, c->side);
+        launch_car_raster(c->s, c->K_, target, st, c->slow_env, 1);
+        hipStreamWaitEvent(st, c->ev_join, 0);
+        launch_car_raster(c->s, c->K_, target, st, c->slow_env, 2);
+        if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
         crl_timer_end(tm, 1, st);
     }
+    if (done_dev) hipMemcpyAsync(done_dev, c->done_env, c->n, hipMemcpyDeviceToDevice, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car step: %s", hipGetErrorString(e));
     return CRL_OK;
