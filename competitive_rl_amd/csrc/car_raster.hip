@@ -39,7 +39,6 @@ struct CandTile {
     float4 bb;        // world AABB of the tile polygon
     float4 bb_all;    // world AABB of tile + border
     int idx, border;
-    int sx0, sx1, sy0, sy1;  // conservative screen-space box of tile + border (culling only)
 };
 
 // inside test against precomputed edges: (bx-ax)*(y-ay) - (by-ay)*(x-ax) >= 0 for every edge
@@ -51,7 +50,7 @@ __device__ inline bool in_edges(const float4 *e, int nv, float x, float y) {
     return true;
 }
 
-static constexpr int kCell = 8, kCellShift = 3, kCellsPerRow = 96 / kCell, kCells = kCellsPerRow * kCellsPerRow, kCellCap = 23;
+static constexpr int kCell = 8, kCellShift = 3, kCellsPerRow = 96 / kCell, kCells = kCellsPerRow * kCellsPerRow;
 
 struct CarPoly {
     int px[8], py[8];
@@ -71,29 +70,6 @@ __device__ inline bool in_convex(const float *poly, int nv, float x, float y) {
     return true;
 }
 
-// pygame draw_fillpoly membership of pixel (x, y)
-__device__ inline bool fillpoly_hit(const CarPoly &p, int x, int y) {
-    if (x < p.x0 || x > p.x1 || y < p.y0 || y > p.y1) return false;
-    if (p.y0 == p.y1) return true;
-    int xs[8], k = 0;
-    for (int i = 0; i < p.n; i++) {
-        const int ip = i ? i - 1 : p.n - 1;
-        int y1 = p.py[ip], y2 = p.py[i], x1, x2;
-        if (y1 < y2) x1 = p.px[ip], x2 = p.px[i];
-        else if (y1 > y2) y2 = p.py[ip], y1 = p.py[i], x2 = p.px[ip], x1 = p.px[i];
-        else continue;
-        if ((y >= y1 && y < y2) || (y == p.y1 && y > y1 && y <= y2)) xs[k++] = (y - y1) * (x2 - x1) / (y2 - y1) + x1;
-    }
-    for (int i = 1; i < k; i++)
-        for (int j = i; j > 0 && xs[j - 1] > xs[j]; j--) {
-            const int t = xs[j];
-            xs[j] = xs[j - 1], xs[j - 1] = t;
-        }
-    for (int i = 0; i + 1 < k; i += 2)
-        if (x >= xs[i] && x <= xs[i + 1]) return true;
-    return false;
-}
-
 __device__ inline IndRect make_rect(double x, double y, double w, double h, int gray) {
     const int l = (int)x, t = (int)y, r = (int)x + (int)w - 1, b = (int)y + (int)h - 1;
     IndRect q;
@@ -106,10 +82,12 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ CandTile cand[kMaxCand];
     __shared__ CarPoly cars[16];
     __shared__ IndRect ind[8];
-    __shared__ int wave_cnt[4];
-    __shared__ int n_cand;
-    __shared__ uint8_t cell_cnt[kCells];           // 255 = overflow: fall back to the full list
-    __shared__ uint8_t cell_list[kCells][kCellCap + 1];
+    __shared__ int wave_cnt[2][4];
+    __shared__ int16_t cand_tile[kMaxCand];       // tile index of each candidate, ascending
+    __shared__ uint16_t cand_cells[kMaxCand];     // culling: cell range cx0 | cx1 << 4 | cy0 << 8 | cy1 << 12
+    __shared__ int cand_ofs[kMaxCand + 1];        // exclusive prefix of the cell counts
+    __shared__ uint32_t cell_tmask[kCells][kMaxCand / 32];  // candidates whose tile polygon may cover a pixel of the cell
+    __shared__ uint32_t cell_bmask[kCells][kMaxCand / 32];  // ... whose border quad may
     __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
     __shared__ int ind_y0;
     __shared__ __attribute__((aligned(16))) uint32_t tile32[96 * 96 / 4];
@@ -134,49 +112,79 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     const float inv_scale = (float)(1.0 / obs_scale), scale_f = (float)obs_scale;
     const float kf = (float)(CAR_PLAYFIELD / 20.0);
 
-    // ---- (1) ordered compaction of the tiles near the view (half-diagonal 48*sqrt(2)/scale < 39)
-    if (tid == 0) n_cand = 0;
-    __syncthreads();
-    const int ntiles = s.ntiles[env];
+    // ---- (1) ordered compaction of the tiles near the view (half-diagonal 48*sqrt(2)/scale < 39):
+    // both halves of the tile range are tested at once (kCarMaxTiles <= 512), then the kept tiles'
+    // polygons are fetched by the first n_cand threads
+    static_assert(kCarMaxTiles <= 512, "compaction covers two tiles per thread");
+    const int ntiles = (dbg & 8) ? 0 : s.ntiles[env];
     const float vr = 39.0f + 1.5f;  // + border width
-    for (int base = 0; base < ntiles; base += 256) {
-        const int t = base + tid;
-        bool keep = false;
-        float4 bb = make_float4(0, 0, 0, 0);
+    bool keep[2];
+    unsigned long long km[2];
+    for (int h = 0; h < 2; h++) {
+        const int t = h * 256 + tid;
+        keep[h] = false;
         if (t < ntiles) {
-            bb = s.tile_aabb_em[env * kCarMaxTiles + t];
-            keep = !(bb.x > off.x + vr || bb.z < off.x - vr || bb.y > off.y + vr || bb.w < off.y - vr);
+            const float4 bb = s.tile_aabb_em[env * kCarMaxTiles + t];
+            keep[h] = !(bb.x > off.x + vr || bb.z < off.x - vr || bb.y > off.y + vr || bb.w < off.y - vr);
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int slot = n_cand;
-        for (int w = 0; w < wave; w++) slot += wave_cnt[w];
-        slot += __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && slot < kMaxCand) {
-            CandTile &c = cand[slot];
-            float pv[10], bv[8];
-            for (int k = 0; k < 10; k++) pv[k] = s.tile_poly_em[(env * kCarMaxTiles + t) * 10 + k];
-            for (int i = 0; i < 5; i++) {
-                const int j = i + 1 < 5 ? i + 1 : 0;
-                c.edge[i] = make_float4(pv[2 * i], pv[2 * i + 1], pv[2 * j] - pv[2 * i], pv[2 * j + 1] - pv[2 * i + 1]);
+    }
+    for (int h = 0; h < 2; h++) {
+        km[h] = __ballot(keep[h]);
+        if (lane == 0) wave_cnt[h][wave] = __popcll(km[h]);
+    }
+    __syncthreads();
+    int nc;
+    {
+        int before[2] = {0, 0}, tot = 0;
+        for (int h = 0; h < 2; h++)
+            for (int w = 0; w < 4; w++) {
+                if (w == wave) before[h] = tot;
+                tot += wave_cnt[h][w];
             }
-            c.bb = bb, c.bb_all = bb;
-            c.idx = t, c.border = s.border_em[env * kCarMaxTiles + t];
-            if (c.border) {
-                float x0 = bb.x, y0 = bb.y, x1 = bb.z, y1 = bb.w;
-                for (int k = 0; k < 8; k++) bv[k] = s.border_poly_em[(env * kCarMaxTiles + t) * 8 + k];
-                for (int i = 0; i < 4; i++) {
-                    const int j = i + 1 < 4 ? i + 1 : 0;
-                    c.bedge[i] = make_float4(bv[2 * i], bv[2 * i + 1], bv[2 * j] - bv[2 * i], bv[2 * j + 1] - bv[2 * i + 1]);
-                    x0 = fminf(x0, bv[2 * i]), y0 = fminf(y0, bv[2 * i + 1]), x1 = fmaxf(x1, bv[2 * i]), y1 = fmaxf(y1, bv[2 * i + 1]);
-                }
-                c.bb_all = make_float4(x0, y0, x1, y1);
-            }
+        nc = min(tot, kMaxCand);
+        for (int h = 0; h < 2; h++) {
+            const int slot = before[h] + __popcll(km[h] & ((1ull << lane) - 1ull));
+            if (keep[h] && slot < kMaxCand) cand_tile[slot] = (int16_t)(h * 256 + tid);
         }
-        __syncthreads();
-        if (tid == 0) n_cand = min(kMaxCand, n_cand + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
-        __syncthreads();
+    }
+    __syncthreads();
+    if (tid < nc) {
+        const int t = cand_tile[tid];
+        CandTile &c = cand[tid];
+        float pv[10], bv[8];
+        const float4 bb = s.tile_aabb_em[env * kCarMaxTiles + t];
+        for (int k = 0; k < 10; k++) pv[k] = s.tile_poly_em[(env * kCarMaxTiles + t) * 10 + k];
+        const int border = s.border_em[env * kCarMaxTiles + t];
+        if (border)
+            for (int k = 0; k < 8; k++) bv[k] = s.border_poly_em[(env * kCarMaxTiles + t) * 8 + k];
+        for (int i = 0; i < 5; i++) {
+            const int j = i + 1 < 5 ? i + 1 : 0;
+            c.edge[i] = make_float4(pv[2 * i], pv[2 * i + 1], pv[2 * j] - pv[2 * i], pv[2 * j + 1] - pv[2 * i + 1]);
+        }
+        c.bb = bb, c.bb_all = bb;
+        c.idx = t, c.border = border;
+        float sx0 = 1e30f, sy0 = 1e30f, sx1 = -1e30f, sy1 = -1e30f;  // conservative screen box of tile + border
+        auto grow = [&](float wx, float wy) {
+            const V2 tt = rotv(-sn, cs, mk(wx, wy) - off);
+            const float X = 48.0f - scale_f * tt.x, Y = 48.0f - scale_f * tt.y;
+            sx0 = fminf(sx0, X), sy0 = fminf(sy0, Y), sx1 = fmaxf(sx1, X), sy1 = fmaxf(sy1, Y);
+        };
+        for (int i = 0; i < 5; i++) grow(pv[2 * i], pv[2 * i + 1]);
+        if (border) {
+            float x0 = bb.x, y0 = bb.y, x1 = bb.z, y1 = bb.w;
+            for (int i = 0; i < 4; i++) {
+                const int j = i + 1 < 4 ? i + 1 : 0;
+                c.bedge[i] = make_float4(bv[2 * i], bv[2 * i + 1], bv[2 * j] - bv[2 * i], bv[2 * j + 1] - bv[2 * i + 1]);
+                x0 = fminf(x0, bv[2 * i]), y0 = fminf(y0, bv[2 * i + 1]), x1 = fmaxf(x1, bv[2 * i]), y1 = fmaxf(y1, bv[2 * i + 1]);
+                grow(bv[2 * i], bv[2 * i + 1]);
+            }
+            c.bb_all = make_float4(x0, y0, x1, y1);
+        }
+        // culling cells the screen box (+1.5 px) meets
+        const int cx0 = max((int)floorf(sx0 - 1.5f), 0) >> kCellShift, cx1 = min((int)ceilf(sx1 + 1.5f), 95) >> kCellShift;
+        const int cy0 = max((int)floorf(sy0 - 1.5f), 0) >> kCellShift, cy1 = min((int)ceilf(sy1 + 1.5f), 95) >> kCellShift;
+        const bool any = cx1 >= cx0 && cy1 >= cy0 && sx1 + 1.5f >= 0.f && sy1 + 1.5f >= 0.f && sx0 - 1.5f <= 95.f && sy0 - 1.5f <= 95.f;
+        cand_cells[tid] = any ? (uint16_t)(cx0 | (cx1 << 4) | (cy0 << 8) | (cy1 << 12)) : (uint16_t)0xFFFF;
     }
 
     // ---- (2) car polygons (threads 0..15) and indicator rectangles (threads 16..23)
@@ -225,22 +233,9 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     }
     __syncthreads();
 
-    // ---- (2b) screen-space culling structures: per candidate a conservative screen box, per
-    // 8x8-pixel cell the ORDERED list of candidates whose box meets it.  Membership itself is
-    // still decided in world space, so culling never changes a pixel.
-    const int nc = n_cand;
-    for (int c = tid; c < nc; c += 256) {
-        CandTile &ct = cand[c];
-        float x0 = 1e30f, y0 = 1e30f, x1 = -1e30f, y1 = -1e30f;
-        const int nv = ct.border ? 9 : 5;
-        for (int i = 0; i < nv; i++) {
-            const float wx = i < 5 ? ct.edge[i].x : ct.bedge[i - 5].x, wy = i < 5 ? ct.edge[i].y : ct.bedge[i - 5].y;
-            const V2 t = rotv(-sn, cs, mk(wx, wy) - off);
-            const float X = 48.0f - scale_f * t.x, Y = 48.0f - scale_f * t.y;
-            x0 = fminf(x0, X), y0 = fminf(y0, Y), x1 = fmaxf(x1, X), y1 = fmaxf(y1, Y);
-        }
-        ct.sx0 = (int)floorf(x0 - 1.5f), ct.sx1 = (int)ceilf(x1 + 1.5f), ct.sy0 = (int)floorf(y0 - 1.5f), ct.sy1 = (int)ceilf(y1 + 1.5f);
-    }
+    // ---- (2b) screen-space culling: per 8x8-pixel cell the candidates (as bit masks, i.e. in draw
+    // order) whose tile polygon / border quad may cover one of its pixel centres.  Membership
+    // itself is still decided in world space, so culling never changes a pixel.
     if (tid < s.players) {
         int x0 = 1 << 30, y0 = 1 << 30, x1 = -(1 << 30), y1 = -(1 << 30);
         for (int p = 0; p < 8; p++) {
@@ -254,24 +249,69 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         for (int r = 0; r < 8; r++) y0 = min(y0, ind[r].y0);
         ind_y0 = y0;
     }
-    __syncthreads();
-    if (tid < kCells) {
-        const int cx0 = (tid % kCellsPerRow) * kCell, cy0 = (tid / kCellsPerRow) * kCell;
-        int cnt = 0;
-        for (int c = 0; c < nc; c++) {
-            const CandTile &ct = cand[c];
-            if (ct.sx1 < cx0 || ct.sx0 > cx0 + kCell - 1 || ct.sy1 < cy0 || ct.sy0 > cy0 + kCell - 1) continue;
-            if (cnt < kCellCap) cell_list[tid][cnt] = (uint8_t)c;
-            cnt++;
+    if (wave == 1) {  // exclusive prefix of the candidates' cell counts (kMaxCand = 2 per lane)
+        int cnt[2];
+        for (int h = 0; h < 2; h++) {
+            const int c = 2 * lane + h;
+            const unsigned r = c < nc ? cand_cells[c] : 0xFFFFu;
+            cnt[h] = r == 0xFFFFu ? 0 : (int)(((r >> 4) & 15u) - (r & 15u) + 1u) * (int)(((r >> 12) & 15u) - ((r >> 8) & 15u) + 1u);
         }
-        cell_cnt[tid] = cnt <= kCellCap ? (uint8_t)cnt : 255;
+        int inc = cnt[0] + cnt[1];
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        const int ex = inc - cnt[0] - cnt[1];
+        cand_ofs[2 * lane] = ex, cand_ofs[2 * lane + 1] = ex + cnt[0];
+        if (lane == 63) cand_ofs[kMaxCand] = inc;
+    }
+    for (int i = tid; i < kCells * (kMaxCand / 32); i += 256) (&cell_tmask[0][0])[i] = 0u, (&cell_bmask[0][0])[i] = 0u;
+    __syncthreads();
+    // one work item per (candidate, cell of its screen box): a separating-edge test of the cell's
+    // pixel centres against the tile polygon and the border quad in screen space (the world ->
+    // screen map is a similarity with positive determinant, so "inside" stays cross >= 0; a
+    // quarter-pixel margin covers rounding).
+    const int n_items = (dbg & 16) ? 0 : cand_ofs[kMaxCand];
+    for (int item = tid; item < n_items; item += 256) {
+        int lo = 0, hi = kMaxCand - 1;  // largest c with cand_ofs[c] <= item
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cand_ofs[mid] <= item) lo = mid;
+            else hi = mid - 1;
+        }
+        const int c = lo, j = item - cand_ofs[c];
+        const unsigned r = cand_cells[c];
+        const int bx0 = r & 15u, cw = (int)((r >> 4) & 15u) - bx0 + 1, by0 = (r >> 8) & 15u;
+        const int jy = (int)(((float)j + 0.5f) * (1.0f / (float)cw));
+        const int cxi = bx0 + (j - jy * cw), cyi = by0 + jy, cell = cyi * kCellsPerRow + cxi;
+        const int cx0 = cxi * kCell, cy0 = cyi * kCell;
+        const CandTile &ct = cand[c];
+        const float px0 = (float)cx0 + 0.25f, px1 = (float)(cx0 + kCell) - 0.25f, py0 = (float)cy0 + 0.25f, py1 = (float)(cy0 + kCell) - 0.25f;
+        auto may_cover = [&](const float4 *e, int nv) {
+            for (int i = 0; i < nv; i++) {
+                const float4 q = e[i];
+                const V2 ta = rotv(-sn, cs, mk(q.x, q.y) - off), tb = rotv(-sn, cs, mk(q.x + q.z, q.y + q.w) - off);
+                const float ax = 48.0f - scale_f * ta.x, ay = 48.0f - scale_f * ta.y;
+                const float dx = (48.0f - scale_f * tb.x) - ax, dy = (48.0f - scale_f * tb.y) - ay;
+                const float tol = -0.25f * (fabsf(dx) + fabsf(dy));
+                const float c00 = dx * (py0 - ay) - dy * (px0 - ax), c10 = dx * (py0 - ay) - dy * (px1 - ax);
+                const float c01 = dx * (py1 - ay) - dy * (px0 - ax), c11 = dx * (py1 - ay) - dy * (px1 - ax);
+                if (fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) < tol) return false;  // every pixel centre is outside this edge
+            }
+            return true;
+        };
+        if (may_cover(ct.edge, 5)) atomicOr(&cell_tmask[cell][c >> 5], 1u << (c & 31));
+        if (ct.border && may_cover(ct.bedge, 4)) atomicOr(&cell_bmask[cell][c >> 5], 1u << (c & 31));
     }
     __syncthreads();
 
     // ---- (3a) background into the LDS tile: 4 consecutive pixels per thread-iteration share one
     // culling cell, so every candidate's edges are read from LDS once per 4 pixels
-    for (int q = tid; q < 96 * 96 / 4; q += 256) {
-        const int sy = q / 24, sx0 = (q - sy * 24) * 4;
+    // A wavefront takes one 16x16-pixel block per iteration (2x2 culling cells), so its lanes walk
+    // nearly the same candidates.
+    for (int blk = wave; blk < 36 && !(dbg & 32); blk += 4) {
+        const int sy = (blk / 6) * 16 + (lane >> 2), sx0 = (blk % 6) * 16 + (lane & 3) * 4;
+        const int q = sy * 24 + (sx0 >> 2);
         float wx[4], wy[4];
         int g[4];
         float ax0 = 3.4e38f, ay0 = 3.4e38f, ax1 = -3.4e38f, ay1 = -3.4e38f;
@@ -287,14 +327,18 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         }
         unsigned open = 0xFu;  // pixels not yet covered by a (later-drawn) polygon
         const int cell = (sy >> kCellShift) * kCellsPerRow + (sx0 >> kCellShift);
-        const int ccount = cell_cnt[cell];
-        const int niter = (dbg & 2) ? 0 : (ccount == 255 ? nc : ccount);
-        for (int ci2 = 0; ci2 < niter && open; ci2++) {
-            const int c = ccount == 255 ? ci2 : cell_list[cell][ci2];
+        for (int wd = 0; wd < kMaxCand / 32 && open && !(dbg & 2); wd++) {
+          const uint32_t tm = cell_tmask[cell][wd], bmk = cell_bmask[cell][wd];
+          uint32_t todo = tm | bmk;
+          while (todo && open) {
+            const int bit = __ffs(todo) - 1;
+            todo &= todo - 1u;
+            const int c = wd * 32 + bit;
+            const bool do_tile = (tm >> bit) & 1u, do_border = (bmk >> bit) & 1u;
             const CandTile &ct = cand[c];
             const float4 ba = ct.bb_all;
             if (ax0 > ba.z || ax1 < ba.x || ay0 > ba.w || ay1 < ba.y) continue;
-            if (ct.border) {  // the border quad is drawn right after its tile, so it is tested first
+            if (do_border) {  // the border quad is drawn right after its tile, so it is tested first
                 unsigned in = open;
                 for (int i = 0; i < 4 && in; i++) {
                     const float4 e = ct.bedge[i];  // one LDS read per edge, shared by the 4 pixels
@@ -308,6 +352,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                     if (in >> k & 1u) g[k] = bg;
                 open &= ~in;
             }
+            if (!do_tile) continue;
             const float4 bb = ct.bb;
             unsigned in = 0;
 #pragma unroll
@@ -324,35 +369,76 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             for (int k = 0; k < 4; k++)
                 if (in >> k & 1u) g[k] = rg;
             open &= ~in;
+          }
         }
         tile32[q] = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
     }
     __syncthreads();
     uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile32);
 
-    // ---- (3b) cars: one work item per (car polygon, pixel of that polygon's box), all 256 lanes
-    // busy; draw order (car 0 wheels, hull, then car 1) is resolved by an LDS atomicMax on
-    // (draw rank << 8 | gray) per pixel, then written over the background.
+    // ---- (3b) cars: one work item per (car polygon, scanline): the crossings of pygame's
+    // draw_fillpoly are computed once per row and the spans written with an LDS atomicMax on
+    // (draw rank << 8 | gray) -- draw order is car 0 wheels, hull, then car 1 -- into a scratch
+    // image of each car's screen box, which is then copied over the background.
     if (!(dbg & 1)) {
-        uint32_t *rank = reinterpret_cast<uint32_t *>(cand);  // candidates are dead after (3a): reuse as [96*96/.. ] scratch
-        for (int c = 0; c < s.players; c++) {
-            const int x0 = max(car_box[c][0], 0), x1 = min(car_box[c][1], 95), y0 = max(car_box[c][2], 0), y1 = min(car_box[c][3], 95);
-            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-            if (w <= 0 || h <= 0 || w * h > kRankCap) continue;  // (a car never spans more than ~20x20 px)
-            for (int p = tid; p < w * h; p += 256) rank[p] = 0u;
-            __syncthreads();
-            for (int item = tid; item < 8 * w * h; item += 256) {
-                const int part = item / (w * h), p = item - part * (w * h);
-                const int yy = p / w, sx = x0 + (p - yy * w), sy = y0 + yy;
-                const CarPoly &cp = cars[c * 8 + part];
-                if (fillpoly_hit(cp, sx, sy)) atomicMax(&rank[p], ((uint32_t)(part + 1) << 8) | (uint32_t)cp.gray);
+        static_assert(sizeof(CandTile) * kMaxCand >= 2 * kRankCap * sizeof(uint32_t), "rank scratch must fit the candidate array");
+        uint32_t *rank = reinterpret_cast<uint32_t *>(cand);  // candidates are dead after (3a): [2][kRankCap] scratch
+        int bx0[2], by0[2], bw[2], bh[2];
+        for (int c = 0; c < 2; c++) {
+            bx0[c] = by0[c] = bw[c] = bh[c] = 0;
+            if (c < s.players) {
+                const int x0 = max(car_box[c][0], 0), x1 = min(car_box[c][1], 95), y0 = max(car_box[c][2], 0), y1 = min(car_box[c][3], 95);
+                const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+                if (w > 0 && h > 0 && w * h <= kRankCap) bx0[c] = x0, by0[c] = y0, bw[c] = w, bh[c] = h;  // (a car never spans more than ~20x20 px)
             }
-            __syncthreads();
-            for (int p = tid; p < w * h; p += 256) {
-                const uint32_t r = rank[p];
+        }
+        for (int c = 0; c < 2; c++)
+            for (int p = tid; p < bw[c] * bh[c]; p += 256) rank[c * kRankCap + p] = 0u;
+        __syncthreads();
+        // rows of polygon k: [max(y0,0), min(y1,95)]
+        int total = 0;
+        for (int k = 0; k < 8 * s.players; k++) total += max(min(cars[k].y1, 95) - max(cars[k].y0, 0) + 1, 0);
+        for (int item = tid; item < total; item += 256) {
+            int k = 0, r = item;
+            for (;; k++) {
+                const int rows = max(min(cars[k].y1, 95) - max(cars[k].y0, 0) + 1, 0);
+                if (r < rows) break;
+                r -= rows;
+            }
+            const CarPoly &cp = cars[k];
+            const int c = k >> 3, part = k & 7;
+            if (bw[c] == 0) continue;
+            const int y = max(cp.y0, 0) + r;
+            int xs[8], nx = 0;
+            if (cp.y0 == cp.y1) {
+                xs[0] = cp.x0, xs[1] = cp.x1, nx = 2;
+            } else {
+                for (int i = 0; i < cp.n; i++) {
+                    const int ip = i ? i - 1 : cp.n - 1;
+                    int y1 = cp.py[ip], y2 = cp.py[i], x1, x2;
+                    if (y1 < y2) x1 = cp.px[ip], x2 = cp.px[i];
+                    else if (y1 > y2) y2 = cp.py[ip], y1 = cp.py[i], x2 = cp.px[ip], x1 = cp.px[i];
+                    else continue;
+                    if ((y >= y1 && y < y2) || (y == cp.y1 && y > y1 && y <= y2)) xs[nx++] = (y - y1) * (x2 - x1) / (y2 - y1) + x1;
+                }
+                for (int i = 1; i < nx; i++)
+                    for (int j = i; j > 0 && xs[j - 1] > xs[j]; j--) {
+                        const int t = xs[j];
+                        xs[j] = xs[j - 1], xs[j - 1] = t;
+                    }
+            }
+            const uint32_t key = ((uint32_t)(part + 1) << 8) | (uint32_t)cp.gray;
+            uint32_t *row = rank + c * kRankCap + (y - by0[c]) * bw[c] - bx0[c];
+            for (int i = 0; i + 1 < nx; i += 2)
+                for (int x = max(xs[i], max(cp.x0, 0)); x <= min(xs[i + 1], min(cp.x1, 95)); x++) atomicMax(&row[x], key);
+        }
+        __syncthreads();
+        for (int c = 0; c < 2; c++) {  // car 1 is drawn over car 0
+            for (int p = tid; p < bw[c] * bh[c]; p += 256) {
+                const uint32_t r = rank[c * kRankCap + p];
                 if (r) {
-                    const int yy = p / w;
-                    tile8[(y0 + yy) * 96 + x0 + (p - yy * w)] = (uint8_t)(r & 255u);
+                    const int yy = p / bw[c];
+                    tile8[(by0[c] + yy) * 96 + bx0[c] + (p - yy * bw[c])] = (uint8_t)(r & 255u);
                 }
             }
             __syncthreads();
