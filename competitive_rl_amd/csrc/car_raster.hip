@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ int wave_cnt[2][4];
     __shared__ int16_t cand_tile[kMaxCand];       // tile index of each candidate, ascending
     __shared__ uint16_t cand_cells[kMaxCand];     // culling: cell range cx0 | cx1 << 4 | cy0 << 8 | cy1 << 12
-    __shared__ int cand_ofs[kMaxCand + 1];        // exclusive prefix of the cell counts
+    __shared__ uint16_t cand_ofs[kMaxCand + 2];   // exclusive prefix of the cell counts (<= 128 * 144)
     __shared__ uint32_t cell_tmask[kCells][kMaxCand / 32];  // candidates whose tile polygon may cover a pixel of the cell
     __shared__ uint32_t cell_bmask[kCells][kMaxCand / 32];  // ... whose border quad may
     __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             if (lane >= d) inc += o;
         }
         const int ex = inc - cnt[0] - cnt[1];
-        cand_ofs[2 * lane] = ex, cand_ofs[2 * lane + 1] = ex + cnt[0];
-        if (lane == 63) cand_ofs[kMaxCand] = inc;
+        cand_ofs[2 * lane] = (uint16_t)ex, cand_ofs[2 * lane + 1] = (uint16_t)(ex + cnt[0]);
+        if (lane == 63) cand_ofs[kMaxCand] = (uint16_t)inc;
     }
     for (int i = tid; i < kCells * (kMaxCand / 32); i += 256) (&cell_tmask[0][0])[i] = 0u, (&cell_bmask[0][0])[i] = 0u;
     __syncthreads();
@@ -276,10 +276,10 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         int lo = 0, hi = kMaxCand - 1;  // largest c with cand_ofs[c] <= item
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (cand_ofs[mid] <= item) lo = mid;
+            if ((int)cand_ofs[mid] <= item) lo = mid;
             else hi = mid - 1;
         }
-        const int c = lo, j = item - cand_ofs[c];
+        const int c = lo, j = item - (int)cand_ofs[c];
         const unsigned r = cand_cells[c];
         const int bx0 = r & 15u, cw = (int)((r >> 4) & 15u) - bx0 + 1, by0 = (r >> 8) & 15u;
         const int jy = (int)(((float)j + 0.5f) * (1.0f / (float)cw));
