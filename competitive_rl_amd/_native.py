@@ -37,7 +37,8 @@ CAR_STATE_DT = np.dtype([
     ("motor_speed", "<f4", (4,)), ("limit_state", "<i4", (4,)), ("gas", "<f8", (4,)), ("omega", "<f8", (4,)), ("phase", "<f8", (4,)),
     ("reward", "<f8"), ("prev_reward", "<f8"), ("tile_visited_count", "<i4"), ("last_block", "<i4"), ("done", "<i4"),
     ("step_count", "<i4"), ("first_step", "<i4"), ("pad", "<i4"),
-    ("wheel_tiles", "<u4", (4, CAR_MAX_TILES // 32)), ("visited", "<u4", (CAR_MAX_TILES // 32,))], align=True)
+    ("wheel_tiles", "<u4", (4, CAR_MAX_TILES // 32)), ("visited", "<u4", (CAR_MAX_TILES // 32,)),
+    ("sleep_time", "<f4", (5,)), ("pad2", "<f4")], align=True)
 CAR_CONTACT_DT = np.dtype([("pair", "<i4"), ("count", "<i4"), ("type", "<i4"), ("ln", "<f4", (2,)), ("lp", "<f4", (2,)),
                            ("pt", "<f4", (2, 2)), ("id", "<u4", (2,)), ("nimp", "<f4", (2,)), ("timp", "<f4", (2,))])
 CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4"), ("n_contact", "<i4"), ("pad", "<i4"),

@@ -259,10 +259,13 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
             }
     }
 
+    float slp[2][5];  // b2Body::m_sleepTime
+    for (int k = 0; k < 2; k++)
+        for (int b = 0; b < 5; b++) slp[k][b] = s.sleep[b * M + k * s.n + env];
     if (nc == 0) {
         // boxes overlap but nothing touches: two independent islands, as in the per-car kernel
-        island_solve(car[1], K, h, dt_ratio);
-        island_solve(car[0], K, h, dt_ratio);
+        island_solve(car[1], K, h, dt_ratio, slp[1]);
+        island_solve(car[0], K, h, dt_ratio, slp[0]);
     } else {
         JointTmp jt[2];
         ContactVC *vc = sh_vc[threadIdx.x];
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
             }
         }
         isl_integrate_pos(car[1], h), isl_integrate_pos(car[0], h);
+        bool solved = false;
 #pragma unroll 1
         for (int it = 0; it < 60; it++) {
             float minSep = 0.0f;
@@ -405,9 +409,17 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
             }
             const bool cok = minSep >= -3.0f * LINEAR_SLOP;
             const bool j1 = isl_joints_pos(car[1], K), j0 = isl_joints_pos(car[0], K);
-            if (cok && j1 && j0) break;
+            if (cok && j1 && j0) {
+                solved = true;
+                break;
+            }
         }
+        // one island: it sleeps only when all ten bodies have been still long enough
+        const float m1 = isl_sleep_scan(car[1], slp[1], h), m0 = isl_sleep_scan(car[0], slp[0], h);
+        if (fminf(m1, m0) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(car[1], slp[1]), isl_put_to_sleep(car[0], slp[0]);
     }
+    for (int k = 0; k < 2; k++)
+        for (int b = 0; b < 5; b++) s.sleep[b * M + k * s.n + env] = slp[k][b];
 
     // ---- store bodies, joints and the manifolds with their impulses
     for (int k = 0; k < 2; k++) {

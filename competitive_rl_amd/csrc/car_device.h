@@ -84,6 +84,7 @@ struct CarSoA {
     // ---- car-car contacts (players == 2)
     int contacts_enabled;
     float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
+    float *sleep;           // [5][M] b2Body::m_sleepTime of hull, wheels 0-3
     int32_t *coupled;       // [n] 1 = the two cars are solved together this step
     int32_t *coupled_list;  // [n] the coupled envs of this step, compacted (any order), and
     int32_t *coupled_count; // [1] how many: the coupled kernel launches dense wavefronts over the list

@@ -208,17 +208,55 @@ __device__ inline bool isl_joints_pos(CarRegs &c, const CarConsts &K) {
     return ok;
 }
 
+// End of b2Island::Solve ("if (allowSleep)", Box2D 2.3 b2Island.cpp): a body slower than the sleep
+// tolerances accumulates m_sleepTime; once every body of the island has been still for
+// b2_timeToSleep and the position solver converged the island is put to sleep, which zeroes the
+// velocities (b2Body::SetAwake(false)).  Car.step wakes every body again on the next step
+// (car_dynamics.py:159-234: joint.motorSpeed assignment, ApplyForceToCenter(..., True)), so the
+// visible effect is the velocity reset.  sleep[] = m_sleepTime of hull, wheels 0-3.
+#define LIN_SLEEP_TOL 0.01f
+#define ANG_SLEEP_TOL (2.0f / 180.0f * 3.14159265359f)
+#define TIME_TO_SLEEP 0.5f
+__device__ inline float isl_sleep_scan(const CarRegs &c, float *sleep, float h) {
+    float min_sleep = 3.402823466e+38f;
+    const float lin2 = LIN_SLEEP_TOL * LIN_SLEEP_TOL, ang2 = ANG_SLEEP_TOL * ANG_SLEEP_TOL;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        const Body &B = b == 0 ? c.H : c.W[b == 0 ? 0 : b - 1];
+        if (B.w * B.w > ang2 || B.vx * B.vx + B.vy * B.vy > lin2) {
+            sleep[b] = 0.0f;
+            min_sleep = 0.0f;
+        } else {
+            sleep[b] += h;
+            min_sleep = fminf(min_sleep, sleep[b]);
+        }
+    }
+    return min_sleep;
+}
+__device__ inline void isl_put_to_sleep(CarRegs &c, float *sleep) {
+    c.H.vx = c.H.vy = c.H.w = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) c.W[w].vx = c.W[w].vy = c.W[w].w = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 5; b++) sleep[b] = 0.0f;
+}
+
 // b2Island::Solve for one car on its own
-__device__ inline void island_solve(CarRegs &c, const CarConsts &K, float h, float dt_ratio) {
+__device__ inline void island_solve(CarRegs &c, const CarConsts &K, float h, float dt_ratio, float *sleep) {
     JointTmp j;
     isl_integrate_vel(c, K, h);
     isl_joints_init(c, j, K, dt_ratio);
 #pragma unroll 1
     for (int it = 0; it < 180; it++) isl_joints_vel(c, j, K, h);
     isl_integrate_pos(c, h);
+    bool solved = false;
 #pragma unroll 1
     for (int it = 0; it < 60; it++)
-        if (isl_joints_pos(c, K)) break;
+        if (isl_joints_pos(c, K)) {
+            solved = true;
+            break;
+        }
+    if (isl_sleep_scan(c, sleep, h) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(c, sleep);
 }
 
 __device__ inline void load_car(const CarSoA &s, int64_t M, int64_t ci, CarRegs &c) {

@@ -261,7 +261,12 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     } else {
         const float h = (float)(1.0 / CAR_FPS);
         const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
-        island_solve(cr, K, h, dt_ratio);
+        float slp[5];  // b2Body::m_sleepTime
+#pragma unroll
+        for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + ci];
+        island_solve(cr, K, h, dt_ratio, slp);
+#pragma unroll
+        for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = slp[b];
         if (car == 0 && s.players == 2) s.coupled[env] = 0, s.n_contact[env] = 0;
     }
     H = cr.H;

@@ -214,6 +214,7 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         for (int q = 0; q < 16; q++) s.visited[q * M + ci] = 0u;
         s.reward[ci] = 0.0, s.prev_reward[ci] = 0.0;
         s.visited_count[ci] = 0, s.last_block[ci] = -1, s.done[ci] = 0, s.step_count[ci] = 0, s.first_step[ci] = 1;
+        for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = 0.0f;
     }
     s.elapsed[env] = 0;
     if (s.n_contact) s.n_contact[env] = 0, s.coupled[env] = 0;

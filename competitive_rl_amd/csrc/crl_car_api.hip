@@ -128,7 +128,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
-    A(wforce, 8 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
 #undef A
@@ -276,7 +276,7 @@ static std::vector<T> pull(const T *dev, size_t count, hipStream_t st) {
 }
 
 struct HostCopy {
-    std::vector<float> body, jimp, jmotor, jspeed;
+    std::vector<float> body, jimp, jmotor, jspeed, sleep;
     std::vector<int32_t> jlimit, visited_count, last_block, done, step_count, first_step, elapsed;
     std::vector<double> wgas, womega, wphase, reward, prev_reward;
     std::vector<int16_t> wtiles;
@@ -289,7 +289,7 @@ static void pull_all(crl_car_ctx *c, HostCopy &h, hipStream_t st) {
     const int64_t n = c->n, M = (int64_t)c->s.players * n;
     const CarSoA &s = c->s;
     h.body = pull(s.body, 30 * M, st), h.jimp = pull(s.jimp, 12 * M, st), h.jmotor = pull(s.jmotor, 4 * M, st);
-    h.jspeed = pull(s.jspeed, 4 * M, st), h.jlimit = pull(s.jlimit, 4 * M, st);
+    h.jspeed = pull(s.jspeed, 4 * M, st), h.jlimit = pull(s.jlimit, 4 * M, st), h.sleep = pull(s.sleep, 5 * M, st);
     h.wgas = pull(s.wgas, 4 * M, st), h.womega = pull(s.womega, 4 * M, st), h.wphase = pull(s.wphase, 4 * M, st);
     h.wtiles = pull(s.wtiles, 4 * kWheelSlots * M, st), h.visited = pull(s.visited, 16 * M, st);
     h.reward = pull(s.reward, M, st), h.prev_reward = pull(s.prev_reward, M, st);
@@ -335,6 +335,7 @@ int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first
             q.reward = h.reward[ci], q.prev_reward = h.prev_reward[ci];
             q.tile_visited_count = h.visited_count[ci], q.last_block = h.last_block[ci], q.done = h.done[ci];
             q.step_count = h.step_count[ci], q.first_step = h.first_step[ci];
+            for (int b = 0; b < 5; b++) q.sleep_time[b] = h.sleep[b * M + ci];
         }
         o.elapsed = h.elapsed[env], o.episode = h.episode[env];
         o.n_contact = h.n_contact[env];
@@ -376,6 +377,7 @@ int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t 
             h.reward[ci] = q.reward, h.prev_reward[ci] = q.prev_reward;
             h.visited_count[ci] = q.tile_visited_count, h.last_block[ci] = q.last_block, h.done[ci] = q.done;
             h.step_count[ci] = q.step_count, h.first_step[ci] = q.first_step;
+            for (int b = 0; b < 5; b++) h.sleep[b * M + ci] = q.sleep_time[b];
         }
         h.elapsed[env] = o.elapsed, h.episode[env] = o.episode;
         h.n_contact[env] = o.n_contact;
@@ -388,7 +390,7 @@ int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t 
     push(h.wtiles, s.wtiles, st), push(h.visited, s.visited, st), push(h.reward, s.reward, st), push(h.prev_reward, s.prev_reward, st);
     push(h.visited_count, s.visited_count, st), push(h.last_block, s.last_block, st), push(h.done, s.done, st);
     push(h.step_count, s.step_count, st), push(h.first_step, s.first_step, st), push(h.elapsed, s.elapsed, st), push(h.episode, s.episode, st);
-    push(h.n_contact, s.n_contact, st), push(h.contact, s.contact, st);
+    push(h.n_contact, s.n_contact, st), push(h.contact, s.contact, st), push(h.sleep, s.sleep, st);
     hipStreamSynchronize(st);
     return CRL_OK;
 }

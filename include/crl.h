@@ -213,6 +213,7 @@ typedef struct crl_car_state {   /* one car: Car (car_dynamics.py:55-129) + its 
     int32_t tile_visited_count, last_block, done, step_count, first_step, pad;
     uint32_t wheel_tiles[4][CRL_CAR_MAX_TILES / 32]; /* w.tiles as bit sets                  */
     uint32_t visited[CRL_CAR_MAX_TILES / 32];        /* tile.road_visited[car]               */
+    float sleep_time[5], pad2;                       /* b2Body::m_sleepTime: hull, wheels 0-3 */
 } crl_car_state;
 
 #define CRL_CAR_MAX_CONTACTS 8

@@ -566,15 +566,52 @@ static void isl_clear_forces(car_state *car) {
     for (int w = 0; w < 4; w++) car->wheel[w].fx = car->wheel[w].fy = 0;
 }
 
+/* End of b2Island::Solve (Box2D 2.3 b2Island.cpp, "if (allowSleep)"): a body slower than the sleep
+ * tolerances accumulates m_sleepTime; once every body of the island has been still for
+ * b2_timeToSleep and the position solver converged, the island is put to sleep, which zeroes the
+ * velocities (b2Body::SetAwake(false)).  Car.step wakes every body again on the next step
+ * (joint.motorSpeed assignment and ApplyForceToCenter(..., True), car_dynamics.py:159-234), so the
+ * visible effect is the velocity reset. */
+#define LIN_SLEEP_TOL 0.01f
+#define ANG_SLEEP_TOL (2.0f / 180.0f * 3.14159265359f)
+#define TIME_TO_SLEEP 0.5f
+static float isl_sleep_scan(car_state *car, float h) {
+    float min_sleep = 3.402823466e+38f;
+    const float lin2 = LIN_SLEEP_TOL * LIN_SLEEP_TOL, ang2 = ANG_SLEEP_TOL * ANG_SLEEP_TOL;
+    for (int b = 0; b < 5; b++) {
+        car_body *B = b == 0 ? &car->hull : &car->wheel[b - 1];
+        if (B->w * B->w > ang2 || B->vx * B->vx + B->vy * B->vy > lin2) {
+            car->sleep_time[b] = 0.0f;
+            min_sleep = 0.0f;
+        } else {
+            car->sleep_time[b] += h;
+            min_sleep = fminf(min_sleep, car->sleep_time[b]);
+        }
+    }
+    return min_sleep;
+}
+static void isl_put_to_sleep(car_state *car) {
+    for (int b = 0; b < 5; b++) {
+        car_body *B = b == 0 ? &car->hull : &car->wheel[b - 1];
+        car->sleep_time[b] = 0.0f;
+        B->vx = B->vy = B->w = 0.0f;
+    }
+}
+
 static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters, int pos_iters) {
     joint_tmp jt[4];
     isl_integrate_vel(car, h);
     isl_joints_init(car, jt, dt_ratio);
     for (int it = 0; it < vel_iters; it++) isl_joints_vel(car, jt, h);
     isl_integrate_pos(car, h);
+    int solved = 0;
     for (int it = 0; it < pos_iters; it++)
-        if (isl_joints_pos(car)) break;
+        if (isl_joints_pos(car)) {
+            solved = 1;
+            break;
+        }
     isl_clear_forces(car);
+    if (isl_sleep_scan(car, h) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(car);
 }
 
 
@@ -932,12 +969,18 @@ static void island_solve_coupled(car_env *e, float h, float dt_ratio, int vel_it
         contacts_vel(e, vc);
     }
     isl_integrate_pos(&e->car[1], h), isl_integrate_pos(&e->car[0], h);
+    int solved = 0;
     for (int it = 0; it < pos_iters; it++) {
         int cok = contacts_pos(e);
         int j1 = isl_joints_pos(&e->car[1]), j0 = isl_joints_pos(&e->car[0]);
-        if (cok && j1 && j0) break;
+        if (cok && j1 && j0) {
+            solved = 1;
+            break;
+        }
     }
     isl_clear_forces(&e->car[1]), isl_clear_forces(&e->car[0]);
+    const float m1 = isl_sleep_scan(&e->car[1], h), m0 = isl_sleep_scan(&e->car[0], h);
+    if (fminf(m1, m0) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(&e->car[1]), isl_put_to_sleep(&e->car[0]);
 }
 
 /* ------------------------------------------------------------------ env */

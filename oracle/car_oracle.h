@@ -22,6 +22,7 @@ typedef struct car_state {
     float imp[4][3], motor_imp[4], motor_speed[4]; /* b2RevoluteJoint m_impulse, m_motorImpulse, m_motorSpeed */
     int32_t limit_state[4];
     double gas[4], brake[4], steer[4], phase[4], omega[4]; /* Car wheel attributes (python floats) */
+    float sleep_time[5], pad_s;                            /* b2Body::m_sleepTime of hull, wheels 0-3 */
 } car_state;
 
 typedef struct car_consts {

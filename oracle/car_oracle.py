@@ -12,7 +12,7 @@ TRACK_DT = np.dtype([("n", "<i4"), ("pad", "<i4"), ("track", "<f8", (MAX_TILES, 
 BODY_DT = np.dtype([(k, "<f4") for k in ("cx", "cy", "a", "vx", "vy", "w", "fx", "fy")])
 CAR_DT = np.dtype([("hull", BODY_DT), ("wheel", BODY_DT, (4,)), ("imp", "<f4", (4, 3)), ("motor_imp", "<f4", (4,)),
                    ("motor_speed", "<f4", (4,)), ("limit_state", "<i4", (4,)), ("gas", "<f8", (4,)), ("brake", "<f8", (4,)),
-                   ("steer", "<f8", (4,)), ("phase", "<f8", (4,)), ("omega", "<f8", (4,))])
+                   ("steer", "<f8", (4,)), ("phase", "<f8", (4,)), ("omega", "<f8", (4,)), ("sleep_time", "<f4", (5,)), ("pad_s", "<f4")])
 CONTACT_DT = np.dtype([("pair", "<i4"), ("count", "<i4"), ("type", "<i4"), ("ln", "<f4", (2,)), ("lp", "<f4", (2,)),
                        ("pt", "<f4", (2, 2)), ("id", "<u4", (2,)), ("nimp", "<f4", (2,)), ("timp", "<f4", (2,))])
 ENV_DT = np.dtype([("trk", TRACK_DT), ("tile32", "<f4", (MAX_TILES, 5, 2)), ("tile_aabb", "<f4", (MAX_TILES, 4)),

@@ -39,6 +39,7 @@ def oracle_to_hip_state(envs):
             q["tile_visited_count"], q["last_block"], q["done"] = e["tile_visited_count"][c], e["last_block"][c], e["done"][c]
             q["step_count"], q["first_step"] = e["step_count"], int(e["inv_dt0"] == 0)
             q["wheel_tiles"], q["visited"] = e["wheel_tiles"][c], e["visited"][c]
+            q["sleep_time"] = o["sleep_time"]
         st[i]["elapsed"] = e["step_count"]
         st[i]["n_contact"] = e["n_contact"]
         for f in ("pair", "count", "type", "ln", "lp", "pt", "id", "nimp", "timp"):
@@ -151,6 +152,7 @@ def test_step_teacher_forced_matches_oracle():
                 assert np.allclose(q["omega"], o["omega"], rtol=1e-6, atol=1e-6), (t, i, c)
                 assert np.allclose(q["gas"], o["gas"]) and np.allclose(q["phase"], o["phase"], rtol=1e-6, atol=1e-6)
                 assert np.array_equal(q["limit_state"], o["limit_state"]), (t, i, c)
+                assert np.array_equal(q["sleep_time"], o["sleep_time"]), (t, i, c, q["sleep_time"], o["sleep_time"])
                 assert np.allclose(q["imp"], o["imp"], rtol=1e-3, atol=1e-4), (t, i, c)
                 assert int(q["tile_visited_count"]) == int(e.e["tile_visited_count"][c]), (t, i, c)
                 assert np.array_equal(q["visited"], e.e["visited"][c]) and np.array_equal(q["wheel_tiles"], e.e["wheel_tiles"][c])
@@ -409,4 +411,48 @@ def test_action_repeat_matches_oracle():
                 assert int(q["step_count"]) == int(e.e["step_count"]) and np.allclose(q["gas"], o["gas"])
                 assert int(q["tile_visited_count"]) == int(e.e["tile_visited_count"][c])
     assert int(envs[0].e["step_count"]) == steps * rep
+    hip.close()
+
+
+def test_island_sleep_matches_oracle():
+    """b2Island's sleep rule (idle cars: timers count up in float32 steps, the island is put to
+    sleep after 0.5 s and its velocities are zeroed) -- free running, cars far apart and touching."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps = 6, 70
+    envs = make_oracle_envs(n)
+    hip = crl.HipCarVecEnv(n)
+    hip.reset()
+    push_tracks(hip, envs)
+    for e in envs:
+        for _ in range(40):
+            e.step([[0.0, 0.0], [0.0, 0.0]])  # settle onto the joints
+    for i, e in enumerate(envs):  # sub-tolerance creep; env 0 stays exactly at rest, env 1 has one fast wheel
+        if i == 0:
+            continue
+        for c in range(2):
+            e.e["car"][c]["hull"]["vx"] = 1e-4 * (i + 1)
+            e.e["car"][c]["wheel"]["vx"] = 1e-4 * (i + 1)
+        if i == 1:
+            e.e["car"][0]["wheel"][2]["w"] = 3.0
+    hip.set_state(oracle_to_hip_state(envs))
+    zero = np.zeros((n, 2, 2), np.float32)
+    slept = 0
+    for t in range(steps):
+        hip.step_device(torch.as_tensor(zero).cuda(), render=False)
+        hs = hip.get_state()
+        for i, e in enumerate(envs):
+            before = e.e["car"]["sleep_time"].copy()
+            e.step(zero[i].astype(np.float64))
+            for c in range(2):
+                q, o = hs[i]["car"][c], e.e["car"][c]
+                assert np.array_equal(q["sleep_time"], o["sleep_time"]), (t, i, c, q["sleep_time"], o["sleep_time"])
+                for f in ("vx", "vy", "w"):
+                    assert abs(float(q["hull"][f]) - float(o["hull"][f])) < 1e-6, (t, i, c, f)
+                    assert np.allclose(q["wheel"][f], o["wheel"][f], atol=1e-6), (t, i, c, f)
+                if np.all(before[c] > 0.4) and np.all(o["sleep_time"] == 0.0):
+                    slept += 1
+                    assert float(q["hull"]["vx"]) == 0.0 and np.all(q["wheel"]["vx"] == 0.0), (t, i, c)
+    assert slept >= n, slept
     hip.close()

@@ -188,3 +188,37 @@ def test_rear_end_collision_pushes_instead_of_passing_through(contacts):
         assert float(e.e["contact"][0]["nimp"].sum()) > 1.0
     else:
         assert min(gaps) < 3.0 and max(ncs) == 0  # without the contact solver the cars overlap
+
+
+def test_island_sleep_zeroes_sub_tolerance_velocities_after_half_a_second():
+    """b2Island::Solve's sleep rule (Box2D 2.3): bodies below the linear (0.01) / angular (2 deg/s)
+    tolerances accumulate m_sleepTime; at 0.5 s (25 steps of 1/50 s, float32 accumulation) the
+    island sleeps: velocities are zeroed and the timers restart.  A fast body keeps them at 0."""
+    e = fresh_env()
+    for _ in range(40):
+        e.step([[0.0, 0.0], [0.0, 0.0]])  # settle onto the joints
+    car = e.e["car"][0]
+    # creep below tolerance: the timer counts up in steps of h and the velocity survives
+    for b in ("hull",):
+        car[b]["vx"], car[b]["vy"], car[b]["w"] = 1e-4, 0.0, 0.0
+    car["wheel"]["vx"], car["wheel"]["vy"], car["wheel"]["w"] = 1e-4, 0.0, 0.0
+    car["sleep_time"][:] = 0.0
+    h = np.float32(1.0 / 50.0)
+    acc, slept_at = np.float32(0.0), None
+    for k in range(40):
+        e.step([[0.0, 0.0], [0.0, 0.0]])
+        acc = np.float32(acc + h)
+        st = e.e["car"][0]["sleep_time"].copy()
+        if slept_at is None and np.all(st == 0.0) and k > 0:
+            slept_at = k
+            break
+        assert np.all(st == acc), (k, st, acc)
+    assert slept_at is not None and 24 <= slept_at <= 26, slept_at
+    c = e.e["car"][0]
+    assert c["hull"]["vx"] == 0.0 and c["hull"]["vy"] == 0.0 and c["hull"]["w"] == 0.0
+    assert np.all(c["wheel"]["vx"] == 0.0) and np.all(c["wheel"]["w"] == 0.0)
+    # a moving car never accumulates sleep time
+    for _ in range(30):
+        e.step([[0.0, 1.0], [0.0, 0.0]])
+    assert np.all(e.e["car"][0]["sleep_time"] == 0.0)
+    assert e.e["car"][0]["hull"]["vx"] ** 2 + e.e["car"][0]["hull"]["vy"] ** 2 > 1.0
