@@ -580,7 +580,9 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     }
     // planes per wave: the whole stack of an env per wave once there are enough envs to fill
     // the chip (256 CUs x 16 waves), one plane per wave below that
-    const int ppw = (p.n >= 8192 && !(q.debug & 16)) ? p.K : 1;
+    static const int ppw_env = getenv("CRL_GRAY_PPW") ? atoi(getenv("CRL_GRAY_PPW")) : 0;  // tuning experiments only
+    int ppw = (p.n >= 8192 && !(q.debug & 16)) ? p.K : 1;
+    if (ppw_env > 0 && p.K % ppw_env == 0) ppw = ppw_env;
     const int64_t waves = p.n * (p.K / ppw);
     const dim3 grid((unsigned)((waves + 3) / 4));
     if (q.debug & ~16)  // any ablation switch: the instrumented instance
