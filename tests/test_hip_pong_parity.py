@@ -393,3 +393,37 @@ def test_single_player_golden_and_tournament_shapes():
         assert torch.equal(a, b) and torch.equal(ra, rb) and torch.equal(da, db)
     for e in (envs, tour, e1, e2):
         e.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 41])
+def test_raw_single_player_and_ragged_sizes(atlas, n):
+    """cPong-v0 raw frames (one view per env: the VIEWS = 1 instance of the address-linear raster)
+    and env counts whose chunk totals are not multiples of the 512-chunk workgroup span."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import pong_oracle as po
+
+    steps = 260
+    rs = np.random.RandomState(100 + n)
+    acts = rs.randint(0, 3, (steps, n)).astype(np.int32)
+    env = crl.HipPongVecEnv(n, seed=9, mode="raw", single_player=True)
+    ora = po.PongOracle(n, atlas, obs_mode=po.RAW, seed=9, single=True)
+    o_h, o_o = env.reset(), ora.reset()
+    assert np.array_equal(o_h.cpu().numpy().reshape(o_o.shape), o_o)
+    for t in range(steps):
+        obs, rew, done, infos = env.step(acts[t])
+        oo, orew, odone = ora.step(acts[t], render=True)
+        assert np.array_equal(rew.cpu().numpy().reshape(orew.shape), orew), t
+        assert np.array_equal(obs.cpu().numpy().reshape(oo.shape), oo), t
+    env.close()
+    # double-player raw at the same ragged sizes
+    env = crl.HipPongVecEnv(n, seed=9, mode="raw")
+    ora = po.PongOracle(n, atlas, obs_mode=po.RAW, seed=9)
+    o_h, o_o = env.reset(), ora.reset()
+    assert np.array_equal(torch.stack(o_h, 1).cpu().numpy(), o_o)
+    acts2 = rs.randint(0, 3, (60, n, 2)).astype(np.int32)
+    for t in range(60):
+        obs, rew, done, infos = env.step(acts2[t])
+        oo, orew, odone = ora.step(acts2[t], render=True)
+        assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo), t
+    env.close()
