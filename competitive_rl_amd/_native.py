@@ -41,7 +41,7 @@ CAR_STATE_DT = np.dtype([
     ("sleep_time", "<f4", (5,)), ("pad2", "<f4")], align=True)
 CAR_CONTACT_DT = np.dtype([("pair", "<i4"), ("count", "<i4"), ("type", "<i4"), ("ln", "<f4", (2,)), ("lp", "<f4", (2,)),
                            ("pt", "<f4", (2, 2)), ("id", "<u4", (2,)), ("nimp", "<f4", (2,)), ("timp", "<f4", (2,))])
-CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4"), ("n_contact", "<i4"), ("pad", "<i4"),
+CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4"), ("n_contact", "<i4"), ("coupled", "<i4"),
                              ("contact", CAR_CONTACT_DT, (8,))], align=True)
 CRL_FLAG_CAR_NO_CONTACTS = 2
 

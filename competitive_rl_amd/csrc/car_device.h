@@ -140,6 +140,7 @@ void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &sr
                       hipStream_t st);
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st);
+void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int max_episode_steps, hipStream_t st);
 // only_env: draw env e iff only_env[e] == want; nullptr = every env

@@ -57,6 +57,67 @@ __device__ inline float poly_dist2(const V2 (&A)[4], const V2 (&B)[5]) {
     return best;
 }
 
+// Second-level "could the cars touch" test: world AABBs of the 8 fixtures of each car (4 hull
+// polygons, 4 wheels; wheels do not collide with wheels), grown by more than the polygon radii.
+// No overlapping pair => b2CollidePolygons would find no manifold point for this env.
+__device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_t M, int64_t c0, int64_t c1) {
+    float bb[2][8][4];
+    for (int k = 0; k < 2; k++) {
+        const int64_t ci = k ? c1 : c0;
+        for (int f = 0; f < 8; f++) {
+            const int o = f < 4 ? 0 : 6 + 6 * (f - 4);
+            const float cx = s.body[(o + 0) * M + ci], cy = s.body[(o + 1) * M + ci], a = s.body[(o + 2) * M + ci];
+            const float sn = sinf(a), cs = cosf(a);
+            const V2 lc = f < 4 ? mk(K.hull_lc[0], K.hull_lc[1]) : mk(0.f, 0.f);
+            const V2 p = mk(cx, cy) - rotv(sn, cs, lc);
+            const int nv = f < 4 ? K.hull_n[f] : 4;
+            float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+            for (int i = 0; i < 8; i++) {
+                if (i < nv) {
+                    const V2 v = f < 4 ? mk(K.hull_poly[f][i][0], K.hull_poly[f][i][1]) : mk(K.wheel_poly[i][0], K.wheel_poly[i][1]);
+                    const V2 wv = rotv(sn, cs, v) + p;
+                    x0 = fminf(x0, wv.x), y0 = fminf(y0, wv.y), x1 = fmaxf(x1, wv.x), y1 = fmaxf(y1, wv.y);
+                }
+            }
+            bb[k][f][0] = x0 - 0.03f, bb[k][f][1] = y0 - 0.03f, bb[k][f][2] = x1 + 0.03f, bb[k][f][3] = y1 + 0.03f;
+        }
+    }
+    bool any = false;
+    for (int fa = 0; fa < 8; fa++)
+        for (int fb = 0; fb < 8; fb++) {
+            if (fa >= 4 && fb >= 4) continue;
+            any = any || !(bb[0][fa][0] > bb[1][fb][2] || bb[1][fb][0] > bb[0][fa][2] || bb[0][fa][1] > bb[1][fb][3] ||
+                           bb[1][fb][1] > bb[0][fa][3]);
+        }
+    return any;
+}
+
+// world.Step -> b2Island::Solve for every car that is an island of its own (one lane per car
+// instance, state in registers); the cars flagged by car_step_kernel are solved together in
+// car_coupled_kernel instead.
+__global__ __launch_bounds__(64) void car_solve_kernel(CarSoA s, CarConsts K) {
+    const int64_t M = (int64_t)s.players * s.n;
+    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= M) return;
+    const int car = ci >= s.n ? 1 : 0;
+    const int64_t env = ci - car * s.n;
+    if (s.players == 2 && s.coupled[env]) return;
+    CarRegs cr;
+    load_car(s, M, ci, cr);
+#pragma unroll
+    for (int w = 0; w < 4; w++) cr.fx[w] = s.wforce[(2 * w + 0) * M + ci], cr.fy[w] = s.wforce[(2 * w + 1) * M + ci];
+    const float h = (float)(1.0 / CAR_FPS);
+    const float dt_ratio = s.first_step[ci] ? 0.0f : (1.0f / h) * h;
+    float slp[5];  // b2Body::m_sleepTime
+#pragma unroll
+    for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + ci];
+    island_solve(cr, K, h, dt_ratio, slp);
+#pragma unroll
+    for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = slp[b];
+    store_car(s, M, ci, cr);
+    s.first_step[ci] = 0;
+}
+
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
                                                       float *__restrict__ rew_out, uint8_t *__restrict__ done_car, int sub,
                                                       int repeat) {
@@ -78,15 +139,12 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
             Wb[w].vx = b[(o + 3) * M], Wb[w].vy = b[(o + 4) * M], Wb[w].w = b[(o + 5) * M];
         }
     }
-    const Body H0 = H;  // pre-step hull pose (the near test must be the same in both lanes)
-    float imp[4][3], motor_imp[4], motor_speed[4];
-    int lim[4];
+    float motor_speed[4];
     double gas[4], omega[4], phase[4];
     int16_t wt[4][kWheelSlots];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        imp[w][0] = s.jimp[(3 * w + 0) * M + ci], imp[w][1] = s.jimp[(3 * w + 1) * M + ci], imp[w][2] = s.jimp[(3 * w + 2) * M + ci];
-        motor_imp[w] = s.jmotor[w * M + ci], motor_speed[w] = s.jspeed[w * M + ci], lim[w] = s.jlimit[w * M + ci];
+        motor_speed[w] = s.jspeed[w * M + ci];
         gas[w] = s.wgas[w * M + ci], omega[w] = s.womega[w * M + ci], phase[w] = s.wphase[w * M + ci];
 #pragma unroll
         for (int k = 0; k < kWheelSlots; k++) wt[w][k] = s.wtiles[(w * kWheelSlots + k) * M + ci];
@@ -94,7 +152,6 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     double reward = s.reward[ci], prev_reward = s.prev_reward[ci];
     int visited_count = s.visited_count[ci], last_block = s.last_block[ci], done = s.done[ci];
     int step_count = s.step_count[ci];
-    const int first_step = s.first_step[ci];
     const int ntiles = s.ntiles[env];
 
     // ---- CarRacing.step: controls for every car, done or not (crmp:549-556)
@@ -231,68 +288,30 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         }
     }
 
-    // ---- world.Step: b2Island::Solve.  A car whose oriented box meets the other car's is handed to
-    // the coupled kernel (car_contact.hip), which adds the car-car contact constraints; everyone
-    // else is an island of its own and is solved here.
-    CarRegs cr;
-    cr.H = H;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        cr.W[w] = Wb[w], cr.fx[w] = fx[w], cr.fy[w] = fy[w];
-        cr.imp[w][0] = imp[w][0], cr.imp[w][1] = imp[w][1], cr.imp[w][2] = imp[w][2];
-        cr.motor_imp[w] = motor_imp[w], cr.motor_speed[w] = motor_speed[w], cr.lim[w] = lim[w];
-    }
+    // ---- world.Step's island solve happens in car_solve_kernel (cars on their own) or
+    // car_coupled_kernel (cars whose fixtures may touch): this kernel only decides which, and hands
+    // over the tyre forces and the joint motor targets.  Bodies and joint impulses are not modified
+    // here, so both lanes of an env read the same pre-solve poses of both cars.
     bool coupled = false;
     if (s.players == 2 && s.contacts_enabled) {
-        // both lanes of an env evaluate the same symmetric test on the pre-solve hull poses
         const int64_t c0 = env, c1 = s.n + env;
-        const float x0 = car == 0 ? H0.cx : s.body[0 * M + c0], y0 = car == 0 ? H0.cy : s.body[1 * M + c0], a0 = car == 0 ? H0.a : s.body[2 * M + c0];
-        const float x1 = car == 1 ? H0.cx : s.body[0 * M + c1], y1 = car == 1 ? H0.cy : s.body[1 * M + c1], a1 = car == 1 ? H0.a : s.body[2 * M + c1];
-        coupled = cars_near(K, x0, y0, a0, x1, y1, a1);
+        coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
+                            s.body[2 * M + c1]);
+        if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
     }
-    if (coupled) {
-        // keep the pre-solve bodies; pass the tyre forces and joint targets to the coupled kernel
 #pragma unroll
-        for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
-        if (car == 0) {
-            s.coupled[env] = 1;
-            s.coupled_list[atomicAdd(s.coupled_count, 1)] = (int32_t)env;
-        }
-    } else {
-        const float h = (float)(1.0 / CAR_FPS);
-        const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
-        float slp[5];  // b2Body::m_sleepTime
-#pragma unroll
-        for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + ci];
-        island_solve(cr, K, h, dt_ratio, slp);
-#pragma unroll
-        for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = slp[b];
-        if (car == 0 && s.players == 2) s.coupled[env] = 0, s.n_contact[env] = 0;
-    }
-    H = cr.H;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        Wb[w] = cr.W[w];
-        imp[w][0] = cr.imp[w][0], imp[w][1] = cr.imp[w][1], imp[w][2] = cr.imp[w][2];
-        motor_imp[w] = cr.motor_imp[w], lim[w] = cr.lim[w];
+    for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
+    if (car == 0 && s.players == 2) {
+        s.coupled[env] = coupled ? 1 : 0;
+        if (coupled) s.coupled_list[atomicAdd(s.coupled_count, 1)] = (int32_t)env;
+        else s.n_contact[env] = 0;
     }
     step_count += 1;
 
-    // ---- store
-    {
-        float *b = s.body + ci;
-        b[0 * M] = H.cx, b[1 * M] = H.cy, b[2 * M] = H.a, b[3 * M] = H.vx, b[4 * M] = H.vy, b[5 * M] = H.w;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const int o = 6 + 6 * w;
-            b[(o + 0) * M] = Wb[w].cx, b[(o + 1) * M] = Wb[w].cy, b[(o + 2) * M] = Wb[w].a;
-            b[(o + 3) * M] = Wb[w].vx, b[(o + 4) * M] = Wb[w].vy, b[(o + 5) * M] = Wb[w].w;
-        }
-    }
+    // ---- store (wheel attributes, sensor contacts, bookkeeping; the motor targets for the solver)
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        s.jimp[(3 * w + 0) * M + ci] = imp[w][0], s.jimp[(3 * w + 1) * M + ci] = imp[w][1], s.jimp[(3 * w + 2) * M + ci] = imp[w][2];
-        s.jmotor[w * M + ci] = motor_imp[w], s.jspeed[w * M + ci] = motor_speed[w], s.jlimit[w * M + ci] = lim[w];
+        s.jspeed[w * M + ci] = motor_speed[w];
         s.wgas[w * M + ci] = gas[w], s.womega[w * M + ci] = omega[w], s.wphase[w * M + ci] = phase[w];
 #pragma unroll
         for (int k = 0; k < kWheelSlots; k++) s.wtiles[(w * kWheelSlots + k) * M + ci] = wt[w][k];
@@ -300,7 +319,6 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     s.reward[ci] = reward, s.prev_reward[ci] = prev_reward;
     s.visited_count[ci] = visited_count, s.last_block[ci] = last_block, s.done[ci] = done;
     s.step_count[ci] = step_count;
-    if (!coupled) s.first_step[ci] = 0;  // (the coupled kernel clears it after using it)
     if (rew_out) {
         // step_rewards accumulate over the repeats in f64 (crmp:584); the running sum is kept in prev_step
         const double acc = (sub == 0 ? 0.0 : s.step_acc[ci]) + step_reward;
@@ -331,6 +349,11 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
     const int64_t M = (int64_t)s.players * s.n;
     if (s.coupled_count) hipMemsetAsync(s.coupled_count, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car, sub, repeat);
+}
+
+void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
+    const int64_t M = (int64_t)s.players * s.n;
+    hipLaunchKernelGGL(car_solve_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
 }
 
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int max_episode_steps,

@@ -221,8 +221,11 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     const bool fork = c->overlap && obs_dev != nullptr;
     crl_timer_begin(tm, 0, st);
     for (int sub = 0; sub < c->repeat; sub++) {  // action repetition: Car.step + world.Step per repeat (crmp:576-603)
+        // Car.step, rewards, done flags, sensor contacts; decides which cars are solved together
         launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, sub, c->repeat, st);
-        if (!(fork && sub == c->repeat - 1)) launch_car_coupled(c->s, c->K_, st);
+        if (fork && sub == c->repeat - 1) break;  // the last world.Step is forked below
+        launch_car_solve(c->s, c->K_, st);
+        launch_car_coupled(c->s, c->K_, st);
     }
     launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, 1000, st);
     if (!fork) {
@@ -244,8 +247,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
         hipEventRecord(c->ev_fork, st);
         hipStreamWaitEvent(c->side, c->ev_fork, 0);
-        launch_car_coupled(c->s, c->K_, c->side);
+        launch_car_coupled(c->s, c->K_, c->side);  // the few coupled envs: next to the per-car solve AND the frames
         hipEventRecord(c->ev_coupled, c->side);
+        launch_car_solve(c->s, c->K_, st);
         crl_timer_end(tm, 0, st);
         crl_timer_begin(tm, 1, st);
         launch_car_raster(c->s, c->K_, target, st, c->slow_env, 0);
@@ -281,7 +285,7 @@ struct HostCopy {
     std::vector<double> wgas, womega, wphase, reward, prev_reward;
     std::vector<int16_t> wtiles;
     std::vector<uint32_t> visited, episode;
-    std::vector<int32_t> n_contact;
+    std::vector<int32_t> n_contact, coupled;
     std::vector<float> contact;
 };
 
@@ -296,6 +300,7 @@ static void pull_all(crl_car_ctx *c, HostCopy &h, hipStream_t st) {
     h.visited_count = pull(s.visited_count, M, st), h.last_block = pull(s.last_block, M, st), h.done = pull(s.done, M, st);
     h.step_count = pull(s.step_count, M, st), h.first_step = pull(s.first_step, M, st);
     h.elapsed = pull(s.elapsed, n, st), h.episode = pull(s.episode, n, st);
+    h.coupled = pull(s.coupled, n, st);
     h.n_contact = pull(s.n_contact, n, st), h.contact = pull(s.contact, (size_t)n * kMaxContacts * kContactWords, st);
     hipStreamSynchronize(st);
 }
@@ -338,7 +343,7 @@ int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first
             for (int b = 0; b < 5; b++) q.sleep_time[b] = h.sleep[b * M + ci];
         }
         o.elapsed = h.elapsed[env], o.episode = h.episode[env];
-        o.n_contact = h.n_contact[env];
+        o.n_contact = h.n_contact[env], o.coupled = h.coupled[env];
         for (int k = 0; k < o.n_contact && k < kMaxContacts; k++)
             memcpy(&o.contact[k], &h.contact[((size_t)env * kMaxContacts + k) * kContactWords], sizeof(crl_car_contact));
     }

@@ -230,7 +230,8 @@ typedef struct crl_car_env_state {
     crl_car_state car[2];
     int32_t elapsed;  /* gym TimeLimit._elapsed_steps */
     uint32_t episode; /* resets so far                */
-    int32_t n_contact, pad;
+    int32_t n_contact;
+    int32_t coupled; /* (get only) 1 = the cars' boxes met and the last step solved them in one kernel */
     crl_car_contact contact[CRL_CAR_MAX_CONTACTS];
 } crl_car_env_state;
 
