@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     const V2 off = hp + mk(cs * 0.0f - sn * 16.0f, sn * 0.0f + cs * 16.0f);
     const double obs_scale = (10 / (100 / sqrt(96.0))) * 1.8;
     const float inv_scale = (float)(1.0 / obs_scale), scale_f = (float)obs_scale;
-    const float kf = (float)(CAR_PLAYFIELD / 20.0);
+    const float kf = (float)(CAR_PLAYFIELD / 20.0), inv_kf = 1.0f / kf;
 
     // ---- (1) ordered compaction of the tiles near the view (half-diagonal 48*sqrt(2)/scale < 39):
     // both halves of the tile range are tested at once (kCarMaxTiles <= 512), then the kept tiles'
@@ -320,9 +320,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             const float dx = ((float)(sx0 + k) + 0.5f) - 48.0f, dy = ((float)sy + 0.5f) - 48.0f;
             const float rx = cs * dx - sn * dy, ry = sn * dx + cs * dy;
             wx[k] = off.x - rx * inv_scale, wy[k] = off.y - ry * inv_scale;
-            const int ix = (int)floorf(wx[k] / kf), iy = (int)floorf(wy[k] / kf);
-            const bool light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
-            g[k] = light ? G_LIGHT : G_GRASS;
+            g[k] = G_GRASS;  // the checker term is resolved after the polygons, for the pixels still open
             ax0 = fminf(ax0, wx[k]), ay0 = fminf(ay0, wy[k]), ax1 = fmaxf(ax1, wx[k]), ay1 = fmaxf(ay1, wy[k]);
         }
         unsigned open = 0xFu;  // pixels not yet covered by a (later-drawn) polygon
@@ -370,6 +368,22 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                 if (in >> k & 1u) g[k] = rg;
             open &= ~in;
           }
+        }
+        // grass checker of the open pixels: floor(w / kf) with kf = PLAYFIELD / 20.  The quotient is
+        // first taken as w * (1 / kf) (error < 4e-6 for |w / kf| < 32); only when that lands within
+        // 1e-4 of an integer -- where the rounding of the true f32 division could matter -- is the
+        // division itself evaluated, so the result is always floorf(w / kf).
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!(open >> k & 1u)) continue;
+            const float qx = wx[k] * inv_kf, qy = wy[k] * inv_kf;
+            float fx = floorf(qx), fy = floorf(qy);
+            const float rx = qx - fx, ry = qy - fy;
+            if (!(fabsf(qx) < 32.0f) || rx < 1e-4f || rx > 1.0f - 1e-4f) fx = floorf(wx[k] / kf);
+            if (!(fabsf(qy) < 32.0f) || ry < 1e-4f || ry > 1.0f - 1e-4f) fy = floorf(wy[k] / kf);
+            const int ix = (int)fx, iy = (int)fy;
+            const bool light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
+            if (light) g[k] = G_LIGHT;
         }
         tile32[q] = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
     }
