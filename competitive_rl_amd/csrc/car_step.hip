@@ -118,9 +118,12 @@ __global__ __launch_bounds__(64) void car_solve_kernel(CarSoA s, CarConsts K) {
     s.first_step[ci] = 0;
 }
 
+static constexpr int kNearCap = 32;
+
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
                                                       float *__restrict__ rew_out, uint8_t *__restrict__ done_car, int sub,
                                                       int repeat) {
+    __shared__ int16_t near_list[kNearCap][64];  // per lane: tiles whose AABB meets the car's (sensor broadphase)
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= M) return;
@@ -241,16 +244,45 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
             }
             cx0 = fminf(cx0, wx0[w]), cy0 = fminf(cy0, wy0[w]), cx1 = fmaxf(cx1, wx1[w]), cy1 = fmaxf(cy1, wy1[w]);
         }
+        // touched tiles lie in [tmin, tmax]: two compares rule out "was touching" for most tiles
+        int tmin = 1 << 30, tmax = -1;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int k = 0; k < kWheelSlots; k++)
+                if (wt[w][k] >= 0) tmin = min(tmin, (int)wt[w][k]), tmax = max(tmax, (int)wt[w][k]);
+        // Broadphase over the track, then the narrow phase -- in two separate loops.  Every lane has
+        // its own track and position, so the tiles near its car sit at unrelated indices; testing them
+        // inside the scan would make the wavefront run the expensive body for the union of all lanes'
+        // tiles (nearly every iteration).  The scan only records the tile indices (ascending, which is
+        // also the order the Begin/End events are raised in) in a per-lane LDS list; the second loop
+        // walks the k-th entry of every lane together.
+        int cnt = 0;
 #pragma unroll 1
-        for (int t = 0; t < ntiles; t++) {
+        for (int t0 = 0; t0 < ntiles; t0 += 8) {
+            float4 bbs[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) bbs[j] = s.tile_aabb[(int64_t)min(t0 + j, ntiles - 1) * s.n + env];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int t = t0 + j;
+                const float4 bb = bbs[j];
+                const bool near_car = !(cx0 > bb.z + 0.05f || cx1 < bb.x - 0.05f || cy0 > bb.w + 0.05f || cy1 < bb.y - 0.05f);
+                bool was_any = false;
+                if (t >= tmin && t <= tmax) {
+#pragma unroll
+                    for (int w = 0; w < 4; w++)
+#pragma unroll
+                        for (int k = 0; k < kWheelSlots; k++) was_any = was_any || wt[w][k] == t;
+                }
+                if (t < ntiles && (near_car || was_any)) {
+                    if (cnt < kNearCap) near_list[cnt][threadIdx.x] = (int16_t)t;
+                    cnt++;
+                }
+            }
+        }
+        auto narrow = [&](int t) {
             const float4 bb = s.tile_aabb[(int64_t)t * s.n + env];
-            const bool near_car = !(cx0 > bb.z + 0.05f || cx1 < bb.x - 0.05f || cy0 > bb.w + 0.05f || cy1 < bb.y - 0.05f);
-            bool was_any = false;
-#pragma unroll
-            for (int w = 0; w < 4; w++)
-#pragma unroll
-                for (int k = 0; k < kWheelSlots; k++) was_any = was_any || wt[w][k] == t;
-            if (!near_car && !was_any) continue;
             V2 tp[5];
 #pragma unroll
             for (int k = 0; k < 5; k++)
@@ -284,6 +316,25 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
                     for (int k = 0; k < kWheelSlots; k++)
                         if (wt[w][k] == t) wt[w][k] = -1;
                 }
+            }
+        };
+#pragma unroll 1
+        for (int k = 0; k < kNearCap; k++) {
+            if (!__any(k < cnt)) break;
+            if (k < cnt) narrow(near_list[k][threadIdx.x]);
+        }
+        if (cnt > kNearCap) {  // more near tiles than list slots (not seen in practice): finish in order
+            const int last = near_list[kNearCap - 1][threadIdx.x];
+#pragma unroll 1
+            for (int t = last + 1; t < ntiles; t++) {
+                const float4 bb = s.tile_aabb[(int64_t)t * s.n + env];
+                const bool near_car = !(cx0 > bb.z + 0.05f || cx1 < bb.x - 0.05f || cy0 > bb.w + 0.05f || cy1 < bb.y - 0.05f);
+                bool was_any = false;
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int k = 0; k < kWheelSlots; k++) was_any = was_any || wt[w][k] == t;
+                if (near_car || was_any) narrow(t);
             }
         }
     }
