@@ -47,5 +47,22 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_c_demo(verbose=False):
+    """examples/c_abi_demo: a caller of include/crl.h without Python or torch (links libcrl_hip.so)."""
+    build()
+    src = os.path.join(ROOT, "examples", "c_abi_demo.cpp")
+    out = os.path.join(ROOT, "examples", "c_abi_demo")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"), src, "-L", os.path.dirname(LIB), "-lcrl_hip",
+           "-Wl,-rpath,$ORIGIN/../competitive_rl_amd", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_c_demo(verbose=True))

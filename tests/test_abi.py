@@ -78,3 +78,12 @@ def test_env_without_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         crl.make_envs("cPongDouble-v0", num_envs=2, frame_stack=None, log_dir=None)
+
+
+def test_c_abi_demo_links_against_the_library():
+    """examples/c_abi_demo.cpp (no Python, no torch) compiles against include/crl.h and links
+    libcrl_hip.so; running it needs a GPU (tests/test_hip_pong_parity.py)."""
+    from competitive_rl_amd.build import build_c_demo
+
+    exe = build_c_demo()
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)

@@ -427,3 +427,17 @@ def test_raw_single_player_and_ragged_sizes(atlas, n):
         oo, orew, odone = ora.step(acts2[t], render=True)
         assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo), t
     env.close()
+
+
+def test_c_abi_demo_runs_without_python_in_the_loop():
+    """The standalone C++ caller of include/crl.h: steps 2 048 envs through crl_create / crl_reset /
+    crl_step / crl_get_state and checks zero-sum rewards and a plausible frame itself (exit code)."""
+    _need_gpu()
+    import subprocess
+
+    from competitive_rl_amd.build import build_c_demo
+
+    exe = build_c_demo()
+    r = subprocess.run([exe, "2048", "120"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "env-steps/s" in r.stdout
