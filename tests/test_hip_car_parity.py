@@ -456,3 +456,44 @@ def test_island_sleep_matches_oracle():
                     assert float(q["hull"]["vx"]) == 0.0 and np.all(q["wheel"]["vx"] == 0.0), (t, i, c)
     assert slept >= n, slept
     hip.close()
+
+
+def test_car_sharding_invariance_and_determinism():
+    """Tracks, birth places and physics are keyed by the GLOBAL env id: two shards with env_id_base
+    0 / n reproduce one 2n batch bit for bit -- observations, rewards, dones, through auto-resets
+    (short episodes are forced by driving the cars off the playfield) -- and a second run of the
+    same batch repeats itself (the coupled list is compacted in arbitrary order; results must not
+    depend on it)."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps = 48, 260
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.rand((steps, 2 * n, 2, 2), generator=g, device="cuda") * 2 - 1
+    acts[:, :, :, 1] = acts[:, :, :, 1].abs()  # full gas: cars leave the playfield and episodes end
+
+    def run(envs, slices):
+        outs = []
+        for e in envs:
+            e.reset()
+        for t in range(steps):
+            o, r, d = [], [], []
+            for e, sl in zip(envs, slices):
+                ob, rw, dn = e.step_device(acts[t, sl].contiguous())
+                o.append(ob.clone()), r.append(rw.clone()), d.append(dn.clone())
+            outs.append((torch.cat(o), torch.cat(r), torch.cat(d)))
+        for e in envs:
+            e.close()
+        return outs
+
+    big = run([crl.HipCarVecEnv(2 * n, seed=11)], [slice(0, 2 * n)])
+    again = run([crl.HipCarVecEnv(2 * n, seed=11)], [slice(0, 2 * n)])
+    shards = run([crl.HipCarVecEnv(n, seed=11, env_id_base=0), crl.HipCarVecEnv(n, seed=11, env_id_base=n)],
+                 [slice(0, n), slice(n, 2 * n)])
+    resets = 0
+    for t in range(steps):
+        for a, b in ((big[t], again[t]), (big[t], shards[t])):
+            assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), t
+            assert torch.equal(a[0], b[0]), t
+        resets += int(big[t][2].sum().item())
+    assert resets > 0, "no episode ended: the test would not cover auto-reset"
