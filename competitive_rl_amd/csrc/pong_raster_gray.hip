@@ -419,6 +419,10 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
     const bool fast_ok = q.t.fast_ok != 0;
     const int dbg = DBG ? q.debug : 0;  // ablation switches (profiling instance only)
 
+    // view-major: a wave writes its env's planes in ascending address order (the four planes of agent
+    // 0's view, then agent 1's) -- 4 % faster than alternating between the two views per plane
+#pragma unroll 1
+    for (int view = 0; view < q.views; view++)
 #pragma unroll 1
     for (int plane = p0; plane < p0 + ppw; plane++) {
         const int rp = 4 - K + plane;  // ring plane
@@ -441,8 +445,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             else if (fa.sl == fb.sl && fa.sr == fb.sr + 1) variant = 2, sp = spb;
             else slow = true;
         }
-#pragma unroll 1
-        for (int view = 0; view < q.views; view++) {
+        {
             const int64_t tile = (env * q.views + view) * K + plane;
             uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + tile * (int64_t)RR);
             uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(obs + tile * (int64_t)RR);
