@@ -429,7 +429,11 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
         uint64_t pa = words_[wave][2 * rp], pb = words_[wave][2 * rp + 1];
         pa = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pa);
         pb = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pb);
-        const Frame fa = unpack_frame(pa), fb = unpack_frame(pb);
+        Frame fa = unpack_frame(pa), fb = unpack_frame(pb);
+        // A pair with one blank frame (the reset observation: a single frame, nothing to max with) equals
+        // the pair of the frame with itself -- max(x, 0) = x -- and then takes the fast path.
+        if (fa.sl == 255 && fb.sl != 255) fa = fb;
+        else if (fb.sl == 255 && fa.sl != 255) fb = fa;
         const bool blank_a = fa.sl == 255, blank_b = fb.sl == 255;
         // The score rows come pre-resized from the band table when the two kept frames show
         // the same score pair, or pairs one point apart (a point scored between the two
