@@ -203,7 +203,9 @@ def test_free_running_stays_close_and_render_matches():
             dy = float(hs[i]["car"][c]["hull"]["cy"]) - float(e.e["car"][c]["hull"]["cy"])
             assert np.hypot(dx, dy) < 1e-2, (i, c, dx, dy)
     print("render mismatch fractions: max", max(mism), "mean", np.mean(mism))
-    assert max(mism) < 0.005, mism
+    # identical definition on both sides; the bar leaves room for a pixel or two per frame flipping on a
+    # polygon edge through the last bit of the device's sinf/cosf (observed: exactly 0)
+    assert max(mism) < 2.5e-4, mism
     palette = {0, 29, 44, 60, 76, 101, 103, 107, 149, 161, 176, 255}
     assert set(np.unique(got).tolist()) <= palette
     assert (got[:, :, 91:, :16] == 255).any()  # the reward read-out is there
