@@ -499,3 +499,28 @@ def test_car_sharding_invariance_and_determinism():
             assert torch.equal(a[0], b[0]), t
         resets += int(big[t][2].sum().item())
     assert resets > 0, "no episode ended: the test would not cover auto-reset"
+
+
+def test_step_pipeline_frames_equal_a_single_render():
+    """crl_step draws its frames in three classes on two streams (envs that can be drawn right after
+    the per-car solve, coupled envs, finished envs after their reset); whatever the class, the frame
+    must be what one render of the post-step state gives."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps = 96, 220
+    env = crl.HipCarVecEnv(n, seed=3)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(8)
+    seen = {"coupled": 0, "done": 0}
+    for t in range(steps):
+        a = torch.rand((n, 2, 2), generator=g, device="cuda") * 2 - 1
+        a[:, :, 1] = a[:, :, 1].abs()  # gas: episodes end by leaving the playfield
+        obs, rew, done = env.step_device(a)
+        obs = obs.clone()
+        st = env.get_state()
+        seen["coupled"] += int(st["coupled"].sum())
+        seen["done"] += int(done.sum().item())
+        assert torch.equal(obs, env.render_current()), t
+    assert seen["coupled"] > 0 and seen["done"] > 0, seen
+    env.close()
