@@ -334,35 +334,43 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             const int c = wd * 32 + bit;
             const bool do_tile = (tm >> bit) & 1u, do_border = (bmk >> bit) & 1u;
             const CandTile &ct = cand[c];
-            const float4 ba = ct.bb_all;
+            // everything the candidate needs comes in with back-to-back LDS reads (no data-dependent
+            // early-out between them: a chain of dependent ~100-cycle reads costs more than the
+            // arithmetic it would save)
+            const float4 ba = ct.bb_all, bb = ct.bb;
+            float4 te[5], be[4];
+#pragma unroll
+            for (int i = 0; i < 5; i++) te[i] = ct.edge[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) be[i] = ct.bedge[i];
+            const int border = ct.border, tidx = ct.idx;
             if (ax0 > ba.z || ax1 < ba.x || ay0 > ba.w || ay1 < ba.y) continue;
             if (do_border) {  // the border quad is drawn right after its tile, so it is tested first
                 unsigned in = open;
-                for (int i = 0; i < 4 && in; i++) {
-                    const float4 e = ct.bedge[i];  // one LDS read per edge, shared by the 4 pixels
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if ((in >> k & 1u) && (e.z * (wy[k] - e.y) - e.w * (wx[k] - e.x)) < 0) in &= ~(1u << k);
+                        if ((be[i].z * (wy[k] - be[i].y) - be[i].w * (wx[k] - be[i].x)) < 0) in &= ~(1u << k);
                 }
-                const int bg = ct.border == 1 ? G_WHITE : G_RED;
+                const int bg = border == 1 ? G_WHITE : G_RED;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (in >> k & 1u) g[k] = bg;
                 open &= ~in;
             }
             if (!do_tile) continue;
-            const float4 bb = ct.bb;
             unsigned in = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if ((open >> k & 1u) && !(wx[k] < bb.x || wx[k] > bb.z || wy[k] < bb.y || wy[k] > bb.w)) in |= 1u << k;
-            for (int i = 0; i < 5 && in; i++) {
-                const float4 e = ct.edge[i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if ((in >> k & 1u) && (e.z * (wy[k] - e.y) - e.w * (wx[k] - e.x)) < 0) in &= ~(1u << k);
+                    if ((te[i].z * (wy[k] - te[i].y) - te[i].w * (wx[k] - te[i].x)) < 0) in &= ~(1u << k);
             }
-            const int rg = ct.idx % 3 == 0 ? 101 : (ct.idx % 3 == 1 ? 103 : 107);
+            const int rg = tidx % 3 == 0 ? 101 : (tidx % 3 == 1 ? 103 : 107);
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (in >> k & 1u) g[k] = rg;
