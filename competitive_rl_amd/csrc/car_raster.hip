@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ int16_t cand_tile[kMaxCand];       // tile index of each candidate, ascending
     __shared__ uint16_t cand_cells[kMaxCand];     // culling: cell range cx0 | cx1 << 4 | cy0 << 8 | cy1 << 12
     __shared__ uint16_t cand_ofs[kMaxCand + 2];   // exclusive prefix of the cell counts (<= 128 * 144)
-    __shared__ uint32_t cell_tmask[kCells][kMaxCand / 32];  // candidates whose tile polygon may cover a pixel of the cell
-    __shared__ uint32_t cell_bmask[kCells][kMaxCand / 32];  // ... whose border quad may
+    __shared__ __attribute__((aligned(16))) uint32_t cell_tmask[kCells][kMaxCand / 32];  // candidates whose tile polygon may cover a pixel of the cell
+    __shared__ __attribute__((aligned(16))) uint32_t cell_bmask[kCells][kMaxCand / 32];  // ... whose border quad may
     __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
     __shared__ int ind_y0;
     __shared__ __attribute__((aligned(16))) uint32_t tile32[96 * 96 / 4];
@@ -325,8 +325,14 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         }
         unsigned open = 0xFu;  // pixels not yet covered by a (later-drawn) polygon
         const int cell = (sy >> kCellShift) * kCellsPerRow + (sx0 >> kCellShift);
-        for (int wd = 0; wd < kMaxCand / 32 && open && !(dbg & 2); wd++) {
-          const uint32_t tm = cell_tmask[cell][wd], bmk = cell_bmask[cell][wd];
+        // (both masks of the cell in two 16-byte reads, not word by word)
+        const uint4 tm4 = *reinterpret_cast<const uint4 *>(cell_tmask[cell]), bm4 = *reinterpret_cast<const uint4 *>(cell_bmask[cell]);
+        static_assert(kMaxCand == 128, "one uint4 per cell mask");
+#pragma unroll
+        for (int wd = 0; wd < kMaxCand / 32; wd++) {
+          if (!open || (dbg & 2)) break;
+          const uint32_t tm = wd == 0 ? tm4.x : wd == 1 ? tm4.y : wd == 2 ? tm4.z : tm4.w;
+          const uint32_t bmk = wd == 0 ? bm4.x : wd == 1 ? bm4.y : wd == 2 ? bm4.z : bm4.w;
           uint32_t todo = tm | bmk;
           while (todo && open) {
             const int bit = __ffs(todo) - 1;
