@@ -288,17 +288,21 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         const CandTile &ct = cand[c];
         const float px0 = (float)cx0 + 0.25f, px1 = (float)(cx0 + kCell) - 0.25f, py0 = (float)cy0 + 0.25f, py1 = (float)(cy0 + kCell) - 0.25f;
         auto may_cover = [&](const float4 *e, int nv) {
-            for (int i = 0; i < nv; i++) {
-                const float4 q = e[i];
-                const V2 ta = rotv(-sn, cs, mk(q.x, q.y) - off), tb = rotv(-sn, cs, mk(q.x + q.z, q.y + q.w) - off);
+            float4 q[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) q[i] = e[i < nv ? i : nv - 1];  // back-to-back LDS reads, no early-out chain
+            bool may = true;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const V2 ta = rotv(-sn, cs, mk(q[i].x, q[i].y) - off), tb = rotv(-sn, cs, mk(q[i].x + q[i].z, q[i].y + q[i].w) - off);
                 const float ax = 48.0f - scale_f * ta.x, ay = 48.0f - scale_f * ta.y;
                 const float dx = (48.0f - scale_f * tb.x) - ax, dy = (48.0f - scale_f * tb.y) - ay;
                 const float tol = -0.25f * (fabsf(dx) + fabsf(dy));
                 const float c00 = dx * (py0 - ay) - dy * (px0 - ax), c10 = dx * (py0 - ay) - dy * (px1 - ax);
                 const float c01 = dx * (py1 - ay) - dy * (px0 - ax), c11 = dx * (py1 - ay) - dy * (px1 - ax);
-                if (fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) < tol) return false;  // every pixel centre is outside this edge
+                if (fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) < tol) may = false;  // every pixel centre is outside this edge
             }
-            return true;
+            return may;
         };
         if (may_cover(ct.edge, 5)) atomicOr(&cell_tmask[cell][c >> 5], 1u << (c & 31));
         if (ct.border && may_cover(ct.bedge, 4)) atomicOr(&cell_bmask[cell][c >> 5], 1u << (c & 31));
