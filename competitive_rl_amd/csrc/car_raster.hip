@@ -54,7 +54,7 @@ static constexpr int kCell = 8, kCellShift = 3, kCellsPerRow = 96 / kCell, kCell
 
 struct CarPoly {
     int px[8], py[8];
-    int n, x0, x1, y0, y1, gray;
+    int n, x0, x1, y0, y1, gray;  // 88 bytes
 };
 
 struct IndRect {
@@ -80,7 +80,7 @@ __device__ inline IndRect make_rect(double x, double y, double w, double h, int 
 __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
                                                          const uint8_t *__restrict__ only_env, int want) {
     __shared__ CandTile cand[kMaxCand];
-    __shared__ CarPoly cars[16];
+    __shared__ __attribute__((aligned(8))) CarPoly cars[16];
     __shared__ IndRect ind[8];
     __shared__ int wave_cnt[2][4];
     __shared__ int16_t cand_tile[kMaxCand];       // tile index of each candidate, ascending
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ __attribute__((aligned(16))) uint32_t cell_tmask[kCells][kMaxCand / 32];  // candidates whose tile polygon may cover a pixel of the cell
     __shared__ __attribute__((aligned(16))) uint32_t cell_bmask[kCells][kMaxCand / 32];  // ... whose border quad may
     __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
+    __shared__ __attribute__((aligned(16))) int poly_row0[20];  // first scanline work item of each car polygon (+ total)
     __shared__ int ind_y0;
     __shared__ __attribute__((aligned(16))) uint32_t tile32[96 * 96 / 4];
     const int64_t n = s.n, M = (int64_t)s.players * n;
@@ -248,6 +249,19 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         int y0 = 1 << 30;
         for (int r = 0; r < 8; r++) y0 = min(y0, ind[r].y0);
         ind_y0 = y0;
+    }
+    if (wave == 1) {  // scanline work items of the car polygons: rows [max(y0,0), min(y1,95)] each, prefix over 16
+        const int k = lane & 15;
+        int rows = 0;
+        if (k < 8 * s.players) rows = max(min(cars[k].y1, 95) - max(cars[k].y0, 0) + 1, 0);
+        int inc = rows;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int o = __shfl_up(inc, d, 16);
+            if (k >= d) inc += o;
+        }
+        if (lane < 16) poly_row0[lane] = inc - rows;
+        if (lane == 15) poly_row0[16] = inc;
     }
     if (wave == 1) {  // exclusive prefix of the candidates' cell counts (kMaxCand = 2 per lane)
         int cnt[2];
@@ -427,42 +441,65 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         for (int c = 0; c < 2; c++)
             for (int p = tid; p < bw[c] * bh[c]; p += 256) rank[c * kRankCap + p] = 0u;
         __syncthreads();
-        // rows of polygon k: [max(y0,0), min(y1,95)]
-        int total = 0;
-        for (int k = 0; k < 8 * s.players; k++) total += max(min(cars[k].y1, 95) - max(cars[k].y0, 0) + 1, 0);
+        // one work item per (polygon, scanline); the item -> polygon map is a 16-entry prefix table
+        const int4 pr0 = *reinterpret_cast<const int4 *>(&poly_row0[0]), pr1 = *reinterpret_cast<const int4 *>(&poly_row0[4]);
+        const int4 pr2 = *reinterpret_cast<const int4 *>(&poly_row0[8]), pr3 = *reinterpret_cast<const int4 *>(&poly_row0[12]);
+        const int total = poly_row0[16];
         for (int item = tid; item < total; item += 256) {
-            int k = 0, r = item;
-            for (;; k++) {
-                const int rows = max(min(cars[k].y1, 95) - max(cars[k].y0, 0) + 1, 0);
-                if (r < rows) break;
-                r -= rows;
+            const int k = (item >= pr0.y) + (item >= pr0.z) + (item >= pr0.w) + (item >= pr1.x) + (item >= pr1.y) + (item >= pr1.z) +
+                          (item >= pr1.w) + (item >= pr2.x) + (item >= pr2.y) + (item >= pr2.z) + (item >= pr2.w) + (item >= pr3.x) +
+                          (item >= pr3.y) + (item >= pr3.z) + (item >= pr3.w);
+            const int r = item - poly_row0[k];
+            // the polygon record comes in with eleven back-to-back 8-byte LDS reads; everything below
+            // indexes registers statically (fully unrolled over the 8 possible vertices)
+            int px[8], py[8], pn, px0, px1, py0, py1, pgray;
+            {
+                const int2 *src = reinterpret_cast<const int2 *>(&cars[k]);
+                int2 a[11];
+#pragma unroll
+                for (int i = 0; i < 11; i++) a[i] = src[i];
+#pragma unroll
+                for (int i = 0; i < 4; i++) px[2 * i] = a[i].x, px[2 * i + 1] = a[i].y, py[2 * i] = a[4 + i].x, py[2 * i + 1] = a[4 + i].y;
+                pn = a[8].x, px0 = a[8].y, px1 = a[9].x, py0 = a[9].y, py1 = a[10].x, pgray = a[10].y;
             }
-            const CarPoly &cp = cars[k];
             const int c = k >> 3, part = k & 7;
             if (bw[c] == 0) continue;
-            const int y = max(cp.y0, 0) + r;
-            int xs[8], nx = 0;
-            if (cp.y0 == cp.y1) {
-                xs[0] = cp.x0, xs[1] = cp.x1, nx = 2;
+            const int y = max(py0, 0) + r;
+            int xs[8];  // crossings of scanline y with the polygon's edges (pygame draw_fillpoly), INT_MAX = none
+#pragma unroll
+            for (int i = 0; i < 8; i++) xs[i] = 0x7FFFFFFF;
+            if (py0 == py1) {
+                xs[0] = px0, xs[1] = px1;
             } else {
-                for (int i = 0; i < cp.n; i++) {
-                    const int ip = i ? i - 1 : cp.n - 1;
-                    int y1 = cp.py[ip], y2 = cp.py[i], x1, x2;
-                    if (y1 < y2) x1 = cp.px[ip], x2 = cp.px[i];
-                    else if (y1 > y2) y2 = cp.py[ip], y1 = cp.py[i], x2 = cp.px[ip], x1 = cp.px[i];
-                    else continue;
-                    if ((y >= y1 && y < y2) || (y == cp.y1 && y > y1 && y <= y2)) xs[nx++] = (y - y1) * (x2 - x1) / (y2 - y1) + x1;
-                }
-                for (int i = 1; i < nx; i++)
-                    for (int j = i; j > 0 && xs[j - 1] > xs[j]; j--) {
-                        const int t = xs[j];
-                        xs[j] = xs[j - 1], xs[j - 1] = t;
+                int lx = px[0], ly = py[0];  // last vertex = predecessor of vertex 0
+#pragma unroll
+                for (int i = 1; i < 8; i++)
+                    if (i == pn - 1) lx = px[i], ly = py[i];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i < pn) {
+                        const int xp = i ? px[i - 1] : lx, yp = i ? py[i - 1] : ly;
+                        int y1 = yp, y2 = py[i], x1 = xp, x2 = px[i];
+                        if (y1 > y2) y2 = yp, y1 = py[i], x2 = xp, x1 = px[i];
+                        if (y1 != y2 && ((y >= y1 && y < y2) || (y == py1 && y > y1 && y <= y2))) xs[i] = (y - y1) * (x2 - x1) / (y2 - y1) + x1;
                     }
+                }
+                // sort ascending (8-input odd-even merge network; INT_MAX entries end up last)
+#define CRL_CE(a, b)                                      \
+    {                                                     \
+        const int lo_ = min(xs[a], xs[b]), hi_ = max(xs[a], xs[b]); \
+        xs[a] = lo_, xs[b] = hi_;                         \
+    }
+                CRL_CE(0, 1) CRL_CE(2, 3) CRL_CE(4, 5) CRL_CE(6, 7) CRL_CE(0, 2) CRL_CE(1, 3) CRL_CE(4, 6) CRL_CE(5, 7) CRL_CE(1, 2) CRL_CE(5, 6)
+                CRL_CE(0, 4) CRL_CE(3, 7) CRL_CE(1, 5) CRL_CE(2, 6) CRL_CE(1, 4) CRL_CE(3, 6) CRL_CE(2, 4) CRL_CE(3, 5) CRL_CE(3, 4)
+#undef CRL_CE
             }
-            const uint32_t key = ((uint32_t)(part + 1) << 8) | (uint32_t)cp.gray;
+            const uint32_t key = ((uint32_t)(part + 1) << 8) | (uint32_t)pgray;
             uint32_t *row = rank + c * kRankCap + (y - by0[c]) * bw[c] - bx0[c];
-            for (int i = 0; i + 1 < nx; i += 2)
-                for (int x = max(xs[i], max(cp.x0, 0)); x <= min(xs[i + 1], min(cp.x1, 95)); x++) atomicMax(&row[x], key);
+#pragma unroll
+            for (int i = 0; i < 8; i += 2)
+                if (xs[i + 1] != 0x7FFFFFFF)
+                    for (int x = max(xs[i], max(px0, 0)); x <= min(xs[i + 1], min(px1, 95)); x++) atomicMax(&row[x], key);
         }
         __syncthreads();
         for (int c = 0; c < 2; c++) {  // car 1 is drawn over car 0
