@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                                                          const uint8_t *__restrict__ only_env, int want) {
     __shared__ CandTile cand[kMaxCand];
     __shared__ __attribute__((aligned(8))) CarPoly cars[16];
-    __shared__ IndRect ind[8];
+    __shared__ __attribute__((aligned(16))) IndRect ind[8];
     __shared__ int wave_cnt[2][4];
     __shared__ int16_t cand_tile[kMaxCand];       // tile index of each candidate, ascending
     __shared__ uint16_t cand_cells[kMaxCand];     // culling: cell range cx0 | cx1 << 4 | cy0 << 8 | cy1 << 12
@@ -518,13 +518,26 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     {
         const int y0 = max(ind_y0, 0);
         const int npx = (96 - y0) * 96;
+        // the eight rectangles in registers (ten 16-byte LDS reads), then branch-free: later rectangles win
+        int rx0[8], rx1[8], ry0[8], ry1[8], rg[8];
+        {
+            const int4 *src = reinterpret_cast<const int4 *>(&ind[0]);
+            int v[40];
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const int4 q4 = src[i];
+                v[4 * i] = q4.x, v[4 * i + 1] = q4.y, v[4 * i + 2] = q4.z, v[4 * i + 3] = q4.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) rx0[r] = v[5 * r], rx1[r] = v[5 * r + 1], ry0[r] = v[5 * r + 2], ry1[r] = v[5 * r + 3], rg[r] = v[5 * r + 4];
+        }
         for (int p = tid; p < npx && !(dbg & 4); p += 256) {
             const int yy = p / 96, sx = p - yy * 96, sy = y0 + yy;
-            for (int r = 7; r >= 0; r--)
-                if (sx >= ind[r].x0 && sx <= ind[r].x1 && sy >= ind[r].y0 && sy <= ind[r].y1) {
-                    tile8[sy * 96 + sx] = (uint8_t)ind[r].gray;
-                    break;
-                }
+            int gray = -1;
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (sx >= rx0[r] && sx <= rx1[r] && sy >= ry0[r] && sy <= ry1[r]) gray = rg[r];
+            if (gray >= 0) tile8[sy * 96 + sx] = (uint8_t)gray;
         }
     }
     __syncthreads();
