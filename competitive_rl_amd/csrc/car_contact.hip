@@ -262,14 +262,53 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
     float slp[2][5];  // b2Body::m_sleepTime
     for (int k = 0; k < 2; k++)
         for (int b = 0; b < 5; b++) slp[k][b] = s.sleep[b * M + k * s.n + env];
+    // The joints always couple the hull with wheel w, so they are solved on REGISTER copies of the two
+    // cars (r0, r1), exactly like the per-car kernel; only the contacts pick their bodies by fixture index
+    // at run time, and they work on the LDS copy.  Velocities (positions in the position phase) are
+    // exchanged between the two copies around every contact pass: 30 independent LDS accesses each way
+    // instead of every joint access being a dependent LDS round trip.
+    CarRegs r0 = car[0], r1 = car[1];
+    auto vel_to_lds = [&]() {
+        car[0].H.vx = r0.H.vx, car[0].H.vy = r0.H.vy, car[0].H.w = r0.H.w, car[1].H.vx = r1.H.vx, car[1].H.vy = r1.H.vy, car[1].H.w = r1.H.w;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            car[0].W[w].vx = r0.W[w].vx, car[0].W[w].vy = r0.W[w].vy, car[0].W[w].w = r0.W[w].w;
+            car[1].W[w].vx = r1.W[w].vx, car[1].W[w].vy = r1.W[w].vy, car[1].W[w].w = r1.W[w].w;
+        }
+    };
+    auto vel_from_lds = [&]() {
+        r0.H.vx = car[0].H.vx, r0.H.vy = car[0].H.vy, r0.H.w = car[0].H.w, r1.H.vx = car[1].H.vx, r1.H.vy = car[1].H.vy, r1.H.w = car[1].H.w;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            r0.W[w].vx = car[0].W[w].vx, r0.W[w].vy = car[0].W[w].vy, r0.W[w].w = car[0].W[w].w;
+            r1.W[w].vx = car[1].W[w].vx, r1.W[w].vy = car[1].W[w].vy, r1.W[w].w = car[1].W[w].w;
+        }
+    };
+    auto pos_to_lds = [&]() {
+        car[0].H.cx = r0.H.cx, car[0].H.cy = r0.H.cy, car[0].H.a = r0.H.a, car[1].H.cx = r1.H.cx, car[1].H.cy = r1.H.cy, car[1].H.a = r1.H.a;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            car[0].W[w].cx = r0.W[w].cx, car[0].W[w].cy = r0.W[w].cy, car[0].W[w].a = r0.W[w].a;
+            car[1].W[w].cx = r1.W[w].cx, car[1].W[w].cy = r1.W[w].cy, car[1].W[w].a = r1.W[w].a;
+        }
+    };
+    auto pos_from_lds = [&]() {
+        r0.H.cx = car[0].H.cx, r0.H.cy = car[0].H.cy, r0.H.a = car[0].H.a, r1.H.cx = car[1].H.cx, r1.H.cy = car[1].H.cy, r1.H.a = car[1].H.a;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            r0.W[w].cx = car[0].W[w].cx, r0.W[w].cy = car[0].W[w].cy, r0.W[w].a = car[0].W[w].a;
+            r1.W[w].cx = car[1].W[w].cx, r1.W[w].cy = car[1].W[w].cy, r1.W[w].a = car[1].W[w].a;
+        }
+    };
     if (nc == 0) {
         // boxes overlap but nothing touches: two independent islands, as in the per-car kernel
-        island_solve(car[1], K, h, dt_ratio, slp[1]);
-        island_solve(car[0], K, h, dt_ratio, slp[0]);
+        island_solve(r1, K, h, dt_ratio, slp[1]);
+        island_solve(r0, K, h, dt_ratio, slp[0]);
     } else {
         JointTmp jt[2];
         ContactVC *vc = sh_vc[threadIdx.x];
-        isl_integrate_vel(car[1], K, h), isl_integrate_vel(car[0], K, h);
+        isl_integrate_vel(r1, K, h), isl_integrate_vel(r0, K, h);
+        vel_to_lds();
         // b2ContactSolver::InitializeVelocityConstraints, then WarmStart
         for (int k = 0; k < nc; k++) {
             Contact &c = ct[k];
@@ -316,11 +355,13 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
                 B.b->w += B.ii * cross(q.rB[j], P), B.b->vx += B.im * P.x, B.b->vy += B.im * P.y;
             }
         }
-        isl_joints_init(car[1], jt[1], K, dt_ratio), isl_joints_init(car[0], jt[0], K, dt_ratio);
+        vel_from_lds();  // (the contact warm start changed the velocities)
+        isl_joints_init(r1, jt[1], K, dt_ratio), isl_joints_init(r0, jt[0], K, dt_ratio);
         const float friction = sqrtf(0.2f * 0.2f);
 #pragma unroll 1
         for (int it = 0; it < 180; it++) {
-            isl_joints_vel(car[1], jt[1], K, h), isl_joints_vel(car[0], jt[0], K, h);
+            isl_joints_vel(r1, jt[1], K, h), isl_joints_vel(r0, jt[0], K, h);
+            vel_to_lds();
             for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolveVelocityConstraints
                 Contact &c = ct[k];
                 ContactVC &q = vc[k];
@@ -373,8 +414,10 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
                     }
                 }
             }
+            vel_from_lds();
         }
-        isl_integrate_pos(car[1], h), isl_integrate_pos(car[0], h);
+        isl_integrate_pos(r1, h), isl_integrate_pos(r0, h);
+        pos_to_lds();
         bool solved = false;
 #pragma unroll 1
         for (int it = 0; it < 60; it++) {
@@ -408,25 +451,24 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
                 }
             }
             const bool cok = minSep >= -3.0f * LINEAR_SLOP;
-            const bool j1 = isl_joints_pos(car[1], K), j0 = isl_joints_pos(car[0], K);
+            pos_from_lds();
+            const bool j1 = isl_joints_pos(r1, K), j0 = isl_joints_pos(r0, K);
+            pos_to_lds();
             if (cok && j1 && j0) {
                 solved = true;
                 break;
             }
         }
         // one island: it sleeps only when all ten bodies have been still long enough
-        const float m1 = isl_sleep_scan(car[1], slp[1], h), m0 = isl_sleep_scan(car[0], slp[0], h);
-        if (fminf(m1, m0) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(car[1], slp[1]), isl_put_to_sleep(car[0], slp[0]);
+        const float m1 = isl_sleep_scan(r1, slp[1], h), m0 = isl_sleep_scan(r0, slp[0], h);
+        if (fminf(m1, m0) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(r1, slp[1]), isl_put_to_sleep(r0, slp[0]);
     }
     for (int k = 0; k < 2; k++)
         for (int b = 0; b < 5; b++) s.sleep[b * M + k * s.n + env] = slp[k][b];
 
     // ---- store bodies, joints and the manifolds with their impulses
-    for (int k = 0; k < 2; k++) {
-        const int64_t ci = k * s.n + env;
-        store_car(s, M, ci, car[k]);
-        s.first_step[ci] = 0;
-    }
+    store_car(s, M, env, r0), store_car(s, M, s.n + env, r1);
+    s.first_step[env] = 0, s.first_step[s.n + env] = 0;
     s.n_contact[env] = nc;
     float *out = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
     for (int k = 0; k < nc; k++) {
