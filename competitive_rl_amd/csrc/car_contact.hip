@@ -194,28 +194,36 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
     // dense over the compacted list of coupled envs: a workgroup holds 111 KB of LDS, so the ones
     // past the end of the list must leave at once (the frames of the other envs are being drawn
     // on the same CUs meanwhile)
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    // TWO LANES PER ENV: lane 2p holds car 0 of pair p, lane 2p+1 car 1.  The joints of a car only couple its
+    // own hull and wheels, so each lane solves its car's joints in registers, both cars at once, exactly like
+    // the per-car kernel.  Only the contacts pick their bodies by fixture index at run time: they are solved
+    // by the even lane on the LDS copy of the two cars, and the lanes exchange velocities (positions in the
+    // position phase) with that copy around every contact pass.  LDS operations of a wavefront complete in
+    // order, so the pair needs no barrier.
+    const int pair = threadIdx.x >> 1, me = threadIdx.x & 1;
+    const int slot = blockIdx.x * 32 + pair;
     if (slot >= *s.coupled_count) return;
     const int64_t env = s.coupled_list[slot];
     const int64_t M = 2 * s.n;
-    // Bodies are picked by fixture index at run time, so the solver state cannot stay in registers;
-    // it lives in LDS (one slice per lane) instead of scratch memory.
-    __shared__ CarRegs sh_car[64][2];
-    __shared__ Contact sh_ct[64][kMaxContacts];
-    __shared__ ContactVC sh_vc[64][kMaxContacts];
-    CarRegs(&car)[2] = sh_car[threadIdx.x];
-    for (int k = 0; k < 2; k++) {
-        const int64_t ci = k * s.n + env;
-        load_car(s, M, ci, car[k]);
-        for (int w = 0; w < 4; w++) car[k].fx[w] = s.wforce[(2 * w + 0) * M + ci], car[k].fy[w] = s.wforce[(2 * w + 1) * M + ci];
+    __shared__ CarRegs sh_car[32][2];
+    __shared__ Contact sh_ct[32][kMaxContacts];
+    __shared__ ContactVC sh_vc[32][kMaxContacts];
+    __shared__ int sh_nc[32];
+    CarRegs(&car)[2] = sh_car[pair];
+    {
+        const int64_t ci = me * s.n + env;
+        load_car(s, M, ci, car[me]);
+        for (int w = 0; w < 4; w++) car[me].fx[w] = s.wforce[(2 * w + 0) * M + ci], car[me].fy[w] = s.wforce[(2 * w + 1) * M + ci];
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int first_step = s.first_step[env];
     const float h = (float)(1.0 / CAR_FPS);
     const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
 
     // ---- Collide: manifolds of the 48 fixture pairs, impulses carried over by contact id
-    Contact *ct = sh_ct[threadIdx.x];
+    Contact *ct = sh_ct[pair];
     int nc = 0;
+    if (me == 0) {  // the even lane runs the narrow phase for the pair
     // bounding circle of every fixture (world centre, radius): rejects most of the 48 pairs cheaply;
     // circles that do not overlap cannot be within the 0.02 contact margin
     float fcx[2][8], fcy[2][8], frad[2][8];
@@ -259,56 +267,54 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
             }
     }
 
-    float slp[2][5];  // b2Body::m_sleepTime
-    for (int k = 0; k < 2; k++)
-        for (int b = 0; b < 5; b++) slp[k][b] = s.sleep[b * M + k * s.n + env];
+        sh_nc[pair] = nc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    nc = sh_nc[pair];
+
+    float slp[5];  // b2Body::m_sleepTime of this lane's car
+    for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + me * s.n + env];
     // The joints always couple the hull with wheel w, so they are solved on REGISTER copies of the two
     // cars (r0, r1), exactly like the per-car kernel; only the contacts pick their bodies by fixture index
     // at run time, and they work on the LDS copy.  Velocities (positions in the position phase) are
     // exchanged between the two copies around every contact pass: 30 independent LDS accesses each way
     // instead of every joint access being a dependent LDS round trip.
-    CarRegs r0 = car[0], r1 = car[1];
+    CarRegs r = car[me];
+    Body &mH = car[me].H;
+    Body(&mW)[4] = car[me].W;
     auto vel_to_lds = [&]() {
-        car[0].H.vx = r0.H.vx, car[0].H.vy = r0.H.vy, car[0].H.w = r0.H.w, car[1].H.vx = r1.H.vx, car[1].H.vy = r1.H.vy, car[1].H.w = r1.H.w;
+        mH.vx = r.H.vx, mH.vy = r.H.vy, mH.w = r.H.w;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            car[0].W[w].vx = r0.W[w].vx, car[0].W[w].vy = r0.W[w].vy, car[0].W[w].w = r0.W[w].w;
-            car[1].W[w].vx = r1.W[w].vx, car[1].W[w].vy = r1.W[w].vy, car[1].W[w].w = r1.W[w].w;
-        }
+        for (int w = 0; w < 4; w++) mW[w].vx = r.W[w].vx, mW[w].vy = r.W[w].vy, mW[w].w = r.W[w].w;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
     auto vel_from_lds = [&]() {
-        r0.H.vx = car[0].H.vx, r0.H.vy = car[0].H.vy, r0.H.w = car[0].H.w, r1.H.vx = car[1].H.vx, r1.H.vy = car[1].H.vy, r1.H.w = car[1].H.w;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        r.H.vx = mH.vx, r.H.vy = mH.vy, r.H.w = mH.w;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            r0.W[w].vx = car[0].W[w].vx, r0.W[w].vy = car[0].W[w].vy, r0.W[w].w = car[0].W[w].w;
-            r1.W[w].vx = car[1].W[w].vx, r1.W[w].vy = car[1].W[w].vy, r1.W[w].w = car[1].W[w].w;
-        }
+        for (int w = 0; w < 4; w++) r.W[w].vx = mW[w].vx, r.W[w].vy = mW[w].vy, r.W[w].w = mW[w].w;
     };
     auto pos_to_lds = [&]() {
-        car[0].H.cx = r0.H.cx, car[0].H.cy = r0.H.cy, car[0].H.a = r0.H.a, car[1].H.cx = r1.H.cx, car[1].H.cy = r1.H.cy, car[1].H.a = r1.H.a;
+        mH.cx = r.H.cx, mH.cy = r.H.cy, mH.a = r.H.a;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            car[0].W[w].cx = r0.W[w].cx, car[0].W[w].cy = r0.W[w].cy, car[0].W[w].a = r0.W[w].a;
-            car[1].W[w].cx = r1.W[w].cx, car[1].W[w].cy = r1.W[w].cy, car[1].W[w].a = r1.W[w].a;
-        }
+        for (int w = 0; w < 4; w++) mW[w].cx = r.W[w].cx, mW[w].cy = r.W[w].cy, mW[w].a = r.W[w].a;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
     auto pos_from_lds = [&]() {
-        r0.H.cx = car[0].H.cx, r0.H.cy = car[0].H.cy, r0.H.a = car[0].H.a, r1.H.cx = car[1].H.cx, r1.H.cy = car[1].H.cy, r1.H.a = car[1].H.a;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        r.H.cx = mH.cx, r.H.cy = mH.cy, r.H.a = mH.a;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            r0.W[w].cx = car[0].W[w].cx, r0.W[w].cy = car[0].W[w].cy, r0.W[w].a = car[0].W[w].a;
-            r1.W[w].cx = car[1].W[w].cx, r1.W[w].cy = car[1].W[w].cy, r1.W[w].a = car[1].W[w].a;
-        }
+        for (int w = 0; w < 4; w++) r.W[w].cx = mW[w].cx, r.W[w].cy = mW[w].cy, r.W[w].a = mW[w].a;
     };
     if (nc == 0) {
         // boxes overlap but nothing touches: two independent islands, as in the per-car kernel
-        island_solve(r1, K, h, dt_ratio, slp[1]);
-        island_solve(r0, K, h, dt_ratio, slp[0]);
+        island_solve(r, K, h, dt_ratio, slp);
     } else {
-        JointTmp jt[2];
-        ContactVC *vc = sh_vc[threadIdx.x];
-        isl_integrate_vel(r1, K, h), isl_integrate_vel(r0, K, h);
+        JointTmp jt;
+        ContactVC *vc = sh_vc[pair];
+        isl_integrate_vel(r, K, h);
         vel_to_lds();
+        if (me == 0) {  // contact constraints and warm start: even lane, LDS copy
         // b2ContactSolver::InitializeVelocityConstraints, then WarmStart
         for (int k = 0; k < nc; k++) {
             Contact &c = ct[k];
@@ -355,13 +361,15 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
                 B.b->w += B.ii * cross(q.rB[j], P), B.b->vx += B.im * P.x, B.b->vy += B.im * P.y;
             }
         }
+        }
         vel_from_lds();  // (the contact warm start changed the velocities)
-        isl_joints_init(r1, jt[1], K, dt_ratio), isl_joints_init(r0, jt[0], K, dt_ratio);
+        isl_joints_init(r, jt, K, dt_ratio);
         const float friction = sqrtf(0.2f * 0.2f);
 #pragma unroll 1
         for (int it = 0; it < 180; it++) {
-            isl_joints_vel(r1, jt[1], K, h), isl_joints_vel(r0, jt[0], K, h);
+            isl_joints_vel(r, jt, K, h);
             vel_to_lds();
+            if (me == 0)
             for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolveVelocityConstraints
                 Contact &c = ct[k];
                 ContactVC &q = vc[k];
@@ -416,12 +424,13 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
             }
             vel_from_lds();
         }
-        isl_integrate_pos(r1, h), isl_integrate_pos(r0, h);
+        isl_integrate_pos(r, h);
         pos_to_lds();
         bool solved = false;
 #pragma unroll 1
         for (int it = 0; it < 60; it++) {
             float minSep = 0.0f;
+            if (me == 0)
             for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolvePositionConstraints
                 const Contact &c = ct[k];
                 const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
@@ -450,25 +459,29 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
                     B.b->cx += B.im * P.x, B.b->cy += B.im * P.y, B.b->a += B.ii * cross(rB, P);
                 }
             }
-            const bool cok = minSep >= -3.0f * LINEAR_SLOP;
+            const bool cok = minSep >= -3.0f * LINEAR_SLOP;  // (meaningful in the even lane)
             pos_from_lds();
-            const bool j1 = isl_joints_pos(r1, K), j0 = isl_joints_pos(r0, K);
+            const bool jok = isl_joints_pos(r, K);
             pos_to_lds();
-            if (cok && j1 && j0) {
+            // contactsOkay && jointsOkay of the whole island: combine the pair
+            const int mine = (me == 0 ? (cok ? 1 : 0) : 1) & (jok ? 1 : 0);
+            const int other = __shfl_xor(mine, 1);
+            if (mine & other) {
                 solved = true;
                 break;
             }
         }
         // one island: it sleeps only when all ten bodies have been still long enough
-        const float m1 = isl_sleep_scan(r1, slp[1], h), m0 = isl_sleep_scan(r0, slp[0], h);
-        if (fminf(m1, m0) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(r1, slp[1]), isl_put_to_sleep(r0, slp[0]);
+        const float mm = isl_sleep_scan(r, slp, h);
+        const float mo = __shfl_xor(mm, 1);
+        if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(r, slp);
     }
-    for (int k = 0; k < 2; k++)
-        for (int b = 0; b < 5; b++) s.sleep[b * M + k * s.n + env] = slp[k][b];
+    for (int b = 0; b < 5; b++) s.sleep[b * M + me * s.n + env] = slp[b];
 
     // ---- store bodies, joints and the manifolds with their impulses
-    store_car(s, M, env, r0), store_car(s, M, s.n + env, r1);
-    s.first_step[env] = 0, s.first_step[s.n + env] = 0;
+    store_car(s, M, me * s.n + env, r);
+    s.first_step[me * s.n + env] = 0;
+    if (me != 0) return;
     s.n_contact[env] = nc;
     float *out = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
     for (int k = 0; k < nc; k++) {
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
 
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st) {
     if (s.players != 2 || !s.contacts_enabled) return;
-    hipLaunchKernelGGL(car_coupled_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k);
+    hipLaunchKernelGGL(car_coupled_kernel, dim3((unsigned)((s.n + 31) / 32)), dim3(64), 0, st, s, k);
 }
 
 }  // namespace crl
