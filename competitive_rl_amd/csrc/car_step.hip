@@ -61,9 +61,12 @@ __device__ inline float poly_dist2(const V2 (&A)[4], const V2 (&B)[5]) {
 // polygons, 4 wheels; wheels do not collide with wheels), grown by more than the polygon radii.
 // No overlapping pair => b2CollidePolygons would find no manifold point for this env.
 __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_t M, int64_t c0, int64_t c1) {
+    // (fully unrolled: the 16 boxes stay in registers)
     float bb[2][8][4];
+#pragma unroll
     for (int k = 0; k < 2; k++) {
         const int64_t ci = k ? c1 : c0;
+#pragma unroll
         for (int f = 0; f < 8; f++) {
             const int o = f < 4 ? 0 : 6 + 6 * (f - 4);
             const float cx = s.body[(o + 0) * M + ci], cy = s.body[(o + 1) * M + ci], a = s.body[(o + 2) * M + ci];
@@ -72,9 +75,10 @@ __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_
             const V2 p = mk(cx, cy) - rotv(sn, cs, lc);
             const int nv = f < 4 ? K.hull_n[f] : 4;
             float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+#pragma unroll
             for (int i = 0; i < 8; i++) {
                 if (i < nv) {
-                    const V2 v = f < 4 ? mk(K.hull_poly[f][i][0], K.hull_poly[f][i][1]) : mk(K.wheel_poly[i][0], K.wheel_poly[i][1]);
+                    const V2 v = f < 4 ? mk(K.hull_poly[f][i][0], K.hull_poly[f][i][1]) : mk(K.wheel_poly[i < 4 ? i : 0][0], K.wheel_poly[i < 4 ? i : 0][1]);
                     const V2 wv = rotv(sn, cs, v) + p;
                     x0 = fminf(x0, wv.x), y0 = fminf(y0, wv.y), x1 = fmaxf(x1, wv.x), y1 = fmaxf(y1, wv.y);
                 }
@@ -83,7 +87,9 @@ __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_
         }
     }
     bool any = false;
+#pragma unroll
     for (int fa = 0; fa < 8; fa++)
+#pragma unroll
         for (int fb = 0; fb < 8; fb++) {
             if (fa >= 4 && fb >= 4) continue;
             any = any || !(bb[0][fa][0] > bb[1][fb][2] || bb[1][fb][0] > bb[0][fa][2] || bb[0][fa][1] > bb[1][fb][3] ||
