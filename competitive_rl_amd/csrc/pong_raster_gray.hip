@@ -544,7 +544,13 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                 for (int it = 0; it < kTileIters; it++)
                     if (lane + 64 * it < chunks) out[lane + 64 * it] = tv[it];
             } else if (vec16) {
-                for (int c = lane; c < chunks; c += 64) out[c] = tl4[c];
+                // all LDS reads first, then the stores (a rolled loop would wait for every read in turn)
+                uint4 ov[kTileIters];
+#pragma unroll
+                for (int it = 0; it < kTileIters; it++) ov[it] = tl4[min(lane + 64 * it, chunks - 1)];
+#pragma unroll
+                for (int it = 0; it < kTileIters; it++)
+                    if (lane + 64 * it < chunks) out[lane + 64 * it] = ov[it];
             } else {
                 const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
                 for (int w = lane; w < (RR >> 2); w += 64) out32[w] = tl32[w];
