@@ -99,6 +99,12 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t me = viewer * n + env;
 
+    // Loads that do not depend on the camera go out first (tile AABBs: unconditional, the slots past the
+    // track hold zeros; the reward for the read-out), so the double-precision camera math covers them.
+    const int ntiles = (dbg & 8) ? 0 : s.ntiles[env];
+    const float4 bb_pre0 = s.tile_aabb_em[env * kCarMaxTiles + tid], bb_pre1 = s.tile_aabb_em[env * kCarMaxTiles + 256 + tid];
+    const double reward_pre = s.reward[me];
+
     // ---- camera_update("rgb_array") for the viewer (uniform across the workgroup)
     const float h_cx = s.body[0 * M + me], h_cy = s.body[1 * M + me], h_a = s.body[2 * M + me];
     const float h_vx = s.body[3 * M + me], h_vy = s.body[4 * M + me], h_w = s.body[5 * M + me];
@@ -116,8 +122,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     // ---- (1) ordered compaction of the tiles near the view (half-diagonal 48*sqrt(2)/scale < 39):
     // both halves of the tile range are tested at once (kCarMaxTiles <= 512), then the kept tiles'
     // polygons are fetched by the first n_cand threads
-    static_assert(kCarMaxTiles <= 512, "compaction covers two tiles per thread");
-    const int ntiles = (dbg & 8) ? 0 : s.ntiles[env];
+    static_assert(kCarMaxTiles == 512, "compaction covers two tiles per thread");
     const float vr = 39.0f + 1.5f;  // + border width
     bool keep[2];
     unsigned long long km[2];
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         const int t = h * 256 + tid;
         keep[h] = false;
         if (t < ntiles) {
-            const float4 bb = s.tile_aabb_em[env * kCarMaxTiles + t];
+            const float4 bb = h ? bb_pre1 : bb_pre0;
             keep[h] = !(bb.x > off.x + vr || bb.z < off.x - vr || bb.y > off.y + vr || bb.w < off.y - vr);
         }
     }
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
 
     // ---- (3c') reward read-out "%05.0f" (white, 1-bit glyphs) blitted last at (0, 91)
     if (s.text_bits && tid < 32 * CRL_CAR_TEXT_ROWS) {
-        const double r = s.reward[me];
+        const double r = reward_pre;
         const double rr = rint(r);  // "%.0f" rounds half to even
         int idx = (int)rr - CRL_CAR_TEXT_RMIN;
         if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
@@ -557,7 +562,14 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     // ---- (3d) stream the tile out: 16 B per lane, 1 KiB contiguous per wave store
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + ((int64_t)env * s.players + viewer) * (96 * 96));
     const uint4 *tile4 = reinterpret_cast<const uint4 *>(tile32);
-    for (int q = tid; q < 96 * 96 / 16; q += 256) out[q] = tile4[q];
+    {
+        uint4 ov[3];  // 576 chunks = 2.25 per thread: LDS reads first, then the stores
+#pragma unroll
+        for (int i = 0; i < 3; i++) ov[i] = tile4[min(tid + 256 * i, 96 * 96 / 16 - 1)];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (tid + 256 * i < 96 * 96 / 16) out[tid + 256 * i] = ov[i];
+    }
 }
 
 // MultipleFrameStack + FlattenMultiAgentObservation + WrapPyTorch (reference
