@@ -39,6 +39,34 @@ __device__ inline void solve33(const M33 &m, const float b[3], float x[3]) {
     x[2] = det * (ex[0] * cyb[0] + ex[1] * cyb[1] + ex[2] * cyb[2]);
 }
 
+// The joint matrices do not change during a step, so the parts of Solve22 / Solve33 that only depend on the
+// matrix (determinant reciprocal, ey x ez) are taken out of the 180 velocity iterations: same operations on the
+// same values, computed once (isl_joints_init) instead of per iteration.
+__device__ inline float det22_of(const M33 &m) {
+    float det = m.ex[0] * m.ey[1] - m.ey[0] * m.ex[1];
+    if (det != 0.0f) det = 1.0f / det;
+    return det;
+}
+__device__ inline V2 solve22_pre(const M33 &m, float det, V2 b) {
+    const float a11 = m.ex[0], a12 = m.ey[0], a21 = m.ex[1], a22 = m.ey[1];
+    return mk(det * (a22 * b.x - a12 * b.y), det * (a11 * b.y - a21 * b.x));
+}
+__device__ inline float det33_of(const M33 &m, float cyz[3]) {
+    const float *ex = m.ex, *ey = m.ey, *ez = m.ez;
+    cyz[0] = ey[1] * ez[2] - ey[2] * ez[1], cyz[1] = ey[2] * ez[0] - ey[0] * ez[2], cyz[2] = ey[0] * ez[1] - ey[1] * ez[0];
+    float det = ex[0] * cyz[0] + ex[1] * cyz[1] + ex[2] * cyz[2];
+    if (det != 0.0f) det = 1.0f / det;
+    return det;
+}
+__device__ inline void solve33_pre(const M33 &m, const float cyz[3], float det, const float b[3], float x[3]) {
+    const float *ex = m.ex, *ey = m.ey, *ez = m.ez;
+    const float cbz[3] = {b[1] * ez[2] - b[2] * ez[1], b[2] * ez[0] - b[0] * ez[2], b[0] * ez[1] - b[1] * ez[0]};
+    const float cyb[3] = {ey[1] * b[2] - ey[2] * b[1], ey[2] * b[0] - ey[0] * b[2], ey[0] * b[1] - ey[1] * b[0]};
+    x[0] = det * (b[0] * cyz[0] + b[1] * cyz[1] + b[2] * cyz[2]);
+    x[1] = det * (ex[0] * cbz[0] + ex[1] * cbz[1] + ex[2] * cbz[2]);
+    x[2] = det * (ex[0] * cyb[0] + ex[1] * cyb[1] + ex[2] * cyb[2]);
+}
+
 // One car's solver state while it lives in registers.
 struct CarRegs {
     Body H, W[4];
@@ -50,6 +78,7 @@ struct CarRegs {
 struct JointTmp {
     V2 rA[4];
     M33 mass[4];
+    float det22[4], det33[4], cyz[4][3];  // matrix-only parts of Solve22 / Solve33
     float motorMass;
 };
 
@@ -84,6 +113,7 @@ __device__ inline void isl_joints_init(CarRegs &c, JointTmp &j, const CarConsts 
         m.ey[1] = mA + mB + r.x * r.x * iA + 0.0f * 0.0f * iB;
         m.ez[1] = r.x * iA + 0.0f * iB;
         m.ex[2] = m.ez[0], m.ey[2] = m.ez[1], m.ez[2] = iA + iB;
+        j.det22[w] = det22_of(m), j.det33[w] = det33_of(m, j.cyz[w]);
         const float ja = c.W[w].a - c.H.a - 0.0f;
         if (ja <= LOWER_ANGLE) {
             if (c.lim[w] != LIM_LOWER) c.imp[w][2] = 0;
@@ -126,13 +156,13 @@ __device__ inline void isl_joints_vel(CarRegs &c, const JointTmp &j, const CarCo
             const float Cdot2 = c.W[w].w - c.H.w;
             const float b[3] = {Cdot1.x, Cdot1.y, Cdot2};
             float im[3];
-            solve33(j.mass[w], b, im);
+            solve33_pre(j.mass[w], j.cyz[w], j.det33[w], b, im);
             im[0] = -im[0], im[1] = -im[1], im[2] = -im[2];
             const float newI = c.imp[w][2] + im[2];
             const bool lower = c.lim[w] == LIM_LOWER;
             if (lower ? newI < 0.0f : newI > 0.0f) {
                 const V2 rhs = (-1.0f * Cdot1) + c.imp[w][2] * mk(j.mass[w].ez[0], j.mass[w].ez[1]);
-                const V2 red = solve22(j.mass[w], rhs);
+                const V2 red = solve22_pre(j.mass[w], j.det22[w], rhs);
                 im[0] = red.x, im[1] = red.y, im[2] = -c.imp[w][2];
                 c.imp[w][0] += red.x, c.imp[w][1] += red.y, c.imp[w][2] = 0;
             } else {
@@ -143,7 +173,7 @@ __device__ inline void isl_joints_vel(CarRegs &c, const JointTmp &j, const CarCo
             c.W[w].vx += mB * P.x, c.W[w].vy += mB * P.y, c.W[w].w += iB * (cross(rB, P) + im[2]);
         } else {
             const V2 Cdot = ((vB + scross(c.W[w].w, rB)) - vA) - scross(c.H.w, r);
-            const V2 im = solve22(j.mass[w], -1.0f * Cdot);
+            const V2 im = solve22_pre(j.mass[w], j.det22[w], -1.0f * Cdot);
             c.imp[w][0] += im.x, c.imp[w][1] += im.y;
             c.H.vx -= mA * im.x, c.H.vy -= mA * im.y, c.H.w -= iA * cross(r, im);
             c.W[w].vx += mB * im.x, c.W[w].vy += mB * im.y, c.W[w].w += iB * cross(rB, im);
