@@ -1,7 +1,7 @@
 // car_contact.hip -- the two cars of an env solved as ONE Box2D island when they can touch.
 //
-// One lane per env, active only where car_step_kernel flagged the env as coupled (oriented boxes
-// overlap).  Restates, in float32, Box2D 2.3's b2CollidePolygons (reference-face clipping, <= 2
+// Two lanes per coupled env (one per car; car_step_kernel flags an env as coupled when the cars'
+// oriented boxes and then fixture boxes overlap, and compacts those envs into a list).  Restates, in float32, Box2D 2.3's b2CollidePolygons (reference-face clipping, <= 2
 // manifold points, contact ids for warm starting) and b2ContactSolver (friction then normal with
 // the 2-point block solver; Baumgarte position correction) around the same joint phases as the
 // single-car island (car_solver.h).  Third-party algorithm, absent from the reference tree

@@ -11,9 +11,14 @@
 //
 // Per workgroup: (1) the tiles whose AABB meets the camera's view box are compacted IN ORDER
 // into LDS (draw order matters: lower tile index is drawn later and wins), (2) the 16 car
-// polygons and 8 indicator rectangles are projected once into LDS, (3) the background is
-// resolved 4 pixels per thread into an LDS tile, cars and indicator bars are patched over their
-// bounding boxes only (one lane per pixel), and the tile is streamed out 16 B per lane.
+// polygons and 8 indicator rectangles are projected once into LDS, and every 8x8-pixel cell
+// gets bit masks of the candidates that can cover it (separating-edge test in screen space),
+// (3) the background is resolved 4 pixels per lane into an LDS tile (a wavefront per 16x16
+// block), car polygons are filled as pygame scanline spans, indicator bars and the reward
+// read-out are patched over, and the tile is streamed out 16 B per lane.
+// Rule of the house: whatever a loop iteration needs from LDS is read with back-to-back loads
+// into registers and evaluated branch-free -- a chain of data-dependent ~100-cycle LDS reads
+// costs more than the arithmetic an early-out saves.
 #include <stdlib.h>
 
 #include "car_device.h"
