@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             // everything the candidate needs comes in with back-to-back LDS reads (no data-dependent
             // early-out between them: a chain of dependent ~100-cycle reads costs more than the
             // arithmetic it would save)
-            const float4 ba = ct.bb_all, bb = ct.bb;
+            const float4 ba = ct.bb_all;
             float4 te[5], be[4];
 #pragma unroll
             for (int i = 0; i < 5; i++) te[i] = ct.edge[i];
@@ -394,10 +394,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                 open &= ~in;
             }
             if (!do_tile) continue;
-            unsigned in = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if ((open >> k & 1u) && !(wx[k] < bb.x || wx[k] > bb.z || wy[k] < bb.y || wy[k] > bb.w)) in |= 1u << k;
+            unsigned in = open;  // (a point outside the polygon's box fails one of the five edge tests anyway)
 #pragma unroll
             for (int i = 0; i < 5; i++) {
 #pragma unroll
