@@ -371,40 +371,62 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
             vel_to_lds();
             if (me == 0)
             for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolveVelocityConstraints
+                // The two bodies' velocities, the constraint data and the accumulated impulses come into
+                // registers with back-to-back LDS reads, the whole contact (friction per point, then the
+                // normal constraint) is solved there in Box2D's order, and everything goes back once.
                 Contact &c = ct[k];
-                ContactVC &q = vc[k];
+                const ContactVC &q = vc[k];
                 const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
+                V2 vA = mk(A.b->vx, A.b->vy), vB = mk(B.b->vx, B.b->vy);
+                float wA = A.b->w, wB = B.b->w;
+                const float mA = A.im, iA = A.ii, mB = B.im, iB = B.ii;
                 const V2 normal = q.normal, tangent = mk(normal.y, -normal.x);
-                for (int j = 0; j < q.count; j++) {
-                    const float vt = dot(rel_vel(A, B, q.rA[j], q.rB[j]), tangent);
-                    float lambda = q.tmass[j] * (-vt);
-                    const float maxF = friction * c.nimp[j];
-                    float ni = c.timp[j] + lambda;
-                    ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
-                    lambda = ni - c.timp[j], c.timp[j] = ni;
-                    apply_imp(A, B, q.rA[j], q.rB[j], lambda * tangent);
+                const int count = q.count;
+                const V2 rA0 = q.rA[0], rB0 = q.rB[0], rA1 = q.rA[1], rB1 = q.rB[1];
+                const float tm0 = q.tmass[0], tm1 = q.tmass[1], nm0 = q.nmass[0], nm1 = q.nmass[1];
+                const float k00 = q.K[0][0], k01 = q.K[0][1], k10 = q.K[1][0], k11 = q.K[1][1];
+                const float ik00 = q.invK[0][0], ik01 = q.invK[0][1], ik10 = q.invK[1][0], ik11 = q.invK[1][1];
+                float nimp0 = c.nimp[0], nimp1 = c.nimp[1], timp0 = c.timp[0], timp1 = c.timp[1];
+                auto relv = [&](V2 ra, V2 rb) { return ((vB + scross(wB, rb)) - vA) - scross(wA, ra); };
+                auto apply = [&](V2 ra, V2 rb, V2 P) {
+                    vA.x -= mA * P.x, vA.y -= mA * P.y, wA -= iA * cross(ra, P);
+                    vB.x += mB * P.x, vB.y += mB * P.y, wB += iB * cross(rb, P);
+                };
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    if (j < count) {
+                        const V2 ra = j ? rA1 : rA0, rb = j ? rB1 : rB0;
+                        float &timp = j ? timp1 : timp0;
+                        const float vt = dot(relv(ra, rb), tangent);
+                        float lambda = (j ? tm1 : tm0) * (-vt);
+                        const float maxF = friction * (j ? nimp1 : nimp0);
+                        float ni = timp + lambda;
+                        ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
+                        lambda = ni - timp, timp = ni;
+                        apply(ra, rb, lambda * tangent);
+                    }
                 }
-                if (q.count == 1) {
-                    const float vn = dot(rel_vel(A, B, q.rA[0], q.rB[0]), normal);
-                    float lambda = -q.nmass[0] * (vn - 0.0f);
-                    const float ni = fmaxf(c.nimp[0] + lambda, 0.0f);
-                    lambda = ni - c.nimp[0], c.nimp[0] = ni;
-                    apply_imp(A, B, q.rA[0], q.rB[0], lambda * normal);
-                } else if (q.count == 2) {
-                    const V2 a = mk(c.nimp[0], c.nimp[1]);
-                    float vn1 = dot(rel_vel(A, B, q.rA[0], q.rB[0]), normal), vn2 = dot(rel_vel(A, B, q.rA[1], q.rB[1]), normal);
+                if (count == 1) {
+                    const float vn = dot(relv(rA0, rB0), normal);
+                    float lambda = -nm0 * (vn - 0.0f);
+                    const float ni = fmaxf(nimp0 + lambda, 0.0f);
+                    lambda = ni - nimp0, nimp0 = ni;
+                    apply(rA0, rB0, lambda * normal);
+                } else if (count == 2) {
+                    const V2 a = mk(nimp0, nimp1);
+                    float vn1 = dot(relv(rA0, rB0), normal), vn2 = dot(relv(rA1, rB1), normal);
                     V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
-                    b = b - mk(q.K[0][0] * a.x + q.K[1][0] * a.y, q.K[0][1] * a.x + q.K[1][1] * a.y);
-                    V2 x = mk(-(q.invK[0][0] * b.x + q.invK[1][0] * b.y), -(q.invK[0][1] * b.x + q.invK[1][1] * b.y));
+                    b = b - mk(k00 * a.x + k10 * a.y, k01 * a.x + k11 * a.y);
+                    V2 x = mk(-(ik00 * b.x + ik10 * b.y), -(ik01 * b.x + ik11 * b.y));
                     bool solved = x.x >= 0.0f && x.y >= 0.0f;
                     if (!solved) {
-                        x = mk(-q.nmass[0] * b.x, 0.0f);
-                        vn2 = q.K[0][1] * x.x + b.y;
+                        x = mk(-nm0 * b.x, 0.0f);
+                        vn2 = k01 * x.x + b.y;
                         solved = x.x >= 0.0f && vn2 >= 0.0f;
                     }
                     if (!solved) {
-                        x = mk(0.0f, -q.nmass[1] * b.y);
-                        vn1 = q.K[1][0] * x.y + b.x;
+                        x = mk(0.0f, -nm1 * b.y);
+                        vn1 = k10 * x.y + b.x;
                         solved = x.y >= 0.0f && vn1 >= 0.0f;
                     }
                     if (!solved) {
@@ -414,13 +436,15 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
                     if (solved) {
                         const V2 d = x - a;
                         const V2 P1 = d.x * normal, P2 = d.y * normal;
-                        A.b->vx -= A.im * (P1.x + P2.x), A.b->vy -= A.im * (P1.y + P2.y);
-                        A.b->w -= A.ii * (cross(q.rA[0], P1) + cross(q.rA[1], P2));
-                        B.b->vx += B.im * (P1.x + P2.x), B.b->vy += B.im * (P1.y + P2.y);
-                        B.b->w += B.ii * (cross(q.rB[0], P1) + cross(q.rB[1], P2));
-                        c.nimp[0] = x.x, c.nimp[1] = x.y;
+                        vA.x -= mA * (P1.x + P2.x), vA.y -= mA * (P1.y + P2.y);
+                        wA -= iA * (cross(rA0, P1) + cross(rA1, P2));
+                        vB.x += mB * (P1.x + P2.x), vB.y += mB * (P1.y + P2.y);
+                        wB += iB * (cross(rB0, P1) + cross(rB1, P2));
+                        nimp0 = x.x, nimp1 = x.y;
                     }
                 }
+                A.b->vx = vA.x, A.b->vy = vA.y, A.b->w = wA, B.b->vx = vB.x, B.b->vy = vB.y, B.b->w = wB;
+                c.nimp[0] = nimp0, c.nimp[1] = nimp1, c.timp[0] = timp0, c.timp[1] = timp1;
             }
             vel_from_lds();
         }
