@@ -79,7 +79,7 @@ struct CarSoA {
     float *tile_poly_em;   // [n][512][10]
     float *border_poly_em; // [n][512][8]
     uint8_t *border_em;    // [n][512]
-    double *track_scratch;  // [512][4][n] the current lap (alpha, beta, x, y), f64
+    double *track_scratch;  // [2500][4][n] every point of the last walk (alpha, beta, x, y), f64
     const uint32_t *text_bits;  // reward read-out bitmaps [CRL_CAR_TEXT_STRINGS][CRL_CAR_TEXT_ROWS] or nullptr
     // ---- car-car contacts (players == 2)
     int contacts_enabled;

@@ -71,8 +71,11 @@ __device__ inline void walk_init(Walk &w) {
     w.x = 1.5 * CAR_TRACK_RAD, w.y = 0, w.beta = 0, w.dest_i = 0, w.laps = 0, w.visited_other_side = 0;
 }
 
-// Lays one track attempt into `trk` (global scratch [512][4] per env, stride n).  Returns n or 0.
-__device__ int create_track(const double u[24], double *__restrict__ trk, int64_t stride) {
+// Walks one track attempt, keeping EVERY point in `pts` (global scratch [kWalkMax][4] per env, stride n:
+// 80 KB per env buys not having to repeat the ~2 500-step f64 walk once the lap's end points are known).
+// On success returns the lap length and, in *first, the index of its first point; 0 otherwise.
+static constexpr int kWalkMax = 2500;
+__device__ int create_track(const double u[24], double *__restrict__ pts, int64_t stride, int *first) {
     const double PI = 3.141592653589793;
     Checkpoints cp;
     cp.start_alpha = 0;
@@ -84,14 +87,15 @@ __device__ int create_track(const double u[24], double *__restrict__ trk, int64_
         if (c == 11) alpha = 2 * PI * c / 12, cp.start_alpha = 2 * PI * (-0.5) / 12, rad = 1.5 * CAR_TRACK_RAD;
         cp.a[c] = alpha, cp.x[c] = rad * cos(alpha), cp.y[c] = rad * sin(alpha);
     }
-    // pass 1: total length and the last two start-line crossings
     Walk w;
     walk_init(w);
-    int n = 0, cross_last = -1, cross_prev = -1, no_freeze = 2500;
+    int n = 0, cross_last = -1, cross_prev = -1, no_freeze = kWalkMax;
     double prev_alpha = 0;
     for (;;) {
         double p[4];
         walk_step(cp, w, p);
+#pragma unroll
+        for (int q = 0; q < 4; q++) pts[((int64_t)n * 4 + q) * stride] = p[q];
         if (n > 0 && p[0] > cp.start_alpha && prev_alpha <= cp.start_alpha) cross_prev = cross_last, cross_last = n;
         prev_alpha = p[0];
         n++;
@@ -101,23 +105,14 @@ __device__ int create_track(const double u[24], double *__restrict__ trk, int64_
     // the reference scans i = n-1 .. 1 and fails at i == 0 before testing it
     const int i2 = cross_last, i1 = cross_prev;
     if (i2 < 1 || i1 < 1) return 0;
-    const int len = (i2 - 1) - i1;
+    const int len = (i2 - 1) - i1;  // points i1 .. i2-2
     if (len <= 0 || len > kCarMaxTiles) return 0;
-    // pass 2: replay and keep points i1 .. i2-2
-    walk_init(w);
-    for (int i = 0; i < i2 - 1; i++) {
-        double p[4];
-        walk_step(cp, w, p);
-        if (i >= i1) {
-            const int k = i - i1;
-#pragma unroll
-            for (int q = 0; q < 4; q++) trk[((int64_t)k * 4 + q) * stride] = p[q];
-        }
-    }
+    const double *trk = pts + (int64_t)i1 * 4 * stride;
     const double fb = trk[1 * stride], fpx = cos(fb), fpy = sin(fb);
     const double a = fpx * (trk[2 * stride] - trk[((int64_t)(len - 1) * 4 + 2) * stride]);
     const double b = fpy * (trk[3 * stride] - trk[((int64_t)(len - 1) * 4 + 3) * stride]);
     if (sqrt(a * a + b * b) > CAR_TRACK_DETAIL_STEP) return 0;
+    *first = i1;
     return len;
 }
 
@@ -227,8 +222,8 @@ __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, Ca
     if (only_done && !done_env[env]) return;
     const uint32_t episode = s.episode[env];
     s.episode[env] = episode + 1;
-    double *trk = s.track_scratch + env;  // [512][4][n]
-    int len = 0, swap = 0;
+    double *pts = s.track_scratch + env;  // [kWalkMax][4][n]
+    int len = 0, swap = 0, first = 0;
     for (int attempt = 0; attempt < 256 && len == 0; attempt++) {
         double u[24];
         if (src.attempts > 0) {
@@ -249,9 +244,9 @@ __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, Ca
                 }
             }
         }
-        len = create_track(u, trk, s.n);
+        len = create_track(u, pts, s.n, &first);
     }
-    finish_reset(s, K, env, trk, len, swap);
+    finish_reset(s, K, env, pts + (int64_t)first * 4 * s.n, len, swap);
 }
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,

@@ -127,7 +127,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(reward, M); A(prev_reward, M); A(step_acc, M); A(visited_count, M); A(last_block, M); A(done, M); A(step_count, M); A(first_step, M);
     A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
-    A(track_scratch, (size_t)kCarMaxTiles * 4 * n);
+    A(track_scratch, (size_t)2500 * 4 * n);  // every point of a walk (car_track.hip: kWalkMax), f64
     A(wforce, 8 * M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
