@@ -35,7 +35,8 @@ def build(force=False, verbose=False):
     objs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-I", os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, s), "-o", o]
+        extra = os.environ.get("CRL_EXTRA_FLAGS_" + s.split(".")[0].upper(), "").split()  # per-file experiments
+        cmd = [hipcc, *FLAGS, *extra, "-I", os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
