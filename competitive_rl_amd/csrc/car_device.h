@@ -79,7 +79,10 @@ struct CarSoA {
     float *tile_poly_em;   // [n][512][10]
     float *border_poly_em; // [n][512][8]
     uint8_t *border_em;    // [n][512]
-    double *track_scratch;  // [2500][4][n] every point of the last walk (alpha, beta, x, y), f64
+    double *track_scratch;  // [2500][4][n] points (alpha, beta, x, y; f64) of the walk generated AHEAD for the env's next episode
+    double *track_scratch_b;  // same shape: where a reset walks inline when no finished walk-ahead is there
+    uint32_t *walk_tag;     // [n] episode index the stored walk belongs to (0xFFFFFFFF = none); written last, device-scope release
+    int32_t *walk_len, *walk_first, *walk_swap;  // [n] lap length, its first point, birth-place swap of the stored walk
     const uint32_t *text_bits;  // reward read-out bitmaps [CRL_CAR_TEXT_STRINGS][CRL_CAR_TEXT_ROWS] or nullptr
     // ---- car-car contacts (players == 2)
     int contacts_enabled;
@@ -138,6 +141,7 @@ struct CarTrackSrc {  // where reset draws come from
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st);
+void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st);
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);

@@ -215,14 +215,11 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
     if (s.n_contact) s.n_contact[env] = 0, s.coupled[env] = 0;
 }
 
-__global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, CarTrackSrc src, int only_done,
-                                                       const uint8_t *__restrict__ done_env) {
-    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
-    if (only_done && !done_env[env]) return;
-    const uint32_t episode = s.episode[env];
-    s.episode[env] = episode + 1;
-    double *pts = s.track_scratch + env;  // [kWalkMax][4][n]
+// The attempts loop of CarRacing.reset (crmp:454-525): fresh draws until a lap closes.  The draws of attempt a
+// only depend on (seed, global env id, episode, a) -- or on the replay stream -- so the walk of an env's NEXT
+// episode can be generated at any time before that reset.
+__device__ void gen_walk(const CarSoA &s, const CarTrackSrc &src, int64_t env, uint32_t episode, double *pts, int *len_out,
+                         int *first_out, int *swap_out) {
     int len = 0, swap = 0, first = 0;
     for (int attempt = 0; attempt < 256 && len == 0; attempt++) {
         double u[24];
@@ -246,13 +243,52 @@ __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, Ca
         }
         len = create_track(u, pts, s.n, &first);
     }
+    *len_out = len, *first_out = first, *swap_out = swap;
+}
+
+// Reset of the finished envs.  The ~4.6 ms walk is normally already there (car_walk_ahead_kernel, tagged with
+// the episode it belongs to); then only the tiles are built and the cars placed.  Without a finished
+// walk-ahead (first episode, a reset right after a reset) the walk is done here, into its own scratch.
+__global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, CarTrackSrc src, int only_done,
+                                                       const uint8_t *__restrict__ done_env) {
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= s.n) return;
+    if (only_done && !done_env[env]) return;
+    const uint32_t episode = s.episode[env];
+    s.episode[env] = episode + 1;
+    int len = 0, swap = 0, first = 0;
+    const double *pts;
+    if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == episode) {
+        len = s.walk_len[env], first = s.walk_first[env], swap = s.walk_swap[env];
+        pts = s.track_scratch + env;
+    } else {
+        gen_walk(s, src, env, episode, s.track_scratch_b + env, &len, &first, &swap);
+        pts = s.track_scratch_b + env;
+    }
     finish_reset(s, K, env, pts + (int64_t)first * 4 * s.n, len, swap);
+}
+
+// Walk-ahead: for every env whose stored walk is not the one its next reset needs, generate it.  Runs on its
+// own stream beside the steps; a reset that comes before it has finished simply walks inline.
+__global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSrc src) {
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= s.n) return;
+    const uint32_t episode = s.episode[env];  // the index the env's next reset will use
+    if (s.walk_tag[env] == episode) return;
+    int len, first, swap;
+    gen_walk(s, src, env, episode, s.track_scratch + env, &len, &first, &swap);
+    s.walk_len[env] = len, s.walk_first[env] = first, s.walk_swap[env] = swap;
+    __hip_atomic_store(&s.walk_tag[env], episode, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st) {
     hipLaunchKernelGGL(car_reset_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k, src, only_done ? 1 : 0,
                        done_env);
+}
+
+void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st) {
+    hipLaunchKernelGGL(car_walk_ahead_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, src);
 }
 
 }  // namespace crl

@@ -29,6 +29,8 @@ struct crl_car_ctx {
     // side stream next to the raster; slow_env = pipeline class per env (car_post_kernel)
     uint8_t *slow_env = nullptr;
     hipStream_t side = nullptr;
+    hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
+    hipEvent_t ev_reset = nullptr;
     hipEvent_t ev_fork = nullptr, ev_coupled = nullptr, ev_term = nullptr, ev_join = nullptr;
     bool overlap = true;
 };
@@ -127,7 +129,9 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(reward, M); A(prev_reward, M); A(step_acc, M); A(visited_count, M); A(last_block, M); A(done, M); A(step_count, M); A(first_step, M);
     A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
-    A(track_scratch, (size_t)2500 * 4 * n);  // every point of a walk (car_track.hip: kWalkMax), f64
+    A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
+    A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
+    A(walk_tag, n); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
     A(wforce, 8 * M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
@@ -155,6 +159,9 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
     c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->gen, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) != hipSuccess ||
+        hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t)) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_coupled, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_term, hipEventDisableTiming) != hipSuccess ||
@@ -170,6 +177,8 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (!c) return;
     hipDeviceSynchronize();
     if (c->side) hipStreamDestroy(c->side);
+    if (c->gen) hipStreamDestroy(c->gen);
+    if (c->ev_reset) hipEventDestroy(c->ev_reset);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_coupled) hipEventDestroy(c->ev_coupled);
     if (c->ev_term) hipEventDestroy(c->ev_term);
@@ -180,7 +189,23 @@ void crl_car_destroy(crl_car_ctx *c) {
     delete c;
 }
 
-void crl_car_seed(crl_car_ctx *c, uint64_t seed) { c->src.seed = seed; }
+// The stored walks depend on the seed / the replay stream: changing either invalidates them.
+static void invalidate_walks(crl_car_ctx *c) {
+    hipDeviceSynchronize();
+    hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t));
+}
+// Queues the walk-ahead of every env whose stored walk is not the one its next reset needs, on the context's own
+// stream, after the reset that `after` has just been given.
+static void queue_walk_ahead(crl_car_ctx *c, hipStream_t after) {
+    if (!c->overlap) return;
+    hipEventRecord(c->ev_reset, after);
+    hipStreamWaitEvent(c->gen, c->ev_reset, 0);
+    launch_car_walk_ahead(c->s, c->src, c->gen);
+}
+void crl_car_seed(crl_car_ctx *c, uint64_t seed) {
+    invalidate_walks(c);
+    c->src.seed = seed;
+}
 int64_t crl_car_obs_bytes(const crl_car_ctx *c) { return (int64_t)c->s.players * c->K * CRL_CAR_OBS * CRL_CAR_OBS; }
 
 // newest frames -> obs_dev, through the frame stack when K > 1
@@ -195,6 +220,7 @@ static void draw(crl_car_ctx *c, uint8_t *obs_dev, bool fill_all, hipStream_t st
 
 int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
     launch_car_reset(c->s, c->K_, c->src, false, nullptr, st);
+    queue_walk_ahead(c, st);
     if (obs_dev) draw(c, obs_dev, true, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car reset: %s", hipGetErrorString(e));
@@ -232,6 +258,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
         if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);
         launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
+        queue_walk_ahead(c, st);
         crl_timer_end(tm, 0, st);
         if (obs_dev) {
             crl_timer_begin(tm, 1, st);
@@ -259,6 +286,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side, c->ev_term, 0);
         launch_car_reset(c->s, c->K_, c->src, true, c->done_env, c->side);
         hipEventRecord(c->ev_join, c->side);
+        queue_walk_ahead(c, c->side);
         launch_car_raster(c->s, c->K_, target, st, c->slow_env, 1);
         hipStreamWaitEvent(st, c->ev_join, 0);
         launch_car_raster(c->s, c->K_, target, st, c->slow_env, 2);
@@ -450,7 +478,7 @@ int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const float 
 }
 
 int crl_car_set_replay_impl(crl_car_ctx *c, const double *u, const uint8_t *swap, int64_t attempts) {
-    hipDeviceSynchronize();
+    invalidate_walks(c);
     if (c->ru) hipFree(c->ru), c->ru = nullptr;
     if (c->rshuffle) hipFree(c->rshuffle), c->rshuffle = nullptr;
     c->src.ru = nullptr, c->src.rshuffle = nullptr, c->src.attempts = 0;
