@@ -133,14 +133,17 @@ __device__ inline void store_poly_ccw(const double (*v)[2], int nv, float *dst, 
 }
 
 // Builds tiles / borders from the lap in `trk` and places both cars.  swap = np.random.shuffle
-// outcome for the two birth places (crmp:508-512).
-__device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const double *trk, int len, int swap) {
+// outcome for the two birth places (crmp:508-512).  Called by a whole wavefront for ONE env: the
+// tiles are independent of each other and go one per lane (20 f64 sin/cos each); only the in-place
+// dilation of the border flags (which chains through the wrap-around, crmp:384-396) is done by one
+// lane, in LDS.
+__device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const double *trk, int len, int swap, uint8_t *flag /* LDS [512] */) {
     const int64_t n = s.n, M = (int64_t)s.players * n;
+    const int lane = threadIdx.x & 63;
     auto T = [&](int i, int q) { return trk[((int64_t)i * 4 + q) * n]; };
-    s.ntiles[env] = len;
-    // red-white border on hard turns: 4 consecutive same-sign turns, then dilated backwards IN
-    // PLACE exactly like the reference loop (crmp:384-396; wrap-around entries chain)
-    for (int i = 0; i < len; i++) {
+    if (lane == 0) s.ntiles[env] = len;
+    // red-white border on hard turns: 4 consecutive same-sign turns ...
+    for (int i = lane; i < len; i += 64) {
         bool good = true;
         double oneside = 0;
         for (int neg = 0; neg < 4; neg++) {
@@ -149,12 +152,16 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
             oneside += sgnd(b1 - b2);
         }
         good = good && fabs(oneside) == 4;
-        s.border[(int64_t)i * n + env] = good ? 1 : 0;
+        flag[i] = good ? 1 : 0;
     }
-    for (int i = 0; i < len; i++)
-        if (s.border[(int64_t)i * n + env])
-            for (int neg = 0; neg < 4; neg++) s.border[(int64_t)(((i - neg) % len + len) % len) * n + env] = 1;
-    for (int i = len - 1; i >= 0; i--) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ... then dilated backwards IN PLACE exactly like the reference loop (wrap-around entries chain)
+    if (lane == 0)
+        for (int i = 0; i < len; i++)
+            if (flag[i])
+                for (int neg = 0; neg < 4; neg++) flag[((i - neg) % len + len) % len] = 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int i = lane; i < len; i += 64) {
         const int j = ((i - 1) % len + len) % len;
         const double b1 = T(i, 1), x1 = T(i, 2), y1 = T(i, 3), b2 = T(j, 1), x2 = T(j, 2), y2 = T(j, 3);
         const double PI = 3.141592653589793;
@@ -170,7 +177,8 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         s.tile_aabb[(int64_t)i * n + env] = make_float4(bb[0], bb[1], bb[2], bb[3]);
         s.tile_aabb_em[env * kCarMaxTiles + i] = make_float4(bb[0], bb[1], bb[2], bb[3]);
         for (int q = 0; q < 10; q++) s.tile_poly_em[(env * kCarMaxTiles + i) * 10 + q] = s.tile_poly[((int64_t)i * 10 + q) * n + env];
-        if (s.border[(int64_t)i * n + env]) {
+        uint8_t bflag = 0;
+        if (flag[i]) {
             const double side = sgnd(b2 - b1);
             const double bp[4][2] = {
                 {x1 + side * CAR_TRACK_WIDTH * cos(b1), y1 + side * CAR_TRACK_WIDTH * sin(b1)},
@@ -179,14 +187,16 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
                 {x2 + side * CAR_TRACK_WIDTH * cos(b2), y2 + side * CAR_TRACK_WIDTH * sin(b2)},
             };
             store_poly_ccw(bp, 4, s.border_poly + (int64_t)i * 8 * n + env, n, nullptr);
-            s.border[(int64_t)i * n + env] = (i % 2 == 0) ? 1 : 2;  // white / red
+            bflag = (i % 2 == 0) ? 1 : 2;  // white / red
             for (int q = 0; q < 8; q++) s.border_poly_em[(env * kCarMaxTiles + i) * 8 + q] = s.border_poly[((int64_t)i * 8 + q) * n + env];
         }
-        s.border_em[env * kCarMaxTiles + i] = s.border[(int64_t)i * n + env];
+        s.border[(int64_t)i * n + env] = bflag;
+        s.border_em[env * kCarMaxTiles + i] = bflag;
     }
     const double ia = T(0, 1), ix = T(0, 2), iy = T(0, 3);
-    s.start_pose[0 * n + env] = (float)ia, s.start_pose[1 * n + env] = (float)ix, s.start_pose[2 * n + env] = (float)iy;
-    for (int car = 0; car < s.players; car++) {
+    if (lane == 0) s.start_pose[0 * n + env] = (float)ia, s.start_pose[1 * n + env] = (float)ix, s.start_pose[2 * n + env] = (float)iy;
+    if (lane < s.players) {
+        const int car = lane;
         const int64_t ci = car * n + env;
         // np.random.shuffle(arange(num_player)): one car always gets birth place 0
         const int birth = s.players == 1 ? 0 : (car == 0 ? (swap ? 1 : 0) : (swap ? 0 : 1));
@@ -209,10 +219,12 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         for (int q = 0; q < 16; q++) s.visited[q * M + ci] = 0u;
         s.reward[ci] = 0.0, s.prev_reward[ci] = 0.0;
         s.visited_count[ci] = 0, s.last_block[ci] = -1, s.done[ci] = 0, s.step_count[ci] = 0, s.first_step[ci] = 1;
-        for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = 0.0f;
+        for (int bq = 0; bq < 5; bq++) s.sleep[bq * M + ci] = 0.0f;
     }
-    s.elapsed[env] = 0;
-    if (s.n_contact) s.n_contact[env] = 0, s.coupled[env] = 0;
+    if (lane == 0) {
+        s.elapsed[env] = 0;
+        if (s.n_contact) s.n_contact[env] = 0, s.coupled[env] = 0;
+    }
 }
 
 // The attempts loop of CarRacing.reset (crmp:454-525): fresh draws until a lap closes.  The draws of attempt a
@@ -251,21 +263,25 @@ __device__ void gen_walk(const CarSoA &s, const CarTrackSrc &src, int64_t env, u
 // walk-ahead (first episode, a reset right after a reset) the walk is done here, into its own scratch.
 __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, CarTrackSrc src, int only_done,
                                                        const uint8_t *__restrict__ done_env) {
-    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
+    // one WAVEFRONT per env: the tiles are built one per lane; a missing walk is done by lane 0
+    __shared__ uint8_t flag[kCarMaxTiles];
+    const int64_t env = blockIdx.x;
+    const int lane = threadIdx.x;
     if (only_done && !done_env[env]) return;
     const uint32_t episode = s.episode[env];
-    s.episode[env] = episode + 1;
     int len = 0, swap = 0, first = 0;
     const double *pts;
     if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == episode) {
         len = s.walk_len[env], first = s.walk_first[env], swap = s.walk_swap[env];
         pts = s.track_scratch + env;
     } else {
-        gen_walk(s, src, env, episode, s.track_scratch_b + env, &len, &first, &swap);
+        if (lane == 0) gen_walk(s, src, env, episode, s.track_scratch_b + env, &len, &first, &swap);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // lane 0's points are read by the whole wave below
+        len = __shfl(len, 0), first = __shfl(first, 0), swap = __shfl(swap, 0);
         pts = s.track_scratch_b + env;
     }
-    finish_reset(s, K, env, pts + (int64_t)first * 4 * s.n, len, swap);
+    if (lane == 0) s.episode[env] = episode + 1;
+    finish_reset(s, K, env, pts + (int64_t)first * 4 * s.n, len, swap, flag);
 }
 
 // Walk-ahead: for every env whose stored walk is not the one its next reset needs, generate it.  Runs on its
@@ -283,8 +299,7 @@ __global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSr
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st) {
-    hipLaunchKernelGGL(car_reset_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k, src, only_done ? 1 : 0,
-                       done_env);
+    hipLaunchKernelGGL(car_reset_kernel, dim3((unsigned)s.n), dim3(64), 0, st, s, k, src, only_done ? 1 : 0, done_env);
 }
 
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st) {
