@@ -219,6 +219,13 @@ static void draw(crl_car_ctx *c, uint8_t *obs_dev, bool fill_all, hipStream_t st
 }
 
 int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
+    // Full reset: every env needs a walk now.  The walk kernel does them one per LANE (64 envs per wavefront);
+    // the reset kernel, one wavefront per env, then only builds the tiles.  (Any walk-ahead still running on the
+    // context's own stream writes the same scratch: wait for it first; a full reset is rare.)
+    if (c->overlap) {
+        hipStreamSynchronize(c->gen);
+        launch_car_walk_ahead(c->s, c->src, st);
+    }
     launch_car_reset(c->s, c->K_, c->src, false, nullptr, st);
     queue_walk_ahead(c, st);
     if (obs_dev) draw(c, obs_dev, true, st);
