@@ -19,7 +19,9 @@ ATLAS_BYTES = 22 * 22 * 34 * 160
 SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "crl_render", "crl_info", "crl_copy_info",
            "crl_terminal_observation", "crl_get_state", "crl_set_state", "crl_set_replay", "crl_render_raw",
            "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version",
-           "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_set_replay"]
+           "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_set_replay",
+           "crl_policy_create", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
+           "crl_policy_set_stack"]
 
 FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
                      ("score_l", "u1"), ("score_r", "u1")])
@@ -93,11 +95,18 @@ def load():
     L.crl_car_get_track.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     L.crl_car_set_track.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp]
     L.crl_car_set_replay.argtypes = [vp, vp, vp, i64]
+    L.crl_policy_create.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.crl_policy_destroy.argtypes = [vp]
+    L.crl_policy_destroy.restype = None
+    L.crl_policy_reset.argtypes = [vp, vp]
+    L.crl_policy_act.argtypes = [vp, vp, i64, vp, i64, vp, vp]
+    L.crl_policy_get_stack.argtypes = [vp, vp, vp]
+    L.crl_policy_set_stack.argtypes = [vp, vp, vp]
     L.crl_last_error.restype = C.c_char_p
     L.crl_version.restype = C.c_char_p
     for name in SYMBOLS:
         getattr(L, name)
-        if name not in ("crl_destroy", "crl_obs_bytes_per_env", "crl_last_error", "crl_version"):
+        if name not in ("crl_destroy", "crl_policy_destroy", "crl_obs_bytes_per_env", "crl_last_error", "crl_version"):
             getattr(L, name).restype = i32
     _lib = L
     return L

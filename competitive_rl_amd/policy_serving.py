@@ -1,0 +1,143 @@
+"""Built-in CNN opponents on the device (reference competitive_rl/utils/policy_serving.py:10-66,
+utils/network.py:73-93, pong/builtin_policies.py:61-91).
+
+``Policy`` has the reference's constructor and call protocol.  The forward pass -- the policy's own
+four-frame stack, LightActorCritic, argmax -- is ONE hand-written HIP kernel behind the C ABI
+(``crl_policy_*`` in include/crl.h); there is no torch model and no CPU path in this module.
+
+Only ``use_light_model=True`` is served: that is what WEAK and MEDIUM use, and the checkpoints of the
+two ActorCritic opponents (STRONG, ALPHA_PONG) are not in the reference tree.
+"""
+import ctypes as C
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+ASSETS = os.path.join(N.PKG, "assets")
+BUILTIN_CHECKPOINTS = {"WEAK": os.path.join(ASSETS, "pong_policy_weak.npz"),
+                       "MEDIUM": os.path.join(ASSETS, "pong_policy_medium.npz")}
+_KEYS = ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "actor_w", "actor_b")
+_SHAPES = {"conv1_w": (16, 4, 4, 4), "conv1_b": (16,), "conv2_w": (16, 16, 2, 2), "conv2_b": (16,), "actor_w": (3, 1600),
+           "actor_b": (3,)}
+
+
+def load_light_weights(checkpoint_path):
+    """``.npz`` written by assets/gen_policy_weights.py, or a reference checkpoint
+    (``torch.save({"model": state_dict, ...})``, policy_serving.py:33-36)."""
+    assert os.path.isfile(checkpoint_path), checkpoint_path
+    if checkpoint_path.endswith(".npz"):
+        z = np.load(checkpoint_path)
+        w = {k: z[k] for k in _KEYS}
+    else:
+        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=False)["model"]
+        w = {"conv1_w": sd["conv1.weight"], "conv1_b": sd["conv1.bias"], "conv2_w": sd["conv2.weight"], "conv2_b": sd["conv2.bias"],
+             "actor_w": sd["actor_linear.weight"], "actor_b": sd["actor_linear.bias"]}
+        w = {k: v.detach().cpu().numpy() for k, v in w.items()}
+    w = {k: np.ascontiguousarray(v, np.float32) for k, v in w.items()}
+    for k in _KEYS:
+        if w[k].shape != _SHAPES[k]:
+            raise ValueError(f"{checkpoint_path}: {k} has shape {w[k].shape}, LightActorCritic on (4, 42, 42) needs {_SHAPES[k]}")
+    return w
+
+
+def _random_light_weights():
+    """No checkpoint: the reference builds the model with torch's default initialisation."""
+    c1, c2, fc = torch.nn.Conv2d(4, 16, 4, 2), torch.nn.Conv2d(16, 16, 2, 2), torch.nn.Linear(1600, 3)
+    w = {"conv1_w": c1.weight, "conv1_b": c1.bias, "conv2_w": c2.weight, "conv2_b": c2.bias, "actor_w": fc.weight, "actor_b": fc.bias}
+    return {k: np.ascontiguousarray(v.detach().numpy(), np.float32) for k, v in w.items()}
+
+
+class Policy:
+    def __init__(self, single_obs_space, single_action_space, num_envs, checkpoint_path="", frame_stack=4, use_light_model=False,
+                 device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("competitive_rl_amd.Policy needs a ROCm GPU; there is no CPU fallback")
+        if not use_light_model:
+            raise NotImplementedError("only LightActorCritic opponents (WEAK, MEDIUM) are served: the reference tree has no "
+                                      "ActorCritic checkpoint (checkpoint-strong.pkl / checkpoint-alphapong.pkl are missing)")
+        self.num_envs = int(num_envs)
+        self.obs_shape = tuple(single_obs_space.shape)
+        if self.obs_shape != (1, 42, 42) or frame_stack != 4 or single_action_space.n != 3:
+            raise ValueError("the built-in opponents are trained on (1, 42, 42) frames, a stack of 4 and 3 actions")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if checkpoint_path:
+            self.weights = load_light_weights(checkpoint_path)
+        else:
+            logging.warning("Loading a policy without checkpoint!")
+            self.weights = _random_light_weights()
+        self._L = N.load()
+        h = C.c_void_p()
+        ptr = [self.weights[k].ctypes.data_as(C.c_void_p) for k in _KEYS]
+        with torch.cuda.device(self.device):
+            N.check(self._L.crl_policy_create(self.device.index or 0, self.num_envs, *ptr, C.byref(h)))
+        self._h = h
+        self._actions = torch.zeros((self.num_envs,), dtype=torch.int32, device=self.device)
+        self._logits = torch.zeros((self.num_envs, 3), dtype=torch.float32, device=self.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.crl_policy_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self):
+        N.check(self._L.crl_policy_reset(self._h, self._stream()))
+
+    def _frames(self, obs):
+        if isinstance(obs, np.ndarray):
+            obs = torch.from_numpy(np.ascontiguousarray(obs))
+        obs = obs.to(self.device)
+        if obs.dtype != torch.uint8:  # DummyVecEnv hands float32 arrays holding 0..255 integers
+            obs = obs.to(torch.uint8)
+        obs = obs.reshape(self.num_envs, 42, 42) if obs.dim() != 4 else obs[:, 0]
+        if obs.stride(2) != 1 or obs.stride(1) != 42 or obs.stride(0) % 4 or obs.data_ptr() % 4:
+            obs = obs.contiguous()
+        return obs
+
+    def act_device(self, obs, out=None, want_logits=False):
+        """Push ``obs`` (N, 1, 42, 42) onto the stack and write the greedy actions (int32) into ``out``
+        (any int32 device view with one element per env, e.g. ``actions[:, 1]`` of an (N, 2) tensor;
+        default: an internal (N,) tensor).  No host synchronisation."""
+        f = self._frames(obs)
+        out = self._actions if out is None else out
+        assert out.dtype == torch.int32 and out.device == self.device and out.shape[0] == self.num_envs and out.numel() == self.num_envs
+        stride = out.stride(0) if self.num_envs > 1 else 1
+        N.check(self._L.crl_policy_act(self._h, C.c_void_p(f.data_ptr()), f.stride(0), C.c_void_p(out.data_ptr()), stride,
+                                       C.c_void_p(self._logits.data_ptr()) if want_logits else None, self._stream()))
+        return out
+
+    def logits(self):
+        """Logits of the last ``act_device(..., want_logits=True)`` call, float32 (N, 3)."""
+        return self._logits
+
+    def get_stack(self):
+        out = torch.empty((self.num_envs, 4, 42, 42), dtype=torch.uint8, device=self.device)
+        N.check(self._L.crl_policy_get_stack(self._h, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def set_stack(self, stack):
+        s = torch.as_tensor(stack).to(self.device, torch.uint8).contiguous()
+        assert tuple(s.shape) == (self.num_envs, 4, 42, 42)
+        N.check(self._L.crl_policy_set_stack(self._h, C.c_void_p(s.data_ptr()), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def compute_action(self, obs, deterministic=True):
+        raise NotImplementedError("the device policy is called with single frames (Policy.__call__ / act_device); "
+                                  "sampling (deterministic=False) is not used by the built-in opponents")
+
+    def __call__(self, obs):
+        """Reference protocol (policy_serving.py:58-66): numpy (N, 1) int64, or an int for one env."""
+        a = self.act_device(obs).to(torch.int64)
+        if self.num_envs == 1:
+            return a.item()
+        return a.view(-1, 1).cpu().numpy()

@@ -1,22 +1,38 @@
 """TournamentEnvWrapper (reference competitive_rl/pong/competitive_pong_env.py:9-53).
 
 Wraps a cPongDouble VecEnv and plays a built-in opponent on the right side, so the caller
-sees a single-agent env.  Built-in opponents served here: RULE_BASED (action 999, resolved by
-the kernel = auto_action) and RANDOM.  The reference's CNN opponents (WEAK / MEDIUM / STRONG)
-are torch policies outside this hot path and are not shipped.
+sees a single-agent env.  Opponents (pong/builtin_policies.py:26-33,61-91): RANDOM, WEAK, MEDIUM,
+RULE_BASED.  WEAK / MEDIUM are the reference's LightActorCritic checkpoints served by one HIP kernel
+(policy_serving.Policy: frame in, action out, straight into the right-hand column of the device
+action array -- no host round trip).  RULE_BASED is action 999, resolved by the step kernel
+(= auto_action).  STRONG is listed by the reference but its checkpoint is not in the reference tree
+(the reference's own wrapper asserts on the missing file), so it is not offered here.
 """
 import random
 
 import numpy as np
 import torch
 
+from . import spaces
+from .policy_serving import BUILTIN_CHECKPOINTS, Policy
 from .vec_env import CHEAT_CODES
 
-BUILTIN_AGENT_NAMES = ["RANDOM", "RULE_BASED"]
+BUILTIN_AGENT_NAMES = ["RANDOM", "WEAK", "MEDIUM", "RULE_BASED"]
+
+# Hard-coded in the reference too (builtin_policies.py:36-37)
+single_obs_space = spaces.Box(0, 255, (1, 42, 42))
+single_act_space = spaces.Discrete(3)
 
 
-def get_compute_action_function(agent_name, num_envs=1):
-    """pong/builtin_policies.py:61-91 for the two rule-free opponents."""
+def get_builtin_agent_names():
+    return BUILTIN_AGENT_NAMES
+
+
+def get_compute_action_function(agent_name, num_envs=1, device=None):
+    """pong/builtin_policies.py:61-91."""
+    if agent_name in BUILTIN_CHECKPOINTS:
+        return Policy(single_obs_space, single_act_space, num_envs, BUILTIN_CHECKPOINTS[agent_name], use_light_model=True,
+                      device=device)
     if agent_name == "RANDOM":
         return lambda obs: np.random.randint(0, 3, size=num_envs)
     if agent_name == "RULE_BASED":
@@ -25,16 +41,23 @@ def get_compute_action_function(agent_name, num_envs=1):
 
 
 class TournamentEnvWrapper:
-    def __init__(self, env, num_envs):
+    def __init__(self, env, num_envs, agent_names=None):
         self.env = env
-        self.agents = {name: get_compute_action_function(name, num_envs) for name in BUILTIN_AGENT_NAMES}
+        device = getattr(env, "device", None)
+        names = get_builtin_agent_names() if agent_names is None else list(agent_names)
+        cnn = [n for n in names if n in BUILTIN_CHECKPOINTS]
+        if cnn and getattr(env, "R", 42) != 42:
+            raise ValueError(f"{cnn} are trained on 42x42 frames (builtin_policies.py:36); make the env with resized_dim=42 "
+                             "or pass agent_names without them")
+        self.agents = {name: get_compute_action_function(name, num_envs, device) for name in names}
         self.agent_names = list(self.agents)
         self.prev_opponent_obs = None
-        self.current_agent_name = "RULE_BASED"
+        self.current_agent_name = "RULE_BASED" if "RULE_BASED" in self.agents else self.agent_names[0]
         self.current_agent = self.agents[self.current_agent_name]
         self.observation_space = env.observation_space[0]
         self.action_space = env.action_space[0]
         self.num_envs = num_envs
+        self._act = None if device is None else torch.zeros((num_envs, 2), dtype=torch.int32, device=device)
 
     def get_agent_names(self):
         return self.agent_names
@@ -48,10 +71,27 @@ class TournamentEnvWrapper:
         self.current_agent = self.agents[self.current_agent_name]
 
     def step(self, action):
-        if isinstance(action, torch.Tensor):
-            action = action.detach().cpu().numpy()
-        tuple_action = np.stack([np.asarray(action).reshape(-1), np.asarray(self.current_agent(self.prev_opponent_obs)).reshape(-1)],
-                                axis=1)
+        if self._act is not None:
+            # device path: our column from the caller; the opponent's column is written in place by the
+            # policy kernel (WEAK / MEDIUM) or is the constant 999 (RULE_BASED) -- no host round trip
+            if isinstance(action, torch.Tensor):
+                mine = action.to(self._act.device, torch.int32).reshape(-1)
+            else:
+                mine = torch.as_tensor(np.asarray(action).reshape(-1), dtype=torch.int32).to(self._act.device)
+            self._act[:, 0] = mine
+            if isinstance(self.current_agent, Policy):
+                self.current_agent.act_device(self.prev_opponent_obs, out=self._act[:, 1])
+            elif self.current_agent_name == "RULE_BASED":
+                self._act[:, 1] = CHEAT_CODES
+            else:
+                theirs = np.asarray(self.current_agent(self.prev_opponent_obs)).reshape(-1)
+                self._act[:, 1] = torch.as_tensor(theirs, dtype=torch.int32).to(self._act.device)
+            tuple_action = self._act
+        else:
+            if isinstance(action, torch.Tensor):
+                action = action.detach().cpu().numpy()
+            tuple_action = np.stack([np.asarray(action).reshape(-1),
+                                     np.asarray(self.current_agent(self.prev_opponent_obs)).reshape(-1)], axis=1)
         obs, rew, done, info = self.env.step(tuple_action)
         self.prev_opponent_obs = obs[1]
         if done.ndim == 2:
@@ -67,4 +107,7 @@ class TournamentEnvWrapper:
         self.env.seed(s)
 
     def close(self):
+        for a in self.agents.values():
+            if isinstance(a, Policy):
+                a.close()
         self.env.close()

@@ -247,6 +247,34 @@ int crl_car_set_track(crl_ctx *ctx, int64_t env, int32_t n, const float *tile_po
  * np_random.uniform draws of one _create_track attempt) and one birth-place swap bit each. */
 int crl_car_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *swap_host, int64_t attempts);
 
+/* ---- built-in CNN opponents of cPongTournament-v0 ----------------------------
+ * Stands in for utils/policy_serving.py:10-66 `Policy(..., use_light_model=True)` as built by
+ * pong/builtin_policies.py:61-91 for WEAK / MEDIUM: LightActorCritic (utils/network.py:73-93:
+ * x/255 -> conv 4->16 k4 s2 -> ReLU -> conv 16->16 k2 s2 -> ReLU -> 1600 -> 3 logits) on the
+ * policy's OWN stack of the last four 42x42 frames it was shown (FrameStackTensor.update without
+ * a mask, utils/utils.py:159-170: never cleared at episode ends), action = argmax of the logits.
+ * Weights are the model tensors of the checkpoint, float32, in torch layout. */
+#define CRL_POLICY_DIM 42
+#define CRL_POLICY_STACK 4
+typedef struct crl_policy crl_policy;
+int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w_host /*[16,4,4,4]*/,
+                      const float *conv1_b_host /*[16]*/, const float *conv2_w_host /*[16,16,2,2]*/,
+                      const float *conv2_b_host /*[16]*/, const float *actor_w_host /*[3,1600]*/,
+                      const float *actor_b_host /*[3]*/, crl_policy **out);
+void crl_policy_destroy(crl_policy *p);
+/* Policy.reset (policy_serving.py:46-47): zero the frame stack. */
+int crl_policy_reset(crl_policy *p, void *stream);
+/* Policy.__call__ (policy_serving.py:58-66): push one 42x42 u8 frame per env (env i at
+ * frame_dev + i * frame_stride bytes; stride a multiple of 4) onto the stack and write the
+ * greedy action of env i to actions_dev[i * action_stride] (int32 elements; pass 2 to fill the
+ * right-hand column of an (N, 2) cPongDouble action array in place).  logits_dev: optional
+ * float32 [N, 3]. */
+int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride, int32_t *actions_dev,
+                   int64_t action_stride, float *logits_dev, void *stream);
+/* The stack as the model sees it: u8 [N, 4, 42, 42], oldest plane first (tests, checkpoints). */
+int crl_policy_get_stack(crl_policy *p, uint8_t *stack_out_dev, void *stream);
+int crl_policy_set_stack(crl_policy *p, const uint8_t *stack_in_dev, void *stream);
+
 const char *crl_last_error(void);
 const char *crl_version(void);
 

@@ -1,0 +1,68 @@
+"""CPU restatement of the reference's built-in CNN Pong opponents.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this; the product
+(competitive_rl_amd) never does.  Pinned to tests/golden/policy_light.npz, which was recorded from
+the reference's own Policy / LightActorCritic with the reference's checkpoints
+(tests/golden/gen_policy_golden.py).
+
+Follows:
+* LightActorCritic.forward (reference utils/network.py:73-93): x/255 -> conv1 4->16 k4 s2 -> ReLU
+  -> conv2 16->16 k2 s2 -> ReLU -> flatten (C, H, W order) -> actor_linear (3) / critic_linear (1);
+* Policy.__call__ / compute_action (utils/policy_serving.py:46-66): the policy keeps its OWN
+  4-frame FrameStackTensor, updated without a mask (never cleared when an episode ends -- the
+  reference notes this itself at :38-40), and plays argmax of the logits;
+* FrameStackTensor.update (utils/utils.py:159-170): roll by one plane, newest plane last.
+
+float32 throughout; the summation order inside a convolution is not defined by the reference
+(torch's CPU convolution), so logits are compared with a tolerance (1e-4 abs) and actions must
+agree wherever the two best logits are further apart than that.
+"""
+import numpy as np
+
+
+def load_weights(path):
+    z = np.load(path)
+    return {k: np.ascontiguousarray(z[k], np.float32) for k in z.files}
+
+
+def _conv(x, w, b, stride):
+    """x [B, C, H, W] f32, w [O, C, k, k] -> [B, O, H', W'] (valid padding)."""
+    B, C, H, W = x.shape
+    O, _, k, _ = w.shape
+    Ho, Wo = (H - k) // stride + 1, (W - k) // stride + 1
+    cols = np.empty((B, Ho, Wo, C, k, k), np.float32)
+    for ky in range(k):
+        for kx in range(k):
+            cols[:, :, :, :, ky, kx] = x[:, :, ky:ky + stride * Ho:stride, kx:kx + stride * Wo:stride].transpose(0, 2, 3, 1)
+    y = cols.reshape(B * Ho * Wo, C * k * k) @ w.reshape(O, -1).T + b
+    return y.reshape(B, Ho, Wo, O).transpose(0, 3, 1, 2).astype(np.float32)
+
+
+def forward(wts, stack_u8):
+    """stack_u8 [B, 4, 42, 42] (oldest plane first) -> (logits [B, 3], value [B]) float32."""
+    x = np.asarray(stack_u8).astype(np.float32) / np.float32(255.0)
+    h = np.maximum(_conv(x, wts["conv1_w"], wts["conv1_b"], 2), 0)
+    h = np.maximum(_conv(h, wts["conv2_w"], wts["conv2_b"], 2), 0)
+    f = h.reshape(h.shape[0], -1)
+    logits = f @ wts["actor_w"].T + wts["actor_b"]
+    value = f @ wts["critic_w"].T + wts["critic_b"]
+    return logits.astype(np.float32), value.reshape(-1).astype(np.float32)
+
+
+class PolicyOracle:
+    """Policy(…, use_light_model=True) of utils/policy_serving.py as a callable on (N, 1, 42, 42) frames."""
+
+    def __init__(self, weights, num_envs):
+        self.w = weights
+        self.stack = np.zeros((num_envs, 4, 42, 42), np.uint8)
+        self.logits = None
+
+    def reset(self):
+        self.stack[:] = 0
+
+    def __call__(self, obs):
+        obs = np.asarray(obs).reshape(self.stack.shape[0], 42, 42)
+        self.stack = np.roll(self.stack, -1, axis=1)
+        self.stack[:, -1] = obs
+        self.logits, self.value = forward(self.w, self.stack)
+        return self.logits.argmax(1).reshape(-1, 1)

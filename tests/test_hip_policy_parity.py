@@ -1,0 +1,121 @@
+"""The HIP opponent-policy kernel (crl_policy_* of include/crl.h) against the numpy oracle and the
+vectors recorded from the reference's Policy with the reference's checkpoints.  float32: logits
+within 1e-4, actions identical (the recorded traces have a top-2 logit gap >= 2e-3)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "policy_light.npz")
+TOL = 1e-4
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+
+
+def make_policy(name, n):
+    import competitive_rl_amd.tournament as T
+
+    return T.get_compute_action_function(name.upper(), n)
+
+
+@pytest.mark.parametrize("name", ["weak", "medium"])
+def test_policy_kernel_replays_reference_trace(name):
+    _need_gpu()
+    g = np.load(GOLD)
+    frames, actions, logits = g[name + "_frames"], g[name + "_actions"], g[name + "_logits"]
+    n = frames.shape[1]
+    pol = make_policy(name, n)
+    for t in range(frames.shape[0]):
+        obs = torch.from_numpy(frames[t][:, None]).cuda()
+        a = pol.act_device(obs, want_logits=True)
+        assert np.abs(pol.logits().cpu().numpy() - logits[t]).max() < TOL, t
+        assert np.array_equal(a.cpu().numpy(), actions[t]), t
+    # the stack the model saw is the last four frames, oldest first -- across episode ends
+    st = pol.get_stack().cpu().numpy()
+    assert np.array_equal(st, frames[-4:].transpose(1, 0, 2, 3))
+    # reference call protocol: numpy (N, 1) int64
+    out = pol(frames[0][:, None])
+    assert out.shape == (n, 1) and out.dtype == np.int64
+    pol.reset()
+    assert int(pol.get_stack().max()) == 0
+    pol.close()
+
+
+@pytest.mark.parametrize("n", [1, 4, 5, 6, 333])
+def test_policy_kernel_vs_oracle_ragged_sizes(n):
+    """Random stacks (workgroups hold five envs: 1, 4, 5, 6 and 333 cover the ragged tails), strided
+    frame and action views, ring rotation over several calls."""
+    _need_gpu()
+    from oracle import policy_oracle as P
+
+    w = P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_medium.npz"))
+    ora = P.PolicyOracle(w, n)
+    pol = make_policy("medium", n)
+    rs = np.random.RandomState(n)
+    st0 = rs.randint(0, 256, (n, 4, 42, 42)).astype(np.uint8)
+    pol.set_stack(st0)
+    ora.stack = st0.copy()
+    both = torch.zeros((n, 2, 1, 42, 42), dtype=torch.uint8, device="cuda")  # the env's (N, 2, K, R, R) layout
+    act = torch.full((n, 2), -7, dtype=torch.int32, device="cuda")
+    for t in range(6):
+        f = rs.randint(0, 256, (n, 42, 42)).astype(np.uint8)
+        if t % 2:
+            f = (f > 200).astype(np.uint8) * 255  # sparse frames like Pong's
+        both[:, 1, 0] = torch.from_numpy(f).cuda()
+        pol.act_device(both[:, 1], out=act[:, 1], want_logits=True)
+        ao = ora(f[:, None])
+        lg = pol.logits().cpu().numpy()
+        assert np.abs(lg - ora.logits).max() < TOL, t
+        srt = np.sort(ora.logits, 1)
+        clear = (srt[:, 2] - srt[:, 1]) > 10 * TOL
+        got = act.cpu().numpy()
+        assert np.array_equal(got[clear, 1], ao.reshape(-1)[clear]), t
+        assert np.all(got[:, 0] == -7)  # the other column of the action array is untouched
+        assert np.array_equal(pol.get_stack().cpu().numpy(), ora.stack), t
+    pol.close()
+
+
+def test_tournament_with_cnn_opponent_matches_oracle_game(atlas):
+    """cPongTournament-v0 with the MEDIUM opponent end to end on the device: the same game as the CPU
+    oracle env stepped with the oracle policy's actions (frames bit-exact, so actions identical)."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import policy_oracle as P
+    from oracle import pong_oracle as po
+
+    n, T = 7, 300
+    tour = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=21)
+    assert tour.get_agent_names() == ["RANDOM", "WEAK", "MEDIUM", "RULE_BASED"]
+    tour.reset_opponent("MEDIUM")
+    env = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=21)
+    ora = P.PolicyOracle(P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_medium.npz")), n)
+    o_h = tour.reset()
+    o_c = env.reset().copy()
+    assert np.array_equal(o_h.cpu().numpy(), o_c[:, 0])
+    rs = np.random.RandomState(5)
+    ndone = 0
+    for t in range(T):
+        mine = rs.randint(0, 3, n)
+        opp = ora(o_c[:, 1]).reshape(-1)
+        o_h, r_h, d_h, _ = tour.step(mine)
+        o_c, r_c, d_c = env.step(np.stack([mine, opp], 1))
+        o_c = o_c.copy()
+        assert np.array_equal(o_h.cpu().numpy(), o_c[:, 0]), t
+        assert np.array_equal(r_h.cpu().numpy().reshape(-1), r_c[:, 0]), t
+        assert np.array_equal(d_h.cpu().numpy().reshape(-1), d_c.astype(bool)), t
+        ndone += int(d_c.sum())
+    # switching opponents keeps each policy's own stack (competitive_pong_env.py:28-34)
+    tour.reset_opponent("WEAK")
+    tour.step(rs.randint(0, 3, n))
+    tour.reset_opponent("RANDOM")
+    tour.step(rs.randint(0, 3, n))
+    tour.close()
+    env.close()

@@ -1,0 +1,50 @@
+"""The numpy restatement of the built-in CNN opponents (oracle/policy_oracle.py) against the vectors
+recorded from the reference's own Policy / LightActorCritic and checkpoints
+(tests/golden/gen_policy_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import policy_oracle as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "policy_light.npz")
+TOL = 1e-4  # float32 logits; the reference's convolution does not define a summation order
+
+
+def weights(name):
+    return P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_%s.npz" % name))
+
+
+@pytest.mark.parametrize("name", ["weak", "medium"])
+def test_network_on_noise_stacks(name):
+    g = np.load(GOLD)
+    lg, v = P.forward(weights(name), g["noise"])
+    assert np.abs(lg - g[name + "_noise_logits"]).max() < TOL
+    crit = np.load(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_%s.npz" % name))
+    assert crit["critic_w"].shape == (1, 1600)
+    assert np.abs(v - g[name + "_noise_values"]).max() < TOL
+
+
+@pytest.mark.parametrize("name", ["weak", "medium"])
+def test_policy_closed_loop_trace(name):
+    """Policy.__call__ semantics: own 4-frame stack, never cleared at episode ends, greedy action."""
+    g = np.load(GOLD)
+    frames, actions, logits = g[name + "_frames"], g[name + "_actions"], g[name + "_logits"]
+    assert g[name + "_dones"].sum() > 0  # the trace crosses episode boundaries
+    pol = P.PolicyOracle(weights(name), frames.shape[1])
+    for t in range(frames.shape[0]):
+        a = pol(frames[t][:, None])
+        assert np.abs(pol.logits - logits[t]).max() < TOL, t
+        assert np.array_equal(a.reshape(-1), actions[t]), t
+    # the first call sees three zero planes and the reset frame
+    assert np.array_equal(pol.stack[:, -1], frames[-1])
+
+
+def test_shipped_names_match_reference_list():
+    """builtin_policies.py:26-33 minus the two agents whose checkpoints the reference does not ship."""
+    import competitive_rl_amd.tournament as T
+
+    assert T.get_builtin_agent_names() == ["RANDOM", "WEAK", "MEDIUM", "RULE_BASED"]
+    assert T.single_obs_space.shape == (1, 42, 42) and T.single_act_space.n == 3

@@ -1,0 +1,48 @@
+"""Time the opponent-policy kernel alone and the cPongTournament-v0 step around it.
+
+    python tools/policy_bench.py [num_envs] [calls]
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import competitive_rl_amd as crl
+from competitive_rl_amd.tournament import get_compute_action_function
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+pol = get_compute_action_function("MEDIUM", n)
+frames = (torch.rand((n, 1, 42, 42), device="cuda") > 0.9).to(torch.uint8) * 255
+for _ in range(5):
+    pol.act_device(frames)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(calls):
+    pol.act_device(frames)
+b.record()
+torch.cuda.synchronize()
+ms = a.elapsed_time(b) / calls
+flop = n * 516800 * 2
+print(f"policy kernel: {ms * 1e3:.1f} us per call at {n} envs = {flop / ms / 1e9:.2f} TFLOP/s fp32 "
+      f"({flop / ms / 1e9 / 78.6 * 100:.1f} % of 78.6 TFLOP/s plain-FMA issue, {flop / ms / 1e9 / 157.3 * 100:.1f} % of packed peak)")
+
+tour = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=1)
+for name in ("RULE_BASED", "MEDIUM"):
+    tour.reset_opponent(name)
+    tour.reset()
+    act = torch.randint(0, 3, (calls + 10, n), device="cuda", dtype=torch.int32)
+    for t in range(10):
+        tour.step(act[t])
+    torch.cuda.synchronize()
+    a.record()
+    for t in range(calls):
+        tour.step(act[10 + t])
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / calls
+    print(f"cPongTournament-v0 vs {name}: {ms * 1e3:.1f} us per step, {n / ms / 1e3:.2f} M env-steps/s")
+tour.close()
