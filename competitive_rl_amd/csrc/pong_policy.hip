@@ -32,111 +32,212 @@ static constexpr int kEnvsPerWg = 5;
 static constexpr int kPos = 100;                       // 10 x 10 conv2 positions
 static constexpr int kPolicyThreads = 512;
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Output channels are processed in PAIRS (2p, 2p + 1) so that the multiply-adds are v_pk_fma_f32
+// (two fp32 FMAs per lane per issue): weights are stored as (w[2p], w[2p + 1]) pairs, uniform per
+// wavefront (scalar loads), the activation is broadcast to both halves.
 struct PolicyWeights {
-    const float *w1;  // [16][64]       conv1.weight [oc][ic][ky][kx]
-    const float *b1;  // [16]
-    const float *w2;  // [16][16][4]    conv2 weights regrouped [ic][oc][ky][kx]
-    const float *b2;  // [16]
-    const float *wa;  // [3][1600]      actor_linear.weight
-    const float *ba;  // [3]
+    const float *stream;  // conv weights in consumption order, 16 batches of 16 pairs per channel pair:
+                          //   [cp 8][ conv1 [ic 4][ky 4][kx 4] | conv2 [oc pair 8][ic half 2][k 4] ] pairs, + one batch of padding
+    const float *b1;      // [16]
+    const f2 *b2;         // [8]
+    const float *wa;      // [3][1600]      actor_linear.weight
+    const float *ba;      // [3]
 };
+
+// A batch of 16 weight pairs in 32 SGPRs.  The compiler puts s_load + s_waitcnt lgkmcnt(0) right in front of
+// every use (scalar loads return out of order, so it can only wait for all of them): ~200 cycles exposed per 16
+// FMAs.  Here the NEXT batch is requested before the current one is consumed, and the wait sits one batch later.
+typedef float v16 __attribute__((ext_vector_type(16)));
+struct WBatch {
+    v16 a, b;
+};
+__device__ inline void wbatch_request(WBatch &w, const float *p) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(w.a), "=&s"(w.b) : "s"(p) : "memory");
+}
+__device__ inline void wbatch_wait(WBatch &w) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w.a), "+s"(w.b)); }
+// Pins a batch's FMAs between the volatile request / wait statements around it (plain asm statements with no
+// dependence on them may otherwise be scheduled across, which puts every wait right behind its own request).
+__device__ inline void fence4(f2 &a, f2 &b, f2 &c, f2 &d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ inline void fence2(f2 &a, f2 &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ inline f2 wbatch_get(const WBatch &w, int i) {  // i: compile-time constant
+    return i < 8 ? f2{w.a[2 * i], w.a[2 * i + 1]} : f2{w.b[2 * (i - 8)], w.b[2 * (i - 8) + 1]};
+}
+
+// acc += w * broadcast(x.lo) / broadcast(x.hi): the compiler materialises a broadcast operand as a second
+// register pair (doubling the 144 input registers), the instruction can select the half itself (op_sel).
+__device__ inline void pk_fma_lo(f2 &acc, f2 w, f2 x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(w), "v"(x));
+}
+__device__ inline void pk_fma_hi(f2 &acc, f2 w, f2 x) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(w), "v"(x));
+}
+__device__ inline void pk_fma_sel(f2 &acc, f2 w, f2 x, int half) {  // `half` is a compile-time constant after unrolling
+    if (half) pk_fma_hi(acc, w, x);
+    else pk_fma_lo(acc, w, x);
+}
+__device__ inline f2 relu2(f2 v) { return f2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}; }
 
 __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(PolicyWeights W, uint8_t *__restrict__ ring, int head,
                                                                            const uint8_t *__restrict__ frame, int64_t frame_stride,
                                                                            int32_t *__restrict__ actions, int64_t action_stride,
                                                                            float *__restrict__ logits_out, int64_t n) {
-    __shared__ __attribute__((aligned(16))) uint8_t sh_in[kEnvsPerWg][CRL_POLICY_STACK][kPlane];  // logical order: oldest first
-    __shared__ float sh_div[256];                                                              // b / 255.0f, correctly rounded
+    // the envs' rings as they lie in HBM (physical plane order), the new frame dropped into plane `head`
+    __shared__ __attribute__((aligned(16))) uint8_t sh_in[kEnvsPerWg][CRL_POLICY_STACK][kPlane];
+    __shared__ float sh_div[256];  // b / 255.0f, correctly rounded
     __shared__ float sh_part[kEnvsPerWg * kPos][3];
+    __shared__ float sh_grp[kEnvsPerWg][3][4];
     __shared__ float sh_logit[kEnvsPerWg][3];
     const int tid = threadIdx.x;
     const int64_t env0 = (int64_t)blockIdx.x * kEnvsPerWg;
 
     if (tid < 256) sh_div[tid] = (float)tid / 255.0f;
-    // stage the four planes (dwords); the new frame also replaces the oldest ring plane
-    for (int i = tid; i < kEnvsPerWg * CRL_POLICY_STACK * kPlaneWords; i += kPolicyThreads) {
-        const int e = i / (CRL_POLICY_STACK * kPlaneWords);
-        const int r = i - e * (CRL_POLICY_STACK * kPlaneWords);
-        const int j = r / kPlaneWords, d = r - j * kPlaneWords;
-        const int64_t env = env0 + e;
-        uint32_t v = 0;
-        if (env < n) {
-            uint32_t *rp = reinterpret_cast<uint32_t *>(ring + env * (int64_t)(CRL_POLICY_STACK * kPlane));
-            if (j < 3) {
-                v = rp[((head + 1 + j) & 3) * kPlaneWords + d];
-            } else {
-                v = reinterpret_cast<const uint32_t *>(frame + env * frame_stride)[d];
-                rp[head * kPlaneWords + d] = v;
-            }
+    // Stage: every load is issued before the first LDS write (a load-then-store loop costs one HBM round
+    // trip per iteration).  Ring: 441 16-byte chunks per env, contiguous over the workgroup's envs.
+    // Frame: 441 dwords per env (frames are only 4-byte aligned).
+    constexpr int kRingChunks = CRL_POLICY_STACK * kPlane / 16;  // 441
+    constexpr int kChunkIters = (kEnvsPerWg * kRingChunks + kPolicyThreads - 1) / kPolicyThreads;
+    constexpr int kWordIters = (kEnvsPerWg * kPlaneWords + kPolicyThreads - 1) / kPolicyThreads;
+    const int envs_here = (int)((n - env0) < kEnvsPerWg ? (n - env0) : kEnvsPerWg);
+    uint4 rc[kChunkIters];
+    uint32_t fw[kWordIters];
+    {
+        const uint4 *rsrc = reinterpret_cast<const uint4 *>(ring + env0 * (int64_t)(CRL_POLICY_STACK * kPlane));
+#pragma unroll
+        for (int k = 0; k < kChunkIters; k++) {
+            const int i = tid + k * kPolicyThreads;
+            rc[k] = i < envs_here * kRingChunks ? rsrc[i] : make_uint4(0, 0, 0, 0);
         }
-        reinterpret_cast<uint32_t *>(&sh_in[e][0][0])[r] = v;
+#pragma unroll
+        for (int k = 0; k < kWordIters; k++) {
+            const int i = tid + k * kPolicyThreads;
+            const int fe = i / kPlaneWords, d = i - fe * kPlaneWords;
+            fw[k] = fe < envs_here ? reinterpret_cast<const uint32_t *>(frame + (env0 + fe) * frame_stride)[d] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kChunkIters; k++) {
+            const int i = tid + k * kPolicyThreads;
+            if (i < kEnvsPerWg * kRingChunks) reinterpret_cast<uint4 *>(&sh_in[0][0][0])[i] = rc[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWordIters; k++) {
+        const int i = tid + k * kPolicyThreads;
+        const int fe = i / kPlaneWords, d = i - fe * kPlaneWords;
+        if (fe < kEnvsPerWg) reinterpret_cast<uint32_t *>(&sh_in[fe][head][0])[d] = fw[k];
+        if (fe < envs_here) reinterpret_cast<uint32_t *>(ring + (env0 + fe) * (int64_t)(CRL_POLICY_STACK * kPlane))[head * kPlaneWords + d] = fw[k];
     }
     __syncthreads();
 
-    const int e = tid / kPos, pos = tid - e * kPos;
+    // No divergent branch around the convolutions: the conv1 bias is fetched with v_readlane from lanes 0..15 of
+    // the wavefront, which must therefore hold it in EVERY wavefront that runs the loop (a wavefront whose live
+    // lanes stop before lane 15 would otherwise read registers that were never written).  Idle lanes (the last
+    // 12 of the workgroup, envs past the end) redo a valid position and drop the result.
+    const float b1i = W.b1[tid & 15];  // lane l of every wavefront holds conv1.bias[l & 15]
+    const int b1lane = __float_as_int(b1i);
+    const int e = tid < kEnvsPerWg * kPos ? tid / kPos : kEnvsPerWg - 1;
+    const int pos = tid < kEnvsPerWg * kPos ? tid - e * kPos : 0;
     const bool live = tid < kEnvsPerWg * kPos && env0 + e < n;
-    if (live) {
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    {
         const int y2 = pos / 10, x2 = pos - y2 * 10;
-        float in[4][6][6];
+        f2 in[4][6][3];  // the 6x6x4 patch as floats, columns (2k, 2k + 1) in one register pair
 #pragma unroll
         for (int ic = 0; ic < 4; ic++)
 #pragma unroll
             for (int r = 0; r < 6; r++) {
-                const uint8_t *row = &sh_in[e][ic][(4 * y2 + r) * kDim + 4 * x2];  // even offset
+                const uint8_t *row = &sh_in[e][(head + 1 + ic) & 3][(4 * y2 + r) * kDim + 4 * x2];  // logical plane ic; even offset
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const uint32_t two = *reinterpret_cast<const uint16_t *>(row + 2 * k);
-                    in[ic][r][2 * k] = sh_div[two & 255u];
-                    in[ic][r][2 * k + 1] = sh_div[two >> 8];
+                    in[ic][r][k] = f2{sh_div[two & 255u], sh_div[two >> 8]};
                 }
             }
-        float acc[16];
+        f2 acc[8];  // conv2 accumulators, output channels (2p, 2p + 1)
 #pragma unroll
-        for (int oc = 0; oc < 16; oc++) acc[oc] = W.b2[oc];
-        for (int c = 0; c < 16; c++) {  // conv1 output channel == conv2 input channel
-            const float *__restrict__ w1 = W.w1 + c * 64;
-            const float bias = W.b1[c];
-            float h00 = bias, h01 = bias, h10 = bias, h11 = bias;
-#pragma unroll
-            for (int ic = 0; ic < 4; ic++)
-#pragma unroll
-                for (int ky = 0; ky < 4; ky++)
-#pragma unroll
-                    for (int kx = 0; kx < 4; kx++) {
-                        const float w = w1[ic * 16 + ky * 4 + kx];
-                        h00 = __builtin_fmaf(w, in[ic][ky][kx], h00);
-                        h01 = __builtin_fmaf(w, in[ic][ky][kx + 2], h01);
-                        h10 = __builtin_fmaf(w, in[ic][ky + 2][kx], h10);
-                        h11 = __builtin_fmaf(w, in[ic][ky + 2][kx + 2], h11);
-                    }
-            h00 = fmaxf(h00, 0.f), h01 = fmaxf(h01, 0.f), h10 = fmaxf(h10, 0.f), h11 = fmaxf(h11, 0.f);
-            const float *__restrict__ w2 = W.w2 + c * 64;
-#pragma unroll
-            for (int oc = 0; oc < 16; oc++) {
-                float a = acc[oc];
-                a = __builtin_fmaf(w2[oc * 4 + 0], h00, a);
-                a = __builtin_fmaf(w2[oc * 4 + 1], h01, a);
-                a = __builtin_fmaf(w2[oc * 4 + 2], h10, a);
-                a = __builtin_fmaf(w2[oc * 4 + 3], h11, a);
-                acc[oc] = a;
-            }
+        for (int p = 0; p < 8; p++) acc[p] = W.b2[p];
+        const float *wp = W.stream;
+        WBatch wa_, wb_;
+        wbatch_request(wa_, wp);
+#define CRL_CONV1_BATCH(WB, IC)                                                  \
+    _Pragma("unroll") for (int ky = 0; ky < 4; ky++)                             \
+        _Pragma("unroll") for (int kx = 0; kx < 4; kx++) {                       \
+        const f2 w = wbatch_get(WB, ky * 4 + kx);                                \
+        pk_fma_sel(h00, w, in[IC][ky][kx >> 1], kx & 1);                         \
+        pk_fma_sel(h01, w, in[IC][ky][(kx >> 1) + 1], kx & 1);                   \
+        pk_fma_sel(h10, w, in[IC][ky + 2][kx >> 1], kx & 1);                     \
+        pk_fma_sel(h11, w, in[IC][ky + 2][(kx >> 1) + 1], kx & 1);               \
+    }                                                                            \
+    fence4(h00, h01, h10, h11);
+#define CRL_CONV2_BATCH(WB, J)                                                   \
+    {                                                                            \
+        f2 a0 = acc[2 * (J)], a1 = acc[2 * (J) + 1];                             \
+        pk_fma_lo(a0, wbatch_get(WB, 0), h00);                                   \
+        pk_fma_lo(a1, wbatch_get(WB, 8), h00);                                   \
+        pk_fma_lo(a0, wbatch_get(WB, 1), h01);                                   \
+        pk_fma_lo(a1, wbatch_get(WB, 9), h01);                                   \
+        pk_fma_lo(a0, wbatch_get(WB, 2), h10);                                   \
+        pk_fma_lo(a1, wbatch_get(WB, 10), h10);                                  \
+        pk_fma_lo(a0, wbatch_get(WB, 3), h11);                                   \
+        pk_fma_lo(a1, wbatch_get(WB, 11), h11);                                  \
+        pk_fma_hi(a0, wbatch_get(WB, 4), h00);                                   \
+        pk_fma_hi(a1, wbatch_get(WB, 12), h00);                                  \
+        pk_fma_hi(a0, wbatch_get(WB, 5), h01);                                   \
+        pk_fma_hi(a1, wbatch_get(WB, 13), h01);                                  \
+        pk_fma_hi(a0, wbatch_get(WB, 6), h10);                                   \
+        pk_fma_hi(a1, wbatch_get(WB, 14), h10);                                  \
+        pk_fma_hi(a0, wbatch_get(WB, 7), h11);                                   \
+        pk_fma_hi(a1, wbatch_get(WB, 15), h11);                                  \
+        fence2(a0, a1);                                                          \
+        acc[2 * (J)] = a0, acc[2 * (J) + 1] = a1;                                \
+    }
+#define CRL_STEP(CUR, NXT, OFS, WORK)   \
+    wbatch_wait(CUR);                   \
+    wbatch_request(NXT, wp + (OFS));    \
+    WORK
+        for (int cp = 0; cp < 8; cp++) {  // conv1 output channels (2cp, 2cp + 1) == conv2 input channels
+            const f2 bias = f2{__int_as_float(__builtin_amdgcn_readlane(b1lane, 2 * cp)), __int_as_float(__builtin_amdgcn_readlane(b1lane, 2 * cp + 1))};
+            f2 h00 = bias, h01 = bias, h10 = bias, h11 = bias;
+            CRL_STEP(wa_, wb_, 32, CRL_CONV1_BATCH(wa_, 0))
+            CRL_STEP(wb_, wa_, 64, CRL_CONV1_BATCH(wb_, 1))
+            CRL_STEP(wa_, wb_, 96, CRL_CONV1_BATCH(wa_, 2))
+            CRL_STEP(wb_, wa_, 128, CRL_CONV1_BATCH(wb_, 3))
+            h00 = relu2(h00), h01 = relu2(h01), h10 = relu2(h10), h11 = relu2(h11);
+            CRL_STEP(wa_, wb_, 160, CRL_CONV2_BATCH(wa_, 0))
+            CRL_STEP(wb_, wa_, 192, CRL_CONV2_BATCH(wb_, 1))
+            CRL_STEP(wa_, wb_, 224, CRL_CONV2_BATCH(wa_, 2))
+            CRL_STEP(wb_, wa_, 256, CRL_CONV2_BATCH(wb_, 3))  // the next channel pair's first batch (padding after the last)
+            wp += 256;
         }
-        float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+        wbatch_wait(wa_);  // drain the padding request
+#undef CRL_STEP
+#undef CRL_CONV1_BATCH
+#undef CRL_CONV2_BATCH
 #pragma unroll
         for (int oc = 0; oc < 16; oc++) {
-            const float f = fmaxf(acc[oc], 0.f);
+            const float f = fmaxf((oc & 1) ? acc[oc >> 1].y : acc[oc >> 1].x, 0.f);
             l0 = __builtin_fmaf(W.wa[0 * 1600 + oc * kPos + pos], f, l0);
             l1 = __builtin_fmaf(W.wa[1 * 1600 + oc * kPos + pos], f, l1);
             l2 = __builtin_fmaf(W.wa[2 * 1600 + oc * kPos + pos], f, l2);
         }
-        sh_part[tid][0] = l0, sh_part[tid][1] = l1, sh_part[tid][2] = l2;
+    }
+    if (live) sh_part[tid][0] = l0, sh_part[tid][1] = l1, sh_part[tid][2] = l2;
+    __syncthreads();
+    // fixed-shape sum over the 100 positions of an env (4 groups of 25, then the 4 groups): the result
+    // does not depend on scheduling
+    if (tid < kEnvsPerWg * 12) {
+        const int pe = tid / 12, r = tid - pe * 12, a = r >> 2, grp = r & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 25; p++) s += sh_part[pe * kPos + grp * 25 + p][a];
+        sh_grp[pe][a][grp] = s;
     }
     __syncthreads();
-    if (tid < kEnvsPerWg * 3) {  // fixed-order sum: results do not depend on scheduling
+    if (tid < kEnvsPerWg * 3) {
         const int pe = tid / 3, a = tid - pe * 3;
-        float s = W.ba[a];
-        for (int p = 0; p < kPos; p++) s += sh_part[pe * kPos + p][a];
-        sh_logit[pe][a] = s;
+        sh_logit[pe][a] = W.ba[a] + ((sh_grp[pe][a][0] + sh_grp[pe][a][1]) + (sh_grp[pe][a][2] + sh_grp[pe][a][3]));
     }
     __syncthreads();
     if (tid < kEnvsPerWg && env0 + tid < n) {
@@ -194,14 +295,16 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
     HIP_TRY(hipSetDevice(device));
     crl_policy *p = new crl_policy();
     p->device = device, p->n = num_envs;
-    // one blob: w1 1024 | b1 16 | w2 1024 | b2 16 | wa 4800 | ba 3 (+ pad)
-    std::vector<float> blob(1024 + 16 + 1024 + 16 + 4800 + 4, 0.f);
-    float *w1 = blob.data(), *b1 = w1 + 1024, *w2 = b1 + 16, *b2 = w2 + 1024, *wa = b2 + 16, *ba = wa + 4800;
-    memcpy(w1, conv1_w, 1024 * sizeof(float));
-    memcpy(b1, conv1_b, 16 * sizeof(float));
-    for (int oc = 0; oc < 16; oc++)  // torch [oc][ic][ky][kx] -> [ic][oc][ky][kx]
+    // one blob: stream 2048 + 32 pad | b1 16 | b2 16 | wa 4800 | ba 3 (+ pad)
+    std::vector<float> blob(2080 + 16 + 16 + 4800 + 4, 0.f);
+    float *st = blob.data(), *b1 = st + 2080, *b2 = b1 + 16, *wa = b2 + 16, *ba = wa + 4800;
+    for (int oc = 0; oc < 16; oc++)  // torch conv1 [oc][tap] -> [oc / 2][tap][oc & 1] at the head of block oc / 2
+        for (int k = 0; k < 64; k++) st[(oc >> 1) * 256 + k * 2 + (oc & 1)] = conv1_w[oc * 64 + k];
+    for (int oc = 0; oc < 16; oc++)  // torch conv2 [oc][ic][ky][kx] -> block ic / 2: [oc / 2][ic & 1][k][oc & 1]
         for (int ic = 0; ic < 16; ic++)
-            for (int k = 0; k < 4; k++) w2[(ic * 16 + oc) * 4 + k] = conv2_w[(oc * 16 + ic) * 4 + k];
+            for (int k = 0; k < 4; k++)
+                st[(ic >> 1) * 256 + 128 + (((oc >> 1) * 2 + (ic & 1)) * 4 + k) * 2 + (oc & 1)] = conv2_w[(oc * 16 + ic) * 4 + k];
+    memcpy(b1, conv1_b, 16 * sizeof(float));
     memcpy(b2, conv2_b, 16 * sizeof(float));
     memcpy(wa, actor_w, 4800 * sizeof(float));
     memcpy(ba, actor_b, 3 * sizeof(float));
@@ -213,8 +316,9 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
         crl_policy_destroy(p);
         return crl_fail(e == hipErrorOutOfMemory ? CRL_ENOMEM : CRL_EHIP, "crl_policy_create: %s", hipGetErrorString(e));
     }
-    p->W.w1 = p->weights, p->W.b1 = p->W.w1 + 1024, p->W.w2 = p->W.b1 + 16, p->W.b2 = p->W.w2 + 1024;
-    p->W.wa = p->W.b2 + 16, p->W.ba = p->W.wa + 4800;
+    const float *base = p->weights;  // hipMalloc: 256-byte aligned, so every 64-byte batch is aligned
+    p->W.stream = base, p->W.b1 = base + 2080, p->W.b2 = reinterpret_cast<const f2 *>(base + 2096);
+    p->W.wa = base + 2112, p->W.ba = base + 6912;
     *out = p;
     return CRL_OK;
 }

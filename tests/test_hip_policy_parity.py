@@ -49,9 +49,9 @@ def test_policy_kernel_replays_reference_trace(name):
     pol.close()
 
 
-@pytest.mark.parametrize("n", [1, 4, 5, 6, 333])
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 6, 7, 9, 333])
 def test_policy_kernel_vs_oracle_ragged_sizes(n):
-    """Random stacks (workgroups hold five envs: 1, 4, 5, 6 and 333 cover the ragged tails), strided
+    """Random stacks (workgroups hold five envs: the sizes cover every ragged tail, 1 to 4 envs in the last group), strided
     frame and action views, ring rotation over several calls."""
     _need_gpu()
     from oracle import policy_oracle as P
@@ -85,7 +85,9 @@ def test_policy_kernel_vs_oracle_ragged_sizes(n):
 
 def test_tournament_with_cnn_opponent_matches_oracle_game(atlas):
     """cPongTournament-v0 with the MEDIUM opponent end to end on the device: the same game as the CPU
-    oracle env stepped with the oracle policy's actions (frames bit-exact, so actions identical)."""
+    oracle env.  The opponent's action must be the oracle policy's wherever its two best logits are
+    clearly apart; in a near-tie (float32 summation order) the oracle env follows the device's choice,
+    so that one flipped action does not turn into a different game."""
     _need_gpu()
     import competitive_rl_amd as crl
     from oracle import policy_oracle as P
@@ -101,17 +103,23 @@ def test_tournament_with_cnn_opponent_matches_oracle_game(atlas):
     o_c = env.reset().copy()
     assert np.array_equal(o_h.cpu().numpy(), o_c[:, 0])
     rs = np.random.RandomState(5)
-    ndone = 0
+    ndone = nclear = 0
     for t in range(T):
         mine = rs.randint(0, 3, n)
         opp = ora(o_c[:, 1]).reshape(-1)
         o_h, r_h, d_h, _ = tour.step(mine)
-        o_c, r_c, d_c = env.step(np.stack([mine, opp], 1))
+        played = tour._act[:, 1].cpu().numpy()
+        srt = np.sort(ora.logits, 1)
+        clear = (srt[:, 2] - srt[:, 1]) > 10 * TOL
+        assert np.array_equal(played[clear], opp[clear]), t
+        nclear += int(clear.sum())
+        o_c, r_c, d_c = env.step(np.stack([mine, played], 1))
         o_c = o_c.copy()
         assert np.array_equal(o_h.cpu().numpy(), o_c[:, 0]), t
         assert np.array_equal(r_h.cpu().numpy().reshape(-1), r_c[:, 0]), t
         assert np.array_equal(d_h.cpu().numpy().reshape(-1), d_c.astype(bool)), t
         ndone += int(d_c.sum())
+    assert nclear > 0.9 * n * T
     # switching opponents keeps each policy's own stack (competitive_pong_env.py:28-34)
     tour.reset_opponent("WEAK")
     tour.step(rs.randint(0, 3, n))
