@@ -17,6 +17,7 @@
 // the 78.6 TFLOP/s a CDNA4 chip issues with plain v_fma_f32 (157 with packed fp32).
 // The stack is a ring of four planes: the new frame overwrites the oldest plane in place, so a call
 // reads 3 planes + the frame and writes 1 plane per env (8.8 KB) instead of rolling the stack.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -28,6 +29,9 @@ namespace crl {
 static constexpr int kDim = CRL_POLICY_DIM;            // 42
 static constexpr int kPlane = kDim * kDim;             // 1764 bytes
 static constexpr int kPlaneWords = kPlane / 4;         // 441
+static constexpr int kPlanePad = 1776;                 // a plane in the ring / in LDS: 111 16-byte chunks (12 bytes of padding)
+static constexpr int kPlaneChunks = kPlanePad / 16;    // 111
+static constexpr int kRingBytes = CRL_POLICY_STACK * kPlanePad;  // 7104 per env
 static constexpr int kEnvsPerWg = 5;
 static constexpr int kPos = 100;                       // 10 x 10 conv2 positions
 static constexpr int kPolicyThreads = 512;
@@ -79,88 +83,132 @@ __device__ inline void pk_fma_sel(f2 &acc, f2 w, f2 x, int half) {  // `half` is
 }
 __device__ inline f2 relu2(f2 v) { return f2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}; }
 
+// Request a group's data straight into LDS (global_load_lds: no registers are held while the loads are in flight):
+// the three ring planes that stay (16-byte chunks, planes are padded to 111 chunks for this) and the new frame
+// (dwords: frames are only 4-byte aligned) into the plane it replaces.  One wavefront-instruction fills a
+// contiguous run of LDS (M0 = run base, lane l lands at base + l * size), so the work is cut into (env, plane,
+// half) and (env, 64-dword run) pieces dealt to the eight wavefronts.
+// Issued as inline asm: with the builtin the compiler assumes that any later LDS read may alias the transfer
+// and waits for vmcnt(0) in front of the convolutions, which is exactly the overlap this is for.  The kernel
+// waits itself (vmcnt(0) + barrier before the buffer is read).  M0 = LDS base of the run (one wait state
+// between writing M0 and the LDS-DMA instruction); the compiler reserves M0 and sets it itself right before any
+// instruction of its own that reads it.
+typedef __attribute__((address_space(3))) void *lptr_t;
+__device__ inline uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(lptr_t)p; }
+__device__ inline void lds_dma_b128(const void *src, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
+__device__ inline void lds_dma_b32(const void *src, uint32_t lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
+__device__ inline void group_request(uint8_t *shbuf, const uint8_t *__restrict__ ring, int head, const uint8_t *__restrict__ frame,
+                                     int64_t frame_stride, int64_t env0, int envs_here, int wave, int lane) {
+    for (int s = wave; s < kEnvsPerWg * 3; s += kPolicyThreads / 64) {
+        const int fe = s / 3, j = s - fe * 3;
+        if (fe >= envs_here) continue;
+        const int pp = (head + 1 + j) & 3;
+        const uint8_t *src = ring + (env0 + fe) * (int64_t)kRingBytes + pp * kPlanePad;
+        uint8_t *dst = shbuf + (fe * CRL_POLICY_STACK + pp) * kPlanePad;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int c = half * 64 + lane;
+            if (c < kPlaneChunks) lds_dma_b128(src + c * 16, lds_addr(dst + half * 1024));
+        }
+    }
+    for (int s = wave; s < kEnvsPerWg * 7; s += kPolicyThreads / 64) {
+        const int fe = s / 7, q = s - fe * 7;
+        if (fe >= envs_here) continue;
+        const int d = q * 64 + lane;
+        const uint8_t *src = frame + (env0 + fe) * frame_stride;
+        uint8_t *dst = shbuf + (fe * CRL_POLICY_STACK + head) * kPlanePad + q * 256;
+        if (d < kPlaneWords) lds_dma_b32(src + d * 4, lds_addr(dst));
+    }
+}
+
+// after the group's loads have landed (vmcnt(0) + barrier): the new frame also replaces plane `head` of the ring
+__device__ inline void group_write_back(const uint8_t *shbuf, uint8_t *__restrict__ ring, int head, int64_t env0, int envs_here, int tid) {
+    for (int i = tid; i < envs_here * kPlaneChunks; i += kPolicyThreads) {
+        const int fe = i / kPlaneChunks, c = i - fe * kPlaneChunks;
+        const uint4 v = reinterpret_cast<const uint4 *>(shbuf + (fe * CRL_POLICY_STACK + head) * kPlanePad)[c];
+        reinterpret_cast<uint4 *>(ring + (env0 + fe) * (int64_t)kRingBytes + head * kPlanePad)[c] = v;
+    }
+}
+
+// Persistent workgroups (one per CU: 173 VGPRs leave two wavefronts per SIMD): workgroup b handles groups b,
+// b + gridDim.x, ...; the next group's 35 KB are requested before the current group's convolutions and land in
+// the other LDS buffer during them, so HBM latency is hidden behind the FMAs.  Tables that do not depend on the
+// group (actor weights, the b/255 table) are staged once.
+template <bool DBG>
 __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(PolicyWeights W, uint8_t *__restrict__ ring, int head,
                                                                            const uint8_t *__restrict__ frame, int64_t frame_stride,
                                                                            int32_t *__restrict__ actions, int64_t action_stride,
-                                                                           float *__restrict__ logits_out, int64_t n) {
-    // the envs' rings as they lie in HBM (physical plane order), the new frame dropped into plane `head`
-    __shared__ __attribute__((aligned(16))) uint8_t sh_in[kEnvsPerWg][CRL_POLICY_STACK][kPlane];
+                                                                           float *__restrict__ logits_out, int64_t n, int dbg_arg) {
+    const int dbg = DBG ? dbg_arg : 0;  // CRL_POLICY_DEBUG (profiling only): 1 skip the convolutions, 2 skip the patch gather
+    __shared__ __attribute__((aligned(16))) uint8_t sh_in[2][kEnvsPerWg][CRL_POLICY_STACK][kPlanePad];
+    __shared__ float sh_wa[3 * 1600];
     __shared__ float sh_div[256];  // b / 255.0f, correctly rounded
+    __shared__ __attribute__((aligned(8))) float sh_b2[16];  // conv2.bias; actor bias: no VMEM loads inside the loop,
+    __shared__ float sh_ba[4];                               // a wait on one would also wait on the group in flight
     __shared__ float sh_part[kEnvsPerWg * kPos][3];
     __shared__ float sh_grp[kEnvsPerWg][3][4];
     __shared__ float sh_logit[kEnvsPerWg][3];
     const int tid = threadIdx.x;
-    const int64_t env0 = (int64_t)blockIdx.x * kEnvsPerWg;
+    const int64_t ngroups = (n + kEnvsPerWg - 1) / kEnvsPerWg;
 
     if (tid < 256) sh_div[tid] = (float)tid / 255.0f;
-    // Stage: every load is issued before the first LDS write (a load-then-store loop costs one HBM round
-    // trip per iteration).  Ring: 441 16-byte chunks per env, contiguous over the workgroup's envs.
-    // Frame: 441 dwords per env (frames are only 4-byte aligned).
-    constexpr int kRingChunks = CRL_POLICY_STACK * kPlane / 16;  // 441
-    constexpr int kChunkIters = (kEnvsPerWg * kRingChunks + kPolicyThreads - 1) / kPolicyThreads;
-    constexpr int kWordIters = (kEnvsPerWg * kPlaneWords + kPolicyThreads - 1) / kPolicyThreads;
-    const int envs_here = (int)((n - env0) < kEnvsPerWg ? (n - env0) : kEnvsPerWg);
-    uint4 rc[kChunkIters];
-    uint32_t fw[kWordIters];
-    {
-        const uint4 *rsrc = reinterpret_cast<const uint4 *>(ring + env0 * (int64_t)(CRL_POLICY_STACK * kPlane));
-#pragma unroll
-        for (int k = 0; k < kChunkIters; k++) {
-            const int i = tid + k * kPolicyThreads;
-            rc[k] = i < envs_here * kRingChunks ? rsrc[i] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < kWordIters; k++) {
-            const int i = tid + k * kPolicyThreads;
-            const int fe = i / kPlaneWords, d = i - fe * kPlaneWords;
-            fw[k] = fe < envs_here ? reinterpret_cast<const uint32_t *>(frame + (env0 + fe) * frame_stride)[d] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < kChunkIters; k++) {
-            const int i = tid + k * kPolicyThreads;
-            if (i < kEnvsPerWg * kRingChunks) reinterpret_cast<uint4 *>(&sh_in[0][0][0])[i] = rc[k];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kWordIters; k++) {
-        const int i = tid + k * kPolicyThreads;
-        const int fe = i / kPlaneWords, d = i - fe * kPlaneWords;
-        if (fe < kEnvsPerWg) reinterpret_cast<uint32_t *>(&sh_in[fe][head][0])[d] = fw[k];
-        if (fe < envs_here) reinterpret_cast<uint32_t *>(ring + (env0 + fe) * (int64_t)(CRL_POLICY_STACK * kPlane))[head * kPlaneWords + d] = fw[k];
-    }
-    __syncthreads();
-
-    // No divergent branch around the convolutions: the conv1 bias is fetched with v_readlane from lanes 0..15 of
-    // the wavefront, which must therefore hold it in EVERY wavefront that runs the loop (a wavefront whose live
-    // lanes stop before lane 15 would otherwise read registers that were never written).  Idle lanes (the last
-    // 12 of the workgroup, envs past the end) redo a valid position and drop the result.
+    if (tid < 16) sh_b2[tid] = reinterpret_cast<const float *>(W.b2)[tid];
+    if (tid < 3) sh_ba[tid] = W.ba[tid];
+    for (int i = tid; i < 3 * 1600; i += kPolicyThreads) sh_wa[i] = W.wa[i];
+    // The conv1 bias is fetched with v_readlane from lanes 0..15 of the wavefront, so there is NO divergent
+    // branch around the convolutions: every wavefront that runs the loop must hold it in those lanes (a
+    // wavefront whose live lanes stop before lane 15 would read registers that were never written).  Idle
+    // lanes (the last 12 of the workgroup, envs past the end) redo a valid position and drop the result.
     const float b1i = W.b1[tid & 15];  // lane l of every wavefront holds conv1.bias[l & 15]
     const int b1lane = __float_as_int(b1i);
     const int e = tid < kEnvsPerWg * kPos ? tid / kPos : kEnvsPerWg - 1;
     const int pos = tid < kEnvsPerWg * kPos ? tid - e * kPos : 0;
-    const bool live = tid < kEnvsPerWg * kPos && env0 + e < n;
-    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    const int y2 = pos / 10, x2 = pos - y2 * 10;
+
+    const int wave = tid >> 6, lane = tid & 63;
+    int64_t g = blockIdx.x;
+    int buf = 0;
     {
-        const int y2 = pos / 10, x2 = pos - y2 * 10;
-        f2 in[4][6][3];  // the 6x6x4 patch as floats, columns (2k, 2k + 1) in one register pair
+        const int64_t env0 = g * kEnvsPerWg;
+        const int envs_here = (int)((n - env0) < kEnvsPerWg ? (n - env0) : kEnvsPerWg);
+        group_request(&sh_in[0][0][0][0], ring, head, frame, frame_stride, env0, envs_here, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        group_write_back(&sh_in[0][0][0][0], ring, head, env0, envs_here, tid);
+    }
+    while (g < ngroups) {
+        const int64_t env0 = g * kEnvsPerWg;
+        const int64_t gn = g + gridDim.x;
+        const int64_t env0n = gn * kEnvsPerWg;
+        const int envs_next = gn < ngroups ? (int)((n - env0n) < kEnvsPerWg ? (n - env0n) : kEnvsPerWg) : 0;
+        group_request(&sh_in[buf ^ 1][0][0][0], ring, head, frame, frame_stride, env0n, envs_next, wave, lane);  // lands during the convolutions
+
+        const bool live = tid < kEnvsPerWg * kPos && env0 + e < n;
+        float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+        {
+            f2 in[4][6][3];  // the 6x6x4 patch as floats, columns (2k, 2k + 1) in one register pair
 #pragma unroll
-        for (int ic = 0; ic < 4; ic++)
+            for (int ic = 0; ic < 4; ic++)
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                const uint8_t *row = &sh_in[e][(head + 1 + ic) & 3][(4 * y2 + r) * kDim + 4 * x2];  // logical plane ic; even offset
+                for (int r = 0; r < 6; r++) {
+                    // logical plane ic (oldest first) is ring plane (head + 1 + ic) & 3; even byte offset
+                    const uint8_t *row = &sh_in[buf][e][(head + 1 + ic) & 3][(4 * y2 + r) * kDim + 4 * x2];
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const uint32_t two = *reinterpret_cast<const uint16_t *>(row + 2 * k);
-                    in[ic][r][k] = f2{sh_div[two & 255u], sh_div[two >> 8]};
+                    for (int k = 0; k < 3; k++) {
+                        const uint32_t two = (dbg & 2) ? (uint32_t)(k + r) : *reinterpret_cast<const uint16_t *>(row + 2 * k);
+                        in[ic][r][k] = (dbg & 2) ? f2{(float)two, 1.f} : f2{sh_div[two & 255u], sh_div[two >> 8]};
+                    }
                 }
-            }
-        f2 acc[8];  // conv2 accumulators, output channels (2p, 2p + 1)
+            f2 acc[8];  // conv2 accumulators, output channels (2p, 2p + 1)
 #pragma unroll
-        for (int p = 0; p < 8; p++) acc[p] = W.b2[p];
-        const float *wp = W.stream;
-        WBatch wa_, wb_;
-        wbatch_request(wa_, wp);
+            for (int p = 0; p < 8; p++) acc[p] = reinterpret_cast<const f2 *>(sh_b2)[p];
+            const float *wp = W.stream;
+            WBatch wa_, wb_;
+            wbatch_request(wa_, wp);
 #define CRL_CONV1_BATCH(WB, IC)                                                  \
     _Pragma("unroll") for (int ky = 0; ky < 4; ky++)                             \
         _Pragma("unroll") for (int kx = 0; kx < 4; kx++) {                       \
@@ -197,60 +245,66 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
     wbatch_wait(CUR);                   \
     wbatch_request(NXT, wp + (OFS));    \
     WORK
-        for (int cp = 0; cp < 8; cp++) {  // conv1 output channels (2cp, 2cp + 1) == conv2 input channels
-            const f2 bias = f2{__int_as_float(__builtin_amdgcn_readlane(b1lane, 2 * cp)), __int_as_float(__builtin_amdgcn_readlane(b1lane, 2 * cp + 1))};
-            f2 h00 = bias, h01 = bias, h10 = bias, h11 = bias;
-            CRL_STEP(wa_, wb_, 32, CRL_CONV1_BATCH(wa_, 0))
-            CRL_STEP(wb_, wa_, 64, CRL_CONV1_BATCH(wb_, 1))
-            CRL_STEP(wa_, wb_, 96, CRL_CONV1_BATCH(wa_, 2))
-            CRL_STEP(wb_, wa_, 128, CRL_CONV1_BATCH(wb_, 3))
-            h00 = relu2(h00), h01 = relu2(h01), h10 = relu2(h10), h11 = relu2(h11);
-            CRL_STEP(wa_, wb_, 160, CRL_CONV2_BATCH(wa_, 0))
-            CRL_STEP(wb_, wa_, 192, CRL_CONV2_BATCH(wb_, 1))
-            CRL_STEP(wa_, wb_, 224, CRL_CONV2_BATCH(wa_, 2))
-            CRL_STEP(wb_, wa_, 256, CRL_CONV2_BATCH(wb_, 3))  // the next channel pair's first batch (padding after the last)
-            wp += 256;
-        }
-        wbatch_wait(wa_);  // drain the padding request
+            for (int cp = 0; cp < ((dbg & 1) ? 0 : 8); cp++) {  // conv1 output channels (2cp, 2cp + 1) == conv2 input channels
+                const f2 bias = f2{__int_as_float(__builtin_amdgcn_readlane(b1lane, 2 * cp)),
+                                   __int_as_float(__builtin_amdgcn_readlane(b1lane, 2 * cp + 1))};
+                f2 h00 = bias, h01 = bias, h10 = bias, h11 = bias;
+                CRL_STEP(wa_, wb_, 32, CRL_CONV1_BATCH(wa_, 0))
+                CRL_STEP(wb_, wa_, 64, CRL_CONV1_BATCH(wb_, 1))
+                CRL_STEP(wa_, wb_, 96, CRL_CONV1_BATCH(wa_, 2))
+                CRL_STEP(wb_, wa_, 128, CRL_CONV1_BATCH(wb_, 3))
+                h00 = relu2(h00), h01 = relu2(h01), h10 = relu2(h10), h11 = relu2(h11);
+                CRL_STEP(wa_, wb_, 160, CRL_CONV2_BATCH(wa_, 0))
+                CRL_STEP(wb_, wa_, 192, CRL_CONV2_BATCH(wb_, 1))
+                CRL_STEP(wa_, wb_, 224, CRL_CONV2_BATCH(wa_, 2))
+                CRL_STEP(wb_, wa_, 256, CRL_CONV2_BATCH(wb_, 3))  // the next channel pair's first batch (padding after the last)
+                wp += 256;
+            }
+            wbatch_wait(wa_);  // drain the padding request
 #undef CRL_STEP
 #undef CRL_CONV1_BATCH
 #undef CRL_CONV2_BATCH
 #pragma unroll
-        for (int oc = 0; oc < 16; oc++) {
-            const float f = fmaxf((oc & 1) ? acc[oc >> 1].y : acc[oc >> 1].x, 0.f);
-            l0 = __builtin_fmaf(W.wa[0 * 1600 + oc * kPos + pos], f, l0);
-            l1 = __builtin_fmaf(W.wa[1 * 1600 + oc * kPos + pos], f, l1);
-            l2 = __builtin_fmaf(W.wa[2 * 1600 + oc * kPos + pos], f, l2);
+            for (int oc = 0; oc < 16; oc++) {
+                const float f = fmaxf((oc & 1) ? acc[oc >> 1].y : acc[oc >> 1].x, 0.f);
+                l0 = __builtin_fmaf(sh_wa[0 * 1600 + oc * kPos + pos], f, l0);
+                l1 = __builtin_fmaf(sh_wa[1 * 1600 + oc * kPos + pos], f, l1);
+                l2 = __builtin_fmaf(sh_wa[2 * 1600 + oc * kPos + pos], f, l2);
+            }
         }
-    }
-    if (live) sh_part[tid][0] = l0, sh_part[tid][1] = l1, sh_part[tid][2] = l2;
-    __syncthreads();
-    // fixed-shape sum over the 100 positions of an env (4 groups of 25, then the 4 groups): the result
-    // does not depend on scheduling
-    if (tid < kEnvsPerWg * 12) {
-        const int pe = tid / 12, r = tid - pe * 12, a = r >> 2, grp = r & 3;
-        float s = 0.f;
+        if (live) sh_part[tid][0] = l0, sh_part[tid][1] = l1, sh_part[tid][2] = l2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's share of the next group has landed
+        __syncthreads();                                    // ... everybody's has; sh_part is published
+        group_write_back(&sh_in[buf ^ 1][0][0][0], ring, head, env0n, envs_next, tid);
+        // fixed-shape sum over the 100 positions of an env (4 groups of 25, then the 4 groups): the result
+        // does not depend on scheduling
+        if (tid < kEnvsPerWg * 12) {
+            const int pe = tid / 12, r = tid - pe * 12, a = r >> 2, grp = r & 3;
+            float s = 0.f;
 #pragma unroll
-        for (int p = 0; p < 25; p++) s += sh_part[pe * kPos + grp * 25 + p][a];
-        sh_grp[pe][a][grp] = s;
-    }
-    __syncthreads();
-    if (tid < kEnvsPerWg * 3) {
-        const int pe = tid / 3, a = tid - pe * 3;
-        sh_logit[pe][a] = W.ba[a] + ((sh_grp[pe][a][0] + sh_grp[pe][a][1]) + (sh_grp[pe][a][2] + sh_grp[pe][a][3]));
-    }
-    __syncthreads();
-    if (tid < kEnvsPerWg && env0 + tid < n) {
-        const float a0 = sh_logit[tid][0], a1 = sh_logit[tid][1], a2 = sh_logit[tid][2];
-        int best = 0;  // argmax, first index wins ties (torch.argmax)
-        float bv = a0;
-        if (a1 > bv) best = 1, bv = a1;
-        if (a2 > bv) best = 2;
-        actions[(env0 + tid) * action_stride] = best;
-        if (logits_out) {
-            float *lo = logits_out + (env0 + tid) * 3;
-            lo[0] = a0, lo[1] = a1, lo[2] = a2;
+            for (int p = 0; p < 25; p++) s += sh_part[pe * kPos + grp * 25 + p][a];
+            sh_grp[pe][a][grp] = s;
         }
+        __syncthreads();
+        if (tid < kEnvsPerWg * 3) {
+            const int pe = tid / 3, a = tid - pe * 3;
+            sh_logit[pe][a] = sh_ba[a] + ((sh_grp[pe][a][0] + sh_grp[pe][a][1]) + (sh_grp[pe][a][2] + sh_grp[pe][a][3]));
+        }
+        __syncthreads();
+        if (tid < kEnvsPerWg && env0 + tid < n) {
+            const float a0 = sh_logit[tid][0], a1 = sh_logit[tid][1], a2 = sh_logit[tid][2];
+            int best = 0;  // argmax, first index wins ties (torch.argmax)
+            float bv = a0;
+            if (a1 > bv) best = 1, bv = a1;
+            if (a2 > bv) best = 2;
+            actions[(env0 + tid) * action_stride] = best;
+            if (logits_out) {
+                float *lo = logits_out + (env0 + tid) * 3;
+                lo[0] = a0, lo[1] = a1, lo[2] = a2;
+            }
+        }
+        g = gn;
+        buf ^= 1;
     }
 }
 
@@ -261,7 +315,7 @@ __global__ void pong_policy_copy_stack_kernel(uint8_t *__restrict__ ring, uint8_
     const int64_t env = i / (CRL_POLICY_STACK * kPlaneWords);
     const int r = (int)(i - env * (CRL_POLICY_STACK * kPlaneWords));
     const int j = r / kPlaneWords, d = r - j * kPlaneWords;
-    uint32_t *rp = reinterpret_cast<uint32_t *>(ring) + env * (CRL_POLICY_STACK * kPlaneWords) + ((head + j) & 3) * kPlaneWords + d;
+    uint32_t *rp = reinterpret_cast<uint32_t *>(ring) + env * (kRingBytes / 4) + ((head + j) & 3) * (kPlanePad / 4) + d;
     uint32_t *ep = reinterpret_cast<uint32_t *>(ext) + i;
     if (to_ring) *rp = *ep;
     else *ep = *rp;
@@ -280,6 +334,7 @@ using namespace crl;
 struct crl_policy {
     int device = 0;
     int64_t n = 0;
+    int cus = 256;
     int head = 0;  // ring plane holding the OLDEST frame (the next one to be replaced)
     float *weights = nullptr;
     uint8_t *ring = nullptr;
@@ -295,6 +350,7 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
     HIP_TRY(hipSetDevice(device));
     crl_policy *p = new crl_policy();
     p->device = device, p->n = num_envs;
+    if (hipDeviceGetAttribute(&p->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || p->cus <= 0) p->cus = 256;
     // one blob: stream 2048 + 32 pad | b1 16 | b2 16 | wa 4800 | ba 3 (+ pad)
     std::vector<float> blob(2080 + 16 + 16 + 4800 + 4, 0.f);
     float *st = blob.data(), *b1 = st + 2080, *b2 = b1 + 16, *wa = b2 + 16, *ba = wa + 4800;
@@ -310,8 +366,8 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
     memcpy(ba, actor_b, 3 * sizeof(float));
     hipError_t e = hipMalloc(&p->weights, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->weights, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&p->ring, (size_t)num_envs * CRL_POLICY_STACK * kPlane);
-    if (e == hipSuccess) e = hipMemset(p->ring, 0, (size_t)num_envs * CRL_POLICY_STACK * kPlane);
+    if (e == hipSuccess) e = hipMalloc(&p->ring, (size_t)num_envs * kRingBytes);
+    if (e == hipSuccess) e = hipMemset(p->ring, 0, (size_t)num_envs * kRingBytes);
     if (e != hipSuccess) {
         crl_policy_destroy(p);
         return crl_fail(e == hipErrorOutOfMemory ? CRL_ENOMEM : CRL_EHIP, "crl_policy_create: %s", hipGetErrorString(e));
@@ -333,7 +389,7 @@ void crl_policy_destroy(crl_policy *p) {
 
 int crl_policy_reset(crl_policy *p, void *stream) {
     if (!p) return crl_fail(CRL_EINVAL, "crl_policy_reset: null policy");
-    HIP_TRY(hipMemsetAsync(p->ring, 0, (size_t)p->n * CRL_POLICY_STACK * kPlane, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(p->ring, 0, (size_t)p->n * kRingBytes, (hipStream_t)stream));
     p->head = 0;
     return CRL_OK;
 }
@@ -343,9 +399,15 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     if (!p || !frame_dev || !actions_dev) return crl_fail(CRL_EINVAL, "crl_policy_act: null argument");
     if (frame_stride < kPlane || (frame_stride & 3) || ((uintptr_t)frame_dev & 3) || action_stride < 1)
         return crl_fail(CRL_EINVAL, "crl_policy_act: frame_stride must be a multiple of 4 and >= 1764, frames 4-byte aligned");
-    const unsigned grid = (unsigned)((p->n + kEnvsPerWg - 1) / kEnvsPerWg);
-    hipLaunchKernelGGL(pong_policy_light_kernel, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head, frame_dev,
-                       frame_stride, actions_dev, action_stride, logits_dev, p->n);
+    static const int dbg = getenv("CRL_POLICY_DEBUG") ? atoi(getenv("CRL_POLICY_DEBUG")) : 0;  // profiling only (wrong outputs)
+    const int64_t groups = (p->n + kEnvsPerWg - 1) / kEnvsPerWg;
+    const unsigned grid = (unsigned)(groups < p->cus ? groups : p->cus);  // persistent: one workgroup per CU
+    if (dbg)
+        hipLaunchKernelGGL(pong_policy_light_kernel<true>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
+                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, dbg);
+    else
+        hipLaunchKernelGGL(pong_policy_light_kernel<false>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
+                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, 0);
     HIP_TRY(hipGetLastError());
     p->head = (p->head + 1) & 3;
     return CRL_OK;
