@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the cPongDouble hot path on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raw|fused84|fused84_newest|car] [--gather none|scalars|obs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raw|fused84|fused84_newest|car|tournament] [--gather none|scalars|obs]
 
 A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated,
 device-resident) random actions, auto-reset included, no host sync inside the timed loop.
@@ -99,12 +99,105 @@ def cpu_baseline_car(cores, budget_s):
             "sample": f"{k} steps x {len(envs)} envs, oracle/car_oracle.c step + 2 renders, 1 thread, {dt:.1f} s"}
 
 
+POLICY_FLOP_PER_ENV = 2 * 516800  # LightActorCritic: conv1 409 600 + conv2 102 400 + actor 4 800 multiply-adds
+FP32_VECTOR_PEAK = 157.3e12       # MI355X packed-fp32 vector peak (256 CUs x 4 SIMDs x 32 FMA lanes x 2.4 GHz x 2)
+
+
+def cpu_baseline_tournament(budget_s=12.0):
+    """CPU restatement of the same loop: oracle Pong env (42x42) + numpy LightActorCritic opponent."""
+    import numpy as np
+
+    from oracle import policy_oracle as P
+    from oracle import pong_oracle as po
+
+    atlas = np.load(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_score_atlas.npz"))["atlas"]
+    cores = len(os.sched_getaffinity(0))
+    n = 256
+    env = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=0)
+    env.set_threads(cores)
+    pol = P.PolicyOracle(P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_medium.npz")), n)
+    obs = env.reset().copy()
+    rs = np.random.RandomState(0)
+    t0, k = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        opp = pol(obs[:, 1]).reshape(-1)
+        obs, _, _ = env.step(np.stack([rs.randint(0, 3, n), opp], 1))
+        k += 1
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c (42x42) + oracle/policy_oracle.py (numpy/BLAS), {dt:.1f} s"}
+
+
+def bench_tournament(args, crl, torch, dist, dev, world, rank, n):
+    """SURVEY 8f N2 + N4: cPongTournament-v0 (42x42) against the MEDIUM CNN opponent, everything on the device."""
+    tour = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=0, device=dev, env_id_base=rank * n)
+    tour.reset_opponent("MEDIUM")
+    tour.reset()
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pool = [torch.randint(0, 3, (n,), generator=g, device=dev, dtype=torch.int32) for _ in range(16)]
+    pol = tour.current_agent
+    for i in range(args.warmup):
+        tour.step_device(pool[i % 16])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    act = pol.act_device
+
+    def timed_act(*a, **k):  # HIP events around the policy kernel, on the stream it is launched on (torch's current)
+        e0, e1 = ev[timed_act.i]
+        e0.record()
+        r = act(*a, **k)
+        e1.record()
+        timed_act.i += 1
+        return r
+
+    timed_act.i = 0
+    pol.act_device = timed_act
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tour.step_device(pool[i % 16])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k_us = sum(a.elapsed_time(b) for a, b in ev) / args.steps * 1e3
+    tour.close()
+    if rank == 0:
+        achieved = POLICY_FLOP_PER_ENV * n / (k_us * 1e-6)
+        line = {
+            "metric": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent",
+            "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cPongTournament-v0 {n} envs/GPU, 42x42 obs, opponent = reference checkpoint-medium (LightActorCritic) "
+                                   "served by the HIP policy kernel, 1 step = 4 frames + 1 opponent forward pass (SURVEY 8f N2+N4)",
+                       "envs_per_gpu": n, "actions": "uniform {0,1,2}, pre-generated on device", "auto_reset": True},
+            "roofline": {"bound": "valu_fp32", "kernel": "pong_policy_light_kernel", "achieved": achieved / 1e12,
+                         "peak": FP32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK, "traffic": None,
+                         "flop_per_launch": POLICY_FLOP_PER_ENV * n, "avg_kernel_us": k_us, "launches_timed": args.steps,
+                         "note": "fp32 vector FMAs (v_pk_fma_f32), not MFMA: the reference plays argmax of fp32 logits; "
+                                 "a plain v_fma_f32 stream peaks at 78.6, packed fp32 measured at 134-142 TFLOP/s on this chip"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_tournament()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["raw", "fused84", "fused84_newest", "car"], default="raw")
+    ap.add_argument("--workload", choices=["raw", "fused84", "fused84_newest", "car", "tournament"], default="raw")
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
     ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,6 +221,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.envs or (16384 if args.workload == "car" else 65536)
+    if args.workload == "tournament":
+        return bench_tournament(args, crl, torch, dist, dev, world, rank, n)
     if args.workload == "car":
         env = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=rank * n)
         raster_bytes, kernel = CAR_STEP_BYTES, "car_raster_kernel"

@@ -34,7 +34,8 @@ static constexpr int kPlaneChunks = kPlanePad / 16;    // 111
 static constexpr int kRingBytes = CRL_POLICY_STACK * kPlanePad;  // 7104 per env
 static constexpr int kEnvsPerWg = 5;
 static constexpr int kPos = 100;                       // 10 x 10 conv2 positions
-static constexpr int kPolicyThreads = 512;
+static constexpr int kPolicyThreads = 256;
+static constexpr int kPasses = 2;                      // 500 positions per group over 256 lanes
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -134,17 +135,19 @@ __device__ inline void group_write_back(const uint8_t *shbuf, uint8_t *__restric
     }
 }
 
-// Persistent workgroups (one per CU: 173 VGPRs leave two wavefronts per SIMD): workgroup b handles groups b,
-// b + gridDim.x, ...; the next group's 35 KB are requested before the current group's convolutions and land in
-// the other LDS buffer during them, so HBM latency is hidden behind the FMAs.  Tables that do not depend on the
-// group (actor weights, the b/255 table) are staged once.
+// Persistent workgroups, TWO per CU, four wavefronts each (173 VGPRs leave two wavefronts per SIMD: one of each
+// workgroup).  A workgroup takes groups b, b + gridDim.x, ... of five envs; per group it (1) pulls the rings and
+// frames into LDS, (2) runs the 500 conv2 positions in two passes of 256 lanes, (3) reduces the logits.  Steps
+// (1) and (3) and the patch gather of (2) keep the FMA pipes idle; the two workgroups of a CU drift apart, so
+// one's idle phases run under the other's convolutions.  Tables that do not depend on the group (actor weights,
+// biases, the b/255 table) are staged once.
 template <bool DBG>
 __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(PolicyWeights W, uint8_t *__restrict__ ring, int head,
                                                                            const uint8_t *__restrict__ frame, int64_t frame_stride,
                                                                            int32_t *__restrict__ actions, int64_t action_stride,
                                                                            float *__restrict__ logits_out, int64_t n, int dbg_arg) {
     const int dbg = DBG ? dbg_arg : 0;  // CRL_POLICY_DEBUG (profiling only): 1 skip the convolutions, 2 skip the patch gather
-    __shared__ __attribute__((aligned(16))) uint8_t sh_in[2][kEnvsPerWg][CRL_POLICY_STACK][kPlanePad];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_in[kEnvsPerWg][CRL_POLICY_STACK][kPlanePad];
     __shared__ float sh_wa[3 * 1600];
     __shared__ float sh_div[256];  // b / 255.0f, correctly rounded
     __shared__ __attribute__((aligned(8))) float sh_b2[16];  // conv2.bias; actor bias: no VMEM loads inside the loop,
@@ -165,29 +168,22 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
     // lanes (the last 12 of the workgroup, envs past the end) redo a valid position and drop the result.
     const float b1i = W.b1[tid & 15];  // lane l of every wavefront holds conv1.bias[l & 15]
     const int b1lane = __float_as_int(b1i);
-    const int e = tid < kEnvsPerWg * kPos ? tid / kPos : kEnvsPerWg - 1;
-    const int pos = tid < kEnvsPerWg * kPos ? tid - e * kPos : 0;
-    const int y2 = pos / 10, x2 = pos - y2 * 10;
-
     const int wave = tid >> 6, lane = tid & 63;
-    int64_t g = blockIdx.x;
-    int buf = 0;
-    {
+    __syncthreads();
+
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int64_t env0 = g * kEnvsPerWg;
         const int envs_here = (int)((n - env0) < kEnvsPerWg ? (n - env0) : kEnvsPerWg);
-        group_request(&sh_in[0][0][0][0], ring, head, frame, frame_stride, env0, envs_here, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        group_write_back(&sh_in[0][0][0][0], ring, head, env0, envs_here, tid);
-    }
-    while (g < ngroups) {
-        const int64_t env0 = g * kEnvsPerWg;
-        const int64_t gn = g + gridDim.x;
-        const int64_t env0n = gn * kEnvsPerWg;
-        const int envs_next = gn < ngroups ? (int)((n - env0n) < kEnvsPerWg ? (n - env0n) : kEnvsPerWg) : 0;
-        group_request(&sh_in[buf ^ 1][0][0][0], ring, head, frame, frame_stride, env0n, envs_next, wave, lane);  // lands during the convolutions
-
-        const bool live = tid < kEnvsPerWg * kPos && env0 + e < n;
+        group_request(&sh_in[0][0][0], ring, head, frame, frame_stride, env0, envs_here, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's share has landed
+        __syncthreads();                                    // ... everybody's has
+        group_write_back(&sh_in[0][0][0], ring, head, env0, envs_here, tid);
+      for (int pass = 0; pass < kPasses; pass++) {
+        const int task = pass * kPolicyThreads + tid;
+        const int e = task < kEnvsPerWg * kPos ? task / kPos : kEnvsPerWg - 1;
+        const int pos = task < kEnvsPerWg * kPos ? task - e * kPos : 0;
+        const int y2 = pos / 10, x2 = pos - y2 * 10;
+        const bool live = task < kEnvsPerWg * kPos && env0 + e < n;
         float l0 = 0.f, l1 = 0.f, l2 = 0.f;
         {
             f2 in[4][6][3];  // the 6x6x4 patch as floats, columns (2k, 2k + 1) in one register pair
@@ -196,7 +192,7 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
                     // logical plane ic (oldest first) is ring plane (head + 1 + ic) & 3; even byte offset
-                    const uint8_t *row = &sh_in[buf][e][(head + 1 + ic) & 3][(4 * y2 + r) * kDim + 4 * x2];
+                    const uint8_t *row = &sh_in[e][(head + 1 + ic) & 3][(4 * y2 + r) * kDim + 4 * x2];
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const uint32_t two = (dbg & 2) ? (uint32_t)(k + r) : *reinterpret_cast<const uint16_t *>(row + 2 * k);
@@ -272,10 +268,9 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
                 l2 = __builtin_fmaf(sh_wa[2 * 1600 + oc * kPos + pos], f, l2);
             }
         }
-        if (live) sh_part[tid][0] = l0, sh_part[tid][1] = l1, sh_part[tid][2] = l2;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's share of the next group has landed
-        __syncthreads();                                    // ... everybody's has; sh_part is published
-        group_write_back(&sh_in[buf ^ 1][0][0][0], ring, head, env0n, envs_next, tid);
+        if (live) sh_part[task][0] = l0, sh_part[task][1] = l1, sh_part[task][2] = l2;
+      }
+        __syncthreads();
         // fixed-shape sum over the 100 positions of an env (4 groups of 25, then the 4 groups): the result
         // does not depend on scheduling
         if (tid < kEnvsPerWg * 12) {
@@ -303,8 +298,7 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
                 lo[0] = a0, lo[1] = a1, lo[2] = a2;
             }
         }
-        g = gn;
-        buf ^= 1;
+        __syncthreads();  // sh_logit / sh_in are rewritten by the next group
     }
 }
 
@@ -401,7 +395,7 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
         return crl_fail(CRL_EINVAL, "crl_policy_act: frame_stride must be a multiple of 4 and >= 1764, frames 4-byte aligned");
     static const int dbg = getenv("CRL_POLICY_DEBUG") ? atoi(getenv("CRL_POLICY_DEBUG")) : 0;  // profiling only (wrong outputs)
     const int64_t groups = (p->n + kEnvsPerWg - 1) / kEnvsPerWg;
-    const unsigned grid = (unsigned)(groups < p->cus ? groups : p->cus);  // persistent: one workgroup per CU
+    const unsigned grid = (unsigned)(groups < 2 * p->cus ? groups : 2 * p->cus);  // persistent: two workgroups per CU
     if (dbg)
         hipLaunchKernelGGL(pong_policy_light_kernel<true>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
                            frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, dbg);

@@ -98,6 +98,22 @@ class TournamentEnvWrapper:
             done = done[:, 0]
         return obs[0], rew[:, 0].reshape(-1, 1), done.reshape(-1, 1), info
 
+    def step_device(self, actions_i32):
+        """Hot-loop entry (no host work, no clones, no sync): ``actions_i32`` is an int32 (N,) device tensor;
+        returns the env's device buffers (obs (N, 2, K, R, R) -- view 0 is the caller's --, rewards (N, 2),
+        done (N,)) like HipPongVecEnv.step_device."""
+        self._act[:, 0] = actions_i32
+        if isinstance(self.current_agent, Policy):
+            self.current_agent.act_device(self.prev_opponent_obs, out=self._act[:, 1])
+        elif self.current_agent_name == "RULE_BASED":
+            self._act[:, 1] = CHEAT_CODES
+        else:
+            self._act[:, 1] = torch.as_tensor(np.asarray(self.current_agent(self.prev_opponent_obs)).reshape(-1),
+                                              dtype=torch.int32).to(self._act.device)
+        buf, rew, done = self.env.step_device(self._act)
+        self.prev_opponent_obs = buf[:, 1]
+        return buf, rew, done
+
     def reset(self, **kwargs):
         obs = self.env.reset(**kwargs)
         self.prev_opponent_obs = obs[1]

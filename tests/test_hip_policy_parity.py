@@ -127,3 +127,25 @@ def test_tournament_with_cnn_opponent_matches_oracle_game(atlas):
     tour.step(rs.randint(0, 3, n))
     tour.close()
     env.close()
+
+
+def test_tournament_step_device_equals_step():
+    """The hot-loop entry (device buffers, no clones) plays the same game as the VecEnv-protocol step."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 11
+    a = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=3)
+    b = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=3)
+    for t_ in (a, b):
+        t_.reset_opponent("WEAK")
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    rs = np.random.RandomState(1)
+    for t in range(120):
+        act = rs.randint(0, 3, n)
+        oa, ra, da, _ = a.step(act)
+        buf, rew, done = b.step_device(torch.from_numpy(act.astype(np.int32)).cuda())
+        assert torch.equal(oa, buf[:, 0]) and torch.equal(ra[:, 0], rew[:, 0]) and torch.equal(da[:, 0], done.bool()), t
+    a.close()
+    b.close()
