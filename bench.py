@@ -171,6 +171,10 @@ def bench_tournament(args, crl, torch, dist, dev, world, rank, n):
     tour.close()
     if rank == 0:
         achieved = POLICY_FLOP_PER_ENV * n / (k_us * 1e-6)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_tournament.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         line = {
             "metric": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent",
             "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,7 +184,7 @@ def bench_tournament(args, crl, torch, dist, dev, world, rank, n):
                                    "served by the HIP policy kernel, 1 step = 4 frames + 1 opponent forward pass (SURVEY 8f N2+N4)",
                        "envs_per_gpu": n, "actions": "uniform {0,1,2}, pre-generated on device", "auto_reset": True},
             "roofline": {"bound": "valu_fp32", "kernel": "pong_policy_light_kernel", "achieved": achieved / 1e12,
-                         "peak": FP32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK, "traffic": None,
+                         "peak": FP32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK, "traffic": traffic,
                          "flop_per_launch": POLICY_FLOP_PER_ENV * n, "avg_kernel_us": k_us, "launches_timed": args.steps,
                          "note": "fp32 vector FMAs (v_pk_fma_f32), not MFMA: the reference plays argmax of fp32 logits; "
                                  "a plain v_fma_f32 stream peaks at 78.6, packed fp32 measured at 134-142 TFLOP/s on this chip"},

@@ -8,7 +8,9 @@ from .vec_env import CHEAT_CODES, HipPongVecEnv, LazyInfos, VecEnv
 from .vec_env_car import HipCarVecEnv
 from .frame_stack import FrameStackTensor
 from .tournament import TournamentEnvWrapper
+from .policy_serving import Policy
+from .competitive_car import make_competitive_car_racing
 from .sharding import ShardSpec, all_gather_step, shard_of
 
-__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "CHEAT_CODES",
+__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "CHEAT_CODES",
            "ShardSpec", "shard_of", "all_gather_step"]

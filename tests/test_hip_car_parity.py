@@ -524,3 +524,45 @@ def test_step_pipeline_frames_equal_a_single_render():
         assert torch.equal(obs, env.render_current()), t
     assert seen["coupled"] > 0 and seen["done"] > 0, seen
     env.close()
+
+
+def test_make_competitive_car_racing_matches_double_env():
+    """make_competitive_car_racing (make_competitive_car_racing.py:10-58): the learner drives car 0, the opponent
+    policy -- evaluated on the observation of the PREVIOUS step or reset -- drives car 1, and only agent 0's
+    outputs come back.  Same game as stepping cCarRacingDouble-v0 by hand with those actions; per-env and
+    batched opponent protocols agree."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, K, T = 6, 4, 25
+    calls = []
+
+    def per_env_policy(o):  # reference protocol: one env's (K, 96, 96) stack in, one action out
+        assert isinstance(o, np.ndarray) and o.shape == (K, 96, 96)
+        calls.append(1)
+        return [float(o[-1, 70:, :].mean() > 120.0) - 0.5, 0.4]
+
+    def batched_policy(o):
+        assert tuple(o.shape) == (n, K, 96, 96)
+        steer = (o[:, -1, 70:, :].float().mean(dim=(1, 2)) > 120.0).float() - 0.5
+        return torch.stack([steer, torch.full_like(steer, 0.4)], 1)
+
+    a = crl.make_competitive_car_racing(per_env_policy, seed=5, num_envs=n, frame_stack=K)
+    b = crl.make_competitive_car_racing(batched_policy, seed=5, num_envs=n, frame_stack=K, batched=True)
+    ref = crl.make_envs("cCarRacingDouble-v0", num_envs=n, seed=5, log_dir=None, frame_stack=K)
+    oa, ob, orf = a.reset(), b.reset(), ref.reset()
+    assert tuple(oa.shape) == (n, K, 96, 96) and a.action_space.shape == (2,)
+    assert torch.equal(oa, ob) and torch.equal(oa, orf[:, :K])
+    assert len(calls) == n
+    rs = np.random.RandomState(2)
+    for t in range(T):
+        mine = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+        opp = batched_policy(orf[:, K:]).cpu().numpy()  # from the previous observation
+        oa, ra, da, ia = a.step(mine)
+        ob, rb, db, _ = b.step(mine)
+        orf, rr, dr, ir = ref.step(np.stack([mine, opp], 1))
+        assert torch.equal(oa, ob) and torch.equal(oa, orf[:, :K]), t
+        assert torch.equal(ra, rr) and torch.equal(ra, rb) and torch.equal(da, dr) and tuple(ra.shape) == (n, 1), t
+        assert ia[0] == {"num_steps": ir[0][0]["num_steps"]}
+    for e in (a, b, ref):
+        e.close()
