@@ -149,3 +149,29 @@ def test_tournament_step_device_equals_step():
         assert torch.equal(oa, buf[:, 0]) and torch.equal(ra[:, 0], rew[:, 0]) and torch.equal(da[:, 0], done.bool()), t
     a.close()
     b.close()
+
+
+def test_policy_abi_rejects_bad_arguments():
+    """Error behaviour across the C ABI: return codes + crl_last_error, no crash."""
+    _need_gpu()
+    import ctypes as C
+
+    import competitive_rl_amd._native as N
+
+    pol = make_policy("weak", 3)
+    L = N.load()
+    frames = torch.zeros((3, 1, 42, 42), dtype=torch.uint8, device="cuda")
+    acts = torch.zeros((3,), dtype=torch.int32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.crl_policy_act(pol._h, C.c_void_p(frames.data_ptr()), 1763, C.c_void_p(acts.data_ptr()), 1, None, st) == -1
+    assert b"frame_stride" in L.crl_last_error()
+    assert L.crl_policy_act(pol._h, None, 1764, C.c_void_p(acts.data_ptr()), 1, None, st) == -1
+    assert L.crl_policy_act(pol._h, C.c_void_p(frames.data_ptr()), 1764, C.c_void_p(acts.data_ptr()), 1, None, st) == 0
+    h = C.c_void_p()
+    assert L.crl_policy_create(0, 0, None, None, None, None, None, None, C.byref(h)) == -1
+    with pytest.raises(NotImplementedError):
+        import competitive_rl_amd as crl
+        import competitive_rl_amd.tournament as T
+        crl.Policy(T.single_obs_space, T.single_act_space, 3, use_light_model=False)
+    pol.close()
+    pol.close()  # idempotent

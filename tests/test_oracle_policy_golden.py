@@ -48,3 +48,26 @@ def test_shipped_names_match_reference_list():
 
     assert T.get_builtin_agent_names() == ["RANDOM", "WEAK", "MEDIUM", "RULE_BASED"]
     assert T.single_obs_space.shape == (1, 42, 42) and T.single_act_space.n == 3
+
+
+def test_policy_has_no_cpu_fallback():
+    """The product Policy is the HIP kernel or nothing: on a box without a GPU it refuses to construct."""
+    import torch
+
+    import competitive_rl_amd as crl
+    import competitive_rl_amd.tournament as T
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        crl.Policy(T.single_obs_space, T.single_act_space, 4, crl.policy_serving.BUILTIN_CHECKPOINTS["WEAK"], use_light_model=True)
+
+
+def test_shipped_weights_are_the_reference_checkpoints():
+    """The npz assets hold the eight model tensors of the reference checkpoints unchanged (shape + a checksum that
+    the golden logits depend on: forward() above would not match otherwise)."""
+    for name in ("weak", "medium"):
+        w = weights(name)
+        assert w["conv1_w"].shape == (16, 4, 4, 4) and w["conv2_w"].shape == (16, 16, 2, 2) and w["actor_w"].shape == (3, 1600)
+        assert all(np.isfinite(v).all() for v in w.values())
+    assert not np.array_equal(weights("weak")["actor_w"], weights("medium")["actor_w"])
