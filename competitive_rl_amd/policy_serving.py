@@ -99,7 +99,8 @@ class Policy:
         obs = obs.to(self.device)
         if obs.dtype != torch.uint8:  # DummyVecEnv hands float32 arrays holding 0..255 integers
             obs = obs.to(torch.uint8)
-        obs = obs.reshape(self.num_envs, 42, 42) if obs.dim() != 4 else obs[:, 0]
+        # (N, C, 42, 42): the newest plane is the last channel (C = 1 under the reference's cPongDouble wrappers)
+        obs = obs.reshape(self.num_envs, 42, 42) if obs.dim() != 4 else obs[:, -1]
         if obs.stride(2) != 1 or obs.stride(1) != 42 or obs.stride(0) % 4 or obs.data_ptr() % 4:
             obs = obs.contiguous()
         return obs
