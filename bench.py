@@ -234,7 +234,7 @@ def main():
                 "(BASELINE config #4)")
     elif args.workload == "raw":
         env = crl.HipPongVecEnv(n, seed=0, mode="raw", device=dev, env_id_base=rank * n)
-        raster_bytes, kernel = RAW_RASTER_BYTES, "pong_raster_raw_linear_kernel"
+        raster_bytes, kernel = RAW_RASTER_BYTES, "pong_raster_raw_sweep_kernel"
         desc = f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)"
     elif args.workload == "fused84_newest":
         # variant of config #3: only the newest plane is written, the consumer keeps the stack

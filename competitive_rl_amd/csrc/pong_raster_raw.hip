@@ -13,8 +13,9 @@
 //   rows >=194: white.
 // Agent 1's view is rows >= 25 mirrored; since every pixel is achromatic (R=G=B) a
 // mirrored chunk is the byte-reversed chunk (29 - c) of the unmirrored row.
-// Two work splits: pong_raster_raw_linear_kernel (production, below) and the original one
-// workgroup per env (thread t writes chunks t, t+256, ...; kept as CRL_RAW_LINEAR=0 for A/B).
+// Three work splits: pong_raster_raw_sweep_kernel (production: address-linear, a thread's four chunks a whole grid
+// apart), pong_raster_raw_linear_kernel (address-linear, a workgroup's chunks contiguous; CRL_RAW_SWEEP=0) and the
+// original one workgroup per env (thread t writes chunks t, t+256, ...; CRL_RAW_SWEEP=0 CRL_RAW_LINEAR=0), kept for A/B.
 #include <stdlib.h>
 
 #include "pong_device.h"
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void pong_raster_raw_kernel(const uint64_t *__
     }
 }
 
-// Address-linear kernel (the production path): workgroup b writes chunks [b * 512, (b + 1) * 512) of
+// Address-linear kernel, workgroup-contiguous (production until the sweep variant below): workgroup b writes chunks [b * 512, (b + 1) * 512) of
 // the WHOLE output tensor -- two 16-byte chunks per thread, 8 KiB per workgroup -- whichever envs
 // they belong to (at most two).  Measured on MI355X at 65 536 envs (13.2 GB per launch):
 //   one workgroup per env, 49 chunks per thread            2 250-2 300 us  (5.8 TB/s)
@@ -139,11 +140,90 @@ __global__ __launch_bounds__(THREADS) void pong_raster_raw_linear_kernel(const u
     }
 }
 
+// Sweep variant of the address-linear kernel: thread t of workgroup b writes chunks b * 256 + t + i * (gridDim.x * 256),
+// i = 0 .. ITERS-1 -- every "round" i of the whole chip is one dense linear sweep over 1/ITERS of the tensor.  Pure-store
+// probes (tools/store_order_probe.hip): a wavefront that walks through a private contiguous span makes the chip write a
+// comb (one tooth per resident wavefront) and loses 8-20 % of the fill rate; stores a whole grid apart do not, however
+// many a wavefront issues.  Per round a workgroup's 4 KB block touches at most two envs (two scalar descriptor loads).
+template <int ITERS, int VIEWS>
+__global__ __launch_bounds__(256) void pong_raster_raw_sweep_kernel(const uint64_t *__restrict__ frames, const uint4 *__restrict__ atlas_rgb,
+                                                                    int ink_row0, int ink_row1, uint4 *__restrict__ obs, int64_t n, int dbg) {
+    constexpr int per_env = VIEWS * kFrameChunks;
+    const int64_t total = n * per_env;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    Frame f0[ITERS], f1[ITERS];
+    int q0[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        int64_t g0 = (int64_t)blockIdx.x * 256 + i * stride;
+        g0 = g0 < total ? g0 : total - 1;
+        const int64_t e0 = g0 / per_env;
+        const int64_t e1 = e0 + 1 < n ? e0 + 1 : e0;
+        f0[i] = unpack_frame(frames[e0]), f1[i] = unpack_frame(frames[e1]);  // uniform -> scalar loads, all issued up front
+        q0[i] = (int)(g0 - e0 * per_env);
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        const int64_t g = (int64_t)blockIdx.x * 256 + i * stride + threadIdx.x;
+        if (g >= total) break;
+        int q = q0[i] + (int)threadIdx.x;
+        const bool second = q >= per_env;
+        q -= second ? per_env : 0;
+        Frame f;
+        f.x = second ? f1[i].x : f0[i].x, f.y = second ? f1[i].y : f0[i].y, f.bl = second ? f1[i].bl : f0[i].bl, f.br = second ? f1[i].br : f0[i].br;
+        f.sl = second ? f1[i].sl : f0[i].sl, f.sr = second ? f1[i].sr : f0[i].sr;
+        const bool blank = f.sl == 255;
+        const uint32_t bg = blank ? 0u : 0xFFFFFFFFu;
+        const int view = q >= kFrameChunks;
+        const int c = q - view * kFrameChunks;
+        const int row = c / kRowChunks;
+        const int cc = c - row * kRowChunks;
+        const bool mirror = view && row >= CRL_PONG_MIRROR_ROW;
+        const int sc = mirror ? (kRowChunks - 1 - cc) : cc;  // source chunk in the unmirrored row
+        uint4 v = make_uint4(bg, bg, bg, bg);
+        if (!blank && !(dbg & 1)) {
+            if (row < CRL_PONG_TOP) {
+                if (row >= ink_row0 && row < ink_row1 && !(dbg & 2)) v = atlas_rgb[(int64_t)((f.sl * 22 + f.sr) * CRL_PONG_TOP + row) * kRowChunks + sc];
+            } else if (row < CRL_PONG_BOTTOM) {
+                const int lo = sc * 16;
+                uint32_t m = 0;
+                if (row >= f.y && row < f.y + CRL_PONG_BALL) m |= span_bits(3 * f.x - lo, 3 * (f.x + CRL_PONG_BALL) - lo);
+                if (row >= f.bl && row < f.bl + CRL_PONG_BAT_H)
+                    m |= span_bits(3 * CRL_PONG_BATL_X - lo, 3 * (CRL_PONG_BATL_X + CRL_PONG_BAT_W) - lo);
+                if (row >= f.br && row < f.br + CRL_PONG_BAT_H)
+                    m |= span_bits(3 * CRL_PONG_BATR_X - lo, 3 * (CRL_PONG_BATR_X + CRL_PONG_BAT_W) - lo);
+                v = make_uint4(nibble_to_bytes(m & 15u), nibble_to_bytes((m >> 4) & 15u), nibble_to_bytes((m >> 8) & 15u),
+                               nibble_to_bytes((m >> 12) & 15u));
+            }
+            if (mirror) v = make_uint4(bswap32(v.w), bswap32(v.z), bswap32(v.y), bswap32(v.x));
+        }
+        obs[g] = v;
+    }
+}
+
 void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *atlas_rgb, int ink_row0, int ink_row1,
                             uint8_t *obs, int views, hipStream_t st) {
     if (n <= 0) return;
     static const int dbg = getenv("CRL_RAW_DEBUG") ? atoi(getenv("CRL_RAW_DEBUG")) : 0;
     static const int lin = getenv("CRL_RAW_LINEAR") ? atoi(getenv("CRL_RAW_LINEAR")) : 2;
+    static const int sweep = getenv("CRL_RAW_SWEEP") ? atoi(getenv("CRL_RAW_SWEEP")) : 4;  // 0: the workgroup-contiguous kernels below
+    if (sweep > 0 && (views == 1 || views == 2)) {
+        const int64_t total = n * views * kFrameChunks;
+        const uint4 *at = reinterpret_cast<const uint4 *>(atlas_rgb);
+        uint4 *ob = reinterpret_cast<uint4 *>(obs);
+#define CRL_LAUNCH_SWEEP(I, V)                                                                                              \
+    hipLaunchKernelGGL((pong_raster_raw_sweep_kernel<I, V>), dim3((unsigned)((total + 256 * I - 1) / (256 * I))), dim3(256), 0, st, frames, \
+                       at, ink_row0, ink_row1, ob, n, dbg)
+        if (views == 2) {
+            if (sweep <= 2) CRL_LAUNCH_SWEEP(2, 2);
+            else if (sweep <= 4) CRL_LAUNCH_SWEEP(4, 2);
+            else CRL_LAUNCH_SWEEP(8, 2);
+        } else {
+            CRL_LAUNCH_SWEEP(4, 1);
+        }
+#undef CRL_LAUNCH_SWEEP
+        return;
+    }
     if (lin > 0 && (views == 1 || views == 2)) {
         const int64_t total = n * views * kFrameChunks;
         const uint4 *at = reinterpret_cast<const uint4 *>(atlas_rgb);

@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"raw": "pong_raster_raw_linear_kernel", "fused84": "pong_raster_gray", "fused84_newest": "pong_raster_gray",
+DOMINANT = {"raw": "pong_raster_raw_sweep_kernel", "fused84": "pong_raster_gray", "fused84_newest": "pong_raster_gray",
             "car": "car_raster_kernel", "tournament": "pong_policy_light_kernel"}
 
 
