@@ -8,15 +8,18 @@
 // One kernel per call: u8 frames in, int32 actions out; nothing else touches HBM but the 7 KB
 // stack per env.  The two convolutions fuse exactly because conv2 is 2x2 with stride 2: each of the
 // 10x10 conv2 positions owns its 2x2 block of conv1 outputs (16 channels) and its 6x6x4 input
-// patch.  One lane per conv2 position, five envs per 512-thread workgroup (500 lanes busy):
-//   conv1: 4 positions x 16 channels x 64 taps = 4 096 FMAs per lane   (weights: scalar loads)
-//   conv2: 16 channels x 64 taps                = 1 024 FMAs per lane   (weights: scalar loads)
-//   actor: 3 x 16 per lane, then a fixed-order sum over the 100 lanes of an env in LDS
-// = 516 800 FMAs per env, fp32 VALU (bf16/fp8 MFMA would change which action wins in close
-// calls; the reference is fp32).  Roofline: 65 536 envs x 1.03 MFLOP = 67.7 GFLOP per call against
-// the 78.6 TFLOP/s a CDNA4 chip issues with plain v_fma_f32 (157 with packed fp32).
-// The stack is a ring of four planes: the new frame overwrites the oldest plane in place, so a call
-// reads 3 planes + the frame and writes 1 plane per env (8.8 KB) instead of rolling the stack.
+// patch.  One lane per conv2 position; a workgroup (256 threads) takes five envs at a time = 500
+// positions in two passes:
+//   conv1: 4 positions x 16 channels x 64 taps = 4 096 FMAs per lane
+//   conv2: 16 channels x 64 taps                = 1 024 FMAs per lane
+//   actor: 3 x 16 per lane, then a fixed-shape sum over the 100 lanes of an env in LDS
+// = 516 800 FMAs per env, fp32 on the vector pipes as v_pk_fma_f32 (output channels in pairs, weights
+// uniform in SGPRs): bf16/fp8 MFMA would change which action wins in close calls, the reference is
+// fp32.  Roofline: 65 536 envs x 1.03 MFLOP = 67.7 GFLOP per call against 157.3 TFLOP/s packed fp32
+// (measured issue rate on this chip 134-142; plain v_fma_f32 76.6).  DESIGN.md 4c has the history.
+// The stack is a ring of four planes (padded to 111 16-byte chunks): the new frame overwrites the
+// oldest plane in place, so a call reads 3 planes + the frame and writes 1 plane per env instead of
+// rolling the stack; both go global -> LDS by LDS-DMA.
 #include <stdlib.h>
 #include <string.h>
 
