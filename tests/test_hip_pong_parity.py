@@ -441,3 +441,42 @@ def test_c_abi_demo_runs_without_python_in_the_loop():
     r = subprocess.run([exe, "2048", "120"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "env-steps/s" in r.stdout
+
+
+def test_step_envs_device_and_host_flows_agree():
+    """step_envs (utils/utils.py:23-60): the reference's host flow (numpy env outputs, numpy episode_rewards) and the
+    device flow (torch env outputs, device episode_rewards, device FrameStackTensor) keep identical books."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, T = 24, 600
+    outs = {}
+    for mode in ("numpy", "torch"):
+        env = crl.make_envs("cPongDouble-v0", num_envs=n, frame_stack=None, log_dir=None, seed=8, output=mode)
+        obs = env.reset()
+        fst = crl.FrameStackTensor(n, (1, 42, 42), 4, "cuda")
+        fst.update(obs[0])
+        ep = np.zeros((n, 1), np.float32) if mode == "numpy" else torch.zeros((n, 1), device="cuda")
+        rr, lr, steps, eps = [], [], 0, 0
+        rs = np.random.RandomState(4)
+        for t in range(T):
+            acts = np.stack([rs.randint(0, 3, n), np.full(n, 999)], 1)
+            env_step = env.step
+
+            class OneAgentReward:  # the trainers use single-agent rewards: feed agent 0's column
+                num_envs = n
+
+                @staticmethod
+                def step(a):
+                    o, r, d, i = env_step(a)
+                    return o, r[:, :1], d, i
+
+            _, _, done, _, masks, eps, steps, ep = crl.step_envs(acts, OneAgentReward, ep, fst, rr, lr, steps, eps, "cuda", False)
+            assert tuple(masks.shape) == (n, 1) and tuple(done.shape) == (n,)
+        outs[mode] = (np.array([float(np.asarray(x).reshape(-1)[0]) for x in rr]), list(lr), steps, eps,
+                      fst.get().cpu().numpy(), ep.cpu().numpy() if mode == "torch" else ep)
+        env.close()
+    a, b = outs["numpy"], outs["torch"]
+    assert a[3] == b[3] > 0 and a[2] == b[2] == n * T
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
