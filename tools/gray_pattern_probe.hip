@@ -46,6 +46,18 @@ __global__ __launch_bounds__(256) void p_wg_4env(uint4* out, int64_t n) {
     uint4* o = out + (int64_t)blockIdx.x * 4 * kEnv;
     for (int c = threadIdx.x; c < 4 * kEnv; c += 256) o[c] = make_uint4(c, 1, 2, 3);
 }
+// P3b: one 1 024-thread workgroup (16 waves) per env: 16 KB per sweep
+__global__ __launch_bounds__(1024) void p_wg1024_env(uint4* out, int64_t n) {
+    touch_lds<38>();
+    uint4* o = out + (int64_t)blockIdx.x * kEnv;
+    for (int c = threadIdx.x; c < kEnv; c += 1024) o[c] = make_uint4(c, 1, 2, 3);
+}
+// P3c: one 1 024-thread workgroup per 4 envs (the production kernel's envs per workgroup), 16 KB per sweep over 226 KB
+__global__ __launch_bounds__(1024) void p_wg1024_4env(uint4* out, int64_t n) {
+    touch_lds<38>();
+    uint4* o = out + (int64_t)blockIdx.x * 4 * kEnv;
+    for (int c = threadIdx.x; c < 4 * kEnv; c += 1024) o[c] = make_uint4(c, 1, 2, 3);
+}
 // P5: address-linear, 1 chunk per thread
 __global__ __launch_bounds__(256) void p_linear(uint4* out, int64_t total) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -71,5 +83,7 @@ int main() {
     run("workgroup per env (4 waves sweep 56 KB), 16 waves/CU", [&] { p_wg_env<38><<<(unsigned)n, 256>>>(out, n); });
     run("workgroup per env, 32 waves/CU", [&] { p_wg_env<16><<<(unsigned)n, 256>>>(out, n); });
     run("workgroup per 4 envs (sweep 226 KB), 16 waves/CU", [&] { p_wg_4env<38><<<(unsigned)(n / 4), 256>>>(out, n); });
+    run("1 024-thread workgroup per env (16 waves sweep 56 KB)", [&] { p_wg1024_env<<<(unsigned)n, 1024>>>(out, n); });
+    run("1 024-thread workgroup per 4 envs (sweep 226 KB)", [&] { p_wg1024_4env<<<(unsigned)(n / 4), 1024>>>(out, n); });
     return 0;
 }
