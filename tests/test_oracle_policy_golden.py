@@ -71,3 +71,20 @@ def test_shipped_weights_are_the_reference_checkpoints():
         assert w["conv1_w"].shape == (16, 4, 4, 4) and w["conv2_w"].shape == (16, 16, 2, 2) and w["actor_w"].shape == (3, 1600)
         assert all(np.isfinite(v).all() for v in w.values())
     assert not np.array_equal(weights("weak")["actor_w"], weights("medium")["actor_w"])
+
+
+@pytest.mark.parametrize("name", ["weak", "medium"])
+def test_reference_checkpoint_loader_matches_shipped_weights(name):
+    """load_light_weights reads the reference's torch checkpoints (build container only: skipped where the reference
+    tree is absent) and yields exactly the tensors shipped as .npz."""
+    import sys
+
+    from competitive_rl_amd.policy_serving import load_light_weights
+
+    pkl = "/root/reference/resources/pong/checkpoint-%s.pkl" % name
+    if not os.path.isfile(pkl):
+        pytest.skip("reference tree not present")
+    sys.dont_write_bytecode = True
+    a, b = load_light_weights(pkl), weights(name)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
