@@ -144,15 +144,16 @@ __device__ inline void group_write_back(const uint8_t *shbuf, uint8_t *__restric
 // (1) and (3) and the patch gather of (2) keep the FMA pipes idle; the two workgroups of a CU drift apart, so
 // one's idle phases run under the other's convolutions.  Tables that do not depend on the group (actor weights,
 // biases, the b/255 table) are staged once.
-template <bool DBG>
+template <int DBG>  // 0 production, 1 ablation switches (CRL_POLICY_DEBUG bits 1, 2), 2 production code + phase cycle counters (4)
 __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(PolicyWeights W, uint8_t *__restrict__ ring, int head,
                                                                            const uint8_t *__restrict__ frame, int64_t frame_stride,
                                                                            int32_t *__restrict__ actions, int64_t action_stride,
-                                                                           float *__restrict__ logits_out, int64_t n, int dbg_arg) {
-    const int dbg = DBG ? dbg_arg : 0;  // CRL_POLICY_DEBUG (profiling only): 1 skip the convolutions, 2 skip the patch gather
+                                                                           float *__restrict__ logits_out, int64_t n, int dbg_arg, int phase_sleeps,
+                                                                           unsigned *__restrict__ ticket) {
+    const int dbg = DBG == 1 ? dbg_arg : 0;  // CRL_POLICY_DEBUG (profiling only): 1 skip the convolutions, 2 skip the patch gather
+    const bool timed = DBG != 0 && (dbg_arg & 4) && n >= 8192;  // the counters go into logits_out (needs n * 12 >= 66 560 bytes)
     __shared__ __attribute__((aligned(16))) uint8_t sh_in[kEnvsPerWg][CRL_POLICY_STACK][kPlanePad];
     __shared__ float sh_wa[3 * 1600];
-    __shared__ float sh_div[256];  // b / 255.0f, correctly rounded
     __shared__ __attribute__((aligned(8))) float sh_b2[16];  // conv2.bias; actor bias: no VMEM loads inside the loop,
     __shared__ float sh_ba[4];                               // a wait on one would also wait on the group in flight
     __shared__ float sh_part[kEnvsPerWg * kPos][3];
@@ -161,7 +162,6 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
     const int tid = threadIdx.x;
     const int64_t ngroups = (n + kEnvsPerWg - 1) / kEnvsPerWg;
 
-    if (tid < 256) sh_div[tid] = (float)tid / 255.0f;
     if (tid < 16) sh_b2[tid] = reinterpret_cast<const float *>(W.b2)[tid];
     if (tid < 3) sh_ba[tid] = W.ba[tid];
     for (int i = tid; i < 3 * 1600; i += kPolicyThreads) sh_wa[i] = W.wa[i];
@@ -173,14 +173,40 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
     const int b1lane = __float_as_int(b1i);
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
+    // The two workgroups of a CU start together and have the same period, so left alone they stay IN phase: both in
+    // the convolutions (sharing the FMA pipes), then both in staging / reduction (pipes idle).  The second half of the
+    // grid (the workgroups that land in the CUs' second slots) starts half a period late.
+    {
+        const int mode = phase_sleeps >> 8, reps = phase_sleeps & 255;
+        const bool late = mode == 0 ? blockIdx.x >= (gridDim.x + 1) / 2 : mode == 1 ? (blockIdx.x & 1) : mode == 2 ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
+        if (late)
+            for (int i = 0; i < reps; i++) __builtin_amdgcn_s_sleep(127);
+    }
 
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    int gcount = 0;
+#define CRL_TICK(K)                                        \
+    if (timed) {                                           \
+        const long long now_ = __builtin_readcyclecounter(); \
+        tacc[K] += now_ - tprev;                           \
+        tprev = now_;                                      \
+    }
+    if (timed) tprev = __builtin_readcyclecounter();
+    // Groups are handed out by a ticket counter, not b, b + grid, ...: the SIMDs favour their OLDEST wavefront, so the
+    // workgroup that reached a CU first runs about twice as fast as its co-resident (cycle-counter timelines: 48 k vs
+    // 96 k cycles per group) and a static split leaves the slow half to finish alone.
+    __shared__ unsigned sh_ticket;
+    for (int64_t g = blockIdx.x; g < ngroups;) {
         const int64_t env0 = g * kEnvsPerWg;
         const int envs_here = (int)((n - env0) < kEnvsPerWg ? (n - env0) : kEnvsPerWg);
+        if (tid == 0) sh_ticket = atomicAdd(ticket, 1u);
         group_request(&sh_in[0][0][0], ring, head, frame, frame_stride, env0, envs_here, wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's share has landed
         __syncthreads();                                    // ... everybody's has
+        const int64_t g_next = (int64_t)gridDim.x + sh_ticket;  // rewritten only after this iteration's last barrier
+        CRL_TICK(0)
         group_write_back(&sh_in[0][0][0], ring, head, env0, envs_here, tid);
+        CRL_TICK(1)
       for (int pass = 0; pass < kPasses; pass++) {
         const int task = pass * kPolicyThreads + tid;
         const int e = task < kEnvsPerWg * kPos ? task / kPos : kEnvsPerWg - 1;
@@ -189,19 +215,38 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
         const bool live = task < kEnvsPerWg * kPos && env0 + e < n;
         float l0 = 0.f, l1 = 0.f, l2 = 0.f;
         {
-            f2 in[4][6][3];  // the 6x6x4 patch as floats, columns (2k, 2k + 1) in one register pair
+            // The 6x6x4 patch as floats, columns (2k, 2k + 1) in one register pair.  Measured with the cycle counter:
+            // this gather, not the FMAs next to it, was a quarter of the kernel when it was 72 ds_read_u16 + 144
+            // look-ups in a b/255 table per lane -- LDS-pipe bound (eight wavefronts of a CU share it), not latency
+            // bound.  Now two ALIGNED dwords per 6-byte row piece in one ds_read2_b32 (the piece starts on a multiple
+            // of 4 for even r and 2 bytes after one for odd r -- known at compile time; an unaligned ds_read_b64 is no
+            // faster than the 216 small reads) and the division on the vector pipes: q = b * fl(1/255) + one
+            // FMA-corrected Newton step = correctly rounded b / 255.0f for every byte (Markstein), i.e. the
+            // reference's x / 255 bit for bit.
+            f2 in[4][6][3];
+            const f2 rcp = f2{1.0f / 255.0f, 1.0f / 255.0f}, m255 = f2{-255.0f, -255.0f};
 #pragma unroll
             for (int ic = 0; ic < 4; ic++)
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
-                    // logical plane ic (oldest first) is ring plane (head + 1 + ic) & 3; even byte offset
+                    // logical plane ic (oldest first) is ring plane (head + 1 + ic) & 3; bytes read past the piece stay
+                    // inside the padded plane
                     const uint8_t *row = &sh_in[e][(head + 1 + ic) & 3][(4 * y2 + r) * kDim + 4 * x2];
+                    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(row - 2 * (r & 1));
+                    uint32_t w0 = (dbg & 2) ? 0x01020304u : p32[0], w1 = (dbg & 2) ? 0x0506u : p32[1];
+                    if (r & 1) w0 = (w0 >> 16) | (w1 << 16), w1 >>= 16;
+                    const f2 b[3] = {f2{(float)(w0 & 255u), (float)((w0 >> 8) & 255u)}, f2{(float)((w0 >> 16) & 255u), (float)(w0 >> 24)},
+                                     f2{(float)(w1 & 255u), (float)((w1 >> 8) & 255u)}};
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
-                        const uint32_t two = (dbg & 2) ? (uint32_t)(k + r) : *reinterpret_cast<const uint16_t *>(row + 2 * k);
-                        in[ic][r][k] = (dbg & 2) ? f2{(float)two, 1.f} : f2{sh_div[two & 255u], sh_div[two >> 8]};
+                        const f2 q = b[k] * rcp;
+                        const f2 rem = __builtin_elementwise_fma(q, m255, b[k]);
+                        in[ic][r][k] = __builtin_elementwise_fma(rem, rcp, q);
                     }
                 }
+            CRL_TICK(2)
+            if (timed && logits_out && tid == 0 && (blockIdx.x == 48 || blockIdx.x == 304) && gcount < 12)
+                reinterpret_cast<long long *>(logits_out)[8192 + (blockIdx.x == 304) * 64 + gcount * 4 + pass * 2] = __builtin_readcyclecounter();
             f2 acc[8];  // conv2 accumulators, output channels (2p, 2p + 1)
 #pragma unroll
             for (int p = 0; p < 8; p++) acc[p] = reinterpret_cast<const f2 *>(sh_b2)[p];
@@ -260,6 +305,9 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
                 wp += 256;
             }
             wbatch_wait(wa_);  // drain the padding request
+            CRL_TICK(3)
+            if (timed && logits_out && tid == 0 && (blockIdx.x == 48 || blockIdx.x == 304) && gcount < 12)
+                reinterpret_cast<long long *>(logits_out)[8192 + (blockIdx.x == 304) * 64 + gcount * 4 + pass * 2 + 1] = __builtin_readcyclecounter();
 #undef CRL_STEP
 #undef CRL_CONV1_BATCH
 #undef CRL_CONV2_BATCH
@@ -272,6 +320,7 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
             }
         }
         if (live) sh_part[task][0] = l0, sh_part[task][1] = l1, sh_part[task][2] = l2;
+        CRL_TICK(4)
       }
         __syncthreads();
         // fixed-shape sum over the 100 positions of an env (4 groups of 25, then the 4 groups): the result
@@ -302,7 +351,21 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
             }
         }
         __syncthreads();  // sh_logit / sh_in are rewritten by the next group
+        CRL_TICK(5)
+        gcount++;
+        g = g_next;
     }
+    if (timed && logits_out && lane == 0 && blockIdx.x < 512) {  // where the hardware put this wavefront (HW_ID: simd, cu, sh, se, ...)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        reinterpret_cast<unsigned *>(logits_out)[4096 + (blockIdx.x * 4 + wave) * 2] = hwid;
+        reinterpret_cast<unsigned *>(logits_out)[4096 + (blockIdx.x * 4 + wave) * 2 + 1] = xcc;
+    }
+    if (timed && logits_out && tid == 0)  // profiling: cycles per phase of this workgroup's first wavefront
+        for (int k = 0; k < 6; k++) logits_out[blockIdx.x * 6 + k] = (float)tacc[k];
+#undef CRL_TICK
 }
 
 // ring <-> logical order (tests, checkpoints): plane j of the model's stack is ring plane (head + j) & 3
@@ -335,6 +398,7 @@ struct crl_policy {
     int head = 0;  // ring plane holding the OLDEST frame (the next one to be replaced)
     float *weights = nullptr;
     uint8_t *ring = nullptr;
+    unsigned *ticket = nullptr;  // next group to hand out (reset before every launch)
     PolicyWeights W{};
 };
 
@@ -363,6 +427,7 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
     memcpy(ba, actor_b, 3 * sizeof(float));
     hipError_t e = hipMalloc(&p->weights, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->weights, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->ticket, 64);
     if (e == hipSuccess) e = hipMalloc(&p->ring, (size_t)num_envs * kRingBytes);
     if (e == hipSuccess) e = hipMemset(p->ring, 0, (size_t)num_envs * kRingBytes);
     if (e != hipSuccess) {
@@ -381,6 +446,7 @@ void crl_policy_destroy(crl_policy *p) {
     (void)hipSetDevice(p->device);
     if (p->weights) (void)hipFree(p->weights);
     if (p->ring) (void)hipFree(p->ring);
+    if (p->ticket) (void)hipFree(p->ticket);
     delete p;
 }
 
@@ -397,14 +463,20 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     if (frame_stride < kPlane || (frame_stride & 3) || ((uintptr_t)frame_dev & 3) || action_stride < 1)
         return crl_fail(CRL_EINVAL, "crl_policy_act: frame_stride must be a multiple of 4 and >= 1764, frames 4-byte aligned");
     static const int dbg = getenv("CRL_POLICY_DEBUG") ? atoi(getenv("CRL_POLICY_DEBUG")) : 0;  // profiling only (wrong outputs)
+    static const int phase = getenv("CRL_POLICY_PHASE") ? atoi(getenv("CRL_POLICY_PHASE")) : 0;  // x 8 128 cycles
     const int64_t groups = (p->n + kEnvsPerWg - 1) / kEnvsPerWg;
-    const unsigned grid = (unsigned)(groups < 2 * p->cus ? groups : 2 * p->cus);  // persistent: two workgroups per CU
-    if (dbg)
-        hipLaunchKernelGGL(pong_policy_light_kernel<true>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
-                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, dbg);
+    static const int per_cu = getenv("CRL_POLICY_WGS") ? atoi(getenv("CRL_POLICY_WGS")) : 2;  // tuning experiments only
+    const unsigned grid = (unsigned)(groups < per_cu * p->cus ? groups : per_cu * p->cus);  // persistent: two workgroups per CU
+    HIP_TRY(hipMemsetAsync(p->ticket, 0, sizeof(unsigned), (hipStream_t)stream));
+    if (dbg == 4)
+        hipLaunchKernelGGL(pong_policy_light_kernel<2>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
+                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, dbg, phase, p->ticket);
+    else if (dbg)
+        hipLaunchKernelGGL(pong_policy_light_kernel<1>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
+                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, dbg, phase, p->ticket);
     else
-        hipLaunchKernelGGL(pong_policy_light_kernel<false>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
-                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, 0);
+        hipLaunchKernelGGL(pong_policy_light_kernel<0>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
+                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, 0, phase, p->ticket);
     HIP_TRY(hipGetLastError());
     p->head = (p->head + 1) & 3;
     return CRL_OK;

@@ -30,6 +30,29 @@ flop = n * 516800 * 2
 print(f"policy kernel: {ms * 1e3:.1f} us per call at {n} envs = {flop / ms / 1e9:.2f} TFLOP/s fp32 "
       f"({flop / ms / 1e9 / 78.6 * 100:.1f} % of 78.6 TFLOP/s plain-FMA issue, {flop / ms / 1e9 / 157.3 * 100:.1f} % of packed peak)")
 
+if os.environ.get("CRL_POLICY_DEBUG", "0") == "4":
+    pol.act_device(frames, want_logits=True)
+    torch.cuda.synchronize()
+    t = pol.logits().reshape(-1)[:512 * 6].reshape(512, 6).double().mean(0) / (n / 5 / 512)
+    names = ["staging", "write-back", "gather", "conv", "actor", "epilogue"]
+    print("cycles per group (first wavefront, mean over workgroups):", {k: int(v) for k, v in zip(names, t.tolist())}, "sum", int(t.sum()))
+    hw = pol.logits().reshape(-1).view(torch.int32)[4096:4096 + 512 * 8].reshape(512, 4, 2).cpu().numpy()
+    import collections
+    def dec(h, x):
+        return (int(x) & 15, (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15, (h >> 4) & 3)  # xcc, se, sh, cu, simd
+    place = collections.defaultdict(list)
+    for b in range(512):
+        for w in range(4):
+            xcc, se, sh, cu, simd = dec(int(hw[b, w, 0]), hw[b, w, 1])
+            place[(xcc, se, sh, cu)].append((b, w, simd))
+    print("CUs used:", len(place), "; first CUs:")
+    for k in sorted(place)[:4]:
+        print("  ", k, sorted(place[k]))
+    tl = pol.logits().reshape(-1).view(torch.int64)[8192:8192 + 128].reshape(2, 16, 4).cpu().numpy()
+    t0 = tl[tl > 0].min()
+    for g in range(10):
+        print("group", g, " WG48 conv pass0 [%d,%d] pass1 [%d,%d]   WG304 pass0 [%d,%d] pass1 [%d,%d]" % tuple(int(v - t0) for v in list(tl[0, g]) + list(tl[1, g])))
+    sys.exit(0)
 tour = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=1)
 for name in ("RULE_BASED", "MEDIUM"):
     tour.reset_opponent(name)
