@@ -143,7 +143,7 @@ __device__ inline void group_write_back(const uint8_t *shbuf, uint8_t *__restric
 // frames into LDS, (2) runs the 500 conv2 positions in two passes of 256 lanes, (3) reduces the logits.  Steps
 // (1) and (3) and the patch gather of (2) keep the FMA pipes idle; the two workgroups of a CU drift apart, so
 // one's idle phases run under the other's convolutions.  Tables that do not depend on the group (actor weights,
-// biases, the b/255 table) are staged once.
+// biases) are staged once.
 template <int DBG>  // 0 production, 1 ablation switches (CRL_POLICY_DEBUG bits 1, 2), 2 production code + phase cycle counters (4)
 __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(PolicyWeights W, uint8_t *__restrict__ ring, int head,
                                                                            const uint8_t *__restrict__ frame, int64_t frame_stride,
