@@ -149,6 +149,7 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int max_episode_steps, hipStream_t st);
 // only_env: draw env e iff only_env[e] == want; nullptr = every env
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
+void car_raster_print_ticks();  // CRL_CAR_DEBUG & 64
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
                       int players, hipStream_t st);
 

@@ -19,6 +19,7 @@
 // Rule of the house: whatever a loop iteration needs from LDS is read with back-to-back loads
 // into registers and evaluated branch-free -- a chain of data-dependent ~100-cycle LDS reads
 // costs more than the arithmetic an early-out saves.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "car_device.h"
@@ -82,6 +83,14 @@ __device__ inline IndRect make_rect(double x, double y, double w, double h, int 
     return q;
 }
 
+// CRL_CAR_DEBUG & 64: cycle counter (s_memtime) at every workgroup barrier, summed per phase over all workgroups
+__device__ unsigned long long g_car_ticks[24];
+#define CAR_TICK(Kk)                                                             \
+    if ((dbg & 64) && tid == 0) {                                                \
+        const long long now_ = __builtin_readcyclecounter();                     \
+        tick_acc[Kk] += (unsigned)(now_ - tick_prev);                            \
+        tick_prev = now_;                                                        \
+    }
 __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
                                                          const uint8_t *__restrict__ only_env, int want) {
     __shared__ CandTile cand[kMaxCand];
@@ -103,12 +112,25 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     if (only_env && only_env[env] != want) return;  // env subset: finished envs / one class of the step pipeline
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t me = viewer * n + env;
+    long long tick_prev = (dbg & 64) ? __builtin_readcyclecounter() : 0;
+    unsigned tick_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // Loads that do not depend on the camera go out first (tile AABBs: unconditional, the slots past the
     // track hold zeros; the reward for the read-out), so the double-precision camera math covers them.
     const int ntiles = (dbg & 8) ? 0 : s.ntiles[env];
     const float4 bb_pre0 = s.tile_aabb_em[env * kCarMaxTiles + tid], bb_pre1 = s.tile_aabb_em[env * kCarMaxTiles + 256 + tid];
     const double reward_pre = s.reward[me];
+    // the glyph row of the reward read-out is a load that depends on that reward: requested here (the reward is needed
+    // for nothing else), used by the last phase -- at its place of use it cost a whole exposed round trip per workgroup
+    uint32_t text_row_pre = 0;
+    if (s.text_bits && tid < 32 * CRL_CAR_TEXT_ROWS) {
+        const double r = reward_pre;
+        const double rr = rint(r);  // "%.0f" rounds half to even
+        int idx = (int)rr - CRL_CAR_TEXT_RMIN;
+        if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
+        idx = min(max(idx, 0), CRL_CAR_TEXT_STRINGS - 1);
+        text_row_pre = s.text_bits[idx * CRL_CAR_TEXT_ROWS + (tid >> 5)];
+    }
 
     // ---- camera_update("rgb_array") for the viewer (uniform across the workgroup)
     const float h_cx = s.body[0 * M + me], h_cy = s.body[1 * M + me], h_a = s.body[2 * M + me];
@@ -144,6 +166,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         if (lane == 0) wave_cnt[h][wave] = __popcll(km[h]);
     }
     __syncthreads();
+    CAR_TICK(0)
     int nc;
     {
         int before[2] = {0, 0}, tot = 0;
@@ -159,6 +182,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         }
     }
     __syncthreads();
+    CAR_TICK(1)
     if (tid < nc) {
         const int t = cand_tile[tid];
         CandTile &c = cand[tid];
@@ -166,8 +190,9 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         const float4 bb = s.tile_aabb_em[env * kCarMaxTiles + t];
         for (int k = 0; k < 10; k++) pv[k] = s.tile_poly_em[(env * kCarMaxTiles + t) * 10 + k];
         const int border = s.border_em[env * kCarMaxTiles + t];
-        if (border)
-            for (int k = 0; k < 8; k++) bv[k] = s.border_poly_em[(env * kCarMaxTiles + t) * 8 + k];
+        // unconditional (the slots of tiles without a border hold zeros): a load that waits for the flag is a second
+        // exposed round trip
+        for (int k = 0; k < 8; k++) bv[k] = s.border_poly_em[(env * kCarMaxTiles + t) * 8 + k];
         for (int i = 0; i < 5; i++) {
             const int j = i + 1 < 5 ? i + 1 : 0;
             c.edge[i] = make_float4(pv[2 * i], pv[2 * i + 1], pv[2 * j] - pv[2 * i], pv[2 * j + 1] - pv[2 * i + 1]);
@@ -243,6 +268,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         ind[r] = q;
     }
     __syncthreads();
+    CAR_TICK(2)
 
     // ---- (2b) screen-space culling: per 8x8-pixel cell the candidates (as bit masks, i.e. in draw
     // order) whose tile polygon / border quad may cover one of its pixel centres.  Membership
@@ -291,6 +317,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     }
     for (int i = tid; i < kCells * (kMaxCand / 32); i += 256) (&cell_tmask[0][0])[i] = 0u, (&cell_bmask[0][0])[i] = 0u;
     __syncthreads();
+    CAR_TICK(3)
     // one work item per (candidate, cell of its screen box): a separating-edge test of the cell's
     // pixel centres against the tile polygon and the border quad in screen space (the world ->
     // screen map is a similarity with positive determinant, so "inside" stays cross >= 0; a
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         if (ct.border && may_cover(ct.bedge, 4)) atomicOr(&cell_bmask[cell][c >> 5], 1u << (c & 31));
     }
     __syncthreads();
+    CAR_TICK(4)
 
     // ---- (3a) background into the LDS tile: 4 consecutive pixels per thread-iteration share one
     // culling cell, so every candidate's edges are read from LDS once per 4 pixels
@@ -427,6 +455,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         tile32[q] = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
     }
     __syncthreads();
+    CAR_TICK(5)
     uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile32);
 
     // ---- (3b) cars: one work item per (car polygon, scanline): the crossings of pygame's
@@ -448,6 +477,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         for (int c = 0; c < 2; c++)
             for (int p = tid; p < bw[c] * bh[c]; p += 256) rank[c * kRankCap + p] = 0u;
         __syncthreads();
+        CAR_TICK(6)
         // one work item per (polygon, scanline); the item -> polygon map is a 16-entry prefix table
         const int4 pr0 = *reinterpret_cast<const int4 *>(&poly_row0[0]), pr1 = *reinterpret_cast<const int4 *>(&poly_row0[4]);
         const int4 pr2 = *reinterpret_cast<const int4 *>(&poly_row0[8]), pr3 = *reinterpret_cast<const int4 *>(&poly_row0[12]);
@@ -509,6 +539,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                     for (int x = max(xs[i], max(px0, 0)); x <= min(xs[i + 1], min(px1, 95)); x++) atomicMax(&row[x], key);
         }
         __syncthreads();
+        CAR_TICK(7)
         for (int c = 0; c < 2; c++) {  // car 1 is drawn over car 0
             for (int p = tid; p < bw[c] * bh[c]; p += 256) {
                 const uint32_t r = rank[c * kRankCap + p];
@@ -518,6 +549,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
                 }
             }
             __syncthreads();
+            CAR_TICK(8)
         }
     }
 
@@ -548,18 +580,15 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         }
     }
     __syncthreads();
+    CAR_TICK(9)
 
     // ---- (3c') reward read-out "%05.0f" (white, 1-bit glyphs) blitted last at (0, 91)
     if (s.text_bits && tid < 32 * CRL_CAR_TEXT_ROWS) {
-        const double r = reward_pre;
-        const double rr = rint(r);  // "%.0f" rounds half to even
-        int idx = (int)rr - CRL_CAR_TEXT_RMIN;
-        if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
-        idx = min(max(idx, 0), CRL_CAR_TEXT_STRINGS - 1);
         const int row = tid >> 5, col = tid & 31, sy = 91 + row;
-        if (sy < 96 && ((s.text_bits[idx * CRL_CAR_TEXT_ROWS + row] >> col) & 1u)) tile8[sy * 96 + col] = 255;
+        if (sy < 96 && ((text_row_pre >> col) & 1u)) tile8[sy * 96 + col] = 255;
     }
     __syncthreads();
+    CAR_TICK(10)
 
     // ---- (3d) stream the tile out: 16 B per lane, 1 KiB contiguous per wave store
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + ((int64_t)env * s.players + viewer) * (96 * 96));
@@ -571,6 +600,11 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
 #pragma unroll
         for (int i = 0; i < 3; i++)
             if (tid + 256 * i < 96 * 96 / 16) out[tid + 256 * i] = ov[i];
+    }
+    CAR_TICK(11)
+    if ((dbg & 64) && tid == 0) {
+        for (int i = 0; i < 12; i++) atomicAdd(&g_car_ticks[i], (unsigned long long)tick_acc[i]);
+        atomicAdd(&g_car_ticks[23], 1ull);
     }
 }
 
@@ -603,6 +637,15 @@ void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const 
                       int players, hipStream_t st) {
     hipLaunchKernelGGL(car_stack_kernel, dim3((unsigned)(players * n)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(frame),
                        reinterpret_cast<uint4 *>(stack), reinterpret_cast<uint4 *>(obs), fill_env, fill_all ? 1 : 0, K, n, players);
+}
+
+void car_raster_print_ticks() {
+    unsigned long long t[24];
+    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_car_ticks), sizeof(t)) != hipSuccess || !t[23]) return;
+    fprintf(stderr, "car_raster phases, mean cycles per workgroup over %llu workgroups:", t[23]);
+    for (int i = 0; i < 23; i++)
+        if (t[i]) fprintf(stderr, " [%d] %llu", i, t[i] / t[23]);
+    fprintf(stderr, "\n");
 }
 
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env, int want) {

@@ -176,6 +176,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
 void crl_car_destroy(crl_car_ctx *c) {
     if (!c) return;
     hipDeviceSynchronize();
+    if (getenv("CRL_CAR_DEBUG") && (atoi(getenv("CRL_CAR_DEBUG")) & 64)) crl::car_raster_print_ticks();
     if (c->side) hipStreamDestroy(c->side);
     if (c->gen) hipStreamDestroy(c->gen);
     if (c->ev_reset) hipEventDestroy(c->ev_reset);
