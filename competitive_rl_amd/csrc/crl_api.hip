@@ -15,6 +15,7 @@
 #include "pong_device.h"
 
 namespace crl {
+void pong_gray_print_ticks();  // CRL_GRAY_DEBUG & 128
 void launch_pong_gray_templates(const GrayParams &p, const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
                                 const uint8_t *y_last, int band_rows, int band_chunks, uint8_t *band, uint8_t *rest,
                                 hipStream_t st);
@@ -358,6 +359,7 @@ void crl_destroy(crl_ctx *c) {
     if (!c) return;
     hipSetDevice(c->o.device);
     hipDeviceSynchronize();
+    if (getenv("CRL_GRAY_DEBUG") && (atoi(getenv("CRL_GRAY_DEBUG")) & 128)) crl::pong_gray_print_ticks();
     if (c->car) crl_car_destroy(c->car);
     for (void *p : c->allocs) hipFree(p);
     for (int w = 0; w < 2; w++)

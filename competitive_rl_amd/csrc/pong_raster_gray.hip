@@ -20,6 +20,7 @@
 // planes are never read back from HBM: traffic = K*R*R*2 bytes of stores per env-step.
 // LDS ordering inside a tile needs no workgroup barrier: one wave owns the tile and LDS
 // operations of a wave complete in issue order.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "pong_device.h"
@@ -387,6 +388,14 @@ __device__ inline uint8_t eval_sep(const uint8_t *__restrict__ tabs, const GrayT
     return (uint8_t)min(max(v, 0), 255);
 }
 
+// CRL_GRAY_DEBUG & 128 (instrumented instance): s_memtime stamps around the phases of a tile, summed over all wavefronts
+__device__ unsigned long long g_gray_ticks[8];
+#define GRAY_TICK(Kk)                                        \
+    if (DBG && (dbg & 128)) {                                \
+        const long long now_ = __builtin_readcyclecounter(); \
+        gtick[Kk] += (unsigned)(now_ - gprev);               \
+        gprev = now_;                                        \
+    }
 template <int MAXT, bool DBG>
 __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw) {
@@ -418,6 +427,8 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
     const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;  // chunks fully inside zero rows
     const bool fast_ok = q.t.fast_ok != 0;
     const int dbg = DBG ? q.debug : 0;  // ablation switches (profiling instance only)
+    unsigned gtick[6] = {0, 0, 0, 0, 0, 0};
+    long long gprev = (DBG && (dbg & 128)) ? __builtin_readcyclecounter() : 0;
 
     // view-major: a wave writes its env's planes in ascending address order (the four planes of agent
     // 0's view, then agent 1's) -- 4 % faster than alternating between the two views per plane
@@ -460,6 +471,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                     for (int w = lane; w < (RR >> 2); w += 64) out32[w] = 0u;
                 continue;
             }
+            GRAY_TICK(0)
             // ---- 1. template loads into registers (L2); the box arithmetic and the row / column
             //         words below overlap their latency, the LDS tile is filled afterwards
             const uint4 *__restrict__ band4 =
@@ -507,15 +519,18 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                 }
             }
             const int total = (dbg & 1) ? 0 : pre[6];
+            GRAY_TICK(1)
             uint32_t *rowpack = rowpack_[wave], *colpack = colpack_[wave];
             if (fast_ok && !(dbg & 2)) {
                 for (int dy = ymin + lane; dy < ymax; dy += 64) rowpack[dy] = row_pack<MAXT>(tabs, q.t, rc, dy);
                 for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
             }
+            GRAY_TICK(2)
 #pragma unroll
             for (int it = 0; it < kTileIters; it++)
                 if (lane + 64 * it < chunks) tl4[lane + 64 * it] = tv[it];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            GRAY_TICK(3)
             for (int p = lane; p < total; p += 64) {
                 int dy, dx;
                 const bool band_px = p < pre[0];
@@ -538,6 +553,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                 tl[dy * R + dx] = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            GRAY_TICK(4)
             // ---- 3. stream the tile out
             if (dbg & 64) {
 #pragma unroll
@@ -556,8 +572,20 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
                 for (int w = lane; w < (RR >> 2); w += 64) out32[w] = tl32[w];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            GRAY_TICK(5)
         }
     }
+    if (DBG && (dbg & 128) && lane == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&g_gray_ticks[i], (unsigned long long)gtick[i]);
+        atomicAdd(&g_gray_ticks[7], 1ull);
+    }
+}
+
+void pong_gray_print_ticks() {
+    unsigned long long t[8];
+    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gray_ticks), sizeof(t)) != hipSuccess || !t[7]) return;
+    fprintf(stderr, "gray env kernel, mean cycles per wavefront (8 tiles) over %llu wavefronts: loop top/ring words %llu | template issue + boxes %llu | "
+            "row/col words %llu | LDS fill %llu | patch %llu | stream-out %llu\n", t[7], t[0] / t[7], t[1] / t[7], t[2] / t[7], t[3] / t[7], t[4] / t[7], t[5] / t[7]);
 }
 
 void launch_pong_gray_templates(const GrayParams &p, const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
