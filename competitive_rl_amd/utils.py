@@ -19,7 +19,8 @@ def _to_numpy(x):
 
 def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_recorder, length_recorder, total_steps,
               total_episodes, device, test):
-    """Step the vectorized environments for one step. Process the reward recording and terminal states."""
+    """One ``envs.step`` plus the books a trainer keeps around it: running episode returns, finished-episode
+    recorders, episode / step totals, and the frame stack (erased where an episode ended)."""
     obs, reward, done, info = envs.step(cpu_actions)
     on_device = isinstance(done, torch.Tensor)
     if isinstance(episode_rewards, torch.Tensor):
@@ -36,10 +37,10 @@ def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_rec
         if done.ndim == 2:  # DummyVecEnv: (N, agents); ``not np.isscalar(done[0])`` in the reference
             done = np.all(done, axis=1)
         done_host = done
-    for idx in np.nonzero(done_host)[0]:  # the episode is done
+    for idx in np.nonzero(done_host)[0]:  # finished episodes only
         idx = int(idx)
         reward_recorder.append(_to_numpy(episode_rewards[idx]).copy())
-        # For CartPole-v0 environment, the length of episodes is not recorded.
+        # envs without a step counter in their info (CartPole) record no length
         if "num_steps" in info[idx]:
             length_recorder.append(info[idx]["num_steps"])
         total_episodes += 1
@@ -56,8 +57,8 @@ def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_rec
         masks = (1.0 - done.to(torch.float32)).to(device).view(-1, 1)
     else:
         masks = torch.from_numpy(1. - done_host.astype(np.float32)).to(device).view(-1, 1)
-    # frame_stack_tensor is refreshed in-place if done happen.
+    # the stack forgets the history of envs that just restarted (mask 0)
     frame_stack_masks = masks.view(-1, 1) if test else masks.view(-1, 1, 1, 1)
-    # If in multiple pong mode, we suppose only the first observation is used to train agent.
+    # two-agent Pong hands back a tuple: the learner is agent 0
     frame_stack_tensor.update(first, frame_stack_masks)
     return obs, reward, done, info, masks, total_episodes, total_steps, episode_rewards
