@@ -114,7 +114,7 @@ class PongOracle:
         self.done = np.zeros((self.n,), np.uint8)
 
     def close(self):
-        if self.h:
+        if self.h and lib is not None:  # (module globals are gone when this runs as __del__ at interpreter exit)
             lib().pong_oracle_destroy(self.h)
             self.h = None
 
