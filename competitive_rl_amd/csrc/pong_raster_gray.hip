@@ -396,10 +396,12 @@ __device__ unsigned long long g_gray_ticks[8];
         gtick[Kk] += (unsigned)(now_ - gprev);               \
         gprev = now_;                                        \
     }
-template <int MAXT, bool DBG>
-__global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
+// TI = 16-byte chunks per lane per tile: 7 holds R <= 84, 2 holds R <= 45 (the reference's default resized_dim = 42:
+// a quarter of the LDS and 40 fewer registers, so more wavefronts cover the per-tile latency chain)
+template <int MAXT, bool DBG, int TI>
+__global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[4][kTileLds];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][TI * 1024];
     __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
     __shared__ uint64_t words_[4][8];
     __shared__ uint32_t rowpack_[4][kMaxR], colpack_[4][kMaxR];
@@ -476,9 +478,9 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             //         words below overlap their latency, the LDS tile is filled afterwards
             const uint4 *__restrict__ band4 =
                 reinterpret_cast<const uint4 *>(q.band) + (int64_t)((slow ? 0 : (variant * 484 + sp)) * 2 + view) * bb;
-            uint4 tv[kTileIters];
+            uint4 tv[TI];
 #pragma unroll
-            for (int it = 0; it < kTileIters; it++) {
+            for (int it = 0; it < TI; it++) {
                 const int c = lane + 64 * it;
                 tv[it] = make_uint4(0, 0, 0, 0);
                 if (dbg & 32) continue;
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             }
             GRAY_TICK(2)
 #pragma unroll
-            for (int it = 0; it < kTileIters; it++)
+            for (int it = 0; it < TI; it++)
                 if (lane + 64 * it < chunks) tl4[lane + 64 * it] = tv[it];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             GRAY_TICK(3)
@@ -557,15 +559,15 @@ __global__ __launch_bounds__(256) void pong_raster_gray_env_kernel(const uint64_
             // ---- 3. stream the tile out
             if (dbg & 64) {
 #pragma unroll
-                for (int it = 0; it < kTileIters; it++)
+                for (int it = 0; it < TI; it++)
                     if (lane + 64 * it < chunks) out[lane + 64 * it] = tv[it];
             } else if (vec16) {
                 // all LDS reads first, then the stores (a rolled loop would wait for every read in turn)
-                uint4 ov[kTileIters];
+                uint4 ov[TI];
 #pragma unroll
-                for (int it = 0; it < kTileIters; it++) ov[it] = tl4[min(lane + 64 * it, chunks - 1)];
+                for (int it = 0; it < TI; it++) ov[it] = tl4[min(lane + 64 * it, chunks - 1)];
 #pragma unroll
-                for (int it = 0; it < kTileIters; it++)
+                for (int it = 0; it < TI; it++)
                     if (lane + 64 * it < chunks) out[lane + 64 * it] = ov[it];
             } else {
                 const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
@@ -624,14 +626,17 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     static const int ppw_env = getenv("CRL_GRAY_PPW") ? atoi(getenv("CRL_GRAY_PPW")) : 0;  // tuning experiments only
     int ppw = (p.n >= 8192 && !(q.debug & 16)) ? p.K : 1;
     if (ppw_env > 0 && p.K % ppw_env == 0) ppw = ppw_env;
+    static const bool small_off = getenv("CRL_GRAY_SMALL_OFF") != nullptr;  // A/B: the R <= 45 instance off
     const int64_t waves = p.n * (p.K / ppw);
     const dim3 grid((unsigned)((waves + 3) / 4));
     if (q.debug & ~16)  // any ablation switch: the instrumented instance
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
     else if (tofs.max_taps <= 3)
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+    else if (p.R * p.R <= 2048 && !small_off)
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
     else
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
 }
 
 }  // namespace crl
