@@ -121,7 +121,6 @@ __device__ inline Box rect_box(const GrayGeom &q, int c0, int c1, int r0, int r1
 
 static constexpr int kTileLds = 7168;  // >= 84*84, multiple of 16
 static constexpr int kTabLds = 6144;   // dense tap tables + first/last maps (4.6 KB at R = 84)
-static constexpr int kTileIters = kTileLds / 16 / 64;  // 16-byte chunks per lane per tile
 static constexpr int kMaxR = 96;       // largest resized_dim the LDS tile holds (84) rounded up
 
 // Rectangles of the two kept frames in VIEW coordinates (agent 1 sees the court mirrored,
