@@ -21,7 +21,7 @@ SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "cr
            "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version",
            "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_set_replay",
            "crl_policy_create", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
-           "crl_policy_set_stack"]
+           "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update"]
 
 FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
                      ("score_l", "u1"), ("score_r", "u1")])
@@ -46,16 +46,25 @@ CAR_CONTACT_DT = np.dtype([("pair", "<i4"), ("count", "<i4"), ("type", "<i4"), (
 CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4"), ("n_contact", "<i4"), ("coupled", "<i4"),
                              ("contact", CAR_CONTACT_DT, (8,))], align=True)
 CRL_FLAG_CAR_NO_CONTACTS = 2
+CRL_CAR_DONE_ANY, CRL_CAR_DONE_CAR0 = 0, 1
+CRL_OBS_U8, CRL_OBS_F32 = 0, 1
+CRL_EACTION = -5
 
 
 class CrlOpts(C.Structure):
     _fields_ = [("env_kind", C.c_int32), ("obs_mode", C.c_int32), ("resized_dim", C.c_int32),
                 ("frame_stack", C.c_int32), ("num_envs", C.c_int64), ("env_id_base", C.c_int64),
-                ("seed", C.c_uint64), ("device", C.c_int32), ("flags", C.c_int32)]
+                ("seed", C.c_uint64), ("device", C.c_int32), ("flags", C.c_int32), ("action_repeat", C.c_int32),
+                ("done_policy", C.c_int32), ("obs_dtype", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CrlError(RuntimeError):
     pass
+
+
+class CrlActionError(CrlError, AssertionError):
+    """An action outside the action space reached the step kernel (the reference's
+    ``assert self.action_space.contains(action)``, pong/base_pong_env.py:42)."""
 
 
 _lib = None
@@ -82,6 +91,11 @@ def load():
     L.crl_render.argtypes = [vp, vp, vp]
     L.crl_copy_info.argtypes = [vp, vp, vp, vp]
     L.crl_terminal_observation.argtypes = [vp, vp, i64, vp, vp]
+    L.crl_terminal_observation_dev.argtypes = [vp, vp, i64, vp, vp]
+    L.crl_check.argtypes = [vp, vp]
+    L.crl_car_info.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.crl_car_copy_info.argtypes = [vp, vp, vp, vp]
+    L.crl_frame_stack_update.argtypes = [vp, vp, i32, i64, vp, i64, i32, i32, i64, vp]
     L.crl_get_state.argtypes = [vp, vp, i64, i64, vp]
     L.crl_set_state.argtypes = [vp, vp, i64, i64, vp]
     L.crl_set_replay.argtypes = [vp, vp, vp, vp, i64]
@@ -114,7 +128,8 @@ def load():
 
 def check(rc):
     if rc != 0:
-        raise CrlError(f"crl error {rc}: {load().crl_last_error().decode()}")
+        msg = f"crl error {rc}: {load().crl_last_error().decode()}"
+        raise (CrlActionError if rc == CRL_EACTION else CrlError)(msg)
 
 
 def load_score_atlas():

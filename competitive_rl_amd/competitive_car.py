@@ -3,7 +3,9 @@
 The reference wraps every cCarRacingDouble-v0 env in ``MultipleFrameStack -> WrapPyTorch ->
 CarRacingWrapper(opponent_policy)`` and puts N of them under a DummyVecEnv: the learner drives car 0,
 ``opponent_policy(o[1])`` -- evaluated on the observation the step (or the reset) just returned -- drives
-car 1 on the NEXT step, and only agent 0's observation / reward / done / info come out.
+car 1 on the NEXT step, and only agent 0's observation / reward / done / info come out -- ``d[0]``: an episode ends when
+car 0 is done or gym's TimeLimit hits; an opponent that finishes first just stays in the world, frozen
+(``done_policy="car0"`` of the car context; pinned by tests/golden/car_wrappers.npz "competitive_k4").
 
 Here the N envs are one HipCarVecEnv batch.  The opponent's actions stay on the device when
 ``batched=True`` (one call with the (N, K, 96, 96) tensor, returning (N, 2)); ``batched=False`` keeps the
@@ -50,7 +52,7 @@ class HipCompetitiveCarVecEnv(VecEnv):
         assert callable(opponent_policy)
         self.opponent_policy, self.batched = opponent_policy, bool(batched)
         self.env = HipCarVecEnv(num_envs, seed=seed, device=device, env_id_base=env_id_base, output="torch", dones=dones,
-                                action_repeat=None, frame_stack=frame_stack, players=2)
+                                action_repeat=None, frame_stack=frame_stack, players=2, done_policy="car0")
         self.K, self.output, self.dones_kind = self.env.K, output, dones
         self.device = self.env.device
         VecEnv.__init__(self, num_envs, spaces.Box(0, 255, (self.K, 96, 96), dtype=np.uint8),

@@ -146,7 +146,9 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
                      hipStream_t st);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
-void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int max_episode_steps, hipStream_t st);
+void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
+                     int max_episode_steps, bool car0_only, hipStream_t st);
+
 // only_env: draw env e iff only_env[e] == want; nullptr = every env
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void car_raster_print_ticks();  // CRL_CAR_DEBUG & 64

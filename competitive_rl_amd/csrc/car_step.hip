@@ -386,17 +386,21 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
 }
 
 // Env-level bookkeeping after the physics: gym TimeLimit (max_episode_steps = 1000,
-// car_racing/register.py:15-26) and FlattenMultiAgentObservation's done = any (atari_wrappers.py:329-330).
+// car_racing/register.py:15-26), then which cars end the env's episode -- any of them under
+// FlattenMultiAgentObservation (atari_wrappers.py:329-330, make_car_racing_double), car 0 alone under
+// CarRacingWrapper (make_competitive_car_racing.py:24-33: `d[0]`; a finished opponent just stays frozen,
+// crmp:578-579).  Also captures info["num_steps"] = CarRacing.step_count (crmp:616-620) before the auto-reset.
 __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *__restrict__ done_car,
                                                        uint8_t *__restrict__ done_env, uint8_t *__restrict__ slow_env,
-                                                       int max_episode_steps) {
+                                                       int32_t *__restrict__ info_steps, int max_episode_steps, int car0_only) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
     const int el = s.elapsed[env] + 1;
     bool d = el >= max_episode_steps;
-    for (int c = 0; c < s.players; c++) d = d || done_car[s.players * env + c];
+    for (int c = 0; c < (car0_only ? 1 : s.players); c++) d = d || done_car[s.players * env + c];
     s.elapsed[env] = el;
     done_env[env] = d ? 1 : 0;
+    if (info_steps) info_steps[env] = s.step_count[env];  // one world clock per env: both cars carry the same count
     // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = after the reset
     if (slow_env) slow_env[env] = d ? 2 : ((s.coupled && s.coupled[env]) ? 1 : 0);
 }
@@ -413,10 +417,10 @@ void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
     hipLaunchKernelGGL(car_solve_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
 }
 
-void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int max_episode_steps,
-                     hipStream_t st) {
+void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
+                     int max_episode_steps, bool car0_only, hipStream_t st) {
     hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env, slow_env,
-                       max_episode_steps);
+                       info_steps, max_episode_steps, car0_only ? 1 : 0);
 }
 
 }  // namespace crl

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, Ca
     const int64_t env = blockIdx.x;
     const int lane = threadIdx.x;
     if (only_done && !done_env[env]) return;
-    const uint32_t episode = s.episode[env];
+    const uint32_t episode = __hip_atomic_load(&s.episode[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int len = 0, swap = 0, first = 0;
     const double *pts;
     if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == episode) {
@@ -280,8 +280,12 @@ __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, Ca
         len = __shfl(len, 0), first = __shfl(first, 0), swap = __shfl(swap, 0);
         pts = s.track_scratch_b + env;
     }
-    if (lane == 0) s.episode[env] = episode + 1;
     finish_reset(s, K, env, pts + (int64_t)first * 4 * s.n, len, swap, flag);
+    // The episode index is what the walk-ahead compares its tag with: it is published only now, with a release, after
+    // every lane has consumed the stored walk -- a walk-ahead wavefront that starts while this reset is still reading
+    // `track_scratch` sees the old index (tag == episode: nothing to do) and cannot overwrite the points under it.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&s.episode[env], episode + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Walk-ahead: for every env whose stored walk is not the one its next reset needs, generate it.  Runs on its
@@ -289,8 +293,9 @@ __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, Ca
 __global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSrc src) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= s.n) return;
-    const uint32_t episode = s.episode[env];  // the index the env's next reset will use
-    if (s.walk_tag[env] == episode) return;
+    // the index the env's next reset will use (acquire: pairs with the release at the end of car_reset_kernel)
+    const uint32_t episode = __hip_atomic_load(&s.episode[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == episode) return;
     int len, first, swap;
     gen_walk(s, src, env, episode, s.track_scratch + env, &len, &first, &swap);
     s.walk_len[env] = len, s.walk_first[env] = first, s.walk_swap[env] = swap;

@@ -93,6 +93,13 @@ struct crl_ctx {
     double *ru = nullptr;
     uint8_t *rbx = nullptr, *rby = nullptr;
     crl_timer tm;
+    // crl_terminal_observation_dev: gathered descriptors (grows on demand, never shrinks)
+    uint64_t *gather = nullptr;
+    int64_t gather_cap = 0;
+    int64_t *idx_dev = nullptr;  // staging for the host-index entry point
+    int64_t idx_cap = 0;
+    // action-containment flag (base_pong_env.py:42): host-mapped, written by the step kernel
+    int32_t *bad_action_host = nullptr, *bad_action_dev = nullptr;
     std::vector<uint8_t> atlas_host;
     crl_car_ctx *car = nullptr;  // set for CRL_ENV_CAR_DOUBLE contexts (everything above unused then)
 };
@@ -119,7 +126,12 @@ static int dev_upload(crl_ctx *c, T **p, const std::vector<T> &v, size_t pad_to 
 void crl_timer_begin(crl_timer *t, int which, hipStream_t st) {
     if (!t || !t->on) return;
     crl_event_pair p;
-    hipEventCreate(&p.a), hipEventCreate(&p.b);
+    if (!t->pool.empty()) {  // events are recycled by crl_kernel_time_ms: none is created inside a timed loop after the first pass
+        p = t->pool.back();
+        t->pool.pop_back();
+    } else {
+        hipEventCreate(&p.a), hipEventCreate(&p.b);
+    }
     hipEventRecord(p.a, st);
     t->ev[which].push_back(p);
 }
@@ -287,8 +299,15 @@ int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **
         opts->env_kind != CRL_ENV_CAR_SINGLE)
         return fail(CRL_EINVAL, "unknown env_kind %d", opts->env_kind);
     if (opts->num_envs <= 0) return fail(CRL_EINVAL, "num_envs must be positive");
+    if (opts->reserved != 0) return fail(CRL_EINVAL, "crl_opts.reserved must be 0 (zero-initialise the struct)");
     if (opts->env_kind == CRL_ENV_CAR_DOUBLE || opts->env_kind == CRL_ENV_CAR_SINGLE) {
         if (opts->frame_stack < 0 || opts->frame_stack > 8) return fail(CRL_EINVAL, "frame_stack must be 1..8");
+        if (opts->action_repeat < 0 || opts->action_repeat > 16) return fail(CRL_EINVAL, "action_repeat %d out of range (0..16)", opts->action_repeat);
+        if (opts->done_policy != CRL_CAR_DONE_ANY && opts->done_policy != CRL_CAR_DONE_CAR0)
+            return fail(CRL_EINVAL, "unknown done_policy %d", opts->done_policy);
+        if (opts->done_policy == CRL_CAR_DONE_CAR0 && opts->env_kind != CRL_ENV_CAR_DOUBLE)
+            return fail(CRL_EINVAL, "CRL_CAR_DONE_CAR0 needs a two-car context");
+        if (opts->obs_dtype != CRL_OBS_U8) return fail(CRL_EINVAL, "CarRacing observations are uint8");
         int nd = 0;
         HIP_TRY(hipGetDeviceCount(&nd));
         if (opts->device < 0 || opts->device >= nd) return fail(CRL_EINVAL, "device %d of %d", opts->device, nd);
@@ -300,6 +319,10 @@ int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **
         *out = cc;
         return CRL_OK;
     }
+    if (opts->action_repeat != 0 || opts->done_policy != 0)
+        return fail(CRL_EINVAL, "action_repeat / done_policy are CarRacing options (must be 0 for Pong)");
+    if (opts->obs_dtype != CRL_OBS_U8 && !(opts->obs_dtype == CRL_OBS_F32 && opts->obs_mode == CRL_OBS_GRAY_RESIZED))
+        return fail(CRL_EINVAL, "obs_dtype %d unsupported for this obs_mode", opts->obs_dtype);
     if (opts->obs_mode == CRL_OBS_GRAY_RESIZED) {
         if (opts->resized_dim < 8 || opts->resized_dim > 84 || (opts->resized_dim * opts->resized_dim) % 4)
             return fail(CRL_EINVAL, "resized_dim %d unsupported (8..84, R*R %% 4 == 0)", opts->resized_dim);
@@ -323,14 +346,26 @@ int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **
 #undef A
     if (rc) { crl_destroy(c); return rc; }
     // zero state, BLANK kept frames (MaxAndSkipEnv._obs_buffer starts as zeros)
-    hipMemset(c->s.serve_ctr, 0, n * 4), hipMemset(c->s.wrap_steps, 0, n * 4), hipMemset(c->s.num_steps, 0, n * 4);
-    hipMemset(c->s.real_reward, 0, n * 8);
     {
         std::vector<uint64_t> blank((size_t)8 * n, kBlankFrame);
-        hipMemcpy(c->s.keep, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
-        hipMemcpy(c->s.ring, blank.data(), 8 * n * 8, hipMemcpyHostToDevice);
-        hipMemcpy(c->s.obs_frames, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
-        hipMemcpy(c->s.term_frames, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
+        hipError_t e = hipMemset(c->s.serve_ctr, 0, n * 4);
+        if (e == hipSuccess) e = hipMemset(c->s.wrap_steps, 0, n * 4);
+        if (e == hipSuccess) e = hipMemset(c->s.num_steps, 0, n * 4);
+        if (e == hipSuccess) e = hipMemset(c->s.real_reward, 0, n * 8);
+        if (e == hipSuccess) e = hipMemcpy(c->s.keep, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->s.ring, blank.data(), 8 * n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->s.obs_frames, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->s.term_frames, blank.data(), 2 * n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&c->bad_action_host, 64, hipHostMallocMapped);
+        if (e == hipSuccess) {
+            *c->bad_action_host = 0;
+            e = hipHostGetDevicePointer((void **)&c->bad_action_dev, c->bad_action_host, 0);
+        }
+        if (e != hipSuccess) {
+            crl_destroy(c);
+            return fail(CRL_EHIP, "create: state initialisation: %s", hipGetErrorString(e));
+        }
+        c->s.bad_action = c->bad_action_dev;
     }
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
     // score band: ink rows and the RGB-expanded copy used by the raw writer
@@ -364,6 +399,13 @@ void crl_destroy(crl_ctx *c) {
     for (void *p : c->allocs) hipFree(p);
     for (int w = 0; w < 2; w++)
         for (auto &p : c->tm.ev[w]) hipEventDestroy(p.a), hipEventDestroy(p.b);
+    for (auto &p : c->tm.pool) hipEventDestroy(p.a), hipEventDestroy(p.b);
+    if (c->ru) hipFree(c->ru);
+    if (c->rbx) hipFree(c->rbx);
+    if (c->rby) hipFree(c->rby);
+    if (c->gather) hipFree(c->gather);
+    if (c->idx_dev) hipFree(c->idx_dev);
+    if (c->bad_action_host) hipHostFree(c->bad_action_host);
     delete c;
 }
 
@@ -384,7 +426,7 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         p.ring = c->s.ring, p.n = c->n, p.R = c->o.resized_dim, p.K = c->o.frame_stack, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
-        p.obs = obs_dev;
+        p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
@@ -393,10 +435,28 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
     return CRL_OK;
 }
 
+// The step kernel raises *bad_action_host (host-mapped memory) when it meets an action outside {0, 1, 2, 999}; reading
+// it here costs no synchronisation -- a set flag belongs to an EARLIER step.
+static int pending_action_error(crl_ctx *c, bool clear) {
+    if (!c->bad_action_host) return CRL_OK;
+    const int32_t v = *(volatile int32_t *)c->bad_action_host;
+    if (!v) return CRL_OK;
+    if (clear) *(volatile int32_t *)c->bad_action_host = 0;
+    return fail(CRL_EACTION, "a Pong action outside {0, 1, 2, %d} was passed to an earlier crl_step (first seen: %d); "
+                "the reference asserts action_space.contains(action) (pong/base_pong_env.py:42)", CRL_PONG_CHEAT, v - 1);
+}
+
+int crl_check(crl_ctx *c, void *stream) {
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return pending_action_error(c, true);
+}
+
 int crl_reset(crl_ctx *c, uint8_t *obs_dev, void *stream) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
     hipStream_t st = (hipStream_t)stream;
     if (c->car) return crl_car_reset(c->car, obs_dev, st);
+    if (int rc = pending_action_error(c, false)) return rc;
     launch_pong_reset(c->s, c->src, c->n, pong_mode(c), st);
     HIP_TRY(hipGetLastError());
     return draw_obs(c, obs_dev, st);
@@ -413,6 +473,7 @@ int crl_step(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_
     if (!c || !actions_void) return fail(CRL_EINVAL, "null ctx/actions");
     hipStream_t st = (hipStream_t)stream;
     if (c->car) return crl_car_step(c->car, (const float *)actions_void, obs_dev, rew_dev, done_dev, st, &c->tm);
+    if (int rc = pending_action_error(c, false)) return rc;
     const int32_t *actions_dev = (const int32_t *)actions_void;
     begin_timed(c, 0, st);
     launch_pong_dynamics(c->s, c->src, actions_dev, c->n, pong_mode(c), rew_dev, done_dev, st);
@@ -438,68 +499,103 @@ int crl_copy_info(crl_ctx *c, float *rr_out, int32_t *ns_out, void *stream) {
     return CRL_OK;
 }
 
+int crl_car_info(crl_ctx *c, const uint8_t **done_car_dev, const int32_t **num_steps_dev) {
+    if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
+    if (done_car_dev) *done_car_dev = crl_car_done_flags(c->car);
+    if (num_steps_dev) *num_steps_dev = crl_car_info_steps(c->car);
+    return CRL_OK;
+}
+
+int crl_car_copy_info(crl_ctx *c, uint8_t *done_car_out, int32_t *num_steps_out, void *stream) {
+    if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = crl_car_players(c->car);
+    if (done_car_out) HIP_TRY(hipMemcpyAsync(done_car_out, crl_car_done_flags(c->car), (size_t)(c->n * P), hipMemcpyDeviceToDevice, st));
+    if (num_steps_out) HIP_TRY(hipMemcpyAsync(num_steps_out, crl_car_info_steps(c->car), (size_t)c->n * 4, hipMemcpyDeviceToDevice, st));
+    return CRL_OK;
+}
+
 int64_t crl_obs_bytes_per_env(const crl_ctx *c) {
     if (!c) return 0;
     if (c->car) return crl_car_obs_bytes(c->car);
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) return pong_views(c) * (int64_t)CRL_PONG_FRAME_BYTES;
-    return pong_views(c) * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim;
+    return pong_views(c) * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim * (c->o.obs_dtype == CRL_OBS_F32 ? 4 : 1);
 }
 
-// Renders `count` frame pairs (host) through a temporary context-less launch.
-static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::vector<uint64_t> &f1, uint8_t *out_dev,
-                        hipStream_t st) {
-    const int64_t m = (int64_t)f0.size();
+// Draws `m` frame pairs that already sit in device memory as a single-plane ring ([8][m], planes 0..2 unused).
+static int render_ring(crl_ctx *c, const uint64_t *ring_dev, int64_t m, uint8_t *out_dev, hipStream_t st) {
     if (m == 0) return CRL_OK;
-    uint64_t *tmp = nullptr;
-    HIP_TRY(hipMalloc((void **)&tmp, (size_t)8 * m * 8));
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
-        HIP_TRY(hipMemcpyAsync(tmp, f0.data(), m * 8, hipMemcpyHostToDevice, st));
-        launch_pong_raster_raw(tmp, m, c->atlas_rgb, c->ink_row0, c->ink_row1, out_dev, pong_views(c), st);
+        launch_pong_raster_raw(ring_dev + 6 * m, m, c->atlas_rgb, c->ink_row0, c->ink_row1, out_dev, pong_views(c), st);
     } else {
-        // single-plane ring: only plane 3 is drawn with K = 1
-        std::vector<uint64_t> ring((size_t)8 * m, kBlankFrame);
-        std::copy(f0.begin(), f0.end(), ring.begin() + 6 * m);
-        std::copy(f1.begin(), f1.end(), ring.begin() + 7 * m);
-        HIP_TRY(hipMemcpyAsync(tmp, ring.data(), ring.size() * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));  // `ring` is a local
         GrayParams p{};
-        p.ring = tmp, p.n = m, p.R = c->o.resized_dim, p.K = 1, p.views = pong_views(c);
+        p.ring = ring_dev, p.n = m, p.R = c->o.resized_dim, p.K = 1, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
-        p.obs = out_dev;
+        p.obs = out_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipFree(tmp));
     return CRL_OK;
+}
+
+static int ensure_gather(crl_ctx *c, int64_t m) {
+    if (m <= c->gather_cap) return CRL_OK;
+    HIP_TRY(hipDeviceSynchronize());  // growing is rare: earlier launches may still read the old scratch
+    if (c->gather) hipFree(c->gather), c->gather = nullptr, c->gather_cap = 0;
+    const int64_t cap = std::max<int64_t>(m, 1024);
+    HIP_TRY(hipMalloc((void **)&c->gather, (size_t)8 * cap * 8));
+    c->gather_cap = cap;
+    return CRL_OK;
+}
+
+// Renders `count` frame pairs given on the host (crl_render_raw).
+static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::vector<uint64_t> &f1, uint8_t *out_dev,
+                        hipStream_t st) {
+    const int64_t m = (int64_t)f0.size();
+    if (m == 0) return CRL_OK;
+    if (int rc = ensure_gather(c, m)) return rc;
+    std::vector<uint64_t> ring((size_t)8 * m, kBlankFrame);
+    std::copy(f0.begin(), f0.end(), ring.begin() + 6 * m);
+    std::copy(f1.begin(), f1.end(), ring.begin() + 7 * m);
+    HIP_TRY(hipMemcpyAsync(c->gather, ring.data(), ring.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // `ring` is a local
+    return render_ring(c, c->gather, m, out_dev, st);
+}
+
+int crl_terminal_observation_dev(crl_ctx *c, const int64_t *env_idx_dev, int64_t count, uint8_t *out_dev, void *stream) {
+    if (!c || (count > 0 && (!env_idx_dev || !out_dev))) return fail(CRL_EINVAL, "null argument");
+    if (count <= 0) return CRL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->car) {
+        // CarRacing keeps the finished envs' last frames (players, 96, 96): one gather kernel
+        const int64_t tile = (int64_t)crl_car_players(c->car) * 96 * 96;
+        crl::launch_car_gather_frames(crl_car_terminal_frames(c->car), env_idx_dev, count, c->n, tile, out_dev, st);
+        HIP_TRY(hipGetLastError());
+        return CRL_OK;
+    }
+    if (int rc = ensure_gather(c, count)) return rc;
+    launch_pong_gather_frames(c->s.term_frames, env_idx_dev, count, c->n, c->gather, st);
+    return render_ring(c, c->gather, count, out_dev, st);
 }
 
 int crl_terminal_observation(crl_ctx *c, const int64_t *env_idx_host, int64_t count, uint8_t *out_dev, void *stream) {
     if (!c || (count > 0 && (!env_idx_host || !out_dev))) return fail(CRL_EINVAL, "null argument");
-    if (c->car) {
-        // CarRacing keeps the finished envs' last frames (players, 96, 96): gather the requested ones
-        const int64_t tile = (int64_t)crl_car_players(c->car) * 96 * 96;
-        for (int64_t k = 0; k < count; k++) {
-            const int64_t i = env_idx_host[k];
-            if (i < 0 || i >= c->n) return fail(CRL_EINVAL, "env index %lld out of range", (long long)i);
-            HIP_TRY(hipMemcpyAsync(out_dev + k * tile, crl_car_terminal_frames(c->car) + i * tile, tile, hipMemcpyDeviceToDevice,
-                                   (hipStream_t)stream));
-        }
-        return CRL_OK;
-    }
+    if (count <= 0) return CRL_OK;
+    for (int64_t k = 0; k < count; k++)
+        if (env_idx_host[k] < 0 || env_idx_host[k] >= c->n) return fail(CRL_EINVAL, "env index %lld out of range", (long long)env_idx_host[k]);
     hipStream_t st = (hipStream_t)stream;
-    std::vector<uint64_t> all((size_t)2 * c->n);
-    HIP_TRY(hipMemcpyAsync(all.data(), c->s.term_frames, all.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    std::vector<uint64_t> f0(count), f1(count);
-    for (int64_t k = 0; k < count; k++) {
-        const int64_t i = env_idx_host[k];
-        if (i < 0 || i >= c->n) return fail(CRL_EINVAL, "env index %lld out of range", (long long)i);
-        f0[k] = all[i], f1[k] = all[c->n + i];
+    if (count > c->idx_cap) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->idx_dev) hipFree(c->idx_dev), c->idx_dev = nullptr, c->idx_cap = 0;
+        const int64_t cap = std::max<int64_t>(count, 1024);
+        HIP_TRY(hipMalloc((void **)&c->idx_dev, (size_t)cap * 8));
+        c->idx_cap = cap;
     }
-    return render_pairs(c, f0, f1, out_dev, st);
+    HIP_TRY(hipMemcpyAsync(c->idx_dev, env_idx_host, (size_t)count * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the caller's index array may be reused on return
+    return crl_terminal_observation_dev(c, c->idx_dev, count, out_dev, stream);
 }
 
 int crl_render_raw(crl_ctx *c, const crl_pong_frame *frames_host, int64_t count, uint8_t *out_dev, void *stream) {
@@ -639,7 +735,7 @@ int crl_kernel_time_ms(crl_ctx *c, int which, double *total_ms, int64_t *launche
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
         t.ms[which] += ms, t.cnt[which]++;
-        hipEventDestroy(p.a), hipEventDestroy(p.b);
+        t.pool.push_back(p);
     }
     t.ev[which].clear();
     if (total_ms) *total_ms = t.ms[which];

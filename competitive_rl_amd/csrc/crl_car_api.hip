@@ -31,9 +31,33 @@ struct crl_car_ctx {
     hipStream_t side = nullptr;
     hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
     hipEvent_t ev_reset = nullptr;
+    hipEvent_t ev_walk = nullptr;  // recorded behind every walk-ahead launch: no new one is queued while it is pending
+    bool walk_pending = false;
+    int32_t *info_steps = nullptr;  // [n] CarRacing.step_count after the step, before the auto-reset (info["num_steps"])
+    bool car0_only = false;         // crl_opts.done_policy == CRL_CAR_DONE_CAR0
     hipEvent_t ev_fork = nullptr, ev_coupled = nullptr, ev_term = nullptr, ev_join = nullptr;
     bool overlap = true;
 };
+
+namespace crl {
+// info["terminal_observation"] of the finished envs a caller lists: frames[idx[k]] -> out[k], 16 bytes per thread
+__global__ __launch_bounds__(256) void car_gather_frames_kernel(const uint4 *__restrict__ frames, const int64_t *__restrict__ idx,
+                                                                int64_t n, int64_t chunks, uint4 *__restrict__ out) {
+    const int64_t k = blockIdx.y, i = idx[k];
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= chunks) return;
+    out[k * chunks + c] = (i >= 0 && i < n) ? frames[i * chunks + c] : make_uint4(0, 0, 0, 0);
+}
+void launch_car_gather_frames(const uint8_t *frames, const int64_t *idx_dev, int64_t count, int64_t n, int64_t tile, uint8_t *out,
+                              hipStream_t st) {
+    const int64_t chunks = tile / 16;  // players * 96 * 96 is a multiple of 16
+    for (int64_t k0 = 0; k0 < count; k0 += 65535) {
+        const int64_t m = std::min<int64_t>(65535, count - k0);
+        hipLaunchKernelGGL(car_gather_frames_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)m), dim3(256), 0, st,
+                           reinterpret_cast<const uint4 *>(frames), idx_dev + k0, n, chunks, reinterpret_cast<uint4 *>(out + k0 * tile));
+    }
+}
+}  // namespace crl
 
 // ---- body constants, the Box2D way (b2PolygonShape::ComputeMass, b2Body::ResetMassData), float32
 static void poly_mass(const V2 *vs, int n, float density, float *mass, V2 *center, float *I) {
@@ -140,9 +164,11 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
     if (!rc) rc = calloc_dev(c, &c->slow_env, n);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
+    if (!rc) rc = calloc_dev(c, &c->info_steps, n);
     if (!rc) rc = calloc_dev(c, &c->term, (size_t)M * 96 * 96);
     c->K = opts->frame_stack < 1 ? 1 : opts->frame_stack;
-    c->repeat = opts->resized_dim >= 1 ? opts->resized_dim : 1;  // CarRacing contexts carry action_repeat in resized_dim
+    c->repeat = opts->action_repeat >= 1 ? opts->action_repeat : 1;
+    c->car0_only = opts->done_policy == CRL_CAR_DONE_CAR0;
     if (c->K > 1) {
         if (!rc) rc = calloc_dev(c, &c->frame, (size_t)M * 96 * 96);
         if (!rc) rc = calloc_dev(c, &c->stack, (size_t)M * c->K * 96 * 96);
@@ -161,6 +187,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->gen, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming) != hipSuccess ||
         hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t)) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_coupled, hipEventDisableTiming) != hipSuccess ||
@@ -180,6 +207,7 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->side) hipStreamDestroy(c->side);
     if (c->gen) hipStreamDestroy(c->gen);
     if (c->ev_reset) hipEventDestroy(c->ev_reset);
+    if (c->ev_walk) hipEventDestroy(c->ev_walk);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_coupled) hipEventDestroy(c->ev_coupled);
     if (c->ev_term) hipEventDestroy(c->ev_term);
@@ -196,12 +224,21 @@ static void invalidate_walks(crl_car_ctx *c) {
     hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t));
 }
 // Queues the walk-ahead of every env whose stored walk is not the one its next reset needs, on the context's own
-// stream, after the reset that `after` has just been given.
-static void queue_walk_ahead(crl_car_ctx *c, hipStream_t after) {
+// stream, after the reset that `after` has just been given.  A launch that finds work runs for milliseconds (one
+// serial f64 walk per lane) while a step takes ~2 ms, so launches are NOT queued behind one another: while the
+// previous one is still pending nothing is added -- it, or the next launch after it, picks up every env that was
+// reset in the meantime (a reset that comes too early for its walk simply walks inline; results never depend on it).
+static void queue_walk_ahead(crl_car_ctx *c, hipStream_t after, bool force = false) {
     if (!c->overlap) return;
+    if (c->walk_pending && !force) {
+        if (hipEventQuery(c->ev_walk) == hipErrorNotReady) return;
+        c->walk_pending = false;
+    }
     hipEventRecord(c->ev_reset, after);
     hipStreamWaitEvent(c->gen, c->ev_reset, 0);
     launch_car_walk_ahead(c->s, c->src, c->gen);
+    hipEventRecord(c->ev_walk, c->gen);
+    c->walk_pending = true;
 }
 void crl_car_seed(crl_car_ctx *c, uint64_t seed) {
     invalidate_walks(c);
@@ -228,7 +265,7 @@ int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         launch_car_walk_ahead(c->s, c->src, st);
     }
     launch_car_reset(c->s, c->K_, c->src, false, nullptr, st);
-    queue_walk_ahead(c, st);
+    queue_walk_ahead(c, st, true);
     if (obs_dev) draw(c, obs_dev, true, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car reset: %s", hipGetErrorString(e));
@@ -236,6 +273,8 @@ int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
 }
 
 const uint8_t *crl_car_terminal_frames(const crl_car_ctx *c) { return c->term; }
+const uint8_t *crl_car_done_flags(const crl_car_ctx *c) { return c->done_car; }
+const int32_t *crl_car_info_steps(const crl_car_ctx *c) { return c->info_steps; }
 int crl_car_players(const crl_car_ctx *c) { return c->s.players; }
 
 int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
@@ -261,7 +300,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, st);
         launch_car_coupled(c->s, c->K_, st);
     }
-    launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, 1000, st);
+    launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, c->info_steps, 1000, c->car0_only, st);
     if (!fork) {
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
         if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);

@@ -17,6 +17,7 @@ struct crl_event_pair {
 struct crl_timer {
     bool on = false;
     std::vector<crl_event_pair> ev[2];
+    std::vector<crl_event_pair> pool;  // recycled events
     double ms[2] = {0, 0};
     int64_t cnt[2] = {0, 0};
 };
@@ -31,6 +32,8 @@ int64_t crl_car_obs_bytes(const crl_car_ctx *c);
 int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st);
 int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st);
 const uint8_t *crl_car_terminal_frames(const crl_car_ctx *c);
+const uint8_t *crl_car_done_flags(const crl_car_ctx *c);
+const int32_t *crl_car_info_steps(const crl_car_ctx *c);
 int crl_car_players(const crl_car_ctx *c);
 int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
                  crl_timer *tm);
@@ -41,3 +44,9 @@ int crl_car_get_track_impl(crl_car_ctx *c, int64_t env, int32_t *n_out, float *t
 int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const float *tile_poly, const float *border_poly,
                            const uint8_t *border, const float *start_pose, hipStream_t st);
 int crl_car_set_replay_impl(crl_car_ctx *c, const double *u, const uint8_t *swap, int64_t attempts);
+
+namespace crl {
+// out[k] = frames[idx[k]] for `count` device-resident env indices (tile = bytes per env)
+void launch_car_gather_frames(const uint8_t *frames, const int64_t *idx_dev, int64_t count, int64_t n, int64_t tile, uint8_t *out,
+                              hipStream_t st);
+}  // namespace crl

@@ -1,0 +1,82 @@
+// frame_stack.hip -- FrameStackTensor.update as ONE pass over the stack.
+//
+// Reference (competitive_rl/utils/utils.py:158-170): `current_obs *= mask`, `roll(-C, dim=1)`, then the newest
+// observation goes into the last C planes -- three full passes over a float32 (N, C*k, H, W) tensor plus a host ->
+// device copy of the observation.  Here the observation is already in HBM (u8 from the env kernels, or f32) and the
+// update is a single in-place sweep: every thread owns one 16-byte column position of one env and walks down the
+// planes (load plane p+C, scale by the env's mask, store plane p; then convert and store the new planes), so the
+// in-place shift has no cross-thread hazard and each wavefront moves 1 KiB contiguous per plane.
+// HBM bytes per env (k planes of hw floats): (k-1)*4*hw read + k*4*hw written + the observation; torch's three ops
+// move ~2.5x that.  Bound: HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crl_internal.h"
+
+namespace crl {
+
+template <int VEC, bool OBS_F32>
+__global__ __launch_bounds__(256) void frame_stack_update_kernel(float *__restrict__ stack, const void *__restrict__ obs,
+                                                                 int64_t obs_env_stride, const float *__restrict__ mask,
+                                                                 int64_t n, int c, int k, int64_t hw) {
+    const int64_t per_env = hw / VEC;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * per_env) return;
+    const int64_t env = t / per_env, x = (t - env * per_env) * VEC;
+    const int planes = c * k, keep = planes - c;
+    const float m = mask ? mask[env] : 1.0f;
+    float *base = stack + env * planes * hw + x;
+    if (VEC == 4) {
+#pragma unroll 4
+        for (int p = 0; p < keep; p++) {
+            float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)(p + c) * hw);
+            if (mask) v.x *= m, v.y *= m, v.z *= m, v.w *= m;
+            *reinterpret_cast<float4 *>(base + (int64_t)p * hw) = v;
+        }
+        for (int q = 0; q < c; q++) {
+            float4 v;
+            if (OBS_F32) {
+                v = *reinterpret_cast<const float4 *>(static_cast<const float *>(obs) + env * obs_env_stride + (int64_t)q * hw + x);
+            } else {
+                const uchar4 u = *reinterpret_cast<const uchar4 *>(static_cast<const uint8_t *>(obs) + env * obs_env_stride + (int64_t)q * hw + x);
+                v = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+            }
+            *reinterpret_cast<float4 *>(base + (int64_t)(keep + q) * hw) = v;
+        }
+    } else {
+        for (int p = 0; p < keep; p++) {
+            float v = base[(int64_t)(p + c) * hw];
+            if (mask) v *= m;
+            base[(int64_t)p * hw] = v;
+        }
+        for (int q = 0; q < c; q++) {
+            const int64_t o = env * obs_env_stride + (int64_t)q * hw + x;
+            base[(int64_t)(keep + q) * hw] = OBS_F32 ? static_cast<const float *>(obs)[o] : (float)static_cast<const uint8_t *>(obs)[o];
+        }
+    }
+}
+
+}  // namespace crl
+
+extern "C" int crl_frame_stack_update(float *stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
+                                      const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream) {
+    if (!stack_dev || !obs_dev) return crl_fail(CRL_EINVAL, "frame_stack_update: null tensor");
+    if (n <= 0 || c <= 0 || k <= 0 || hw <= 0) return crl_fail(CRL_EINVAL, "frame_stack_update: bad shape n=%lld c=%d k=%d hw=%lld", (long long)n, c, k, (long long)hw);
+    if (obs_dtype != CRL_OBS_U8 && obs_dtype != CRL_OBS_F32) return crl_fail(CRL_EINVAL, "frame_stack_update: obs_dtype %d", obs_dtype);
+    if (obs_env_stride < (int64_t)c * hw) return crl_fail(CRL_EINVAL, "frame_stack_update: obs_env_stride %lld < c*hw", (long long)obs_env_stride);
+    hipStream_t st = (hipStream_t)stream;
+    const bool f32 = obs_dtype == CRL_OBS_F32;
+    const size_t obs_align = f32 ? 16 : 4;
+    const bool vec = hw % 4 == 0 && ((uintptr_t)stack_dev % 16) == 0 && ((uintptr_t)obs_dev % obs_align) == 0 &&
+                     (obs_env_stride * (f32 ? 4 : 1)) % (int64_t)obs_align == 0;
+    const int64_t threads = n * (vec ? hw / 4 : hw);
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    using namespace crl;
+    if (vec && f32) hipLaunchKernelGGL((frame_stack_update_kernel<4, true>), grid, block, 0, st, stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    else if (vec) hipLaunchKernelGGL((frame_stack_update_kernel<4, false>), grid, block, 0, st, stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    else if (f32) hipLaunchKernelGGL((frame_stack_update_kernel<1, true>), grid, block, 0, st, stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    else hipLaunchKernelGGL((frame_stack_update_kernel<1, false>), grid, block, 0, st, stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return crl_fail(CRL_EHIP, "frame_stack_update: %s", hipGetErrorString(e));
+    return CRL_OK;
+}

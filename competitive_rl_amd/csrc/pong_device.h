@@ -26,6 +26,7 @@ struct PongSoA {
     uint64_t *term_frames;  // [2][n]  frames of the last terminal observation
     float *real_reward;     // [n][2]
     int32_t *num_steps;     // [n]
+    int32_t *bad_action;    // host-mapped flag: first action outside {0, 1, 2, 999} seen, stored as action + 1 (0 = none)
 };
 
 struct ServeSrc {
@@ -127,8 +128,11 @@ __device__ inline int auto_action(double ball_sx, int bat_cy, int ball_cy) {
 
 __device__ inline int decode_action(int a, double sx_for_side, int bat_y, int ball_y) {
     if (a == CRL_PONG_CHEAT) return auto_action(sx_for_side, bat_y + (CRL_PONG_BAT_H >> 1), ball_y + (CRL_PONG_BALL >> 1));
-    return a - 1;
+    // BAT_DIRECTIONS[a] (base_pong_env.py:13); anything else fails the reference's `action_space.contains` assert
+    // (:42) -- here the bat stays put and the step kernel raises the context's flag (CRL_EACTION)
+    return (unsigned)a < 3u ? a - 1 : 0;
 }
+__device__ inline bool action_ok(int a) { return (unsigned)a < 3u || a == CRL_PONG_CHEAT; }
 
 __device__ inline int bat_move(int32_t &y, int dir) {
     int mv = dir * 4;
@@ -204,6 +208,10 @@ struct PongMode {
 void launch_pong_reset(const PongSoA &s, const ServeSrc &src, int64_t n, PongMode mode, hipStream_t st);
 void launch_pong_dynamics(const PongSoA &s, const ServeSrc &src, const int32_t *actions, int64_t n, PongMode mode,
                           float *rew, uint8_t *done, hipStream_t st);
+// out[(6, 7) * count + k] = frames[(0, 1) * n + idx[k]]: the pairs of `count` device-resident env indices as the newest
+// plane of a single-plane ring (planes 0..2 are not written: K = 1 never reads them)
+void launch_pong_gather_frames(const uint64_t *frames, const int64_t *idx_dev, int64_t count, int64_t n, uint64_t *ring_out,
+                               hipStream_t st);
 void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *atlas_rgb, int ink_row0, int ink_row1,
                             uint8_t *obs, int views, hipStream_t st);
 
@@ -228,6 +236,7 @@ struct GrayParams {
     const int32_t *xsi, *ysi;       // source index per tap
     const float *xalpha, *yalpha;   // weight per tap
     uint8_t *obs;                   // [n][2][K][R][R]
+    bool obs_f32;                   // obs is float32 (CRL_OBS_F32): same values, widened in the store epilogue
 };
 void launch_pong_raster_gray(const GrayParams &p, hipStream_t st);
 

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void pong_dynamics_kernel(PongSoA s, ServeSrc 
     PongEnv e = load_env(s, i);
     // cPong-v0: one action per env, the right bat is the AutoBat = CHEAT_CODES on that side
     const int2 a = single ? make_int2(actions[i], CRL_PONG_CHEAT) : reinterpret_cast<const int2 *>(actions)[i];
+    if (!action_ok(a.x) || !action_ok(a.y)) *s.bad_action = (action_ok(a.x) ? a.y : a.x) + 1;  // rare; any writer wins
     int r_l, r_r;
     bool done;
     if (!WRAPPED) {
@@ -108,6 +109,22 @@ __global__ __launch_bounds__(256) void pong_dynamics_kernel(PongSoA s, ServeSrc 
     }
     s.ring[6 * n + i] = f0, s.ring[7 * n + i] = f1;
     store_env(s, i, e);
+}
+
+__global__ __launch_bounds__(256) void pong_gather_frames_kernel(const uint64_t *__restrict__ frames, const int64_t *__restrict__ idx,
+                                                                 int64_t count, int64_t n, uint64_t *__restrict__ ring_out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int64_t i = idx[k];
+    const bool ok = i >= 0 && i < n;
+    ring_out[6 * count + k] = ok ? frames[i] : kBlankFrame;
+    ring_out[7 * count + k] = ok ? frames[n + i] : kBlankFrame;
+}
+
+void launch_pong_gather_frames(const uint64_t *frames, const int64_t *idx_dev, int64_t count, int64_t n, uint64_t *ring_out,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(pong_gather_frames_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, frames, idx_dev, count, n,
+                       ring_out);
 }
 
 void launch_pong_reset(const PongSoA &s, const ServeSrc &src, int64_t n, PongMode mode, hipStream_t st) {

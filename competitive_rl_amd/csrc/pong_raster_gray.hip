@@ -397,7 +397,10 @@ __device__ unsigned long long g_gray_ticks[8];
     }
 // TI = 16-byte chunks per lane per tile: 7 holds R <= 84, 2 holds R <= 45 (the reference's default resized_dim = 42:
 // a quarter of the LDS and 40 fewer registers, so more wavefronts cover the per-tile latency chain)
-template <int MAXT, bool DBG, int TI>
+// F32: the observation tensor is float32 (DummyVecEnv's buffers, utils/dummy_vec_env.py:37-44): the tile is built in
+// LDS as bytes exactly as for uint8 and widened in the store epilogue -- every store instruction still writes 1 KiB
+// contiguous (lane l reads the dword of pixels 4l..4l+3 of a 256-pixel group and stores them as one float4).
+template <int MAXT, bool DBG, int TI, bool F32>
 __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][TI * 1024];
@@ -465,8 +468,11 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_ker
             const int64_t tile = (env * q.views + view) * K + plane;
             uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + tile * (int64_t)RR);
             uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(obs + tile * (int64_t)RR);
+            float4 *__restrict__ outf = reinterpret_cast<float4 *>(obs) + tile * (int64_t)(RR >> 2);  // F32: RR % 4 == 0
             if (blank_a && blank_b) {  // plane erased by a done (FrameStackTensor mask)
-                if (vec16)
+                if (F32)
+                    for (int w = lane; w < (RR >> 2); w += 64) outf[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (vec16)
                     for (int c = lane; c < chunks; c += 64) out[c] = make_uint4(0, 0, 0, 0);
                 else
                     for (int w = lane; w < (RR >> 2); w += 64) out32[w] = 0u;
@@ -556,7 +562,18 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_ker
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             GRAY_TICK(4)
             // ---- 3. stream the tile out
-            if (dbg & 64) {
+            if (F32) {
+                const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
+                constexpr int NG = TI * 4;  // 256-pixel groups of the LDS tile
+                uint32_t px[NG];
+#pragma unroll
+                for (int gi = 0; gi < NG; gi++) px[gi] = tl32[min(lane + 64 * gi, (RR >> 2) - 1)];
+#pragma unroll
+                for (int gi = 0; gi < NG; gi++)
+                    if (lane + 64 * gi < (RR >> 2))
+                        outf[lane + 64 * gi] = make_float4((float)(px[gi] & 255u), (float)((px[gi] >> 8) & 255u), (float)((px[gi] >> 16) & 255u),
+                                                           (float)(px[gi] >> 24));
+            } else if (dbg & 64) {
 #pragma unroll
                 for (int it = 0; it < TI; it++)
                     if (lane + 64 * it < chunks) out[lane + 64 * it] = tv[it];
@@ -615,7 +632,7 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         q.debug = dbg;
     }
     const int64_t tiles = p.n * q.views * p.K;
-    if (q.debug & 8) {
+    if ((q.debug & 8) && !p.obs_f32) {
         hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
                            p.obs);
         return;
@@ -628,14 +645,23 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     static const bool small_off = getenv("CRL_GRAY_SMALL_OFF") != nullptr;  // A/B: the R <= 45 instance off
     const int64_t waves = p.n * (p.K / ppw);
     const dim3 grid((unsigned)((waves + 3) / 4));
+    if (p.obs_f32) {
+        if (tofs.max_taps <= 3)
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        else if (p.R * p.R <= 2048 && !small_off)
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        else
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        return;
+    }
     if (q.debug & ~16)  // any ablation switch: the instrumented instance
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
     else if (tofs.max_taps <= 3)
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
     else if (p.R * p.R <= 2048 && !small_off)
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
     else
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
 }
 
 }  // namespace crl

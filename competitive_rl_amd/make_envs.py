@@ -16,7 +16,7 @@ _HIP_IDS = ("cPongDouble-v0", "cPong-v0", "cPongTournament-v0", "cCarRacingDoubl
 
 def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronous=False, resized_dim=42,
               frame_stack=4, action_repeat=None, *, backend="hip", device=None, output="torch",
-              obs_dtype="uint8", env_id_base=0, stack_planes=1):
+              obs_dtype="uint8", env_id_base=0, stack_planes=1, score_atlas=None):
     """Create a vectorised environment.
 
     :param env_id: "cPongDouble-v0" is served by the HIP backend (other reference ids are
@@ -31,6 +31,7 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
     :param frame_stack: must be None for cPongDouble-v0 (make_envs.py:105-106).
     :param stack_planes: GPU extra -- fuse FrameStackTensor's K-plane stack into the step
         (obs (N, K, R, R) per agent).
+    :param score_atlas: GPU extra -- gray glyph images of the score band (default: the baked FreeSansBold atlas).
     """
     asynchronous = asynchronous and num_envs > 1
     if backend != "hip":
@@ -42,7 +43,7 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
         from .tournament import TournamentEnvWrapper
 
         envs = make_envs("cPongDouble-v0", seed, log_dir, num_envs, asynchronous, resized_dim, None, backend=backend,
-                         device=device, output=output, obs_dtype=obs_dtype, env_id_base=env_id_base)
+                         device=device, output=output, obs_dtype=obs_dtype, env_id_base=env_id_base, score_atlas=score_atlas)
         return TournamentEnvWrapper(envs, num_envs)
     if log_dir:
         os.makedirs(log_dir, exist_ok=True)
@@ -50,7 +51,8 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
         k = 1 if frame_stack is None else int(frame_stack)
         return HipPongVecEnv(num_envs, seed=seed, mode="wrapped", resized_dim=resized_dim, frame_stack=k, device=device,
                              env_id_base=env_id_base, output=output, obs_dtype=obs_dtype,
-                             dones="subproc" if asynchronous else "dummy", single_player=True, stack_replicate=True)
+                             dones="subproc" if asynchronous else "dummy", single_player=True, stack_replicate=True,
+                             score_atlas=score_atlas)
     if env_id == "cCarRacing-v0":  # make_car_racing (car_racing/register.py:29-40): FrameStack, one car
         return HipCarVecEnv(num_envs, seed=seed, device=device, env_id_base=env_id_base, output=output,
                             dones="subproc" if asynchronous else "dummy", action_repeat=action_repeat,
@@ -63,4 +65,4 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
         assert frame_stack is None
     return HipPongVecEnv(num_envs, seed=seed, mode="wrapped", resized_dim=resized_dim, frame_stack=stack_planes,
                          device=device, env_id_base=env_id_base, output=output, obs_dtype=obs_dtype,
-                         dones="subproc" if asynchronous else "dummy")
+                         dones="subproc" if asynchronous else "dummy", score_atlas=score_atlas)

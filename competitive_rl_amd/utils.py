@@ -1,11 +1,23 @@
-"""``step_envs`` -- the step of every training loop of the reference (competitive_rl/utils/utils.py:23-60), SURVEY 8f N1.
+"""``step_envs``: one vector-env step plus the books a trainer keeps around it (interface of reference
+competitive_rl/utils/utils.py:23-60).  Behaviour pinned by tests/golden/step_envs.npz, recorded from
+the reference's function.
 
-Same signature, same bookkeeping, same return tuple.  The reference moves every observation host -> device each
-step (``torch.from_numpy(obs.astype(float32)).to(device)`` inside ``FrameStackTensor.update``); with the HIP env the
-observation is already a device tensor and goes into the (device) ``FrameStackTensor`` without leaving HBM.  What does
-cross to the host per step is what the recorders need: the ``done`` flags (N bytes) and, when ``episode_rewards`` is a
-numpy array as in the reference's trainers, the rewards (N floats).  Pass a device tensor as ``episode_rewards`` to
-keep those on the device too.
+What the call does, in terms of its arguments (all updated in place or returned, as in the reference):
+
+* ``episode_rewards`` (N, A): running return per env and agent -- the step's rewards are added, rows of envs whose
+  episode ended are recorded and then cleared;
+* ``reward_recorder`` / ``length_recorder``: one entry per finished episode (its return row; ``info["num_steps"]``
+  when the env reports it -- CartPole-style envs do not);
+* ``total_episodes`` / ``total_steps``: counters (episodes finished; N env-steps per call);
+* ``frame_stack_tensor``: gets the learner's observation (agent 0's of a two-agent tuple) with a mask that
+  erases the history of envs that just restarted;
+* returns ``(obs, reward, done, info, masks, total_episodes, total_steps, episode_rewards)`` with ``done``
+  reduced to one flag per env and ``masks`` = 1 - done as an (N, 1) float tensor on ``device``.
+
+With the HIP env everything the step produced is already in HBM: observations go straight into the device
+``FrameStackTensor`` (one kernel), masks are built on the device, and ``episode_rewards`` may itself be a device
+tensor.  The only host traffic is the N done flags (the recorders are host lists) and, for a numpy
+``episode_rewards``, the N x A rewards.
 """
 import numpy as np
 import torch
@@ -13,52 +25,71 @@ import torch
 __all__ = ["step_envs"]
 
 
-def _to_numpy(x):
-    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+def _per_env_done(done):
+    """One flag per env: a vector env with A agents reports (N, A) (DummyVecEnv broadcasts the env's scalar),
+    a SubprocVecEnv-style one (N,)."""
+    if isinstance(done, torch.Tensor):
+        return done.bool().all(dim=1) if done.dim() == 2 else done.bool()
+    done = np.asarray(done)
+    return done.astype(bool).all(axis=1) if done.ndim == 2 else done.astype(bool)
+
+
+class _Returns:
+    """The running ``episode_rewards`` array, host (numpy) or device (torch), behind one interface."""
+
+    def __init__(self, arr):
+        self.arr, self.on_device = arr, isinstance(arr, torch.Tensor)
+
+    def add(self, reward):
+        if self.on_device:
+            r = reward if isinstance(reward, torch.Tensor) else torch.as_tensor(np.asarray(reward))
+            self.arr += r.to(self.arr.device, self.arr.dtype).reshape(self.arr.shape)
+        else:
+            r = reward.detach().cpu().numpy() if isinstance(reward, torch.Tensor) else np.asarray(reward)
+            self.arr += r.reshape(self.arr.shape)
+
+    def rows(self, idx):
+        """Copies of the listed rows as numpy arrays (what the reward recorder keeps)."""
+        if len(idx) == 0:
+            return []
+        picked = self.arr[torch.as_tensor(idx, device=self.arr.device)].cpu().numpy() if self.on_device else self.arr[idx]
+        return [np.array(row) for row in picked]
+
+    def clear(self, ended, ended_host):
+        if self.on_device:
+            e = ended if isinstance(ended, torch.Tensor) else torch.as_tensor(ended_host)
+            self.arr.masked_fill_(e.to(self.arr.device).reshape(-1, 1), 0)
+        else:
+            self.arr[ended_host] = 0
 
 
 def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_recorder, length_recorder, total_steps,
               total_episodes, device, test):
-    """One ``envs.step`` plus the books a trainer keeps around it: running episode returns, finished-episode
-    recorders, episode / step totals, and the frame stack (erased where an episode ended)."""
+    shape_before = episode_rewards.shape
     obs, reward, done, info = envs.step(cpu_actions)
-    on_device = isinstance(done, torch.Tensor)
-    if isinstance(episode_rewards, torch.Tensor):
-        r = reward if isinstance(reward, torch.Tensor) else torch.as_tensor(np.asarray(reward))
-        episode_rewards += r.to(episode_rewards.device, episode_rewards.dtype).reshape(episode_rewards.shape)
-    else:
-        episode_rewards += _to_numpy(reward).reshape(episode_rewards.shape)
-    episode_rewards_old_shape = episode_rewards.shape
-    if on_device:
-        done = done.all(dim=1) if done.dim() == 2 else done
-        done_host = done.cpu().numpy()
-    else:
-        done = np.asarray(done)
-        if done.ndim == 2:  # DummyVecEnv: (N, agents); ``not np.isscalar(done[0])`` in the reference
-            done = np.all(done, axis=1)
-        done_host = done
-    for idx in np.nonzero(done_host)[0]:  # finished episodes only
-        idx = int(idx)
-        reward_recorder.append(_to_numpy(episode_rewards[idx]).copy())
-        # envs without a step counter in their info (CartPole) record no length
-        if "num_steps" in info[idx]:
-            length_recorder.append(info[idx]["num_steps"])
-        total_episodes += 1
-    if isinstance(episode_rewards, torch.Tensor):
-        dm = done if on_device else torch.as_tensor(done_host)
-        episode_rewards *= (1.0 - dm.to(episode_rewards.device, episode_rewards.dtype)).reshape(-1, 1)
-    else:
-        episode_rewards *= (1. - done_host.astype(np.float32)).reshape(-1, 1)
-    assert episode_rewards.shape == episode_rewards_old_shape
+    learner_obs = obs[0] if isinstance(obs, tuple) else obs  # two-agent Pong: the learner is agent 0
+    num_envs = learner_obs.shape[0]
 
-    first = obs[0] if isinstance(obs, tuple) else obs
-    total_steps += first.shape[0]
-    if on_device:
-        masks = (1.0 - done.to(torch.float32)).to(device).view(-1, 1)
+    ended = _per_env_done(done)
+    ended_host = ended.cpu().numpy() if isinstance(ended, torch.Tensor) else ended
+
+    returns = _Returns(episode_rewards)
+    returns.add(reward)
+    finished = np.flatnonzero(ended_host)
+    reward_recorder.extend(returns.rows(finished))
+    for i in finished:
+        entry = info[int(i)]
+        if "num_steps" in entry:
+            length_recorder.append(entry["num_steps"])
+    total_episodes += len(finished)
+    returns.clear(ended, ended_host)
+    assert episode_rewards.shape == shape_before
+    total_steps += num_envs
+
+    if isinstance(ended, torch.Tensor):
+        masks = (~ended).to(device=device, dtype=torch.float32).reshape(num_envs, 1)
     else:
-        masks = torch.from_numpy(1. - done_host.astype(np.float32)).to(device).view(-1, 1)
-    # the stack forgets the history of envs that just restarted (mask 0)
-    frame_stack_masks = masks.view(-1, 1) if test else masks.view(-1, 1, 1, 1)
-    # two-agent Pong hands back a tuple: the learner is agent 0
-    frame_stack_tensor.update(first, frame_stack_masks)
-    return obs, reward, done, info, masks, total_episodes, total_steps, episode_rewards
+        masks = torch.from_numpy((~ended_host).astype(np.float32)).to(device).reshape(num_envs, 1)
+    stack_mask = masks if test else masks.reshape(num_envs, 1, 1, 1)
+    frame_stack_tensor.update(learner_obs, stack_mask)
+    return obs, reward, ended, info, masks, total_episodes, total_steps, episode_rewards

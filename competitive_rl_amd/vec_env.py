@@ -68,13 +68,22 @@ class LazyInfos:
     cost more than the simulation).  Behaves like the reference's list of dicts:
     ``infos[i]`` -> ``{"real_reward": [l, r], "num_steps": k}`` plus
     ``"terminal_observation"`` on the step that ended env i's episode
-    (atari_wrappers.py:179-180, dummy_vec_env.py:55-57).  Host copies happen on first use.
+    (atari_wrappers.py:179-180, dummy_vec_env.py:55-57).  Host copies happen on first use; the
+    terminal observations of ALL envs that finished in this step are drawn by one library call
+    (device index list, no per-env round trip).
+
+    Validity: the scalar fields are snapshots and stay valid; ``terminal_observation`` is drawn
+    from the context's record of each env's most recent terminal frames and (with a frame stack)
+    the previous observation buffer, so it must be read before the env is stepped again --
+    afterwards it raises instead of returning a later episode's frames.
     """
 
     def __init__(self, env, wrapped, done, real_reward, num_steps, single=False):
         self._env, self._wrapped, self._single = env, wrapped, single
         self._done_dev, self._rr_dev, self._ns_dev = done, real_reward, num_steps
         self._host = None
+        self._serial = env._serial
+        self._term = None  # env index -> terminal observation, filled by the first request
 
     def __len__(self):
         return self._env.num_envs
@@ -83,6 +92,14 @@ class LazyInfos:
         if self._host is None:
             self._host = (self._done_dev.cpu().numpy(), self._rr_dev.cpu().numpy(), self._ns_dev.cpu().numpy())
         return self._host
+
+    def _terminal(self, i):
+        if self._term is None:
+            if self._env._serial != self._serial:
+                raise RuntimeError("terminal_observation of a past step: read infos[i] before stepping the env again")
+            idx = torch.nonzero(self._done_dev).reshape(-1)
+            self._term = dict(zip(idx.cpu().tolist(), self._env.terminal_observation(idx)))
+        return self._term[i]
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -98,7 +115,7 @@ class LazyInfos:
             d["real_reward"] = float(rr[i, 0]) if self._single else [float(rr[i, 0]), float(rr[i, 1])]
             d["num_steps"] = int(ns[i])
         if done[i]:
-            d["terminal_observation"] = self._env.terminal_observation([i])[0]
+            d["terminal_observation"] = self._terminal(int(i))
         return d
 
     def __iter__(self):
@@ -160,7 +177,8 @@ class HipPongVecEnv(VecEnv):
                          obs_mode=N.CRL_OBS_GRAY_RESIZED if mode == "wrapped" else N.CRL_OBS_RAW_RGB,
                          resized_dim=self.R if mode == "wrapped" else 0, frame_stack=self.K if mode == "wrapped" else 1,
                          num_envs=int(num_envs), env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1),
-                         device=self.device.index or 0, flags=N.CRL_FLAG_STACK_REPLICATE if stack_replicate else 0)
+                         device=self.device.index or 0, flags=N.CRL_FLAG_STACK_REPLICATE if stack_replicate else 0,
+                         obs_dtype=N.CRL_OBS_F32 if (obs_dtype == "float32" and mode == "wrapped") else N.CRL_OBS_U8)
         self._atlas = N.load_score_atlas() if score_atlas is None else np.ascontiguousarray(score_atlas, np.uint8)
         assert self._atlas.size == N.ATLAS_BYTES
         h = C.c_void_p()
@@ -179,8 +197,12 @@ class HipPongVecEnv(VecEnv):
         else:
             VecEnv.__init__(self, n, spaces.Tuple([box, box]), spaces.Tuple([spaces.Discrete(3), spaces.Discrete(3)]))
         dev = self.device
-        self._obs = [torch.empty(self._obs_shape, dtype=torch.uint8, device=dev) for _ in range(2)]
+        # float32 observations (DummyVecEnv's buffer dtype): the wrapped raster stores them directly; the raw RGB frames are
+        # uint8 in the library and widened by torch on request (a 53 GB tensor at 65 536 envs -- not a hot path)
+        self._buf_dtype = torch.float32 if (obs_dtype == "float32" and mode == "wrapped") else torch.uint8
+        self._obs = [torch.empty(self._obs_shape, dtype=self._buf_dtype, device=dev) for _ in range(2)]
         self._flip = 0
+        self._serial = 0  # steps + resets so far: lazy infos check it before drawing terminal observations
         self._rew = torch.zeros((n,) if self.single else (n, 2), dtype=torch.float32, device=dev)
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
         self._actions = torch.zeros((n,) if self.single else (n, 2), dtype=torch.int32, device=dev)
@@ -193,7 +215,7 @@ class HipPongVecEnv(VecEnv):
 
     def _format_obs(self, buf):
         views = [buf[:, v] for v in range(self.V)]
-        if self.obs_dtype == "float32":  # DummyVecEnv's buffer dtype (Box default)
+        if self.obs_dtype == "float32" and buf.dtype != torch.float32:  # raw mode only
             views = [v.float() for v in views]
         if self.output == "numpy":
             views = [v.cpu().numpy() for v in views]
@@ -215,15 +237,20 @@ class HipPongVecEnv(VecEnv):
         self._check_open()
         buf = self._obs[self._flip]
         self._flip ^= 1
+        self._serial += 1
         N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
         return self._format_obs(buf)
 
     def step_async(self, actions):
         self._check_open()
         if isinstance(actions, torch.Tensor):
-            a = actions.to(device=self.device, dtype=torch.int32)
+            a = actions.to(device=self.device, dtype=torch.int32)  # checked on the device (CRL_EACTION)
         else:
-            a = torch.as_tensor(np.asarray(actions), dtype=torch.int32).to(self.device)
+            host = np.asarray(actions)
+            # `assert self.action_space.contains(action)` (pong/base_pong_env.py:42; 999 is decoded first, :116-134)
+            if not np.isin(host, (0, 1, 2, CHEAT_CODES)).all():
+                raise AssertionError(f"actions outside the action space {{0, 1, 2, {CHEAT_CODES}}}: {np.unique(host)[:8]}")
+            a = torch.as_tensor(host, dtype=torch.int32).to(self.device)
         want = (self.num_envs,) if self.single else (self.num_envs, 2)
         if self.single and a.dim() == 2 and a.shape[1] == 1:
             a = a[:, 0]
@@ -232,10 +259,16 @@ class HipPongVecEnv(VecEnv):
         self._actions = a.contiguous()
         self.waiting = True
 
+    def check(self):
+        """Synchronises and raises if an action outside the action space reached a step kernel since the last
+        check (device-resident actions are validated by the kernel; the bat of such an action does not move)."""
+        N.check(self._L.crl_check(self._h, self._stream()))
+
     def step_wait(self):
         self._check_open()
         buf = self._obs[self._flip]
         self._flip ^= 1
+        self._serial += 1
         N.check(self._L.crl_step(self._h, C.c_void_p(self._actions.data_ptr()), C.c_void_p(buf.data_ptr()),
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
         self.waiting = False
@@ -296,25 +329,39 @@ class HipPongVecEnv(VecEnv):
 
     # ------------------------------------------------------------------ extras (parity tests, checkpoint)
     def terminal_observation(self, env_indices):
-        """Observation the episode of each listed env ended on (its most recent done step)."""
-        idx = np.ascontiguousarray(env_indices, np.int64)
-        shape = (len(idx), self.V, 210, 160, 3) if self.mode == "raw" else (len(idx), self.V, self.R, self.R)
-        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
-        N.check(self._L.crl_terminal_observation(self._h, idx.ctypes.data_as(C.c_void_p), len(idx),
-                                                 C.c_void_p(out.data_ptr()), self._stream()))
+        """Observation the episode of each listed env ended on (its most recent done step).  ``env_indices`` may be a
+        device tensor (e.g. ``torch.nonzero(done)``): the whole batch is then gathered and drawn on the device by one
+        call, without a host round trip."""
+        if isinstance(env_indices, torch.Tensor):
+            idx = env_indices.to(device=self.device, dtype=torch.int64).reshape(-1).contiguous()
+            m = idx.numel()
+        else:
+            host_idx = np.ascontiguousarray(env_indices, np.int64).reshape(-1)
+            if ((host_idx < 0) | (host_idx >= self.num_envs)).any():
+                raise IndexError(f"env index out of range: {host_idx}")
+            idx = torch.as_tensor(host_idx).to(self.device)
+            m = len(host_idx)
+        shape = (m, self.V, 210, 160, 3) if self.mode == "raw" else (m, self.V, self.R, self.R)
+        out = torch.empty(shape, dtype=self._buf_dtype, device=self.device)
+        if m:
+            N.check(self._L.crl_terminal_observation_dev(self._h, C.c_void_p(idx.data_ptr()), m, C.c_void_p(out.data_ptr()),
+                                                         self._stream()))
+        if self.obs_dtype == "float32" and out.dtype != torch.float32:
+            out = out.float()
+        stacked = self.mode != "raw" and self.stack_replicate and self.K > 1
+        if stacked:
+            # FrameStack wrapper: the terminal observation is the whole stack = the K-1 newest
+            # planes of the previous observation + the terminal frame (atari_wrappers.py:249-252)
+            prev = self._prev_buf[idx][:, :, 1:]
+            out = torch.cat([prev, out[:, :, None]], dim=2)
+        if self.output == "numpy":
+            out = out.cpu().numpy()
         res = []
-        for k in range(len(idx)):
-            if self.mode == "raw":
+        for k in range(m):
+            if self.mode == "raw" or stacked:
                 pair = tuple(out[k, v] for v in range(self.V))
-            elif self.stack_replicate and self.K > 1:
-                # FrameStack wrapper: the terminal observation is the whole stack = the K-1 newest
-                # planes of the previous observation + the terminal frame (atari_wrappers.py:249-252)
-                prev = self._prev_buf[int(idx[k])]
-                pair = tuple(torch.cat([prev[v, 1:], out[k, v][None]]) for v in range(self.V))
             else:
                 pair = tuple(out[k, v][None] for v in range(self.V))  # (1, R, R) each, WrapPyTorch layout
-            if self.output == "numpy":
-                pair = tuple(p.cpu().numpy() for p in pair)
             res.append(pair[0] if self.single else pair)
         return res
 
@@ -362,7 +409,9 @@ class HipPongVecEnv(VecEnv):
         if not (actions_i32.is_contiguous() and actions_i32.dtype == torch.int32 and actions_i32.device == self.device):
             raise AssertionError("step_device needs a contiguous int32 tensor on the env's device")
         buf = self._obs[self._flip]
+        self._prev_buf = self._obs[self._flip ^ 1]
         self._flip ^= 1
+        self._serial += 1
         N.check(self._L.crl_step(self._h, C.c_void_p(actions_i32.data_ptr()),
                                  C.c_void_p(buf.data_ptr()) if render else None,
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))

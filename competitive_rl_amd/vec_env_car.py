@@ -19,20 +19,34 @@ from .vec_env import VecEnv, _EnvList
 
 class CarLazyInfos:
     """``infos[i]`` -> ``{0: {"num_steps": k, "reward": r0}, 1: {...}}`` (crmp:618-620,
-    atari_wrappers.py:327-328) without building N dicts per step."""
+    atari_wrappers.py:327-328) without building N dicts per step.  ``num_steps`` is ``CarRacing.step_count``
+    read from the device state (it advances by ``action_repeat`` per step); ``TimeLimit.truncated`` appears on
+    the step gym's TimeLimit ends (``not done`` of what the env returned: a dict there, hence False for two
+    cars).  All terminal observations of a step are fetched by one library call; they must be read before the
+    env is stepped again (the older planes of a stacked terminal observation live in the previous buffer)."""
 
-    def __init__(self, n, rew, steps, env=None, done=None):
-        self._n, self._rew_dev, self._steps_dev, self._host = n, rew, steps, None
-        self._env, self._done_dev = env, done
+    def __init__(self, env, rew, steps, done, done_car, elapsed):
+        self._env, self._n = env, env.num_envs
+        self._dev = (rew, steps, done, done_car, elapsed)
+        self._host = None
+        self._serial = env._serial
+        self._term = None
 
     def __len__(self):
         return self._n
 
+    def _terminal(self, i):
+        if self._term is None:
+            if self._env._serial != self._serial:
+                raise RuntimeError("terminal_observation of a past step: read infos[i] before stepping the env again")
+            idx = torch.nonzero(self._dev[2]).reshape(-1)
+            self._term = dict(zip(idx.cpu().tolist(), self._env.terminal_observation(idx)))
+        return self._term[i]
+
     def __getitem__(self, i):
         if self._host is None:
-            self._host = (self._rew_dev.cpu().numpy(), self._steps_dev.cpu().numpy(),
-                          self._done_dev.cpu().numpy() if self._done_dev is not None else None)
-        r, st, dn = self._host
+            self._host = tuple(t.cpu().numpy() for t in self._dev)
+        r, st, dn, dc, el = self._host
         if i < 0:
             i += self._n
         if not 0 <= i < self._n:
@@ -41,8 +55,10 @@ class CarLazyInfos:
             d = {"num_steps": int(st[i])}
         else:
             d = {k: {"num_steps": int(st[i]), "reward": float(r[i, k])} for k in range(2)}
-        if dn is not None and dn[i]:
-            d["terminal_observation"] = self._env.terminal_observation([i])[0]
+        if el[i] >= 1000:  # gym TimeLimit (max_episode_steps=1000, car_racing/register.py:15-26)
+            d["TimeLimit.truncated"] = (not bool(dc[i, 0])) if r.shape[1] == 1 else False
+        if dn[i]:
+            d["terminal_observation"] = self._terminal(int(i))
         return d
 
     def __iter__(self):
@@ -54,13 +70,13 @@ class CarLazyInfos:
 
 class HipCarVecEnv(VecEnv):
     def __init__(self, num_envs, seed=0, device=None, env_id_base=0, output="torch", dones="dummy", action_repeat=None,
-                 frame_stack=None, players=2, car_contacts=True):
+                 frame_stack=None, players=2, car_contacts=True, done_policy="any"):
         if not torch.cuda.is_available():
             raise RuntimeError("HipCarVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
         self.action_repeat = 1 if action_repeat is None else int(action_repeat)
         assert 1 <= self.action_repeat <= 16
-        assert output in ("torch", "numpy") and dones in ("dummy", "subproc")
+        assert output in ("torch", "numpy") and dones in ("dummy", "subproc") and done_policy in ("any", "car0")
         self._L = N.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.device.index is None:
@@ -70,9 +86,10 @@ class HipCarVecEnv(VecEnv):
         assert players in (1, 2)
         self.P = int(players)  # 2 = cCarRacingDouble-v0, 1 = cCarRacing-v0
         opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE if players == 2 else N.CRL_ENV_CAR_SINGLE, obs_mode=0,
-                         resized_dim=self.action_repeat, frame_stack=self.K, num_envs=int(num_envs),
+                         resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
                          env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0,
-                         flags=0 if car_contacts else N.CRL_FLAG_CAR_NO_CONTACTS)
+                         flags=0 if car_contacts else N.CRL_FLAG_CAR_NO_CONTACTS, action_repeat=self.action_repeat,
+                         done_policy=N.CRL_CAR_DONE_CAR0 if done_policy == "car0" else N.CRL_CAR_DONE_ANY)
         h = C.c_void_p()
         self._text = N.load_car_text()  # reward read-out bitmaps of the indicator strip
         with torch.cuda.device(self.device):
@@ -88,7 +105,9 @@ class HipCarVecEnv(VecEnv):
         self._rew = torch.zeros((n, self.P), dtype=torch.float32, device=dev)
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
         self._actions = torch.zeros((n, self.P, 2), dtype=torch.float32, device=dev)
-        self._steps = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self._elapsed = torch.zeros((n,), dtype=torch.int32, device=dev)  # gym TimeLimit._elapsed_steps mirror (infos only)
+        self._serial = 0
+        self._prev_buf = self._obs[1]
         self.envs = _EnvList(self)
 
     def _stream(self):
@@ -110,8 +129,9 @@ class HipCarVecEnv(VecEnv):
         self._check_open()
         buf = self._obs[self._flip]
         self._flip ^= 1
+        self._serial += 1
         N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
-        self._steps.zero_()
+        self._elapsed.zero_()
         return self._out(buf)
 
     def step_async(self, actions):
@@ -131,18 +151,27 @@ class HipCarVecEnv(VecEnv):
         if not (actions_f32.is_contiguous() and actions_f32.dtype == torch.float32 and actions_f32.device == self.device):
             raise AssertionError("step_device needs a contiguous float32 tensor on the env's device")
         buf = self._obs[self._flip]
+        self._prev_buf = self._obs[self._flip ^ 1]  # observation before this step (the stack's older planes)
         self._flip ^= 1
+        self._serial += 1
         N.check(self._L.crl_step(self._h, C.c_void_p(actions_f32.data_ptr()), C.c_void_p(buf.data_ptr()) if render else None,
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
         return buf, self._rew, self._done
 
+    def _info_snapshot(self):
+        """Copies of the library's per-step info arrays: per-car done flags (N, P) u8, CarRacing.step_count (N,) i32."""
+        dc = torch.empty((self.num_envs, self.P), dtype=torch.uint8, device=self.device)
+        ns = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        N.check(self._L.crl_car_copy_info(self._h, C.c_void_p(dc.data_ptr()), C.c_void_p(ns.data_ptr()), self._stream()))
+        return dc, ns
+
     def step_wait(self):
         self._check_open()
         buf, rew, done = self.step_device(self._actions)
-        self._steps += 1
-        self._prev_buf = self._obs[self._flip]  # observation before this step (the stack's older planes)
-        infos = CarLazyInfos(self.num_envs, rew.clone(), self._steps.clone(), env=self, done=done.clone())
-        self._steps.mul_((~done.bool()).to(torch.int32))
+        self._elapsed += 1
+        dc, ns = self._info_snapshot()
+        infos = CarLazyInfos(self, rew.clone(), ns, done.clone(), dc, self._elapsed.clone())
+        self._elapsed.mul_((~done.bool()).to(torch.int32))
         r0 = rew[:, :1].clone()
         d = done.bool()
         d = d[:, None].clone() if self.dones_kind == "dummy" else d.clone()
@@ -168,20 +197,26 @@ class HipCarVecEnv(VecEnv):
         return list(self._obs[self._flip ^ 1][:, 0].cpu().numpy())
 
     def terminal_observation(self, env_indices):
-        """Observation (P*K, 96, 96) each listed env's episode ended on, at its most recent done step."""
-        idx = np.ascontiguousarray(env_indices, np.int64)
-        out = torch.empty((len(idx), self.P, 96, 96), dtype=torch.uint8, device=self.device)
-        N.check(self._L.crl_terminal_observation(self._h, idx.ctypes.data_as(C.c_void_p), len(idx), C.c_void_p(out.data_ptr()),
-                                                 self._stream()))
-        res = []
-        for k in range(len(idx)):
-            if self.K > 1:  # MultipleFrameStack / FrameStack: K-1 newest planes of the previous obs + the last frame
-                prev = self._prev_buf[int(idx[k])].view(self.P, self.K, 96, 96)
-                o = torch.cat([prev[:, 1:], out[k][:, None]], dim=1).reshape(self.P * self.K, 96, 96)
-            else:
-                o = out[k]
-            res.append(o.cpu().numpy() if self.output == "numpy" else o)
-        return res
+        """Observation (P*K, 96, 96) each listed env's episode ended on, at its most recent done step.  ``env_indices``
+        may be a device tensor (``torch.nonzero(done)``): one gather kernel, no host round trip."""
+        if isinstance(env_indices, torch.Tensor):
+            idx = env_indices.to(device=self.device, dtype=torch.int64).reshape(-1).contiguous()
+        else:
+            host_idx = np.ascontiguousarray(env_indices, np.int64).reshape(-1)
+            if ((host_idx < 0) | (host_idx >= self.num_envs)).any():
+                raise IndexError(f"env index out of range: {host_idx}")
+            idx = torch.as_tensor(host_idx).to(self.device)
+        m = idx.numel()
+        out = torch.empty((m, self.P, 96, 96), dtype=torch.uint8, device=self.device)
+        if m:
+            N.check(self._L.crl_terminal_observation_dev(self._h, C.c_void_p(idx.data_ptr()), m, C.c_void_p(out.data_ptr()),
+                                                         self._stream()))
+        if self.K > 1:  # MultipleFrameStack / FrameStack: K-1 newest planes of the previous obs + the last frame
+            prev = self._prev_buf[idx].view(m, self.P, self.K, 96, 96)
+            out = torch.cat([prev[:, :, 1:], out[:, :, None]], dim=2).reshape(m, self.P * self.K, 96, 96)
+        if self.output == "numpy":
+            out = out.cpu().numpy()
+        return [out[k] for k in range(m)]
 
     # ---- parity / checkpoint helpers
     def get_state(self):

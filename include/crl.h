@@ -43,7 +43,13 @@ extern "C" {
 #define CRL_PONG_ATLAS_SCORES 22
 #define CRL_PONG_ATLAS_BYTES (22 * 22 * CRL_PONG_TOP * CRL_PONG_W)
 
-enum { CRL_OK = 0, CRL_EINVAL = -1, CRL_EHIP = -2, CRL_ENOMEM = -3, CRL_ESTATE = -4 };
+enum { CRL_OK = 0, CRL_EINVAL = -1, CRL_EHIP = -2, CRL_ENOMEM = -3, CRL_ESTATE = -4,
+       /* an earlier crl_step was given a Pong action outside {0, 1, 2, 999}: the reference asserts
+          action_space.contains(action) (pong/base_pong_env.py:42).  Device-resident actions are
+          checked by the step kernel; the flag reaches the host without a sync, so the error is
+          reported by the first crl_step / crl_reset / crl_check that sees it (the offending bat did
+          not move).  crl_check clears it. */
+       CRL_EACTION = -5 };
 
 enum crl_env_kind {
     CRL_ENV_PONG_DOUBLE = 1, /* cPongDouble-v0                                                    */
@@ -112,7 +118,7 @@ typedef struct crl_opts {
     int32_t env_kind;    /* crl_env_kind                                             */
     int32_t obs_mode;    /* crl_obs_mode                                             */
     int32_t resized_dim; /* Pong: R = 84 or 42 (make_envs.py:67 resized_dim), 0 for raw;
-                            CarRacing: action_repeat (0 or 1 = none)                 */
+                            CarRacing: ignored                                       */
     int32_t frame_stack; /* K planes per agent in GRAY_RESIZED mode (1 or 4)         */
     int64_t num_envs;    /* envs owned by THIS context (one shard)                   */
     int64_t env_id_base; /* global id of env 0 of this shard: RNG is keyed by global
@@ -120,7 +126,30 @@ typedef struct crl_opts {
     uint64_t seed;       /* make_envs(seed=...)                                      */
     int32_t device;      /* HIP device ordinal                                       */
     int32_t flags;       /* CRL_FLAG_*                                                  */
+    int32_t action_repeat; /* CarRacing(action_repeat=...) (car_racing_multi_players.py:162,576):
+                              0 or 1 = none, at most 16; Pong: must be 0                */
+    int32_t done_policy;   /* CarRacing: crl_car_done_policy; Pong: must be 0           */
+    int32_t obs_dtype;     /* crl_obs_dtype of obs_dev (GRAY_RESIZED Pong contexts; others: U8) */
+    int32_t reserved;      /* must be 0                                                 */
 } crl_opts;
+
+/* Which cars end an env's episode under the VecEnv (CarRacing contexts) */
+enum crl_car_done_policy {
+    /* make_car_racing_double: FlattenMultiAgentObservation returns any(done.values())
+       (utils/atari_wrappers.py:329-330) */
+    CRL_CAR_DONE_ANY = 0,
+    /* make_competitive_car_racing: CarRacingWrapper returns d[0]
+       (car_racing/make_competitive_car_racing.py:24-33); a finished car 1 stays in the world,
+       frozen (car_racing_multi_players.py:578-579), while car 0 drives on */
+    CRL_CAR_DONE_CAR0 = 1,
+};
+/* Element type of the observation tensor handed to crl_reset / crl_step / crl_render */
+enum crl_obs_dtype {
+    CRL_OBS_U8 = 0,
+    /* DummyVecEnv's observation buffers are float32 holding 0..255 (utils/dummy_vec_env.py:37-44;
+       SURVEY 8d config-3 variant, 225 792 B/env): same values, widened in the raster's store */
+    CRL_OBS_F32 = 1,
+};
 
 typedef struct crl_ctx crl_ctx;
 
@@ -167,6 +196,16 @@ int crl_copy_info(crl_ctx *ctx, float *real_reward_out_dev, int32_t *num_steps_o
  * auto-reset (with a K-stack the caller prepends the K-1 newest planes it already holds). */
 int crl_terminal_observation(crl_ctx *ctx, const int64_t *env_idx_host, int64_t count,
                              uint8_t *out_dev, void *stream);
+
+/* The same with the env indices in DEVICE memory (e.g. torch.nonzero(done)): descriptors are gathered
+ * by a kernel and drawn on `stream` -- no device-to-host copy, no allocation (a scratch buffer grows
+ * on demand), no synchronisation.  This is what the host mirror's lazy infos use to fetch every
+ * finished env of a step in one call. */
+int crl_terminal_observation_dev(crl_ctx *ctx, const int64_t *env_idx_dev, int64_t count,
+                                 uint8_t *out_dev, void *stream);
+
+/* Synchronises `stream` and reports (then clears) a pending CRL_EACTION. */
+int crl_check(crl_ctx *ctx, void *stream);
 
 /* Parity tests + checkpoint/resume: whole-state copy, host AoS <-> device SoA.
  * Synchronises `stream`. */
@@ -246,6 +285,22 @@ int crl_car_set_track(crl_ctx *ctx, int64_t env, int32_t n, const float *tile_po
 /* Replay mode for CarRacing.reset's randomness: per env `attempts` rows of 24 uniforms (the
  * np_random.uniform draws of one _create_track attempt) and one birth-place swap bit each. */
 int crl_car_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *swap_host, int64_t attempts);
+
+/* CarRacing.step's per-car returns that the VecEnv folds away, as device arrays valid until the
+ * next step: done_car u8 (N, players) = the `done` dict (car_racing_multi_players.py:618),
+ * num_steps i32 (N) = info[k]["num_steps"] = CarRacing.step_count after the step (:616-620),
+ * captured before the auto-reset. */
+int crl_car_info(crl_ctx *ctx, const uint8_t **done_car_dev, const int32_t **num_steps_dev);
+/* Same data copied (device to device, on `stream`) into caller-owned arrays; either may be NULL. */
+int crl_car_copy_info(crl_ctx *ctx, uint8_t *done_car_out_dev, int32_t *num_steps_out_dev, void *stream);
+
+/* ---- FrameStackTensor.update on device (utils/utils.py:158-170) -----------------
+ * stack f32 (N, C*k, H, W), in place:  stack *= mask[n];  planes shift down by C (roll -C on dim 1);
+ * the last C planes = obs.  One pass over the tensor (torch's mul + roll + slice-assign are three).
+ * obs: (N, C, H, W) with `obs_env_stride` ELEMENTS between envs (a view of a wider tensor is fine),
+ * u8 or f32 per `obs_dtype` (crl_obs_dtype); mask: f32 (N) or NULL (= all ones).  hw = H*W. */
+int crl_frame_stack_update(float *stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
+                           const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream);
 
 /* ---- built-in CNN opponents of cPongTournament-v0 ----------------------------
  * Stands in for utils/policy_serving.py:10-66 `Policy(..., use_light_model=True)` as built by

@@ -190,6 +190,28 @@ class ObservationWrapper(Wrapper):
         return self.observation(o), r, d, i
 
 
+class TimeLimit(Wrapper):
+    """gym.wrappers.TimeLimit as ``gym.make`` applies it for ``register(max_episode_steps=...)`` [from memory of
+    gym 0.10-0.21: count steps since reset; at the limit set info["TimeLimit.truncated"] = not done and done = True]."""
+
+    def __init__(self, env, max_episode_steps):
+        Wrapper.__init__(self, env)
+        self._max_episode_steps = max_episode_steps
+        self._elapsed_steps = None
+
+    def step(self, action):
+        observation, reward, done, info = self.env.step(action)
+        self._elapsed_steps += 1
+        if self._elapsed_steps >= self._max_episode_steps:
+            info["TimeLimit.truncated"] = not done
+            done = True
+        return observation, reward, done, info
+
+    def reset(self, **kw):
+        self._elapsed_steps = 0
+        return self.env.reset(**kw)
+
+
 _REGISTRY = {}
 
 
@@ -203,12 +225,13 @@ def make_gym():
     gym.logger = types.SimpleNamespace(set_level=lambda *_: None)
     gym.error = types.SimpleNamespace(Error=Exception)
 
-    def register(id, entry_point, kwargs=None, **_):
-        _REGISTRY[id] = (entry_point, kwargs or {})
+    def register(id, entry_point, kwargs=None, max_episode_steps=None, **_):
+        _REGISTRY[id] = (entry_point, kwargs or {}, max_episode_steps)
 
     def make(id, **kw):
-        ep, k = _REGISTRY[id]
-        return ep(**{**k, **kw})
+        ep, k, limit = _REGISTRY[id]
+        env = ep(**{**k, **kw})
+        return env if limit is None else TimeLimit(env, limit)
 
     gym.make = make
     envs = types.ModuleType("gym.envs")

@@ -37,7 +37,7 @@ def test_state_struct_layout_matches_header():
     assert N.STATE_DT.itemsize == 120 and N.FRAME_DT.itemsize == 8
     assert N.STATE_DT == po.STATE_DT
     assert po.lib().pong_oracle_state_size() == 120
-    assert ctypes.sizeof(N.CrlOpts) == 48
+    assert ctypes.sizeof(N.CrlOpts) == 64  # crl_opts: 48 bytes of round 1 + action_repeat, done_policy, obs_dtype, reserved
 
 
 def test_create_rejects_bad_arguments_without_gpu():
@@ -56,6 +56,20 @@ def test_create_rejects_bad_arguments_without_gpu():
     o.num_envs, o.obs_mode, o.resized_dim, o.frame_stack = 4, 1, 85, 1
     assert L.crl_create(ctypes.byref(o), atlas.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == -1
     assert L.crl_step(None, None, None, None, None, None) == -1
+    # options that belong to the other env family, or an unknown policy, are refused before any GPU call
+    o = N.CrlOpts(env_kind=1, obs_mode=0, resized_dim=0, frame_stack=1, num_envs=4, action_repeat=4)
+    assert L.crl_create(ctypes.byref(o), atlas.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == -1
+    assert b"CarRacing options" in L.crl_last_error()
+    o = N.CrlOpts(env_kind=2, num_envs=4, frame_stack=1, action_repeat=84)
+    assert L.crl_create(ctypes.byref(o), None, ctypes.byref(h)) == -1 and b"action_repeat" in L.crl_last_error()
+    o = N.CrlOpts(env_kind=2, num_envs=4, frame_stack=1, done_policy=3)
+    assert L.crl_create(ctypes.byref(o), None, ctypes.byref(h)) == -1 and b"done_policy" in L.crl_last_error()
+    o = N.CrlOpts(env_kind=1, obs_mode=0, num_envs=4, frame_stack=1, obs_dtype=1)
+    assert L.crl_create(ctypes.byref(o), atlas.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == -1 and b"obs_dtype" in L.crl_last_error()
+    o = N.CrlOpts(env_kind=1, obs_mode=0, num_envs=4, frame_stack=1, reserved=9)
+    assert L.crl_create(ctypes.byref(o), atlas.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)) == -1 and b"reserved" in L.crl_last_error()
+    assert L.crl_frame_stack_update(None, None, 0, 0, None, 1, 1, 1, 1, None) == -1
+    assert L.crl_check(None, None) == -1 and L.crl_car_info(None, None, None) == -1
 
 
 def test_product_has_no_oracle_dependency():

@@ -1,0 +1,219 @@
+"""CarRacing wrapper chains + DummyVecEnv conventions against tests/golden/car_wrappers.npz, recorded
+from the reference's own ``make_car_racing_double`` / ``make_car_racing`` / ``make_competitive_car_racing`` over a scripted
+simulator whose frames are symbolic ids (tests/golden/gen_car_wrappers_golden.py).
+
+* CPU: the oracle's restatement of the chains (oracle/car_wrappers.py) over the same scripted simulator reproduces every
+  recorded output.
+* ``-m gpu``: the HIP env follows the recorded plan -- same episode ends (a car is put outside the playfield where the
+  plan says it finishes), same actions -- and every observation plane, reward, done flag and info field it returns is
+  the one the recording names, with the frames taken from an un-stacked twin env running in lockstep.
+"""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CONFIGS = {  # name -> (players, frame_stack, action_repeat, mode, steps compared on the GPU)
+    "double_k0_r1": (2, None, None, "double", 80),
+    "double_k4_r1": (2, 4, None, "double", 1060),
+    "double_k4_r2": (2, 4, 2, "double", 80),
+    "single_k0": (1, None, None, "single", 80),
+    "single_k4": (1, 4, None, "single", 1060),
+    "competitive_k4": (2, 4, None, "competitive", 1060),
+}
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(G, "car_wrappers.npz"))
+
+
+def frame(rank, episode, t, agent):
+    f = np.zeros((96, 96, 1), np.uint8)
+    f[0, :4, 0] = (rank, episode, t & 255, (t >> 8) * 4 + agent)
+    return f
+
+
+def decode(obs_chw):
+    return np.asarray(obs_chw)[:, 0, :4].astype(np.uint8)
+
+
+def reward_of(rank, episode, t, agent):
+    return (1 if agent == 0 else -1) * ((rank + 1) * 64 + episode * 8 + t / 16.0)
+
+
+def opponent_from_ids(ids):
+    ids = np.asarray(ids, np.float64)
+    return np.array([ids[1] / 16 - ids[2] / 64, ids[2] / 128 - 0.5])
+
+
+class Scripted:
+    """The generator's stub simulator: symbolic frames, id-valued rewards, planned per-car done steps."""
+
+    def __init__(self, rank, players, plan, repeat):
+        self.rank, self.P, self.plan, self.repeat, self.episode, self.received = rank, players, plan, repeat or 1, -1, []
+
+    def reset(self):
+        self.episode += 1
+        self.t = self.step_count = 0
+        self.done = {k: False for k in range(self.P)}
+        o = {k: frame(self.rank, self.episode, 0, k) for k in range(self.P)}
+        return o if self.P > 1 else o[0]
+
+    def step(self, action):
+        self.t += 1
+        self.step_count += self.repeat
+        self.received.append([np.asarray(action[k] if self.P > 1 else action, np.float64).reshape(-1)[:2] for k in range(self.P)])
+        for k in range(self.P):
+            if self.plan[self.episode][k] and self.t >= self.plan[self.episode][k]:
+                self.done[k] = True
+        o = {k: frame(self.rank, self.episode, self.t, k) for k in range(self.P)}
+        r = {k: reward_of(self.rank, self.episode, self.t, k) for k in range(self.P)}
+        if self.P == 1:
+            return o[0], r[0], self.done[0], {"num_steps": self.step_count}
+        return o, r, dict(self.done), {k: {"num_steps": self.step_count} for k in range(self.P)}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_oracle_wrapper_chain_matches_reference(g, name):
+    from oracle.car_wrappers import CarDummyVecEnv
+
+    players, K, rep, mode, _ = CONFIGS[name]
+    N = 3
+    bases = [Scripted(i, players, g["plans"][i], rep) for i in range(N)]
+    venv = CarDummyVecEnv(bases, players, K, mode, opponent_policy=lambda o1: opponent_from_ids(decode(o1)[-1]))
+    o0 = venv.reset()
+    assert tuple(o0.shape[1:]) == tuple(g[f"{name}/meta_obs_shape"][1:])
+    assert np.array_equal(np.stack([decode(o) for o in o0]), g[f"{name}/obs0"])
+    term = {(int(t), int(i)): k for k, (t, i) in enumerate(zip(g[f"{name}/term_t"], g[f"{name}/term_i"]))}
+    acts = g[f"{name}/acts"]
+    for t in range(len(acts)):
+        o, r, d, infos = venv.step(acts[t])
+        assert r.shape == tuple(g[f"{name}/meta_rew_shape"]) and d.shape == tuple(g[f"{name}/meta_done_shape"])
+        assert np.array_equal(np.stack([decode(x) for x in o]), g[f"{name}/obs"][t]), t
+        assert np.array_equal(r.astype(np.float64), g[f"{name}/rew"][t]) and np.array_equal(d, g[f"{name}/done"][t]), t
+        for i in range(N):
+            inf = infos[i]
+            two = mode == "double"
+            assert (inf[0]["num_steps"] if two else inf["num_steps"]) == g[f"{name}/num_steps"][t][i]
+            if two:
+                assert [inf[0]["reward"], inf[1]["reward"]] == list(g[f"{name}/info_reward"][t][i])
+            assert (int(inf["TimeLimit.truncated"]) if "TimeLimit.truncated" in inf else -1) == g[f"{name}/truncated"][t][i]
+            assert ("terminal_observation" in inf) == ((t, i) in term)
+            if (t, i) in term:
+                assert np.array_equal(decode(inf["terminal_observation"]), g[f"{name}/term_obs"][term[(t, i)]])
+    got = np.array([[np.stack(b.received[t]) for b in bases] for t in range(len(acts))])
+    assert np.array_equal(got, g[f"{name}/received"])
+    assert g[f"{name}/done"].sum() >= 1 and len(term) == int(g[f"{name}/done"].sum())
+
+
+def test_fixture_shows_the_rules(g):
+    d, c = g["double_k4_r1/done"][:, :, 0], g["competitive_k4/done"][:, :, 0]
+    # env 0's second episode: only car 1 finishes (step 5).  any-done ends it there; d[0] lets it run on
+    assert d[:7 + 5, 0].sum() == 2 and c[:7 + 5, 0].sum() == 1
+    assert (g["double_k4_r1/truncated"] == 0).any()            # TimeLimit fired; `not done` of a dict is False
+    assert (g["single_k4/truncated"] == 1).any()
+    assert g["double_k4_r2/num_steps"][0].tolist() == [2, 2, 2]   # step_count advances by action_repeat
+
+
+# --------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_hip_car_env_follows_the_recorded_plan(g, name):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    import competitive_rl_amd as crl
+
+    players, K, rep, mode, T = CONFIGS[name]
+    N, plans = 3, g["plans"]
+    policy = "car0" if mode == "competitive" else "any"
+    ids_now = [None] * N  # ids of agent 1's newest frame, per env (what the scripted opponent keys on)
+
+    def opponent(obs1):   # batched: ignores the pixels, answers from the frame ids the test tracks
+        return torch.as_tensor(np.stack([opponent_from_ids(ids_now[i]) for i in range(N)]).astype(np.float32))
+
+    if mode == "competitive":
+        env = crl.make_competitive_car_racing(opponent, seed=11, num_envs=N, frame_stack=K, batched=True)
+        inner = env.env
+    else:
+        env = crl.HipCarVecEnv(N, seed=11, frame_stack=K, action_repeat=rep, players=players)
+        inner = env
+    twin = crl.HipCarVecEnv(N, seed=11, frame_stack=None, action_repeat=rep, players=players, done_policy=policy)
+
+    frames = {}
+    ep, tt = [0] * N, [0] * N
+
+    def remember(obs_twin, which=None):
+        for i in (range(N) if which is None else which):
+            for a in range(players):
+                frames[(i, ep[i], tt[i], a)] = obs_twin[i, a].clone()
+            ids_now[i] = (i, ep[i], tt[i] & 255, (tt[i] >> 8) * 4 + 1)
+
+    def expect(ids):  # (planes, 4) ids -> (planes, 96, 96) pixels
+        return torch.stack([frames[(int(r), int(e), int(t3) + 256 * (int(q) >> 2), int(q) & 3)] for r, e, t3, q in ids])
+
+    o_t = twin.reset()
+    remember(o_t)
+    o = env.reset()
+    for i in range(N):
+        assert torch.equal(o[i], expect(g[f"{name}/obs0"][i])), i
+    term = {(int(t), int(i)): k for k, (t, i) in enumerate(zip(g[f"{name}/term_t"], g[f"{name}/term_i"]))}
+    acts = g[f"{name}/acts"].astype(np.float32)
+    for t in range(T):
+        # the plan: a car that finishes at its next step is put outside the playfield now (both envs alike)
+        force = [(i, k) for i in range(N) for k in range(players) if plans[i][ep[i]][k] == tt[i] + 1]
+        if force:
+            for e_ in (inner, twin):
+                st = e_.get_state()
+                for i, k in force:
+                    for body in ("hull", "wheel"):
+                        st[i]["car"][k][body]["cx"] += 900.0
+                e_.set_state(st)
+        if mode == "competitive":
+            want_recv = g[f"{name}/received"][t]
+            o, r, d, infos = env.step(acts[t])
+            sent = env._act.cpu().numpy().astype(np.float64)
+            assert np.array_equal(sent, want_recv), t                   # learner -> car 0, opponent's LAST answer -> car 1
+            twin.step(env._act.clone())
+        else:
+            o, r, d, infos = env.step(acts[t])
+            twin.step(acts[t])
+        # what the un-stacked twin produced this step
+        rew_t, done_t = twin._rew.clone(), twin._done.bool().cpu().numpy()
+        dc_t, ns_t = (x.cpu().numpy() for x in twin._info_snapshot())
+        fin = [i for i in range(N) if done_t[i]]
+        for i in range(N):
+            tt[i] += 1
+        live = [i for i in range(N) if not done_t[i]]
+        remember(twin._obs[twin._flip ^ 1], live)
+        if fin:
+            tf = twin.terminal_observation(fin)
+            for j, i in enumerate(fin):
+                for a in range(players):
+                    frames[(i, ep[i], tt[i], a)] = tf[j][a].clone()
+        # ---- against the recording
+        assert np.array_equal(d.cpu().numpy(), g[f"{name}/done"][t]), t
+        assert np.array_equal(d.cpu().numpy()[:, 0], done_t), t
+        assert torch.equal(r[:, 0], rew_t[:, 0]), t                       # agent 0's reward
+        for i in range(N):
+            inf = infos[i]
+            if mode == "double":
+                assert inf[0]["num_steps"] == inf[1]["num_steps"] == g[f"{name}/num_steps"][t][i], (t, i)
+                assert [inf[0]["reward"], inf[1]["reward"]] == [float(rew_t[i, 0]), float(rew_t[i, 1])]
+            else:
+                assert inf["num_steps"] == g[f"{name}/num_steps"][t][i], (t, i)
+            assert ns_t[i] == g[f"{name}/num_steps"][t][i]
+            if mode != "competitive":
+                assert (int(inf["TimeLimit.truncated"]) if "TimeLimit.truncated" in inf else -1) == g[f"{name}/truncated"][t][i], (t, i)
+            assert ("terminal_observation" in inf) == ((t, i) in term), (t, i)
+            if (t, i) in term:
+                assert torch.equal(inf["terminal_observation"], expect(g[f"{name}/term_obs"][term[(t, i)]])), (t, i)
+        for i in fin:
+            ep[i] += 1
+            tt[i] = 0
+        remember(twin._obs[twin._flip ^ 1], fin)
+        for i in range(N):
+            assert torch.equal(o[i], expect(g[f"{name}/obs"][t][i])), (t, i)
+    env.close(), twin.close()

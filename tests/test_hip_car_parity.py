@@ -231,7 +231,9 @@ def test_car_api_surface_and_time_limit():
         if t == 999:  # gym TimeLimit: max_episode_steps = 1000
             assert bool(done.all())
             i0 = info[0]
-            assert set(i0.keys()) == {0, 1, "terminal_observation"} and i0[0]["num_steps"] == 1000 and "reward" in i0[1]
+            # keys as recorded from the reference chain (tests/golden/car_wrappers.npz): TimeLimit adds its flag
+            assert set(i0.keys()) == {0, 1, "terminal_observation", "TimeLimit.truncated"} and i0["TimeLimit.truncated"] is False
+            assert i0[0]["num_steps"] == 1000 and "reward" in i0[1]
             assert tuple(i0["terminal_observation"].shape) == (2, 96, 96)
     assert n_done == 6
     st = envs.get_state()

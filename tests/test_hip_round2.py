@@ -1,0 +1,223 @@
+"""GPU tests of what round 2 added behind the C ABI: action containment (base_pong_env.py:42), the float32 store
+epilogue (SURVEY 8d config-3 variant), other resized_dim values against the oracle, device-side terminal
+observations, the car-0-only done rule, BASELINE config #4 at its real size, and the info validity window."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+
+
+def test_action_containment_host_and_device():
+    """pong/base_pong_env.py:42 asserts action_space.contains(action).  Host arrays are checked on the host; device
+    tensors by the step kernel: the bat of a bad action does not move, and the error surfaces at the next call."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from competitive_rl_amd._native import CrlActionError
+
+    n = 64
+    env = crl.HipPongVecEnv(n, seed=1, mode="raw")
+    env.reset()
+    with pytest.raises(AssertionError):
+        env.step(np.full((n, 2), 5))
+    with pytest.raises(AssertionError):
+        env.step(np.full((n, 2), -1))
+    ok = torch.ones((n, 2), dtype=torch.int32, device="cuda")
+    env.step_device(ok)
+    env.check()                                       # nothing pending
+    st0 = env.get_state()
+    bad = ok.clone()
+    bad[7, 0] = 5
+    env.step_device(bad)
+    st1 = env.get_state()
+    assert st1["bat_l_y"][7] == st0["bat_l_y"][7]    # the reference would not have stepped; here the bat stays put
+    with pytest.raises(CrlActionError) as e:
+        env.check()
+    assert isinstance(e.value, AssertionError) and "5" in str(e.value)
+    env.check()                                       # cleared
+    env.step_device(bad)
+    torch.cuda.synchronize()
+    with pytest.raises(CrlActionError):
+        env.step_device(ok)                           # the next step reports the earlier one
+    env.close()
+
+
+@pytest.mark.parametrize("R,K", [(84, 4), (42, 1), (64, 2)])
+def test_float32_store_epilogue_equals_uint8(atlas, R, K):
+    """obs_dtype="float32" (DummyVecEnv's buffer dtype) is produced by the raster's store epilogue, not by a torch
+    pass: same values as the uint8 path -- and as the oracle -- on every step, terminal observations included."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import pong_oracle as po
+
+    n, steps = 70, 130
+    rs = np.random.RandomState(R + K)
+    f = crl.HipPongVecEnv(n, seed=4, mode="wrapped", resized_dim=R, frame_stack=K, obs_dtype="float32")
+    ora = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=R, frame_stack=K, seed=4)
+    of = torch.stack(f.reset(), 1)
+    assert of.dtype == torch.float32 and f._obs[0].dtype == torch.float32
+    assert np.array_equal(of.cpu().numpy(), ora.reset().astype(np.float32))
+    seen = 0
+    for t in range(steps):
+        a = rs.randint(0, 3, (n, 2))
+        obs, rew, done, infos = f.step(a)
+        oo, orew, odone = ora.step(a)
+        assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo.astype(np.float32)), t
+        assert np.array_equal(rew.cpu().numpy(), orew)
+        for i in np.nonzero(odone)[0][:2]:
+            term = infos[int(i)]["terminal_observation"]
+            assert term[0].dtype == torch.float32
+            assert np.array_equal(torch.stack(term).cpu().numpy()[:, 0], ora.terminal_observation(int(i)).astype(np.float32))
+            seen += 1
+    assert seen > 0
+    f.close()
+
+
+@pytest.mark.parametrize("R", [64, 32, 48])
+def test_other_resized_dims_match_oracle(atlas, R):
+    """crl_create accepts any even resized_dim in 8..84; sizes other than the reference's 84 / 42 take the same
+    kernels (up to five taps per axis) or the per-pixel evaluator: bit-exact against the oracle as well."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import pong_oracle as po
+
+    n, steps, K = 48, 120, 4
+    rs = np.random.RandomState(R)
+    env = crl.HipPongVecEnv(n, seed=2, mode="wrapped", resized_dim=R, frame_stack=K)
+    ora = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=R, frame_stack=K, seed=2)
+    assert np.array_equal(torch.stack(env.reset(), 1).cpu().numpy(), ora.reset())
+    for t in range(steps):
+        a = rs.randint(0, 3, (n, 2))
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = ora.step(a)
+        assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo), (R, t)
+        assert np.array_equal(rew.cpu().numpy(), orew) and np.array_equal(done[:, 0].cpu().numpy().astype(np.uint8), odone)
+    env.close()
+
+
+def test_terminal_observations_by_device_index_and_validity_window(atlas):
+    """All finished envs of a step are drawn by one crl_terminal_observation_dev call from a device index list;
+    reading them after the env has moved on raises instead of returning another episode's frames."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import pong_oracle as po
+
+    n = 300
+    env = crl.HipPongVecEnv(n, seed=6, mode="wrapped", resized_dim=42, frame_stack=1)
+    ora = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=6)
+    env.reset(), ora.reset()
+    rs = np.random.RandomState(0)
+    checked, stale = 0, None
+    for t in range(160):
+        a = rs.randint(0, 3, (n, 2))
+        obs, rew, done, infos = env.step(a)
+        _, _, odone = ora.step(a)
+        idx = torch.nonzero(done[:, 0]).reshape(-1)
+        if stale is not None and stale[2] == t - 1:
+            with pytest.raises(RuntimeError):                           # the env has been stepped since
+                stale[0][stale[1]]
+        if idx.numel():
+            if stale is None:
+                stale = (infos, int(idx[0]), t)                         # untouched: read only after the next step
+                continue
+            got = env.terminal_observation(idx)                         # device index list
+            host = env.terminal_observation(idx.cpu().numpy())           # host index list (copied to the device)
+            for k, i in enumerate(idx.cpu().tolist()):
+                want = ora.terminal_observation(i)
+                assert np.array_equal(torch.stack(got[k]).cpu().numpy()[:, 0], want)
+                assert torch.equal(torch.stack(got[k]), torch.stack(host[k]))
+                assert torch.equal(torch.stack(infos[i]["terminal_observation"]), torch.stack(got[k]))
+                checked += 1
+    assert checked >= 3 and stale is not None
+    with pytest.raises(IndexError):
+        env.terminal_observation([n])
+    env.close()
+
+
+def test_car0_done_policy_and_infos():
+    """make_competitive_car_racing's rule (d[0], make_competitive_car_racing.py:24-33): a finished OPPONENT does not end
+    the episode -- it stays where it is, frozen, while car 0 drives on; the default rule (any) ends it."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 6
+    a = crl.HipCarVecEnv(n, seed=3, done_policy="car0")
+    b = crl.HipCarVecEnv(n, seed=3, done_policy="any")
+    for e in (a, b):
+        e.reset()
+        st = e.get_state()
+        for body in ("hull", "wheel"):
+            st["car"][:, 1][body]["cx"][2] += 900.0   # env 2: car 1 leaves the playfield
+        e.set_state(st)
+    acts = np.zeros((n, 2, 2), np.float32)
+    acts[:, :, 1] = 0.5
+    for t in range(5):
+        oa, ra, da, ia = a.step(acts)
+        ob, rb, db, ib = b.step(acts)
+        assert not bool(da.any()), t
+        assert bool(db[2, 0]) == (t == 0) and int(db.sum()) == (1 if t == 0 else 0)
+        dc, ns = (x.cpu().numpy() for x in a._info_snapshot())
+        assert dc[2].tolist() == [0, 1] and dc[[0, 1, 3, 4, 5]].sum() == 0 and (ns == t + 1).all()
+        assert ia[2][1]["reward"] == (float(np.float32(-0.1)) if t == 0 else 0.0)      # the frozen car earns nothing more
+        assert ia[2][0]["num_steps"] == t + 1 and ia[2][0]["reward"] < 0
+    sa = a.get_state()
+    assert sa["car"][2, 1]["done"] == 1 and sa["car"][2, 0]["done"] == 0 and sa["episode"][2] == 1
+    assert abs(float(sa["car"][2, 1]["hull"]["vx"])) < 1e-6             # no forces on the finished car
+    a.close(), b.close()
+
+
+def test_full_size_car_properties():
+    """BASELINE config #4 at its real size (16 384 envs): determinism checksum, reward bounds, TimeLimit,
+    observation invariants."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps = 16384, 30
+
+    def run():
+        env = crl.HipCarVecEnv(n, seed=0)
+        first = env.reset()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        tot_done = 0
+        rsum = torch.zeros((n, 2), device="cuda")
+        for t in range(steps):
+            a = torch.rand((n, 2, 2), generator=g, device="cuda") * 2 - 1
+            buf, rew, done = env.step_device(a)
+            assert bool(((rew >= -0.1001) & (rew < 20.0)).all()), t            # -0.1 per step, +1000/len(track) per new tile
+            rsum += rew
+            tot_done += int(done.sum())
+        torch.cuda.synchronize()
+        ck = int(buf.reshape(-1).view(torch.int32).sum(dtype=torch.int64))
+        st = env.get_state()
+        env.close()
+        return first.clone(), buf.clone(), ck, st, tot_done, rsum
+
+    first, buf, ck, st, tot_done, rsum = run()
+    palette = torch.tensor([0, 29, 44, 60, 76, 101, 103, 107, 149, 161, 176, 255], device="cuda", dtype=torch.uint8)
+    assert bool(torch.isin(buf, palette).all()) and bool(torch.isin(first, palette).all())
+    own = (buf[:, 0] == 60).sum(dim=(1, 2))                                     # every viewer sees its own red hull
+    assert int(own.min()) > 0 and int((buf[:, 1] == 60).sum(dim=(1, 2)).min()) > 0
+    assert bool((buf[:, :, 86:, :] != 161).all()) and bool((buf[:, :, 86:, :] != 176).all())   # indicator strip: no grass
+    assert (st["elapsed"] <= steps).all() and ((st["elapsed"] == steps) | (st["episode"] > 1)).all()
+    assert bool((rsum.abs() < 20.0 * steps).all()) and tot_done < n // 50
+    first2, buf2, ck2, st2, tot_done2, _ = run()
+    assert ck == ck2 and tot_done == tot_done2 and torch.equal(first, first2) and torch.equal(buf, buf2)
+    for f in ("cx", "cy", "a", "vx", "vy", "w"):
+        assert np.array_equal(st["car"]["hull"][f], st2["car"]["hull"][f])
+
+    # TimeLimit at full size: park the clock at 999 steps -> every env ends on the next step and restarts
+    env = crl.HipCarVecEnv(n, seed=0)
+    env.reset()
+    s = env.get_state()
+    s["elapsed"] = 999
+    env.set_state(s)
+    _, _, done = env.step_device(torch.zeros((n, 2, 2), device="cuda"))
+    assert bool(done.all())
+    s = env.get_state()
+    assert (s["elapsed"] == 0).all() and (s["episode"] == 2).all()
+    env.close()
