@@ -173,6 +173,10 @@ def test_hip_car_env_follows_the_recorded_plan(g, name):
                 e_.set_state(st)
         if mode == "competitive":
             want_recv = g[f"{name}/received"][t]
+            # the opponent is asked INSIDE step(), about the observation this step returns: name that frame now
+            for i in range(N):
+                ends = plans[i][ep[i]][0] == tt[i] + 1 or tt[i] + 1 == 1000
+                ids_now[i] = (i, ep[i] + 1, 0, 1) if ends else (i, ep[i], (tt[i] + 1) & 255, ((tt[i] + 1) >> 8) * 4 + 1)
             o, r, d, infos = env.step(acts[t])
             sent = env._act.cpu().numpy().astype(np.float64)
             assert np.array_equal(sent, want_recv), t                   # learner -> car 0, opponent's LAST answer -> car 1
