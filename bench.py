@@ -1,117 +1,144 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the cPongDouble hot path on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raw|fused84|fused84_newest|car|tournament] [--gather none|scalars|obs]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|raw|fused84|fused84_f32|fused84_newest|car|tournament]
+                    [--envs E] [--gather none|scalars|obs] [--no-cpu-baseline]
 
-A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated,
-device-resident) random actions, auto-reset included, no host sync inside the timed loop.
-Default workload = BASELINE.json configs[1]: cPongDouble-v0, 65 536 envs per GPU, raw
-(N, 2, 210, 160, 3) uint8 observations (1 env-step = 1 frame).  Prints ONE JSON line on rank 0.
+A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated, device-resident) random
+actions, auto-reset included, no host sync inside the timed loop.  The headline (``metric`` / ``value``) is
+BASELINE.json configs[1]: cPongDouble-v0, 65 536 envs per GPU, raw (N, 2, 210, 160, 3) uint8 observations, 1 env-step =
+1 frame.  With the default ``--workload all`` on one GPU the same process then measures every other single-GPU
+configuration (fused gray+84x84+4-stack u8 and its float32 variant, cCarRacingDouble, the tournament loop) the same way
+and attaches them under ``"configs"``, each with its own ``roofline`` and ``cpu_baseline``.  ONE JSON line on rank 0.
 
-Envs shard across GPUs with no data-path collective (weak scaling: 65 536 envs per GPU);
-`--gather obs` adds the RCCL all-gather of BASELINE config #5 (xGMI-bound by construction).
+``--gpus N`` without a launcher starts N fresh worker processes itself (one per GPU, before anything touches the GPU);
+under ``torch.distributed.run`` the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* of the environment are used.  Envs shard
+across GPUs with no data-path collective (weak scaling: 65 536 envs per GPU); ``--gather obs|scalars`` adds the RCCL
+all-gather of BASELINE config #5 (one packed collective per step on a side stream, overlapped with the next step).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic HBM bytes per env per launch, DESIGN.md "Kernels" (201 713 B/env-step
-# for raw = 201 600 obs + 113 state/scalars; the frame-descriptor hand-off adds 8 B each way)
-RAW_RASTER_BYTES = 2 * 100800 + 8
-FUSED_RASTER_BYTES = {84: 2 * 4 * 84 * 84 + 8 * 8}
-# CarRacing raster: obs 2*96*96 stored + ~1.6 KB body/joint state + ~4.7 KB track read (~24 900 B/env-step)
-CAR_STEP_BYTES = 24900
-HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
+# ---- algorithmic HBM bytes per env per launch of the dominant kernel (DESIGN.md "Kernels")
+RAW_BYTES = 2 * 100800 + 8                 # both RGB views stored + the 8-byte frame descriptor read
+FUSED_BYTES = 2 * 4 * 84 * 84 + 8 * 8      # (2, 4, 84, 84) u8 stored + the eight descriptors of the stack
+FUSED_F32_BYTES = 4 * 2 * 4 * 84 * 84 + 8 * 8
+NEWEST_BYTES = 2 * 84 * 84 + 16
+CAR_BYTES = 24900                          # obs 18 432 + state r/w ~1 600 + track read ~4 700 + visited bits
+HBM_PEAK = 8.0e12                          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a float4 copy sustains)
+FP32_PEAK = 157.3e12                       # fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md)
+POLICY_FLOP = 2 * 516800                   # LightActorCritic: conv1 409 600 + conv2 102 400 + actor 4 800 multiply-adds
+# cCarRacingDouble f32 FLOP per env-step, counted from the code paths (DESIGN.md 4b "FLOP model"): island solve
+# 2 cars x (180 velocity iterations x 4 joints x 58 + joint init 4 x 70 + positions ~3 x 4 x 120 + integration 5 x 14)
+# = 87 600; wheel model 2 x 4 x 64 (f64, counted once); sensor contacts ~2 x (300 AABB tests x 4 + 6 narrow pairs x 820)
+# = 12 240; raster 2 views x 9 216 px x ~38 (inverse map 10, ~4 candidate tiles x 5 edges x ... resolved per 8x8 cell,
+# car polygons, luma) = 700 400.  Total ~0.80 MFLOP; profiles/flops_car.json (SQ_INSTS_VALU_* counters) overrides it.
+CAR_FLOP_MODEL = 87600 + 512 + 12240 + 700400
 
 
-def cpu_baseline(workload, budget_s=12.0):
-    """The oracle (CPU restatement of the reference path) timed on this host's cores on a
-    bounded sample of the same workload.  Reported baseline, never the product path."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="all",
+                    choices=["all", "raw", "fused84", "fused84_f32", "fused84_newest", "car", "tournament"])
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
+    ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` with no launcher around it: N fresh children, one per GPU.  Runs before torch is
+    imported -- a process that has touched the GPU is never re-executed; the parent only waits."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+# =============================================================================================== CPU baselines
+def cpu_baselines(workloads, budget_s=8.0):
+    """Rank 0, one GPU only, BEFORE the GPU is touched: the oracle timed on this host's cores on bounded samples of
+    the same workloads -- (a) in the reference's SubprocVecEnv architecture (one process per env, pipes, pickled
+    observations; oracle/subproc_baseline.py), which is the reported ``value``; (b) as one OpenMP batch over all
+    cores (upper bound of a compiled port); plus BASELINE config #1 (4 envs, synchronous).  Never the product path."""
     import numpy as np
 
-    from competitive_rl_amd import _native
     from oracle import pong_oracle as po
+    from oracle import subproc_baseline as sb
 
     cores = len(os.sched_getaffinity(0))
-    atlas = _native.load_score_atlas()
-    if workload == "car":
-        return cpu_baseline_car(cores, budget_s)
-    if workload == "fused84_newest":
-        workload = "fused84"
-    if workload == "raw":
-        n = 64 * cores
-        env = po.PongOracle(n, atlas, obs_mode=po.RAW, seed=0)
-        threads = cores
-    else:
-        n = 16 * cores
-        env = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=84, frame_stack=4, seed=0)
-        threads = cores
-    env.set_threads(threads)
-    env.reset()
-    rs = np.random.RandomState(0)
-    acts = rs.randint(0, 3, (8, n, 2)).astype(np.int32)
-    env.step(acts[0])
-    t0 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t0 < budget_s:
-        env.step(acts[k % 8])
-        k += 1
-    dt = time.perf_counter() - t0
-    env.close()
-    return {"value": n * k / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c ({workload}), OpenMP over {threads} threads, {dt:.1f} s"}
+    atlas = np.load(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_score_atlas.npz"))["atlas"]
+    out = {}
+
+    def openmp_port(kind, n):
+        env = po.PongOracle(n, atlas, obs_mode=po.RAW if kind == "raw" else po.GRAY, resized_dim=84 if kind == "fused84" else 42,
+                            frame_stack=4 if kind == "fused84" else 1, seed=0)
+        env.set_threads(cores)
+        env.reset()
+        rs = np.random.RandomState(0)
+        acts = rs.randint(0, 3, (8, n, 2)).astype(np.int32)
+        env.step(acts[0])
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s * 0.6:
+            env.step(acts[k % 8])
+            k += 1
+        dt = time.perf_counter() - t0
+        env.close()
+        return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c ({kind}) as one OpenMP batch over {cores} threads, {dt:.1f} s"}
+
+    def subproc(kind, label):
+        v, k, dt = sb.time_subproc(kind, cores, budget_s)
+        return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port", "architecture": "subproc-arch",
+                "sample": f"{k} lock-steps x {cores} one-env worker processes ({label}), duplex pipes, pickled obs per step "
+                          f"(architecture of utils/subproc_vec_env.py:11-118), {dt:.1f} s"}
+
+    for wl in workloads:
+        if wl == "raw":
+            b = subproc("raw", "raw 2 x (210,160,3) u8 per env-step")
+            b["openmp_port"] = openmp_port("raw", 64 * cores)
+        elif wl in ("fused84", "fused84_f32", "fused84_newest"):
+            b = subproc("gray_84", "skip-4 + max-2 + gray + 84x84 INTER_AREA, 2 x (1,84,84) per env-step")
+            b["openmp_port"] = openmp_port("fused84", 16 * cores)
+        elif wl == "car":
+            b = subproc("car", "Box2D-style step + two 96x96 renders per env-step")
+        elif wl == "tournament":
+            b = cpu_baseline_tournament(po, atlas, cores, budget_s * 0.8)
+        else:
+            continue
+        out[wl] = b
+    if "raw" in workloads:  # BASELINE config #1: make_envs(num_envs=4, asynchronous=False), 42x42, 1000 steps
+        v, k, dt = sb.time_dummy("gray_42", 4, 1000)
+        out["raw"]["config1_dummy_n4"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port", "architecture": "dummy-arch",
+                                          "sample": f"{k} steps x 4 envs in one process (DummyVecEnv loop, utils/dummy_vec_env.py:51-63), "
+                                                    f"resized_dim 42, {dt:.1f} s"}
+    return out
 
 
-def cpu_baseline_car(cores, budget_s):
-    """Oracle CarRacing envs stepped + rendered serially on one core (scalar port)."""
-    import ctypes as C
-
-    import numpy as np
-
-    from oracle import car_oracle as co
-
-    L = co.lib()
-    L.car_oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    rs = np.random.RandomState(0)
-    envs = []
-    for i in range(4):
-        e = co.CarEnv()
-        while e.reset(rs.random_sample(24 * 8), i % 2) < 0:
-            pass
-        e.step(None)
-        envs.append(e)
-    out = np.zeros((96, 96), np.uint8)
-    t0 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t0 < budget_s:
-        for e in envs:
-            e.step(rs.uniform(-1, 1, (2, 2)))
-            for v in range(2):
-                L.car_oracle_render(e.buf.ctypes.data, v, out.ctypes.data)
-        k += 1
-    dt = time.perf_counter() - t0
-    return {"value": len(envs) * k / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{k} steps x {len(envs)} envs, oracle/car_oracle.c step + 2 renders, 1 thread, {dt:.1f} s"}
-
-
-POLICY_FLOP_PER_ENV = 2 * 516800  # LightActorCritic: conv1 409 600 + conv2 102 400 + actor 4 800 multiply-adds
-FP32_VECTOR_PEAK = 157.3e12       # MI355X packed-fp32 vector peak (256 CUs x 4 SIMDs x 32 FMA lanes x 2.4 GHz x 2)
-
-
-def cpu_baseline_tournament(budget_s=12.0):
-    """CPU restatement of the same loop: oracle Pong env (42x42) + numpy LightActorCritic opponent."""
+def cpu_baseline_tournament(po, atlas, cores, budget_s):
+    """CPU restatement of the tournament loop: oracle Pong env (42x42) + numpy LightActorCritic opponent."""
     import numpy as np
 
     from oracle import policy_oracle as P
-    from oracle import pong_oracle as po
 
-    atlas = np.load(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_score_atlas.npz"))["atlas"]
-    cores = len(os.sched_getaffinity(0))
     n = 256
     env = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=0)
     env.set_threads(cores)
@@ -126,199 +153,200 @@ def cpu_baseline_tournament(budget_s=12.0):
     dt = time.perf_counter() - t0
     env.close()
     return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c (42x42) + oracle/policy_oracle.py (numpy/BLAS), {dt:.1f} s"}
+            "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c (42x42, OpenMP) + oracle/policy_oracle.py (numpy/BLAS), {dt:.1f} s"}
 
 
-def bench_tournament(args, crl, torch, dist, dev, world, rank, n):
-    """SURVEY 8f N2 + N4: cPongTournament-v0 (42x42) against the MEDIUM CNN opponent, everything on the device."""
-    tour = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=0, device=dev, env_id_base=rank * n)
-    tour.reset_opponent("MEDIUM")
-    tour.reset()
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pool = [torch.randint(0, 3, (n,), generator=g, device=dev, dtype=torch.int32) for _ in range(16)]
-    pol = tour.current_agent
+# =============================================================================================== GPU workloads
+def traffic_of(name):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_gpu.sh (profiles/traffic_*.json):
+    measured in a separate profiled run of this same command, not in this process."""
+    f = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
+    if not os.path.exists(f):
+        return None, None
+    d = json.load(open(f))
+    return d.get("hbm_bytes_per_launch"), f"profiles/traffic_{name}.json: {d.get('source', 'rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE')}"
+
+
+def run_workload(name, args, G):
+    """Builds the env for `name`, does W warm-up steps, times exactly K steps (barrier + synchronize on both sides, max
+    over ranks) and returns the result dict (value, ms_per_step, roofline ...)."""
+    torch, crl, dist, dev, world, rank = G["torch"], G["crl"], G["dist"], G["dev"], G["world"], G["rank"]
+    n = args.envs or (16384 if name == "car" else 65536)
+    base = rank * n
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    policy_events = None
+    if name == "tournament":
+        env = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=0, device=dev, env_id_base=base)
+        env.reset_opponent("MEDIUM")
+        pool = [torch.randint(0, 3, (n,), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
+        pol, act = env.current_agent, env.current_agent.act_device
+        policy_events = []
+
+        def timed_act(*a, **k):  # HIP events around the policy kernel, on the stream it is launched on (torch's current)
+            if timed_act.on:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = act(*a, **k)
+                e1.record()
+                policy_events.append((e0, e1))
+                return r
+            return act(*a, **k)
+
+        timed_act.on = False
+        pol.act_device = timed_act
+        inner = env.env
+        desc = (f"cPongTournament-v0 {n} envs/GPU, 42x42 obs, opponent = reference checkpoint-medium (LightActorCritic) served by the "
+                "HIP policy kernel, 1 step = 4 frames + 1 opponent forward pass (SURVEY 8f N2+N4)")
+        kernel, dtype, actions_desc = "pong_policy_light_kernel", "f32", "uniform {0,1,2}"
+    elif name == "car":
+        env = inner = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=base)
+        pool = [torch.rand((n, 2, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
+        desc = (f"cCarRacingDouble-v0 {n} envs/GPU, (N,2,96,96) u8 obs + Box2D-style car dynamics with car-car contacts, "
+                "1 step = 1 CarRacing.step (BASELINE config #4)")
+        kernel, dtype, actions_desc = "car_raster_kernel", "f32", "uniform [-1,1]^2 per car"
+    else:
+        kw = {"raw": dict(mode="raw"),
+              "fused84": dict(mode="wrapped", resized_dim=84, frame_stack=4),
+              "fused84_f32": dict(mode="wrapped", resized_dim=84, frame_stack=4, obs_dtype="float32"),
+              "fused84_newest": dict(mode="wrapped", resized_dim=84, frame_stack=1)}[name]
+        env = inner = crl.HipPongVecEnv(n, seed=0, device=dev, env_id_base=base, **kw)
+        pool = [torch.randint(0, 3, (n, 2), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
+        desc = {"raw": f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)",
+                "fused84": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack (N,2,4,84,84) u8, 1 step = 4 frames "
+                           "(BASELINE config #3)",
+                "fused84_f32": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack, float32 output (N,2,4,84,84) "
+                               "as DummyVecEnv's buffers hold it (SURVEY 8d config-3 variant, 225 792 B/env), 1 step = 4 frames",
+                "fused84_newest": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA, newest plane only (N,2,1,84,84) u8, "
+                                  "1 step = 4 frames (variant of BASELINE config #3)"}[name]
+        kernel = "pong_raster_raw_sweep_kernel" if name == "raw" else "pong_raster_gray_env_kernel"
+        dtype, actions_desc = "u8", "uniform {0,1,2}"
+    env.reset()
+
+    gather_state = G.get("gather")
+
+    def step(i):
+        out = env.step_device(pool[i % 16])
+        if world > 1 and args.gather != "none":
+            gather_state.wait(materialize=False)  # at most one collective in flight: gather(t) overlaps simulate(t+1)
+            gather_state.launch(out if args.gather == "obs" else out[1:])
+
     for i in range(args.warmup):
-        tour.step_device(pool[i % 16])
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    act = pol.act_device
-
-    def timed_act(*a, **k):  # HIP events around the policy kernel, on the stream it is launched on (torch's current)
-        e0, e1 = ev[timed_act.i]
-        e0.record()
-        r = act(*a, **k)
-        e1.record()
-        timed_act.i += 1
-        return r
-
-    timed_act.i = 0
-    pol.act_device = timed_act
+    inner.kernel_time_ms(0), inner.kernel_time_ms(1)
+    inner.kernel_timing(True)
+    if policy_events is not None:
+        timed_act.on = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        tour.step_device(pool[i % 16])
+        step(i)
+    if world > 1 and args.gather != "none":
+        gather_state.wait(materialize=False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    inner.kernel_timing(False)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    k_us = sum(a.elapsed_time(b) for a, b in ev) / args.steps * 1e3
-    tour.close()
-    if rank == 0:
-        achieved = POLICY_FLOP_PER_ENV * n / (k_us * 1e-6)
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_tournament.json")
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        line = {
-            "metric": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent",
-            "value": world * n * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cPongTournament-v0 {n} envs/GPU, 42x42 obs, opponent = reference checkpoint-medium (LightActorCritic) "
-                                   "served by the HIP policy kernel, 1 step = 4 frames + 1 opponent forward pass (SURVEY 8f N2+N4)",
-                       "envs_per_gpu": n, "actions": "uniform {0,1,2}, pre-generated on device", "auto_reset": True},
-            "roofline": {"bound": "valu_fp32", "kernel": "pong_policy_light_kernel", "achieved": achieved / 1e12,
-                         "peak": FP32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK, "traffic": traffic,
-                         "flop_per_launch": POLICY_FLOP_PER_ENV * n, "avg_kernel_us": k_us, "launches_timed": args.steps,
-                         "note": "fp32 vector FMAs (v_pk_fma_f32), not MFMA: the reference plays argmax of fp32 logits; "
-                                 "a plain v_fma_f32 stream peaks at 78.6, packed fp32 measured at 134-142 TFLOP/s on this chip"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_tournament()
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    dyn_ms, dyn_n = inner.kernel_time_ms(0)
+    ras_ms, ras_n = inner.kernel_time_ms(1)
+    env.close()
+    res = {"value": world * n * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3, "dtype": dtype,
+           "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",
+                      "actions": actions_desc + ", pre-generated on device", "auto_reset": True}}
+    if rank != 0:
+        return res
+    if name == "tournament":
+        k_us = sum(a.elapsed_time(b) for a, b in policy_events) / max(len(policy_events), 1) * 1e3
+        ach = POLICY_FLOP * n / (k_us * 1e-6)
+        traffic, tsrc = traffic_of(name)
+        res["roofline"] = {"bound": "valu_fp32", "kernel": kernel, "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
+                           "frac": ach / FP32_PEAK, "traffic": traffic, "traffic_source": tsrc, "flop_per_launch": POLICY_FLOP * n,
+                           "avg_kernel_us": k_us, "launches_timed": len(policy_events),
+                           "note": "fp32 (exact products; the reference plays the argmax of fp32 logits): fp32 MFMA and packed fp32 "
+                                   "VALU share one 157.3 TFLOP/s peak (MI355X_MICROARCH.md)"}
+        return res
+    ras_s = ras_ms / max(ras_n, 1) * 1e-3
+    bytes_per_env = {"raw": RAW_BYTES, "fused84": FUSED_BYTES, "fused84_f32": FUSED_F32_BYTES, "fused84_newest": NEWEST_BYTES, "car": CAR_BYTES}[name]
+    ach = bytes_per_env * n / ras_s if ras_s > 0 else 0.0
+    traffic, tsrc = traffic_of(name)
+    res["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                       "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": bytes_per_env * n, "avg_kernel_us": ras_s * 1e6,
+                       "launches_timed": ras_n, "dynamics_kernel_avg_us": dyn_ms / max(dyn_n, 1) * 1e3}
+    if name == "car":
+        flop, fsrc = CAR_FLOP_MODEL, "bench.py CAR_FLOP_MODEL (counted from the code paths, DESIGN.md 4b)"
+        ff = os.path.join(ROOT, "profiles", "flops_car.json")
+        if os.path.exists(ff):
+            d = json.load(open(ff))
+            flop, fsrc = d["f32_flop_per_env_step"], "profiles/flops_car.json: " + d.get("source", "")
+        fl = flop * res["value"] / world
+        res["roofline"]["note"] = ("reported against HBM as required, but the step is not HBM-bound: see roofline_valu.  avg_kernel_us = the raster "
+                                   "window of a step (launches for the three env classes incl. the wait for the side stream)")
+        res["roofline_valu"] = {"bound": "valu_fp32", "achieved": fl / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / FP32_PEAK,
+                                "flop_per_env_step": flop, "flop_source": fsrc,
+                                "limiter": "neither roof: the island solves are 180 x 4 dependent Gauss-Seidel joint updates per car (one "
+                                           "lane each, VALU latency), the raster is per-pixel point-in-polygon tests; see DESIGN.md 4b"}
+    return res
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["raw", "fused84", "fused84_newest", "car", "tournament"], default="raw")
-    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
-    ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    multi = args.workload == "all" and world == 1
+    names = ["raw", "fused84", "fused84_f32", "car", "tournament"] if multi else [("raw" if args.workload == "all" else args.workload)]
+    # the CPU baselines run first: worker processes are started while this process has not initialised the GPU
+    cpu = {}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baselines(names)
 
     import torch
     import torch.distributed as dist
 
     import competitive_rl_amd as crl
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    G = dict(torch=torch, crl=crl, dist=dist, dev=dev, world=world, rank=rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-
-    n = args.envs or (16384 if args.workload == "car" else 65536)
-    if args.workload == "tournament":
-        return bench_tournament(args, crl, torch, dist, dev, world, rank, n)
-    if args.workload == "car":
-        env = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=rank * n)
-        raster_bytes, kernel = CAR_STEP_BYTES, "car_raster_kernel"
-        desc = (f"cCarRacingDouble-v0 {n} envs/GPU, (N,2,96,96) u8 obs + Box2D-style car dynamics, 1 step = 1 CarRacing.step "
-                "(BASELINE config #4)")
-    elif args.workload == "raw":
-        env = crl.HipPongVecEnv(n, seed=0, mode="raw", device=dev, env_id_base=rank * n)
-        raster_bytes, kernel = RAW_RASTER_BYTES, "pong_raster_raw_sweep_kernel"
-        desc = f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)"
-    elif args.workload == "fused84_newest":
-        # variant of config #3 (SURVEY 8d): only the newest plane is written, the consumer keeps the stack
-        env = crl.HipPongVecEnv(n, seed=0, mode="wrapped", resized_dim=84, frame_stack=1, device=dev, env_id_base=rank * n)
-        raster_bytes, kernel = 2 * 84 * 84 + 16, "pong_raster_gray_env_kernel"
-        desc = (f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA, newest plane only (N,2,1,84,84) u8, "
-                "1 step = 4 frames (variant of BASELINE config #3)")
-    else:
-        env = crl.HipPongVecEnv(n, seed=0, mode="wrapped", resized_dim=84, frame_stack=4, device=dev,
-                                env_id_base=rank * n)
-        raster_bytes, kernel = FUSED_RASTER_BYTES[84], "pong_raster_gray_env_kernel"
-        desc = (f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack (N,2,4,84,84) u8, "
-                "1 step = 4 frames (BASELINE config #3)")
-    env.reset()
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    if args.workload == "car":
-        pool = [torch.rand((n, 2, 2), generator=g, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
-    else:
-        pool = [torch.randint(0, 3, (n, 2), generator=g, device=dev, dtype=torch.int32) for _ in range(16)]
-
-    def gather(buf, rew, done):
-        if world == 1 or args.gather == "none":
-            return
-        if args.gather == "scalars":
-            crl.all_gather_step((rew, done))
-        else:
-            crl.all_gather_step((buf, rew, done))
-
-    for i in range(args.warmup):
-        out = env.step_device(pool[i % 16])
-        gather(*out)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    env.kernel_time_ms(0), env.kernel_time_ms(1)
-    env.kernel_timing(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = env.step_device(pool[i % 16])
-        gather(*out)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    env.kernel_timing(False)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    dyn_ms, dyn_n = env.kernel_time_ms(0)
-    ras_ms, ras_n = env.kernel_time_ms(1)
-    done_frac = float(out[2].float().mean().item())
-    env.close()
-
+        G["gather"] = crl.StepGather(overlap=True)
+    results = {}
+    for nm in names:
+        results[nm] = run_workload(nm, args, G)
+        torch.cuda.empty_cache()
     if rank == 0:
-        value = world * n * args.steps / dt
-        ras_avg_s = ras_ms / max(ras_n, 1) * 1e-3
-        achieved = raster_bytes * n / ras_avg_s if ras_avg_s > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        line = {
-            "metric": ("env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU" if args.workload == "car"
-                       else "env-steps/sec (whole node), cPongDouble 65536 envs per GPU"),
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",
-                       "actions": ("uniform [-1,1]^2 per car" if args.workload == "car" else "uniform {0,1,2}") + ", pre-generated on device",
-                       "auto_reset": True},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "bytes_per_launch": raster_bytes * n, "avg_kernel_us": ras_avg_s * 1e6,
-                         "launches_timed": ras_n,
-                         "dynamics_kernel_avg_us": dyn_ms / max(dyn_n, 1) * 1e3},
-        }
-        if args.workload == "car":
-            line["roofline"]["note"] = ("reported against HBM as required; the path is ALU/latency bound (DESIGN.md 4b). avg_kernel_us = the "
-                                        "raster window of a step: launches for the three env classes incl. the wait for the side stream "
-                                        "(coupled solve, resets); one full-batch launch alone takes ~1.66 ms")
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload)
+        head = results[names[0]]
+        metric = {"car": "env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU",
+                  "tournament": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent"}.get(
+            names[0], "env-steps/sec (whole node), cPongDouble 65536 envs per GPU")
+        line = {"metric": metric, "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"],
+                "data": "synthetic", "config": head["config"], "roofline": head.get("roofline")}
+        if "roofline_valu" in head:
+            line["roofline_valu"] = head["roofline_valu"]
+        if world > 1 and args.gather != "none":
+            line["config"]["gather"] = args.gather + " (one packed all_gather_into_tensor per step on a side stream, overlapped with the next step)"
+        if names[0] in cpu:
+            line["cpu_baseline"] = cpu[names[0]]
+        if multi:
+            line["configs"] = {}
+            for nm in names[1:]:
+                r = dict(results[nm])
+                r["steps"], r["warmup"] = args.steps, args.warmup
+                if nm in cpu:
+                    r["cpu_baseline"] = cpu[nm]
+                line["configs"][nm] = r
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -11,7 +11,7 @@ from .tournament import TournamentEnvWrapper
 from .policy_serving import Policy
 from .competitive_car import make_competitive_car_racing
 from .utils import step_envs
-from .sharding import ShardSpec, all_gather_step, shard_of
+from .sharding import ShardSpec, StepGather, all_gather_step, shard_of
 
 __all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "step_envs", "CHEAT_CODES",
-           "ShardSpec", "shard_of", "all_gather_step"]
+           "ShardSpec", "shard_of", "all_gather_step", "StepGather"]

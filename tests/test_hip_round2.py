@@ -220,3 +220,66 @@ def test_full_size_car_properties():
     s = env.get_state()
     assert (s["elapsed"] == 0).all() and (s["episode"] == 2).all()
     env.close()
+
+
+def _two_gpu_worker(rank, world, port, out_dir):
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    import competitive_rl_amd as crl
+
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+    total, steps = 512, 60
+    sh = crl.shard_of(total, world, rank)
+    env = crl.HipPongVecEnv(sh.count, seed=21, mode="wrapped", resized_dim=42, frame_stack=1, env_id_base=sh.base, device=f"cuda:{rank}")
+    env.reset()
+    acts = torch.as_tensor(np.random.RandomState(5).randint(0, 3, (steps, total, 2)).astype(np.int32)).cuda()
+    g = crl.StepGather(overlap=True)
+    got = []
+    for t in range(steps):
+        out = env.step_device(acts[t, sh.base:sh.base + sh.count].contiguous())
+        g.launch(out)                       # ONE packed RCCL all-gather on a side stream ...
+        if t + 1 < steps:
+            pass                            # ... while the next step could already be simulated
+        got.append([x.cpu().numpy().copy() for x in g.wait()])
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "g.npz"), obs=np.stack([o[0] for o in got]), rew=np.stack([o[1] for o in got]),
+                 done=np.stack([o[2] for o in got]))
+    env.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
+    """BASELINE config #5 in small: two HIP shards on two GPUs + the single packed RCCL all-gather == one unsharded HIP batch.
+    Needs two visible GPUs (the driver's multi-GPU node); skipped on a one-GPU box."""
+    _need_gpu()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import socket
+
+    import torch.multiprocessing as mp
+
+    import competitive_rl_amd as crl
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.start_processes(_two_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    got = np.load(tmp_path / "g.npz")
+    total, steps = 512, 60
+    env = crl.HipPongVecEnv(total, seed=21, mode="wrapped", resized_dim=42, frame_stack=1)
+    env.reset()
+    acts = torch.as_tensor(np.random.RandomState(5).randint(0, 3, (steps, total, 2)).astype(np.int32)).cuda()
+    for t in range(steps):
+        buf, rew, done = env.step_device(acts[t].contiguous())
+        assert np.array_equal(got["obs"][t], buf.cpu().numpy()) and np.array_equal(got["rew"][t], rew.cpu().numpy())
+        assert np.array_equal(got["done"][t], done.cpu().numpy()), t
+    env.close()
