@@ -59,7 +59,7 @@ __device__ inline BRef body_of(CarRegs &c, const CarConsts &K, int fixture) {
 }
 __device__ inline XF xf_of(const BRef &r) {
     XF t;
-    t.s = sinf(r.b->a), t.c = cosf(r.b->a);
+    crl_sincosf(r.b->a, &t.s, &t.c);
     t.p = mk(r.b->cx, r.b->cy) - rotv(t.s, t.c, r.lc);
     return t;
 }

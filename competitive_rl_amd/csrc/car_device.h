@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/crl.h"
+#include "../../include/crl_rot.h"
 
 namespace crl {
 
@@ -116,7 +117,8 @@ struct Body {
 // axis test.  Symmetric in its arguments' roles, evaluated identically by both lanes of an env.
 __host__ __device__ inline bool cars_near(const CarConsts &K, float x0, float y0, float a0, float x1, float y1, float a1) {
     const float ex = 1.75f + 0.2f, ey = 2.75f + 0.2f;
-    const float s0 = sinf(a0), c0 = cosf(a0), s1 = sinf(a1), c1 = cosf(a1);
+    float s0, c0, s1, c1;
+    crl_sincosf(a0, &s0, &c0), crl_sincosf(a1, &s1, &c1);
     // box centres = hull origins (body origin = centre of mass - R * localCenter)
     const float ox0 = x0 - (c0 * K.hull_lc[0] - s0 * K.hull_lc[1]), oy0 = y0 - (s0 * K.hull_lc[0] + c0 * K.hull_lc[1]);
     const float ox1 = x1 - (c1 * K.hull_lc[0] - s1 * K.hull_lc[1]), oy1 = y1 - (s1 * K.hull_lc[0] + c1 * K.hull_lc[1]);

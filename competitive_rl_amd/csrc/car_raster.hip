@@ -138,8 +138,9 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     double angle = (double)h_a;
     const double vx = (double)h_vx, vy = (double)h_vy;
     if (vx * vx + vy * vy > 0.5 * 0.5) angle = atan2(-vx, vy);
-    const float af = (float)angle, sn = sinf(af), cs = cosf(af);
-    const float hs = sinf(h_a), hc = cosf(h_a);
+    const float af = (float)angle;
+    float sn, cs, hs, hc;
+    crl_sincosf(af, &sn, &cs), crl_sincosf(h_a, &hs, &hc);
     const V2 hp = mk(h_cx, h_cy) - rotv(hs, hc, mk(K.hull_lc[0], K.hull_lc[1]));
     const V2 off = hp + mk(cs * 0.0f - sn * 16.0f, sn * 0.0f + cs * 16.0f);
     const double obs_scale = (10 / (100 / sqrt(96.0))) * 1.8;
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         const int64_t ci = k * n + env;
         const int o = part < 4 ? 6 + 6 * part : 0;
         const float bx = s.body[(o + 0) * M + ci], by = s.body[(o + 1) * M + ci], ba = s.body[(o + 2) * M + ci];
-        const float bs = sinf(ba), bc = cosf(ba);
+        float bs, bc;
+        crl_sincosf(ba, &bs, &bc);
         const V2 lc = part < 4 ? mk(0.f, 0.f) : mk(K.hull_lc[0], K.hull_lc[1]);
         const V2 bp = mk(bx, by) - rotv(bs, bc, lc);
         CarPoly q;

@@ -102,7 +102,8 @@ __device__ inline void isl_joints_init(CarRegs &c, JointTmp &j, const CarConsts 
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int w = 3 - q;
-        const float sA = sinf(c.H.a), cA = cosf(c.H.a);
+        float sA, cA;
+        crl_sincosf(c.H.a, &sA, &cA);
         j.rA[w] = rotv(sA, cA, mk(K.anchor[w][0], K.anchor[w][1]) - lcA);
         const V2 r = j.rA[w];
         M33 &m = j.mass[w];
@@ -221,7 +222,8 @@ __device__ inline bool isl_joints_pos(CarRegs &c, const CarConsts &K) {
             const float li = -motorMass * C;
             c.H.a -= iA * li, c.W[w].a += iB * li;
         }
-        const float sA = sinf(c.H.a), cA = cosf(c.H.a);
+        float sA, cA;
+        crl_sincosf(c.H.a, &sA, &cA);
         const V2 r = rotv(sA, cA, mk(K.anchor[w][0], K.anchor[w][1]) - lcA), rB = mk(0.f, 0.f);
         const V2 C = ((mk(c.W[w].cx, c.W[w].cy) + rB) - mk(c.H.cx, c.H.cy)) - r;
         const float posErr = sqrtf(dot(C, C));

@@ -70,7 +70,8 @@ __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_
         for (int f = 0; f < 8; f++) {
             const int o = f < 4 ? 0 : 6 + 6 * (f - 4);
             const float cx = s.body[(o + 0) * M + ci], cy = s.body[(o + 1) * M + ci], a = s.body[(o + 2) * M + ci];
-            const float sn = sinf(a), cs = cosf(a);
+            float sn, cs;
+            crl_sincosf(a, &sn, &cs);
             const V2 lc = f < 4 ? mk(K.hull_lc[0], K.hull_lc[1]) : mk(0.f, 0.f);
             const V2 p = mk(cx, cy) - rotv(sn, cs, lc);
             const int nv = f < 4 ? K.hull_n[f] : 4;
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
             for (int k = 0; k < kWheelSlots; k++) on_road = on_road || wt[w][k] >= 0;
             double friction_limit = CAR_FRICTION_LIMIT * 0.6;
             if (on_road) friction_limit = fmax(friction_limit, CAR_FRICTION_LIMIT * 1.0);
-            const float qs = sinf(Wb[w].a), qc = cosf(Wb[w].a);
+            float qs, qc;
+            crl_sincosf(Wb[w].a, &qs, &qc);
             const double forw0 = (double)(qc * 0.0f - qs * 1.0f), forw1 = (double)(qs * 0.0f + qc * 1.0f);
             const double side0 = (double)(qc * 1.0f - qs * 0.0f), side1 = (double)(qs * 1.0f + qc * 0.0f);
             const double vx = (double)Wb[w].vx, vy = (double)Wb[w].vy;
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         reward -= 0.1 / repeat;
         step_reward += reward - prev_reward;
         prev_reward = reward;
-        const float hs = sinf(H.a), hc = cosf(H.a);
+        float hs, hc;
+        crl_sincosf(H.a, &hs, &hc);
         const V2 p = mk(H.cx, H.cy) - rotv(hs, hc, mk(K.hull_lc[0], K.hull_lc[1]));  // hull.position
         if (visited_count == ntiles) done = 1;
         if (fabs((double)p.x) > CAR_PLAYFIELD || fabs((double)p.y) > CAR_PLAYFIELD) done = 1;
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         float cx0 = 3.4e38f, cy0 = 3.4e38f, cx1 = -3.4e38f, cy1 = -3.4e38f;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const float qs = sinf(Wb[w].a), qc = cosf(Wb[w].a);
+            float qs, qc;
+            crl_sincosf(Wb[w].a, &qs, &qc);
             wx0[w] = wy0[w] = 3.4e38f, wx1[w] = wy1[w] = -3.4e38f;
 #pragma unroll
             for (int k = 0; k < 4; k++) {

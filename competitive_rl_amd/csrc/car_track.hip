@@ -201,7 +201,9 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         // np.random.shuffle(arange(num_player)): one car always gets birth place 0
         const int birth = s.players == 1 ? 0 : (car == 0 ? (swap ? 1 : 0) : (swap ? 0 : 1));
         const double x0 = ix - (birth % 2) * 5, y0 = iy - floor(birth / 2.0) * 10;
-        const float a = (float)ia, sa = sinf(a), ca = cosf(a);
+        const float a = (float)ia;
+        float sa, ca;
+        crl_sincosf(a, &sa, &ca);
         const V2 com = mk((float)x0, (float)y0) + rotv(sa, ca, mk(K.hull_lc[0], K.hull_lc[1]));
         float *b = s.body + ci;
         for (int k = 0; k < 30; k++) b[k * M] = 0.f;

@@ -89,6 +89,7 @@ struct crl_ctx {
     int band_rows = 0, band_chunks = 0, zero_row0 = 0, zero_row1 = 0;
     uint8_t *tab_blob = nullptr;
     GrayTabOfs tofs{};
+    uint8_t *tile_hdr = nullptr;  // [n * views * K] 64-byte tile headers of the address-linear gray writer
     // replay
     double *ru = nullptr;
     uint8_t *rbx = nullptr, *rby = nullptr;
@@ -259,6 +260,7 @@ static int setup_gray(crl_ctx *c) {
     if ((rc = dev_upload(c, &c->atlas_gray, c->atlas_host))) return rc;
     if ((rc = dev_alloc(c, &c->band, (size_t)3 * 484 * 2 * c->band_chunks * 16))) return rc;
     if ((rc = dev_alloc(c, &c->rest, (size_t)chunks * 16))) return rc;
+    if ((rc = dev_alloc(c, &c->tile_hdr, (size_t)c->n * pong_views(c) * c->o.frame_stack * 64))) return rc;
     HIP_TRY(hipMemset(c->rest, 0, (size_t)chunks * 16));
     GrayParams p{};
     p.R = R, p.K = c->o.frame_stack, p.atlas_gray = c->atlas_gray;
@@ -426,7 +428,7 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         p.ring = c->s.ring, p.n = c->n, p.R = c->o.resized_dim, p.K = c->o.frame_stack, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
-        p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32;
+        p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32, p.hdr = c->tile_hdr;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }

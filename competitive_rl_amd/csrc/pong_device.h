@@ -237,6 +237,7 @@ struct GrayParams {
     const float *xalpha, *yalpha;   // weight per tap
     uint8_t *obs;                   // [n][2][K][R][R]
     bool obs_f32;                   // obs is float32 (CRL_OBS_F32): same values, widened in the store epilogue
+    void *hdr;                      // scratch for the address-linear writer: 64 B per (env, view, plane) tile, or nullptr
 };
 void launch_pong_raster_gray(const GrayParams &p, hipStream_t st);
 

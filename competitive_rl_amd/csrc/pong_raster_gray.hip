@@ -599,6 +599,182 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_ker
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Address-linear writer (round 2; CRL_GRAY_SWEEP=0 falls back to the env kernel above).
+//
+// Why: only a chip-wide dense sweep of stores reaches the fill rate; a wavefront streaming its own 56 KB env writes a
+// comb.  Here the output tensor is cut into 1-KiB blocks (64 chunks of 16 B: 1/7 of a 7 056-byte tile at
+// R = 84) and block b is written by wavefront b -- workgroups are dispatched in index order, so at any instant the chip
+// writes one dense window of the tensor, like a fill.  What makes that affordable:
+//   * a tiny HEADER kernel first computes, one lane per tile, everything that is uniform over a tile: blank / fast / slow,
+//     the band-table row of its score pair, the rectangles in view coordinates, the six output boxes and which of the
+//     tile's blocks a box touches (64 B per tile, 2 % of the step's traffic);
+//   * a wavefront reads its tile's header with scalar loads; blocks no box touches (more than half) are the template
+//     chunk -- score band rows from the band table, zeros for the court, the white bottom rows -- stored straight away;
+//   * a touched block is composed in 1 KiB of LDS exactly as the env kernel does for a whole tile (row / column
+//     membership words, one lane per affected pixel, same f32 operation order), restricted to the block's rows.
+struct __attribute__((aligned(64))) GrayTileHdr {
+    uint8_t box[6][4];     // x0, y0, w, h of the six rectangles' output boxes (w*h = 0: none)
+    int16_t rc[8];         // Rects: ax, ay, bx, by, la, lb, ra, rb (view coordinates; -1000 = none)
+    uint32_t band_off;     // first chunk of this tile's score rows in the band table
+    uint8_t kind;          // 0 = blank plane (zeros), 1 = fast, 2 = per-pixel evaluator (unrelated scores / one blank frame)
+    uint8_t blockmask;     // bit k: block k of the tile holds pixels of a box
+    uint8_t pad[2];
+    uint64_t pa, pb;       // the two kept frames (slow path)
+};
+static_assert(sizeof(GrayTileHdr) == 64, "header layout");
+
+__global__ __launch_bounds__(256) void pong_gray_header_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayGeom q,
+                                                               GrayTileHdr *__restrict__ hdr) {
+    const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = q.K, tiles_per_env = q.views * K;
+    if (tile >= n * tiles_per_env) return;
+    const int64_t env = tile / tiles_per_env;
+    const int t = (int)(tile - env * tiles_per_env), view = t / K, plane = t - view * K, rp = 4 - K + plane;
+    const uint64_t pa = ring[(int64_t)(2 * rp) * n + env], pb = ring[(int64_t)(2 * rp + 1) * n + env];
+    Frame fa = unpack_frame(pa), fb = unpack_frame(pb);
+    if (fa.sl == 255 && fb.sl != 255) fa = fb;  // the reset observation: a single frame, max(x, 0) = x
+    else if (fb.sl == 255 && fa.sl != 255) fb = fa;
+    GrayTileHdr h;
+    memset(&h, 0, sizeof(h));
+    h.pa = pa, h.pb = pb;
+    if (fa.sl == 255) {  // both blank: plane erased by a done
+        hdr[tile] = h;
+        return;
+    }
+    bool slow = false;
+    int variant = 0, sp = fa.sl * 22 + fa.sr;
+    if (fa.sl != fb.sl || fa.sr != fb.sr) {
+        const int spb = fb.sl * 22 + fb.sr;
+        if (fb.sl == fa.sl + 1 && fb.sr == fa.sr) variant = 1;
+        else if (fb.sl == fa.sl && fb.sr == fa.sr + 1) variant = 2;
+        else if (fa.sl == fb.sl + 1 && fa.sr == fb.sr) variant = 1, sp = spb;
+        else if (fa.sl == fb.sl && fa.sr == fb.sr + 1) variant = 2, sp = spb;
+        else slow = true;
+    }
+    if (!q.t.fast_ok) slow = true;
+    h.kind = slow ? 2 : 1;
+    h.band_off = (uint32_t)(((slow ? 0 : (variant * 484 + sp)) * 2 + view) * q.band_chunks);
+    const bool m = view == 1;
+    Rects rc;
+    rc.ax = m ? CRL_PONG_W - fa.x - CRL_PONG_BALL : fa.x, rc.ay = fa.y;
+    rc.bx = m ? CRL_PONG_W - fb.x - CRL_PONG_BALL : fb.x, rc.by = fb.y;
+    rc.la = m ? fa.br : fa.bl, rc.ra = m ? fa.bl : fa.br;
+    rc.lb = m ? fb.br : fb.bl, rc.rb = m ? fb.bl : fb.br;
+    h.rc[0] = (int16_t)rc.ax, h.rc[1] = (int16_t)rc.ay, h.rc[2] = (int16_t)rc.bx, h.rc[3] = (int16_t)rc.by;
+    h.rc[4] = (int16_t)rc.la, h.rc[5] = (int16_t)rc.lb, h.rc[6] = (int16_t)rc.ra, h.rc[7] = (int16_t)rc.rb;
+    const uint8_t *tabs = q.tab_blob;
+    const Box none = {0, 0, 0, 0};
+    Box bx[6];
+    const bool same_ball = rc.ax == rc.bx && rc.ay == rc.by;
+    bx[0] = rect_box_lds(tabs, q.t, rc.ax, rc.ax + CRL_PONG_BALL, max(rc.ay, CRL_PONG_TOP), min(rc.ay + CRL_PONG_BALL, CRL_PONG_BOTTOM));
+    bx[1] = rect_box_lds(tabs, q.t, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.la, rc.la + CRL_PONG_BAT_H);
+    bx[2] = rect_box_lds(tabs, q.t, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.ra, rc.ra + CRL_PONG_BAT_H);
+    bx[3] = same_ball ? none : rect_box_lds(tabs, q.t, rc.bx, rc.bx + CRL_PONG_BALL, max(rc.by, CRL_PONG_TOP), min(rc.by + CRL_PONG_BALL, CRL_PONG_BOTTOM));
+    bx[4] = rc.la == rc.lb ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.lb, rc.lb + CRL_PONG_BAT_H);
+    bx[5] = rc.ra == rc.rb ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.rb, rc.rb + CRL_PONG_BAT_H);
+    unsigned mask = 0;
+    const int R = q.R;
+    for (int i = 0; i < 6; i++) {
+        if (bx[i].w * bx[i].h <= 0) bx[i] = none;
+        h.box[i][0] = (uint8_t)bx[i].x0, h.box[i][1] = (uint8_t)bx[i].y0, h.box[i][2] = (uint8_t)bx[i].w, h.box[i][3] = (uint8_t)bx[i].h;
+        for (int r = bx[i].y0; r < bx[i].y0 + bx[i].h; r++) {
+            const int lo = r * R + bx[i].x0, hi = lo + bx[i].w - 1;
+            mask |= 1u << (lo >> 10);
+            mask |= 1u << (hi >> 10);
+        }
+    }
+    h.blockmask = (uint8_t)mask;
+    hdr[tile] = h;
+}
+
+__global__ __launch_bounds__(256) void pong_raster_gray_sweep_kernel(const GrayTileHdr *__restrict__ hdrs, int64_t n_tiles, GrayCtx g,
+                                                                     GrayGeom q, uint8_t *__restrict__ obs) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4][1024];
+    __shared__ uint32_t rowpack_[4][16], colpack_[4][kMaxR];
+    constexpr int MAXT = 3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int R = q.R, RR = R * R, chunks = RR >> 4, bpt = (chunks + 63) >> 6;  // blocks per tile (7 at R = 84)
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t tile = b / bpt;
+    if (tile >= n_tiles) return;
+    const int blk = (int)(b - tile * bpt);
+    const GrayTileHdr *hp = hdrs + tile;
+    const int c = blk * 64 + lane;          // chunk of the tile
+    const bool active = c < chunks;
+    uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + tile * (int64_t)RR) + c;
+    const uint32_t kind = hp->kind;
+    if (kind == 0) {
+        if (active) *out = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    // template chunk: score rows from the band table, zeros for the court, the rest of the empty court otherwise
+    const int bb = q.band_chunks;
+    const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (active) {
+        if (c < bb) v = reinterpret_cast<const uint4 *>(q.band)[hp->band_off + c];
+        else if (c < zc0 || c >= zc1) v = reinterpret_cast<const uint4 *>(q.rest)[c];
+    }
+    if (kind == 2) {  // rare: unrelated scores under the max, or a blank buffer (set_state / the never-written buffers)
+        if (active) {
+            const Frame fa = unpack_frame(hp->pa), fb = unpack_frame(hp->pb);
+            const int tiles_per_env = q.views * q.K, view = (int)(tile % tiles_per_env) / q.K;
+            uint8_t px[16];
+            for (int k = 0; k < 16; k++) {
+                const int p = c * 16 + k, dy = p / R, dx = p - dy * R;
+                px[k] = eval_pixel(g, fa, fb, view, dy, dx);
+            }
+            uint4 o;
+            memcpy(&o, px, 16);
+            *out = o;
+        }
+        return;
+    }
+    if (!((hp->blockmask >> blk) & 1)) {
+        if (active) *out = v;
+        return;
+    }
+    // ---- a touched block: compose it in LDS
+    uint8_t *tl = lds[wave];
+    reinterpret_cast<uint4 *>(tl)[lane] = v;
+    const int P0 = blk * 1024, P1 = min(P0 + 1024, RR);
+    const int r0 = P0 / R, r1 = (P1 - 1) / R;   // first / last output row with pixels in this block
+    Rects rc;
+    rc.ax = hp->rc[0], rc.ay = hp->rc[1], rc.bx = hp->rc[2], rc.by = hp->rc[3];
+    rc.la = hp->rc[4], rc.lb = hp->rc[5], rc.ra = hp->rc[6], rc.rb = hp->rc[7];
+    int bx0[6], by0[6], bw[6], bh[6], pre[7];
+    pre[0] = 0;
+    int xmin = R, xmax = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int x0 = hp->box[i][0], y0 = hp->box[i][1], w = hp->box[i][2], h = hp->box[i][3];
+        const int ylo = max(y0, r0), yhi = min(y0 + h, r1 + 1);
+        bx0[i] = x0, by0[i] = ylo, bw[i] = w, bh[i] = max(yhi - ylo, 0);
+        pre[i + 1] = pre[i] + bw[i] * bh[i];
+        if (bw[i] * bh[i] > 0) xmin = min(xmin, x0), xmax = max(xmax, x0 + w);
+    }
+    const uint8_t *tabs = q.tab_blob;  // dense tap tables, read through L1 (a few hundred bytes per touched block)
+    uint32_t *rowpack = rowpack_[wave], *colpack = colpack_[wave];
+    if (lane <= r1 - r0) rowpack[lane] = row_pack<MAXT>(tabs, q.t, rc, r0 + lane);
+    for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int total = pre[6];
+    for (int p = lane; p < total; p += 64) {
+        int x0 = bx0[0], y0 = by0[0], w = bw[0], base = 0;
+#pragma unroll
+        for (int k = 1; k < 6; k++)
+            if (p >= pre[k]) x0 = bx0[k], y0 = by0[k], w = bw[k], base = pre[k];
+        const int o = p - base;
+        const int yy = (int)(((float)o + 0.5f) * (1.0f / (float)max(w, 1)));  // o / w, exact for these sizes
+        const int dy = y0 + yy, dx = x0 + (o - yy * w);
+        const int idx = dy * R + dx - P0;
+        if ((unsigned)idx < 1024u) tl[idx] = eval_sep<MAXT>(tabs, q.t, R, rowpack[dy - r0], colpack[dx], dy, dx);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (active) *out = reinterpret_cast<const uint4 *>(tl)[lane];
+}
+
 void pong_gray_print_ticks() {
     unsigned long long t[8];
     if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gray_ticks), sizeof(t)) != hipSuccess || !t[7]) return;
@@ -635,6 +811,16 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     if ((q.debug & 8) && !p.obs_f32) {
         hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
                            p.obs);
+        return;
+    }
+    // address-linear writer: uint8 output, 16-byte-aligned tiles, three-tap tables (R = 84 and similar sizes)
+    static const int sweep_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 1;
+    if (sweep_env && !p.obs_f32 && !q.debug && p.hdr && (p.R * p.R) % 16 == 0 && tofs.max_taps <= 3 && tofs.fast_ok) {
+        GrayTileHdr *hdr = reinterpret_cast<GrayTileHdr *>(p.hdr);
+        hipLaunchKernelGGL(pong_gray_header_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, p.ring, p.n, q, hdr);
+        const int bpt = ((p.R * p.R >> 4) + 63) >> 6;
+        const int64_t blocks = tiles * bpt;
+        hipLaunchKernelGGL(pong_raster_gray_sweep_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, hdr, tiles, g, q, p.obs);
         return;
     }
     // planes per wave: the whole stack of an env per wave once there are enough envs to fill

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "car_oracle.h"
+#include "../include/crl_rot.h" /* the one sin/cos evaluation shared with the HIP kernels */
 
 /* ---- constants (crmp:54-88, cd:17-51) */
 #define SCALE 6.0
@@ -247,7 +248,7 @@ const car_consts *car_oracle_consts(void) {
 
 /* b2Body state <-> transform: xf.q = b2Rot(a); xf.p = c - q * localCenter */
 static void body_xf(const car_body *b, v2 lc, float *s, float *c, v2 *p) {
-    *s = sinf(b->a), *c = cosf(b->a);
+    crl_sincosf(b->a, s, c);
     *p = vsub(V(b->cx, b->cy), rot(*s, *c, lc));
 }
 
@@ -257,7 +258,8 @@ void car_oracle_place(car_state *car, double init_angle, double init_x, double i
     memset(car, 0, sizeof(*car));
     init_x -= birth_place_index % 2 * 5;
     init_y -= floor(birth_place_index / 2.0) * 10;
-    float a = (float)init_angle, s = sinf(a), c = cosf(a);
+    float a = (float)init_angle, s, c;
+    crl_sincosf(a, &s, &c);
     v2 p = V((float)init_x, (float)init_y);
     v2 com = vadd(p, rot(s, c, V(K.hull_lc[0], K.hull_lc[1])));
     car->hull.cx = com.x, car->hull.cy = com.y, car->hull.a = a;
@@ -425,7 +427,8 @@ static void isl_joints_init(car_state *car, joint_tmp *jt, float dt_ratio) {
         int w = 3 - q;
         car_body *B = &car->wheel[w];
         joint_tmp *j = &jt[w];
-        float sA = sinf(H->a), cA = cosf(H->a);
+        float sA, cA;
+        crl_sincosf(H->a, &sA, &cA);
         j->rA = rot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA));
         j->rB = V(0, 0); /* rot(qB, localAnchorB - localCenterB) = 0 */
         v2 rA = j->rA, rB = j->rB;
@@ -544,7 +547,8 @@ static int isl_joints_pos(car_state *car) {
                 li = -mm * C;
                 H->a -= iA * li, B->a += iB * li;
             }
-            float sA = sinf(H->a), cA = cosf(H->a);
+            float sA, cA;
+            crl_sincosf(H->a, &sA, &cA);
             v2 rA = rot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA)), rB = V(0, 0);
             v2 C = vsub(vsub(vadd(V(B->cx, B->cy), rB), V(H->cx, H->cy)), rA);
             float posErr = sqrtf(vdot(C, C));
@@ -654,7 +658,7 @@ static bref body_of(car_env *e, int car, int fixture) {
 }
 static xform xf_of(const bref *r) {
     xform t;
-    t.s = sinf(r->b->a), t.c = cosf(r->b->a);
+    crl_sincosf(r->b->a, &t.s, &t.c);
     t.p = vsub(V(r->b->cx, r->b->cy), rot(t.s, t.c, r->lc));
     return t;
 }
@@ -1021,7 +1025,8 @@ int car_oracle_reset(car_env *e, const double *u, int max_attempts, int shuffle_
 }
 
 static void wheel_world_poly(const car_body *b, v2 *out) {
-    float s = sinf(b->a), c = cosf(b->a);
+    float s, c;
+    crl_sincosf(b->a, &s, &c);
     for (int k = 0; k < 4; k++) out[k] = vadd(rot(s, c, V(K.wheel_poly[k][0], K.wheel_poly[k][1])), V(b->cx, b->cy));
 }
 
@@ -1097,7 +1102,9 @@ void car_oracle_step_repeat(car_env *e, const double (*actions)[2], int repeat, 
                 car_body *B = &car->wheel[w];
                 double ms, f[2];
                 double ja = (double)(B->a - car->hull.a - 0.0f);
-                car_oracle_wheel(dt, car->steer[w], car->gas[w], car->brake[w], ja, (double)sinf(B->a), (double)cosf(B->a), (double)B->vx, (double)B->vy,
+                float qs, qc;
+                crl_sincosf(B->a, &qs, &qc);
+                car_oracle_wheel(dt, car->steer[w], car->gas[w], car->brake[w], ja, (double)qs, (double)qc, (double)B->vx, (double)B->vy,
                                  car_oracle_wheel_on_road(e, c, w), &car->omega[w], &car->phase[w], &ms, f);
                 car->motor_speed[w] = (float)ms;
                 B->fx += (float)f[0], B->fy += (float)f[1];
@@ -1210,7 +1217,8 @@ void car_oracle_render(const car_env *e, int viewer, uint8_t *out) {
     double angle = (double)me->hull.a;
     double vx = (double)me->hull.vx, vy = (double)me->hull.vy;
     if (vx * vx + vy * vy > 0.5 * 0.5) angle = atan2(-vx, vy);
-    float af = (float)angle, s = sinf(af), c = cosf(af);
+    float af = (float)angle, s, c;
+    crl_sincosf(af, &s, &c);
     float hs, hc;
     v2 hp;
     body_xf(&me->hull, V(K.hull_lc[0], K.hull_lc[1]), &hs, &hc, &hp);

@@ -1,9 +1,10 @@
 """cCarRacingDouble: HIP path (through the C ABI) against the CPU oracle.
 
-Tolerances (BASELINE.md parity bar): float state within 1e-5 per step from identical pre-step
-state (teacher-forced) -- device sinf/cosf/atan2 are not bit-identical to glibc's; integer
-outcomes (tile visits, done, limit states) exact; free-running trajectories are chaotic and only
-checked loosely."""
+Bar (north_star: within 1e-5 on CarRacing float state): since both sides evaluate one shared sin/cos
+(include/crl_rot.h) and neither contracts multiply-adds, the float32 physics is BIT-IDENTICAL -- bodies, joint and
+contact impulses, with and without car-car contacts, teacher-forced and free-running -- and the tests below assert
+exactly that (tolerance 0).  Only the procedural track (float64 sin/cos/atan2 of the device library vs glibc) is
+compared with a tolerance (2e-4); the physics tests therefore push the oracle's tracks into the HIP env."""
 import ctypes as C
 import os
 
@@ -140,27 +141,23 @@ def test_step_teacher_forced_matches_oracle():
         hs = hip.get_state()
         for i, e in enumerate(envs):
             r, d = e.step(acts[i].astype(np.float64))
-            assert np.allclose(rew[i], r, atol=1e-6), (t, i, rew[i], r)
-            tol = 1e-5 if int(e.e["n_contact"]) == 0 else 1e-4  # the contact solver is branchy: looser bar while touching
+            assert np.array_equal(rew[i], r.astype(np.float32)), (t, i, rew[i], r)
             for c in range(2):
                 q, o = hs[i]["car"][c], e.e["car"][c]
-                for f in ("cx", "cy", "a", "vx", "vy", "w"):
-                    for got, want in ((q["hull"][f], o["hull"][f]), *zip(q["wheel"][f], o["wheel"][f])):
-                        err = abs(float(got) - float(want)) / max(1.0, abs(float(want)))
-                        worst = max(worst, err) if tol == 1e-5 else worst
-                        assert err < tol, (t, i, c, f, got, want, int(e.e["n_contact"]))
-                assert np.allclose(q["omega"], o["omega"], rtol=1e-6, atol=1e-6), (t, i, c)
-                assert np.allclose(q["gas"], o["gas"]) and np.allclose(q["phase"], o["phase"], rtol=1e-6, atol=1e-6)
+                for f in ("cx", "cy", "a", "vx", "vy", "w"):   # tolerance 0: bit-identical float32, touching or not
+                    assert q["hull"][f] == o["hull"][f], (t, i, c, f, q["hull"][f], o["hull"][f], int(e.e["n_contact"]))
+                    assert np.array_equal(q["wheel"][f], o["wheel"][f]), (t, i, c, f, int(e.e["n_contact"]))
+                assert np.array_equal(q["omega"], o["omega"]) and np.array_equal(q["gas"], o["gas"]), (t, i, c)   # f64 wheel model
+                assert np.array_equal(q["phase"], o["phase"]), (t, i, c)
                 assert np.array_equal(q["limit_state"], o["limit_state"]), (t, i, c)
                 assert np.array_equal(q["sleep_time"], o["sleep_time"]), (t, i, c, q["sleep_time"], o["sleep_time"])
-                assert np.allclose(q["imp"], o["imp"], rtol=1e-3, atol=1e-4), (t, i, c)
+                assert np.array_equal(q["imp"], o["imp"]) and np.array_equal(q["motor_imp"], o["motor_imp"]), (t, i, c)
                 assert int(q["tile_visited_count"]) == int(e.e["tile_visited_count"][c]), (t, i, c)
                 assert np.array_equal(q["visited"], e.e["visited"][c]) and np.array_equal(q["wheel_tiles"], e.e["wheel_tiles"][c])
                 assert int(q["last_block"]) == int(e.e["last_block"][c]) and int(q["done"]) == int(e.e["done"][c])
-                assert abs(float(q["reward"]) - float(e.e["reward"][c])) < 1e-9
+                assert float(q["reward"]) == float(e.e["reward"][c])
         visits = sum(int(e.e["tile_visited_count"].sum()) for e in envs)
     assert visits > 4 * n, visits
-    print("worst relative state error", worst)
     hip.close()
 
 
@@ -199,9 +196,9 @@ def test_free_running_stays_close_and_render_matches():
     hs = hip.get_state()
     for i, e in enumerate(envs):
         for c in range(2):
-            dx = float(hs[i]["car"][c]["hull"]["cx"]) - float(e.e["car"][c]["hull"]["cx"])
-            dy = float(hs[i]["car"][c]["hull"]["cy"]) - float(e.e["car"][c]["hull"]["cy"])
-            assert np.hypot(dx, dy) < 1e-2, (i, c, dx, dy)
+            # free-running for 120 steps (re-synchronised only by the oracle's own state every 20): still the same bits
+            for f in ("cx", "cy", "a", "vx", "vy", "w"):
+                assert hs[i]["car"][c]["hull"][f] == e.e["car"][c]["hull"][f], (i, c, f)
     print("render mismatch fractions: max", max(mism), "mean", np.mean(mism))
     # identical definition on both sides; the bar leaves room for a pixel or two per frame flipping on a
     # polygon edge through the last bit of the device's sinf/cosf (observed: exactly 0)
@@ -331,8 +328,7 @@ def test_single_car_env_matches_car0_of_double():
 
 def test_car_car_contacts_teacher_forced():
     """Cars driven into each other: manifolds, warm-started impulses and the coupled island solve
-    against the oracle, re-synchronised every step (the contact solver is branchy, so the float
-    tolerance is 1e-4 here)."""
+    against the oracle, re-synchronised every step: bit-identical, contact impulses included."""
     _need_gpu()
     import competitive_rl_amd as crl
 
@@ -374,15 +370,14 @@ def test_car_car_contacts_teacher_forced():
                 q, o = hs[i]["contact"][k], e.e["contact"][k]
                 assert int(q["pair"]) == int(o["pair"]) and int(q["count"]) == int(o["count"]) and int(q["type"]) == int(o["type"])
                 assert np.array_equal(q["id"][:int(o["count"])], o["id"][:int(o["count"])])
-                assert np.allclose(q["nimp"], o["nimp"], rtol=2e-3, atol=2e-3), (t, i, k, q["nimp"], o["nimp"])
+                cnt = int(o["count"])
+                assert np.array_equal(q["nimp"][:cnt], o["nimp"][:cnt]) and np.array_equal(q["timp"][:cnt], o["timp"][:cnt]), (t, i, k)
             for c in range(2):
                 q, o = hs[i]["car"][c], e.e["car"][c]
                 for f in ("cx", "cy", "a", "vx", "vy", "w"):
-                    for got, want in ((q["hull"][f], o["hull"][f]), *zip(q["wheel"][f], o["wheel"][f])):
-                        err = abs(float(got) - float(want)) / max(1.0, abs(float(want)))
-                        worst = max(worst, err)
-                        assert err < 1e-4, (t, i, c, f, got, want)
-    print("contacts: worst relative state error", worst, "env-steps with contacts", touched, "max contacts", max_nc)
+                    assert q["hull"][f] == o["hull"][f] and np.array_equal(q["wheel"][f], o["wheel"][f]), (t, i, c, f, nc)
+                assert np.array_equal(q["imp"], o["imp"]), (t, i, c)
+    print("contacts: env-steps with contacts", touched, "max contacts", max_nc)
     assert touched > 50 and max_nc >= 1
     hip.close()
 
@@ -407,11 +402,11 @@ def test_action_repeat_matches_oracle():
         hs = hip.get_state()
         for i, e in enumerate(envs):
             r, d = e.step_repeat(acts[i].astype(np.float64), rep)
-            assert np.allclose(rew[i], r, atol=1e-6), (t, i, rew[i], r)
+            assert np.array_equal(rew[i], r.astype(np.float32)), (t, i, rew[i], r)
             for c in range(2):
                 q, o = hs[i]["car"][c], e.e["car"][c]
                 for f in ("cx", "cy", "a", "vx", "vy", "w"):
-                    assert abs(float(q["hull"][f]) - float(o["hull"][f])) <= 3e-5 * max(1.0, abs(float(o["hull"][f]))), (t, i, c, f)
+                    assert q["hull"][f] == o["hull"][f] and np.array_equal(q["wheel"][f], o["wheel"][f]), (t, i, c, f)
                 assert int(q["step_count"]) == int(e.e["step_count"]) and np.allclose(q["gas"], o["gas"])
                 assert int(q["tile_visited_count"]) == int(e.e["tile_visited_count"][c])
     assert int(envs[0].e["step_count"]) == steps * rep
@@ -453,8 +448,7 @@ def test_island_sleep_matches_oracle():
                 q, o = hs[i]["car"][c], e.e["car"][c]
                 assert np.array_equal(q["sleep_time"], o["sleep_time"]), (t, i, c, q["sleep_time"], o["sleep_time"])
                 for f in ("vx", "vy", "w"):
-                    assert abs(float(q["hull"][f]) - float(o["hull"][f])) < 1e-6, (t, i, c, f)
-                    assert np.allclose(q["wheel"][f], o["wheel"][f], atol=1e-6), (t, i, c, f)
+                    assert q["hull"][f] == o["hull"][f] and np.array_equal(q["wheel"][f], o["wheel"][f]), (t, i, c, f)
                 if np.all(before[c] > 0.4) and np.all(o["sleep_time"] == 0.0):
                     slept += 1
                     assert float(q["hull"]["vx"]) == 0.0 and np.all(q["wheel"]["vx"] == 0.0), (t, i, c)
