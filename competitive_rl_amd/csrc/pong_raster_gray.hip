@@ -614,13 +614,14 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_ker
 //   * a touched block is composed in 1 KiB of LDS exactly as the env kernel does for a whole tile (row / column
 //     membership words, one lane per affected pixel, same f32 operation order), restricted to the block's rows.
 struct __attribute__((aligned(64))) GrayTileHdr {
-    uint8_t box[6][4];     // x0, y0, w, h of the six rectangles' output boxes (w*h = 0: none)
-    int16_t rc[8];         // Rects: ax, ay, bx, by, la, lb, ra, rb (view coordinates; -1000 = none)
+    // first 16 bytes = all an untouched segment needs (one scalar load)
     uint32_t band_off;     // first chunk of this tile's score rows in the band table
     uint8_t kind;          // 0 = blank plane (zeros), 1 = fast, 2 = per-pixel evaluator (unrelated scores / one blank frame)
-    uint8_t blockmask;     // bit k: block k of the tile holds pixels of a box
-    uint8_t pad[2];
-    uint64_t pa, pb;       // the two kept frames (slow path)
+    uint8_t pad[3];
+    uint64_t chunkmask;    // bit j: chunks [8 j, 8 j + 8) of the tile hold pixels of a box
+    uint8_t box[6][4];     // x0, y0, w, h of the six rectangles' output boxes (w*h = 0: none)
+    int16_t rc[8];         // Rects: ax, ay, bx, by, la, lb, ra, rb (view coordinates)
+    uint8_t pad2[8];
 };
 static_assert(sizeof(GrayTileHdr) == 64, "header layout");
 
@@ -637,7 +638,6 @@ __global__ __launch_bounds__(256) void pong_gray_header_kernel(const uint64_t *_
     else if (fb.sl == 255 && fa.sl != 255) fb = fa;
     GrayTileHdr h;
     memset(&h, 0, sizeof(h));
-    h.pa = pa, h.pb = pb;
     if (fa.sl == 255) {  // both blank: plane erased by a done
         hdr[tile] = h;
         return;
@@ -673,106 +673,154 @@ __global__ __launch_bounds__(256) void pong_gray_header_kernel(const uint64_t *_
     bx[3] = same_ball ? none : rect_box_lds(tabs, q.t, rc.bx, rc.bx + CRL_PONG_BALL, max(rc.by, CRL_PONG_TOP), min(rc.by + CRL_PONG_BALL, CRL_PONG_BOTTOM));
     bx[4] = rc.la == rc.lb ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.lb, rc.lb + CRL_PONG_BAT_H);
     bx[5] = rc.ra == rc.rb ? none : rect_box_lds(tabs, q.t, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.rb, rc.rb + CRL_PONG_BAT_H);
-    unsigned mask = 0;
+    uint64_t mask = 0;
     const int R = q.R;
     for (int i = 0; i < 6; i++) {
         if (bx[i].w * bx[i].h <= 0) bx[i] = none;
         h.box[i][0] = (uint8_t)bx[i].x0, h.box[i][1] = (uint8_t)bx[i].y0, h.box[i][2] = (uint8_t)bx[i].w, h.box[i][3] = (uint8_t)bx[i].h;
         for (int r = bx[i].y0; r < bx[i].y0 + bx[i].h; r++) {
             const int lo = r * R + bx[i].x0, hi = lo + bx[i].w - 1;
-            mask |= 1u << (lo >> 10);
-            mask |= 1u << (hi >> 10);
+            mask |= 1ull << (lo >> 7);  // pixel -> chunk (16 px) -> group of 8 chunks
+            mask |= 1ull << (hi >> 7);
         }
     }
-    h.blockmask = (uint8_t)mask;
+    h.chunkmask = mask;
     hdr[tile] = h;
 }
 
-__global__ __launch_bounds__(256) void pong_raster_gray_sweep_kernel(const GrayTileHdr *__restrict__ hdrs, int64_t n_tiles, GrayCtx g,
-                                                                     GrayGeom q, uint8_t *__restrict__ obs) {
+// One wavefront per 1-KiB-ALIGNED block of the output tensor (chunks [64 b, 64 b + 64) of the whole tensor), NB blocks per
+// wavefront a whole grid apart.  What the probes and the first versions of this kernel showed:
+//   * every wavefront store must be a full, aligned KiB: tiles cut into 6 x 64 + 57 chunks write at 4.2 TB/s, aligned
+//     blocks at 6.8 (tools/sweep_overhead_probe.hip).  A 7 056-byte tile is not a multiple of 1 KiB, so a block holds the
+//     tail of one tile and the head of the next: up to two SEGMENTS;
+//   * the CU's four SIMDs share ONE scalar unit (one scalar instruction per cycle): at the fill rate a CU has ~95 cycles
+//     per KiB, and a version whose per-block bookkeeping (tile index, header decode, mask tests: ~150 instructions) ran
+//     on the scalar unit was bound by exactly that (900 us with no loads and no raster work at all).  So the bookkeeping
+//     is LANE-PARALLEL here: every lane derives its own tile and chunk, reads its tile's header with a vector load
+//     (one or two distinct addresses per wavefront: a broadcast), and only the branch decisions are wave-level votes.
+__device__ inline int opaque_zero() {  // a zero the compiler must treat as per-lane: keeps uniform arithmetic off the scalar unit
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
+template <int RT, int NB>
+__global__ __launch_bounds__(256) void pong_raster_gray_sweep_kernel(const GrayTileHdr *__restrict__ hdrs, int n_tiles, GrayCtx g, GrayGeom q,
+                                                                     uint8_t *__restrict__ obs, int dbg, const uint64_t *__restrict__ ring,
+                                                                     int64_t n, int stride) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][1024];
     __shared__ uint32_t rowpack_[4][16], colpack_[4][kMaxR];
     constexpr int MAXT = 3;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int R = q.R, RR = R * R, chunks = RR >> 4, bpt = (chunks + 63) >> 6;  // blocks per tile (7 at R = 84)
-    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t tile = b / bpt;
-    if (tile >= n_tiles) return;
-    const int blk = (int)(b - tile * bpt);
-    const GrayTileHdr *hp = hdrs + tile;
-    const int c = blk * 64 + lane;          // chunk of the tile
-    const bool active = c < chunks;
-    uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + tile * (int64_t)RR) + c;
-    const uint32_t kind = hp->kind;
-    if (kind == 0) {
-        if (active) *out = make_uint4(0, 0, 0, 0);
-        return;
-    }
-    // template chunk: score rows from the band table, zeros for the court, the rest of the empty court otherwise
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int R = RT ? RT : q.R, RR = R * R, chunks = RR >> 4;   // RT = resized_dim at compile time (84), 0 = run-time value
+    const int total = n_tiles * chunks;
     const int bb = q.band_chunks;
     const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (active) {
-        if (c < bb) v = reinterpret_cast<const uint4 *>(q.band)[hp->band_off + c];
-        else if (c < zc0 || c >= zc1) v = reinterpret_cast<const uint4 *>(q.rest)[c];
+    const uint4 *__restrict__ band4 = reinterpret_cast<const uint4 *>(q.band);
+    const uint4 *__restrict__ rest4 = reinterpret_cast<const uint4 *>(q.rest);
+    int gl[NB], tile[NB], c[NB];
+    uint4 h[NB], v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {  // ---- every block's header words (16 B per lane, a broadcast), all in flight together
+        gl[i] = ((int)blockIdx.x * 256 + (int)threadIdx.x) + i * stride * 64;   // this lane's chunk, whole-tensor index (< 2^31)
+        const int gg = min(gl[i], total - 1);
+        tile[i] = gg / chunks, c[i] = gg - tile[i] * chunks;
+        h[i] = *reinterpret_cast<const uint4 *>(hdrs + tile[i]);
     }
-    if (kind == 2) {  // rare: unrelated scores under the max, or a blank buffer (set_state / the never-written buffers)
-        if (active) {
-            const Frame fa = unpack_frame(hp->pa), fb = unpack_frame(hp->pb);
-            const int tiles_per_env = q.views * q.K, view = (int)(tile % tiles_per_env) / q.K;
-            uint8_t px[16];
-            for (int k = 0; k < 16; k++) {
-                const int p = c * 16 + k, dy = p / R, dx = p - dy * R;
-                px[k] = eval_pixel(g, fa, fb, view, dy, dx);
-            }
-            uint4 o;
-            memcpy(&o, px, 16);
-            *out = o;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {  // ---- every block's template chunk: score rows from the band table, zeros for the court, ...
+        const uint32_t kind = h[i].y & 255u;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (kind != 0 && !(dbg & 4)) {
+            if (c[i] < bb) v[i] = band4[h[i].x + c[i]];
+            else if (c[i] < zc0 || c[i] >= zc1) v[i] = rest4[c[i]];
         }
-        return;
     }
-    if (!((hp->blockmask >> blk) & 1)) {
-        if (active) *out = v;
-        return;
-    }
-    // ---- a touched block: compose it in LDS
-    uint8_t *tl = lds[wave];
-    reinterpret_cast<uint4 *>(tl)[lane] = v;
-    const int P0 = blk * 1024, P1 = min(P0 + 1024, RR);
-    const int r0 = P0 / R, r1 = (P1 - 1) / R;   // first / last output row with pixels in this block
-    Rects rc;
-    rc.ax = hp->rc[0], rc.ay = hp->rc[1], rc.bx = hp->rc[2], rc.by = hp->rc[3];
-    rc.la = hp->rc[4], rc.lb = hp->rc[5], rc.ra = hp->rc[6], rc.rb = hp->rc[7];
-    int bx0[6], by0[6], bw[6], bh[6], pre[7];
-    pre[0] = 0;
-    int xmin = R, xmax = 0;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const int x0 = hp->box[i][0], y0 = hp->box[i][1], w = hp->box[i][2], h = hp->box[i][3];
-        const int ylo = max(y0, r0), yhi = min(y0 + h, r1 + 1);
-        bx0[i] = x0, by0[i] = ylo, bw[i] = w, bh[i] = max(yhi - ylo, 0);
-        pre[i + 1] = pre[i] + bw[i] * bh[i];
-        if (bw[i] * bh[i] > 0) xmin = min(xmin, x0), xmax = max(xmax, x0 + w);
-    }
-    const uint8_t *tabs = q.tab_blob;  // dense tap tables, read through L1 (a few hundred bytes per touched block)
-    uint32_t *rowpack = rowpack_[wave], *colpack = colpack_[wave];
-    if (lane <= r1 - r0) rowpack[lane] = row_pack<MAXT>(tabs, q.t, rc, r0 + lane);
-    for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const int total = pre[6];
-    for (int p = lane; p < total; p += 64) {
-        int x0 = bx0[0], y0 = by0[0], w = bw[0], base = 0;
+    for (int i = 0; i < NB; i++) {
+        const bool active = gl[i] < total;
+        uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs) + gl[i];
+        const uint32_t kind = h[i].y & 255u;
+        // bit j of the tile's 64-bit mask: chunks [8 j, 8 j + 8) hold pixels of a box
+        const uint32_t mword = (c[i] >> 3) < 32 ? h[i].z : h[i].w;
+        const bool mine = active && (kind == 2 || (kind == 1 && ((mword >> ((c[i] >> 3) & 31)) & 1u) && !(dbg & 1)));
+        if (!__any(mine)) {  // most blocks: the template, stored straight away
+            if (active) *out = v[i];
+            continue;
+        }
+        // ---- a block with box pixels: compose it in LDS, segment by segment (wave-uniform tile each)
+        uint8_t *tl = lds[wave];
+        reinterpret_cast<uint4 *>(tl)[lane] = v[i];
+        const int tileA = __builtin_amdgcn_readfirstlane(tile[i]), tileZ = __builtin_amdgcn_readlane(tile[i], 63);
+        const int cA = __builtin_amdgcn_readfirstlane(c[i]);
+        const int split = tileZ != tileA ? chunks - cA : 64;   // lanes [0, split) are segment A, the rest segment B (the next tile)
+        const uint8_t *tabs = q.tab_blob;  // dense tap tables, read through L1 (a few hundred bytes per touched segment)
+        uint32_t *rowpack = rowpack_[wave], *colpack = colpack_[wave];
+        const int vz = opaque_zero();
+#pragma unroll 1
+        for (int seg = 0; seg < 2; seg++) {
+            if (seg == 1 && tileZ == tileA) break;
+            const bool in_seg = (lane < split) == (seg == 0);
+            if (!__any(mine && in_seg)) continue;
+            const int tl_id = seg ? tileZ : tileA;
+            const int c0 = seg ? 0 : cA, c1 = seg ? 64 - split : cA + split;   // the segment's chunks of its tile
+            const int l0 = seg ? split : 0;                                    // first lane / LDS chunk of the segment
+            const int P0 = c0 * 16, P1 = c1 * 16;
+            // the header again, per lane (vector loads + vector arithmetic: every lane needs all six boxes)
+            const GrayTileHdr *hp = hdrs + (tl_id + vz);
+            const uint4 hw = *reinterpret_cast<const uint4 *>(hp);
+            if ((hw.y & 255u) == 2u) {  // rare: unrelated scores under the max, or a blank buffer (set_state / the never-written buffers)
+                const int tiles_per_env = q.views * q.K, env = tl_id / tiles_per_env, tt = tl_id - env * tiles_per_env;
+                const int view = tt / q.K, rp = 4 - q.K + (tt - view * q.K);
+                Frame fa = unpack_frame(ring[(int64_t)(2 * rp) * n + env]), fb = unpack_frame(ring[(int64_t)(2 * rp + 1) * n + env]);
+                if (fa.sl == 255 && fb.sl != 255) fa = fb;
+                else if (fb.sl == 255 && fa.sl != 255) fb = fa;
+                for (int p = P0 + lane; p < P1; p += 64) {
+                    const int dy = p / R, dx = p - dy * R;
+                    tl[p - P0 + l0 * 16] = eval_pixel(g, fa, fb, view, dy, dx);
+                }
+                continue;
+            }
+            const uint4 hb = reinterpret_cast<const uint4 *>(hp)[1];   // boxes 0..3
+            const uint4 hc = reinterpret_cast<const uint4 *>(hp)[2];   // boxes 4..5, rects ax ay bx by
+            const uint2 hd = reinterpret_cast<const uint2 *>(hp)[6];   // rects la lb ra rb
+            const int r0 = P0 / R, r1 = (P1 - 1) / R;   // first / last output row with pixels in this segment
+            Rects rc;
+            rc.ax = (int16_t)(hc.z & 0xFFFFu), rc.ay = (int16_t)(hc.z >> 16), rc.bx = (int16_t)(hc.w & 0xFFFFu), rc.by = (int16_t)(hc.w >> 16);
+            rc.la = (int16_t)(hd.x & 0xFFFFu), rc.lb = (int16_t)(hd.x >> 16), rc.ra = (int16_t)(hd.y & 0xFFFFu), rc.rb = (int16_t)(hd.y >> 16);
+            const uint32_t bw32[6] = {hb.x, hb.y, hb.z, hb.w, hc.x, hc.y};
+            int bx0[6], by0[6], bw[6], pre[7];
+            pre[0] = 0;
+            int xmin = R, xmax = 0;
 #pragma unroll
-        for (int k = 1; k < 6; k++)
-            if (p >= pre[k]) x0 = bx0[k], y0 = by0[k], w = bw[k], base = pre[k];
-        const int o = p - base;
-        const int yy = (int)(((float)o + 0.5f) * (1.0f / (float)max(w, 1)));  // o / w, exact for these sizes
-        const int dy = y0 + yy, dx = x0 + (o - yy * w);
-        const int idx = dy * R + dx - P0;
-        if ((unsigned)idx < 1024u) tl[idx] = eval_sep<MAXT>(tabs, q.t, R, rowpack[dy - r0], colpack[dx], dy, dx);
+            for (int k = 0; k < 6; k++) {
+                const int x0 = bw32[k] & 255u, y0 = (bw32[k] >> 8) & 255u, w = (bw32[k] >> 16) & 255u, hh = bw32[k] >> 24;
+                const int ylo = max(y0, r0), yhi = min(y0 + hh, r1 + 1), cnt = w * max(yhi - ylo, 0);
+                bx0[k] = x0, by0[k] = ylo, bw[k] = w;
+                pre[k + 1] = pre[k] + cnt;
+                if (cnt > 0) xmin = min(xmin, x0), xmax = max(xmax, x0 + w);
+            }
+            if (lane <= r1 - r0) rowpack[lane] = row_pack<MAXT>(tabs, q.t, rc, r0 + lane);
+            for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const int npx = __builtin_amdgcn_readfirstlane(pre[6]);
+            for (int p = lane; p < npx; p += 64) {
+                int x0 = bx0[0], y0 = by0[0], w = bw[0], base = 0;
+#pragma unroll
+                for (int k = 1; k < 6; k++)
+                    if (p >= pre[k]) x0 = bx0[k], y0 = by0[k], w = bw[k], base = pre[k];
+                const int o = p - base;
+                const int yy = (int)(((float)o + 0.5f) * (1.0f / (float)max(w, 1)));  // o / w, exact for these sizes
+                const int dy = y0 + yy, dx = x0 + (o - yy * w);
+                const int idx = dy * R + dx - P0;
+                if ((unsigned)idx < (unsigned)(P1 - P0)) tl[idx + l0 * 16] = eval_sep<MAXT>(tabs, q.t, R, rowpack[dy - r0], colpack[dx], dy, dx);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (active) *out = reinterpret_cast<const uint4 *>(tl)[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the LDS block is reused by the wave's next block
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (active) *out = reinterpret_cast<const uint4 *>(tl)[lane];
 }
 
 void pong_gray_print_ticks() {
@@ -813,14 +861,30 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
                            p.obs);
         return;
     }
-    // address-linear writer: uint8 output, 16-byte-aligned tiles, three-tap tables (R = 84 and similar sizes)
-    static const int sweep_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 1;
-    if (sweep_env && !p.obs_f32 && !q.debug && p.hdr && (p.R * p.R) % 16 == 0 && tofs.max_taps <= 3 && tofs.fast_ok) {
+    // address-linear writer (uint8 output, 16-byte-aligned tiles, three-tap tables: R = 84 and similar sizes).  OFF by default:
+    // bit-exact, but 1.0-2.0 ms against the env kernel's 0.75 ms at 65 536 envs -- every block has to read per-tile metadata
+    // first, and a dependent read in a store-saturated memory system takes microseconds.
+    static const int sweep_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
+    if (sweep_env && !p.obs_f32 && !q.debug && p.hdr && (p.R * p.R) % 16 == 0 && tofs.max_taps <= 3 && tofs.fast_ok && tiles * (p.R * p.R >> 4) < (1ll << 31) && (p.R * p.R >> 4) <= 512) {
         GrayTileHdr *hdr = reinterpret_cast<GrayTileHdr *>(p.hdr);
         hipLaunchKernelGGL(pong_gray_header_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, p.ring, p.n, q, hdr);
-        const int bpt = ((p.R * p.R >> 4) + 63) >> 6;
-        const int64_t blocks = tiles * bpt;
-        hipLaunchKernelGGL(pong_raster_gray_sweep_kernel, dim3((unsigned)((blocks + 3) / 4)), dim3(256), 0, st, hdr, tiles, g, q, p.obs);
+        static const int sdbg = getenv("CRL_GRAY_SWEEP_DEBUG") ? atoi(getenv("CRL_GRAY_SWEEP_DEBUG")) : 0;
+        static const int nb_env = getenv("CRL_GRAY_SWEEP_NB") ? atoi(getenv("CRL_GRAY_SWEEP_NB")) : 2;
+        const int64_t wblocks = (tiles * (p.R * p.R >> 4) + 63) / 64;   // 1-KiB blocks of the whole tensor
+        const int nb = wblocks < 8192 ? 1 : nb_env;
+        const int stride = (int)(((wblocks + nb - 1) / nb + 3) / 4 * 4);  // blocks per round, a multiple of the 4 waves of a workgroup
+        const dim3 grid((unsigned)(stride / 4));
+#define CRL_SWEEP(RTv, NBv) hipLaunchKernelGGL((pong_raster_gray_sweep_kernel<RTv, NBv>), grid, dim3(256), 0, st, hdr, (int)tiles, g, q, p.obs, sdbg, p.ring, p.n, stride)
+        if (p.R == 84) {
+            if (nb == 1) CRL_SWEEP(84, 1);
+            else if (nb == 2) CRL_SWEEP(84, 2);
+            else if (nb == 8) CRL_SWEEP(84, 8);
+            else CRL_SWEEP(84, 4);
+        } else {
+            if (nb == 1) CRL_SWEEP(0, 1);
+            else CRL_SWEEP(0, 4);
+        }
+#undef CRL_SWEEP
         return;
     }
     // planes per wave: the whole stack of an env per wave once there are enough envs to fill

@@ -283,3 +283,40 @@ def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
         assert np.array_equal(got["obs"][t], buf.cpu().numpy()) and np.array_equal(got["rew"][t], rew.cpu().numpy())
         assert np.array_equal(got["done"][t], done.cpu().numpy()), t
     env.close()
+
+
+def test_address_linear_gray_writer_is_bit_exact_too():
+    """The optional address-linear fused-84 writer (CRL_GRAY_SWEEP=1: header kernel + aligned 1-KiB-block sweep, DESIGN.md
+    4.3) against the oracle, in a child process because the switch is read once per process."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import competitive_rl_amd as crl
+from competitive_rl_amd import _native
+from oracle import pong_oracle as po
+atlas = _native.load_score_atlas()
+for K, n in ((4, 130), (1, 67)):
+    env = crl.HipPongVecEnv(n, seed=5, mode="wrapped", resized_dim=84, frame_stack=K)
+    ora = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=84, frame_stack=K, seed=5)
+    assert np.array_equal(torch.stack(env.reset(), 1).cpu().numpy(), ora.reset())
+    rs = np.random.RandomState(K)
+    for t in range(150):
+        a = rs.randint(0, 3, (n, 2))
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = ora.step(a)
+        assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo), (K, t)
+    st = env.get_state(); st["score_l"][:3] = 7; st["keep"]["score_l"][:3, 0] = 2; env.set_state(st)   # unrelated scores: slow path
+    os_ = ora.state; os_["score_l"][:3] = 7; os_["keep"]["score_l"][:3, 0] = 2
+    a = rs.randint(0, 3, (n, 2))
+    obs, _, _, _ = env.step(a); oo, _, _ = ora.step(a)
+    assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo)
+    env.close()
+print("sweep ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRL_GRAY_SWEEP="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sweep ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
