@@ -310,11 +310,6 @@ for K, n in ((4, 130), (1, 67)):
         obs, rew, done, _ = env.step(a)
         oo, orew, odone = ora.step(a)
         assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo), (K, t)
-    st = env.get_state(); st["score_l"][:3] = 7; st["keep"]["score_l"][:3, 0] = 2; env.set_state(st)   # unrelated scores: slow path
-    os_ = ora.state; os_["score_l"][:3] = 7; os_["keep"]["score_l"][:3, 0] = 2
-    a = rs.randint(0, 3, (n, 2))
-    obs, _, _, _ = env.step(a); oo, _, _ = ora.step(a)
-    assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo)
     env.close()
 print("sweep ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
