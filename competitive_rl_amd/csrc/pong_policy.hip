@@ -368,6 +368,284 @@ __global__ __launch_bounds__(kPolicyThreads) void pong_policy_light_kernel(Polic
 #undef CRL_TICK
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 MFMA version (round 2; CRL_POLICY_MFMA=0 selects the packed-FMA kernel above for A/B).
+//
+// v_mfma_f32_16x16x4_f32 multiplies exact f32 products at the vector peak (64 FLOP/clk/SIMD, MI355X_MICROARCH.md) but
+// on the matrix pipe: the VALU stays free for the patch conversion, and the weights sit in VGPRs once per wavefront --
+// no scalar weight stream, whose s_waitcnt in front of every 16 FMAs cost the packed-FMA kernel a third of its time.
+//
+// Both convolutions are computed TRANSPOSED, D^T[oc][pos] = W[oc][tap] x im2col^T[tap][pos], on tiles of 16 conv2
+// positions q = env * 100 + pos2 (8 envs per group = 50 tiles, no padding):
+//   conv1: the 2x2 conv1 outputs under a conv2 position form four parity CLASSES c = (ky0, kx0); per class one
+//          accumulator tile D1[c] (rows = 16 output channels, cols = the 16 positions), 16 MFMAs each: step (ky, kx)
+//          takes A = W1[oc = l & 15][ic = l >> 4][ky][kx] and B = x[ic = l >> 4][4 y2 + 2 ky0 + ky][4 x2 + 2 kx0 + kx] / 255
+//          -- lane (position l & 15, plane l >> 4) needs the 6 x 6 patch of ONE plane: six aligned ds_read2_b32 per tile;
+//   conv2: the accumulator layout (lane = position, registers r = channels 4 (l >> 4) + r) IS the B operand of the
+//          next product: step (c, r) takes B = relu(D1[c][r]) as it stands and A = W2[oc2 = l & 15][ic = 4 (l >> 4) + r][c]
+//          -- no transpose, no LDS round trip between the layers;
+//   actor: each lane folds its four conv2 channels into three partial logits, two cross-lane adds finish the
+//          position, and the 100 positions of an env are summed in a fixed shape (4 x 25, then 4) as before.
+// 80 MFMAs per 16 positions = 500 per env: 65 536 envs x 500 x 32 cycles / 1 024 SIMDs = 1.02 M cycles (427 us at 2.4 GHz).
+// One persistent 512-thread workgroup per CU -- two wavefronts per SIMD: a lone wavefront issues a vector instruction
+// every 4 cycles, and the ~300 non-matrix instructions of a tile (gather, x / 255, relu, actor) next to its 80 MFMAs made
+// the one-wavefront version 2.4x slower than the matrix pipe allows (1 018 us); with a partner, one's vector work runs
+// under the other's MFMAs.  Groups are handed out by the ticket counter, the NEXT group's rings and frames land in the
+// other half of a double buffer by LDS-DMA while this one is computed.
+typedef float f4 __attribute__((ext_vector_type(4)));
+#ifndef CRL_MFMA_WAVES
+#define CRL_MFMA_WAVES 8
+#endif
+#ifndef CRL_MFMA_PREFETCH
+#define CRL_MFMA_PREFETCH 0
+#endif
+static constexpr int kME = 8;                       // envs per group
+static constexpr int kMTiles = kME * kPos / 16;     // 50 tiles of 16 conv2 positions
+static constexpr int kMWaves = CRL_MFMA_WAVES;                    // wavefronts per workgroup: two per SIMD (one gathers / converts while the other's MFMAs run)
+static constexpr int kMThreads = 64 * kMWaves;
+static constexpr int kMBuf = kME * CRL_POLICY_STACK * kPlanePad;  // 56 832 bytes per staging buffer
+static constexpr int kMLdsRest = (3 * 1600 + kME * kPos * 3 + kME * 12 + kME * 3 + 4) * 4;
+static constexpr int kMLds = 2 * kMBuf + kMLdsRest;
+
+__device__ inline void group_request_m(uint8_t *shbuf, const uint8_t *__restrict__ ring, int head, const uint8_t *__restrict__ frame,
+                                       int64_t frame_stride, int64_t env0, int envs_here, int wave, int lane) {
+    for (int s = wave; s < kME * 3; s += kMWaves) {
+        const int fe = s / 3, j = s - fe * 3;
+        if (fe >= envs_here) continue;
+        const int pp = (head + 1 + j) & 3;
+        const uint8_t *src = ring + (env0 + fe) * (int64_t)kRingBytes + pp * kPlanePad;
+        uint8_t *dst = shbuf + (fe * CRL_POLICY_STACK + pp) * kPlanePad;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int c = half * 64 + lane;
+            if (c < kPlaneChunks) lds_dma_b128(src + c * 16, lds_addr(dst + half * 1024));
+        }
+    }
+    for (int s = wave; s < kME * 7; s += kMWaves) {
+        const int fe = s / 7, q = s - fe * 7;
+        if (fe >= envs_here) continue;
+        const int d = q * 64 + lane;
+        const uint8_t *src = frame + (env0 + fe) * frame_stride;
+        uint8_t *dst = shbuf + (fe * CRL_POLICY_STACK + head) * kPlanePad + q * 256;
+        if (d < kPlaneWords) lds_dma_b32(src + d * 4, lds_addr(dst));
+    }
+}
+
+struct PolicyWeightsM {
+    const float *w1, *b1, *w2, *b2, *wa, *ba;  // torch layouts: conv1 [16][4][4][4], conv2 [16][16][2][2], actor [3][1600]
+};
+
+__global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWeightsM W, uint8_t *__restrict__ ring, int head,
+                                                                  const uint8_t *__restrict__ frame, int64_t frame_stride,
+                                                                  int32_t *__restrict__ actions, int64_t action_stride,
+                                                                  float *__restrict__ logits_out, int64_t n, unsigned *__restrict__ ticket, int dbg,
+                                                                  int nbuf) {
+    // nbuf = 2: the next group streams into the other staging buffer during the convolutions; nbuf = 1 (hybrid mode, where
+    // the packed-FMA kernel shares the CU and its LDS): one buffer, refilled after the tile loop
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *sh_buf = smem;                                             // [nbuf][kME][4][kPlanePad]
+    float *sh_wa = reinterpret_cast<float *>(smem + nbuf * kMBuf);      // [3][1600]
+    float *sh_part = sh_wa + 3 * 1600;                                  // [kME * 100][3]
+    float *sh_grp = sh_part + kME * kPos * 3;                           // [kME][3][4]
+    float *sh_logit = sh_grp + kME * 12;                                // [kME][3]
+    unsigned *sh_ticket = reinterpret_cast<unsigned *>(sh_logit + kME * 3);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lj = lane & 15, lk = lane >> 4;
+    const int64_t ngroups = (n + kME - 1) / kME;
+
+    for (int i = tid; i < 3 * 1600; i += kMThreads) sh_wa[i] = W.wa[i];
+    // the wavefront's weights, once: A operands of every MFMA step
+    float w1[16], w2[4][4];
+#pragma unroll
+    for (int s = 0; s < 16; s++) w1[s] = W.w1[lj * 64 + lk * 16 + s];                      // W1[oc = lj][ic = lk][ky = s / 4][kx = s % 4]
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) w2[c][r] = W.w2[(lj * 16 + 4 * lk + r) * 4 + c];      // W2[oc2 = lj][ic = 4 lk + r][ky0, kx0 = c]
+    f4 bias1, bias2;
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias1[r] = W.b1[4 * lk + r], bias2[r] = W.b2[4 * lk + r];  // D rows = channels 4 lk + r
+    float ba0 = W.ba[0], ba1 = W.ba[1], ba2 = W.ba[2];
+    // Every load above must have RETURNED before the first LDS-DMA request is issued: the compiler waits for a load at its
+    // first use with a vmcnt(N) that counts only the loads it knows of -- inside the tile loop that wait would also drain
+    // the next group's LDS-DMA transfers (inline asm, invisible to it) and serialise staging with the convolutions.
+#pragma unroll
+    for (int s = 0; s < 16; s++) asm volatile("" : "+v"(w1[s]));
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(w2[c][r]));
+    asm volatile("" : "+v"(bias1), "+v"(bias2), "+v"(ba0), "+v"(ba1), "+v"(ba2));
+    __syncthreads();  // sh_wa is staged
+
+    // Three groups are in play: g (being computed), g1 (streaming into the other buffer) and the ticket for the one after
+    // (a returning global atomic takes microseconds: it is requested at the top of an iteration and read at its end).
+    int64_t g = blockIdx.x, g1 = ngroups;
+    int cur = 0;
+    if (g < ngroups) {
+        const int64_t env0 = g * kME;
+        if (tid == 0) *sh_ticket = atomicAdd(ticket, 1u);
+        group_request_m(sh_buf, ring, head, frame, frame_stride, env0, (int)((n - env0) < kME ? (n - env0) : kME), wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        g1 = (int64_t)gridDim.x + *sh_ticket;
+        __syncthreads();
+    }
+    long long tk[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    const long long tstart = tprev;
+#define MTICK(K)                                                \
+    if (dbg & 4) {                                              \
+        const long long now_ = __builtin_readcyclecounter();    \
+        tk[K] += now_ - tprev;                                  \
+        tprev = now_;                                           \
+    }
+    while (g < ngroups) {
+        const int64_t env0 = g * kME;
+        const int envs_here = (int)((n - env0) < kME ? (n - env0) : kME);
+        uint8_t *buf = sh_buf + (nbuf == 2 ? cur : 0) * kMBuf;
+        if (tid == 0) *sh_ticket = atomicAdd(ticket, 1u);
+        if (nbuf == 2 && g1 < ngroups) {  // the next group streams into the other buffer during the convolutions
+            const int64_t e1 = g1 * kME;
+            group_request_m(sh_buf + (cur ^ 1) * kMBuf, ring, head, frame, frame_stride, e1, (int)((n - e1) < kME ? (n - e1) : kME), wave, lane);
+        }
+        // the new frame also replaces plane `head` of the ring in HBM
+        for (int i = tid; i < envs_here * kPlaneChunks; i += kMThreads) {
+            const int fe = i / kPlaneChunks, c = i - fe * kPlaneChunks;
+            reinterpret_cast<uint4 *>(ring + (env0 + fe) * (int64_t)kRingBytes + head * kPlanePad)[c] =
+                reinterpret_cast<const uint4 *>(buf + (fe * CRL_POLICY_STACK + head) * kPlanePad)[c];
+        }
+        MTICK(0)
+        // The patch of tile t + kMWaves is gathered and converted WHILE tile t's MFMAs run: the two are independent, so the
+        // scheduler threads the vector work between the matrix instructions (a wavefront that converts first and multiplies
+        // afterwards leaves the matrix pipe idle 44 % of the time even with a partner on the SIMD).
+        auto gather = [&](int t, float (&xo)[6][6]) {
+            const int q = 16 * t + lj, e = q / kPos, pos = q - e * kPos, y2 = pos / 10, x2 = pos - y2 * 10;
+            // this lane's 6 x 6 patch of plane ic = lk, as x / 255 (correctly rounded: Markstein).  Two ALIGNED dwords per 6-byte
+            // row piece: (4 y2 + r) * 42 + 4 x2 is a multiple of 4 for even r and 2 past one for odd r -- known at compile time.
+            const float rcp = 1.0f / 255.0f;
+            const uint8_t *base = buf + (e * CRL_POLICY_STACK + ((head + 1 + lk) & 3)) * kPlanePad + (4 * y2) * kDim + 4 * x2;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const uint32_t *p32 = reinterpret_cast<const uint32_t *>(base + r * kDim - 2 * (r & 1));
+                uint32_t w0 = p32[0], w1_ = p32[1];
+                if (r & 1) w0 = (w0 >> 16) | (w1_ << 16), w1_ >>= 16;
+                const float b[6] = {(float)(w0 & 255u), (float)((w0 >> 8) & 255u), (float)((w0 >> 16) & 255u), (float)(w0 >> 24),
+                                    (float)(w1_ & 255u), (float)((w1_ >> 8) & 255u)};
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const float qv = b[k] * rcp;
+                    const float rem = __builtin_fmaf(qv, -255.0f, b[k]);
+                    xo[r][k] = __builtin_fmaf(rem, rcp, qv);
+                }
+            }
+        };
+        float xnext[6][6];
+        if (!CRL_MFMA_PREFETCH) {
+        } else if (dbg & 1) {  // ablation: no gather
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) xnext[r][k] = 0.25f * (float)(r + k + lk);
+        } else if (wave < kMTiles) gather(wave, xnext);
+        for (int t = wave; t < kMTiles; t += kMWaves) {
+            const int q = 16 * t + lj, e = q / kPos, pos = q - e * kPos;
+            float xin[6][6];
+            if (CRL_MFMA_PREFETCH) {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) xin[r][k] = xnext[r][k];
+                if (t + kMWaves < kMTiles && !(dbg & 1)) gather(t + kMWaves, xnext);
+            } else {
+                gather(t, xin);
+            }
+            // ---- conv1: four parity classes, 16 MFMAs each (independent accumulator chains)
+            f4 d1[4] = {bias1, bias1, bias1, bias1};
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    d1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], xin[2 * (c >> 1) + (s >> 2)][2 * (c & 1) + (s & 3)], d1[c], 0, 0, 0);
+            // ---- conv2: the accumulators are the B operands as they stand
+            f4 d2a = bias2, d2b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float hval = fmaxf(d1[c][r], 0.f);
+                    if ((c * 4 + r) & 1) d2b = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[c][r], hval, d2b, 0, 0, 0);
+                    else d2a = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[c][r], hval, d2a, 0, 0, 0);
+                }
+            if (dbg & 2) {  // ablation: no actor / cross-lane sums
+                if (lk == 0) sh_part[q * 3] = d2a[0] + d2b[1];
+                continue;
+            }
+            // ---- actor: lane (position lj, channels 4 lk + r)
+            float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float f = fmaxf(d2a[r] + d2b[r], 0.f);
+                const int wi = (4 * lk + r) * kPos + pos;
+                l0 = __builtin_fmaf(sh_wa[wi], f, l0);
+                l1 = __builtin_fmaf(sh_wa[1600 + wi], f, l1);
+                l2 = __builtin_fmaf(sh_wa[3200 + wi], f, l2);
+            }
+            // the four channel groups of a position sit 16 lanes apart: (g0 + g1) + (g2 + g3), a fixed order
+            l0 += __shfl_xor(l0, 16), l1 += __shfl_xor(l1, 16), l2 += __shfl_xor(l2, 16);
+            l0 += __shfl_xor(l0, 32), l1 += __shfl_xor(l1, 32), l2 += __shfl_xor(l2, 32);
+            if (lk == 0) sh_part[q * 3 + 0] = l0, sh_part[q * 3 + 1] = l1, sh_part[q * 3 + 2] = l2;
+        }
+        MTICK(1)
+        __syncthreads();
+        MTICK(2)
+        if (nbuf == 1 && g1 < ngroups) {  // single buffer: every tile of this group has been read
+            const int64_t e1 = g1 * kME;
+            group_request_m(sh_buf, ring, head, frame, frame_stride, e1, (int)((n - e1) < kME ? (n - e1) : kME), wave, lane);
+        }
+        // fixed-shape sum over the 100 positions of an env (4 groups of 25, then the 4 groups)
+        if (tid < kME * 12) {
+            const int pe = tid / 12, r = tid - pe * 12, a = r >> 2, grp = r & 3;
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < 25; p++) s += sh_part[(pe * kPos + grp * 25 + p) * 3 + a];
+            sh_grp[(pe * 3 + a) * 4 + grp] = s;
+        }
+        __syncthreads();
+        if (tid < kME * 3) {
+            const int pe = tid / 3, a = tid - pe * 3;
+            const float *gp = sh_grp + (pe * 3 + a) * 4;
+            sh_logit[pe * 3 + a] = (a == 0 ? ba0 : a == 1 ? ba1 : ba2) + ((gp[0] + gp[1]) + (gp[2] + gp[3]));
+        }
+        __syncthreads();
+        if (tid < envs_here) {
+            const float a0 = sh_logit[tid * 3], a1 = sh_logit[tid * 3 + 1], a2 = sh_logit[tid * 3 + 2];
+            int best = 0;  // argmax, first index wins ties (torch.argmax)
+            float bv = a0;
+            if (a1 > bv) best = 1, bv = a1;
+            if (a2 > bv) best = 2;
+            actions[(env0 + tid) * action_stride] = best;
+            if (logits_out) {
+                float *lo = logits_out + (env0 + tid) * 3;
+                lo[0] = a0, lo[1] = a1, lo[2] = a2;
+            }
+        }
+        MTICK(3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's share of the next group has landed (and the ticket is back)
+        __syncthreads();                                    // ... everybody's has; this group's LDS scratch is free again
+        MTICK(4)
+        cur ^= 1;
+        g = g1;
+        g1 = (int64_t)gridDim.x + *sh_ticket;
+        __syncthreads();                                    // everyone has read the ticket before lane 0 overwrites it
+    }
+    if ((dbg & 4) && logits_out && lane == 0 && blockIdx.x < 64) {  // profiling: cycles per phase of every wavefront of the first workgroups
+        float *o = logits_out + (blockIdx.x * kMWaves + wave) * 6;
+        for (int k = 0; k < 5; k++) o[k] = (float)tk[k];
+        o[5] = (float)(__builtin_readcyclecounter() - tstart);
+    }
+#undef MTICK
+}
+
 // ring <-> logical order (tests, checkpoints): plane j of the model's stack is ring plane (head + j) & 3
 __global__ void pong_policy_copy_stack_kernel(uint8_t *__restrict__ ring, uint8_t *__restrict__ ext, int head, int64_t words, int to_ring) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -400,6 +678,10 @@ struct crl_policy {
     uint8_t *ring = nullptr;
     unsigned *ticket = nullptr;  // next group to hand out (reset before every launch)
     PolicyWeights W{};
+    hipStream_t side = nullptr;  // hybrid mode: the MFMA kernel's stream, forked from / joined to the caller's
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float *raw = nullptr;        // the checkpoint tensors in torch layout (MFMA kernel): w1 1024 | b1 16 | w2 1024 | b2 16 | wa 4800 | ba 3
+    PolicyWeightsM WM{};
 };
 
 extern "C" {
@@ -427,12 +709,28 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
     memcpy(ba, actor_b, 3 * sizeof(float));
     hipError_t e = hipMalloc(&p->weights, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->weights, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&p->ticket, 64);
+    if (e == hipSuccess) e = hipMalloc(&p->ticket, 128);  // [0]: packed-FMA kernel's counter, [16]: MFMA kernel's (hybrid mode)
     if (e == hipSuccess) e = hipMalloc(&p->ring, (size_t)num_envs * kRingBytes);
     if (e == hipSuccess) e = hipMemset(p->ring, 0, (size_t)num_envs * kRingBytes);
     if (e != hipSuccess) {
         crl_policy_destroy(p);
         return crl_fail(e == hipErrorOutOfMemory ? CRL_ENOMEM : CRL_EHIP, "crl_policy_create: %s", hipGetErrorString(e));
+    }
+    {
+        std::vector<float> raw(1024 + 16 + 1024 + 16 + 4800 + 4, 0.f);
+        memcpy(raw.data(), conv1_w, 1024 * 4), memcpy(raw.data() + 1024, conv1_b, 16 * 4), memcpy(raw.data() + 1040, conv2_w, 1024 * 4);
+        memcpy(raw.data() + 2064, conv2_b, 16 * 4), memcpy(raw.data() + 2080, actor_w, 4800 * 4), memcpy(raw.data() + 6880, actor_b, 3 * 4);
+        e = hipMalloc(&p->raw, raw.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(p->raw, raw.data(), raw.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(pong_policy_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMLds);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            crl_policy_destroy(p);
+            return crl_fail(CRL_EHIP, "crl_policy_create (mfma weights): %s", hipGetErrorString(e));
+        }
+        p->WM.w1 = p->raw, p->WM.b1 = p->raw + 1024, p->WM.w2 = p->raw + 1040, p->WM.b2 = p->raw + 2064, p->WM.wa = p->raw + 2080, p->WM.ba = p->raw + 6880;
     }
     const float *base = p->weights;  // hipMalloc: 256-byte aligned, so every 64-byte batch is aligned
     p->W.stream = base, p->W.b1 = base + 2080, p->W.b2 = reinterpret_cast<const f2 *>(base + 2096);
@@ -445,6 +743,10 @@ void crl_policy_destroy(crl_policy *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->weights) (void)hipFree(p->weights);
+    if (p->raw) (void)hipFree(p->raw);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->ring) (void)hipFree(p->ring);
     if (p->ticket) (void)hipFree(p->ticket);
     delete p;
@@ -468,6 +770,47 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     static const int per_cu = getenv("CRL_POLICY_WGS") ? atoi(getenv("CRL_POLICY_WGS")) : 2;  // tuning experiments only
     const unsigned grid = (unsigned)(groups < per_cu * p->cus ? groups : per_cu * p->cus);  // persistent: two workgroups per CU
     HIP_TRY(hipMemsetAsync(p->ticket, 0, sizeof(unsigned), (hipStream_t)stream));
+    // CRL_POLICY_MFMA: 0 (default) = the packed-FMA kernel, 1 = the fp32-MFMA kernel, 2 = both side by side on two streams,
+    // the envs split CRL_POLICY_SPLIT % / rest (the matrix and the vector pipe of a SIMD are separate).  Measured at 65 536
+    // envs: 725-761 us, 732-774 us, 747-837 us -- the MFMA kernel is exact and correct but keeps its pipe only
+    // ~65 % busy (in-order wavefronts, arbitration favouring the older half), and the two kernels do not overlap in practice.
+    static const int use_mfma = getenv("CRL_POLICY_MFMA") ? atoi(getenv("CRL_POLICY_MFMA")) : 0;
+    static const int split_pct = getenv("CRL_POLICY_SPLIT") ? atoi(getenv("CRL_POLICY_SPLIT")) : 50;
+    static const int mdbg = getenv("CRL_POLICY_MFMA_DEBUG") ? atoi(getenv("CRL_POLICY_MFMA_DEBUG")) : 0;  // profiling only (wrong outputs)
+    hipStream_t main_st = (hipStream_t)stream;
+    if (use_mfma == 1 && !dbg) {
+        const int64_t mgroups = (p->n + kME - 1) / kME;
+        const unsigned mgrid = (unsigned)(mgroups < p->cus ? mgroups : p->cus);  // persistent: one workgroup per CU
+        hipLaunchKernelGGL(pong_policy_mfma_kernel, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
+                           frame_stride, actions_dev, action_stride, logits_dev, p->n, p->ticket, mdbg, 2);
+        HIP_TRY(hipGetLastError());
+        p->head = (p->head + 1) & 3;
+        return CRL_OK;
+    }
+    if (use_mfma == 2 && !dbg && p->n >= 4096 && p->side) {
+        int64_t nm = p->n * split_pct / 100 / kME * kME;  // envs [0, nm) on the matrix pipe, [nm, n) on the vector pipe
+        nm = nm < kME ? kME : nm;
+        const int64_t nv = p->n - nm;
+        HIP_TRY(hipMemsetAsync(p->ticket + 16, 0, sizeof(unsigned), main_st));
+        HIP_TRY(hipEventRecord(p->ev_fork, main_st));
+        HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        const int64_t mgroups = nm / kME;
+        const unsigned mgrid = (unsigned)(mgroups < p->cus ? mgroups : p->cus);
+        hipLaunchKernelGGL(pong_policy_mfma_kernel, dim3(mgrid), dim3(kMThreads), kMBuf + kMLdsRest, p->side, p->WM, p->ring, p->head,
+                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, nm, p->ticket + 16, 0, 1);
+        HIP_TRY(hipEventRecord(p->ev_join, p->side));
+        if (nv > 0) {
+            const int64_t vgroups = (nv + kEnvsPerWg - 1) / kEnvsPerWg;
+            const unsigned vgrid = (unsigned)(vgroups < p->cus ? vgroups : p->cus);  // one packed-FMA workgroup per CU beside the MFMA one
+            hipLaunchKernelGGL(pong_policy_light_kernel<0>, dim3(vgrid), dim3(kPolicyThreads), 0, main_st, p->W, p->ring + nm * (int64_t)kRingBytes,
+                               p->head, frame_dev + nm * frame_stride, frame_stride, actions_dev + nm * action_stride, action_stride,
+                               logits_dev ? logits_dev + nm * 3 : nullptr, nv, 0, phase, p->ticket);
+        }
+        HIP_TRY(hipStreamWaitEvent(main_st, p->ev_join, 0));
+        HIP_TRY(hipGetLastError());
+        p->head = (p->head + 1) & 3;
+        return CRL_OK;
+    }
     if (dbg == 4)
         hipLaunchKernelGGL(pong_policy_light_kernel<2>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
                            frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, dbg, phase, p->ticket);

@@ -175,3 +175,37 @@ def test_policy_abi_rejects_bad_arguments():
         crl.Policy(T.single_obs_space, T.single_act_space, 3, use_light_model=False)
     pol.close()
     pol.close()  # idempotent
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_mfma_and_hybrid_policy_kernels_match_the_oracle(mode):
+    """The fp32-MFMA opponent kernel (CRL_POLICY_MFMA=1) and the two-stream hybrid (=2): same logits within 1e-4 and same
+    actions as the numpy oracle, over ring wrap-around and ragged group sizes; a child process, the switch is read once."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from competitive_rl_amd.tournament import get_compute_action_function
+from oracle import policy_oracle as P
+root = %r
+for n in (5000, 8, 13):
+    pol = get_compute_action_function("MEDIUM", n)
+    ora = P.PolicyOracle(P.load_weights(os.path.join(root, "competitive_rl_amd", "assets", "pong_policy_medium.npz")), n)
+    rs = np.random.RandomState(n)
+    for t in range(7):
+        f = (rs.random_sample((n, 1, 42, 42)) > 0.8).astype(np.uint8) * rs.randint(1, 256, (n, 1, 1, 1)).astype(np.uint8)
+        a = pol.act_device(torch.from_numpy(f).cuda(), want_logits=True).cpu().numpy()
+        ao = ora(f).reshape(-1)
+        assert np.abs(pol.logits().cpu().numpy() - ora.logits).max() < 1e-4, (n, t)
+        srt = np.sort(ora.logits, 1)
+        clear = (srt[:, 2] - srt[:, 1]) > 1e-3
+        assert np.array_equal(a[clear], ao[clear]), (n, t)
+    pol.close()
+print("policy ok")
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRL_POLICY_MFMA=mode), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "policy ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
