@@ -1,9 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes for
 # one bench workload.  Usage: tools/profile_gpu.sh <workload> <tag>
-# Outputs under gpurun_out/prof_<tag>/ ; summaries are later copied into profiles/.
+# Outputs under gpurun_out/prof_<tag>/ ; summaries are later copied into profiles/ (tools/collect_profiles.py).
+# rocprofv3 is given the program itself (python3 bench.py ...), never a shell wrapper; --pmc passes are separate
+# from the kernel-trace/stats pass and use --kernel-trace only.
 set -u
-WL=${1:-raw}; TAG=${2:-r01_$WL}
+WL=${1:-raw}; TAG=${2:-r02_$WL}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -11,8 +13,12 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
+if [ "$WL" = "car" ]; then
+  # counted f32 / f64 vector FLOP of a CarRacing step (bench.py roofline_valu): wave-instruction counts per class
+  rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_flops -- python3 $REPO/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_pmc_flops.json 2> $OUT/pmc_flops.err
+fi
 cd $REPO
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+tail -25 $OUT/summary.txt
 # keep only small files for the merge back
 find $OUT -name '*.csv' -size +4M -delete

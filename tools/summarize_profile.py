@@ -33,6 +33,23 @@ def main(out):
         for k, v in acc.items():
             print(k[:90], "launches", len(v), "mean", sum(v) / len(v), "min", min(v), "max", max(v))
             res.setdefault(k, {})[cname] = sum(v) / len(v)
+    # counted vector FLOP (car only): wave-instruction counts x 64 lanes; FMA = 2 FLOP; summed over every kernel launch of the run
+    fl = os.path.join(out, "pmc_flops")
+    if os.path.isdir(fl):
+        tot = defaultdict(float)
+        launches = defaultdict(int)
+        for f in find(fl, "*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if "car_" in r["Kernel_Name"]:
+                    tot[r["Counter_Name"]] += float(r["Counter_Value"])
+                    if r["Counter_Name"] == "SQ_INSTS_VALU":
+                        launches[r["Kernel_Name"].split("(")[0]] += 1
+        steps = launches.get("crl::car_post_kernel", 0) or 1
+        f32 = 64.0 * (tot["SQ_INSTS_VALU_ADD_F32"] + tot["SQ_INSTS_VALU_MUL_F32"] + tot["SQ_INSTS_VALU_TRANS_F32"] + 2 * tot["SQ_INSTS_VALU_FMA_F32"])
+        f64 = 64.0 * (tot["SQ_INSTS_VALU_ADD_F64"] + tot["SQ_INSTS_VALU_MUL_F64"] + 2 * tot["SQ_INSTS_VALU_FMA_F64"])
+        print("== counted vector FLOP (car kernels) ==", dict(tot), "steps", steps)
+        res["__flops__"] = {"f32_flop_per_step": f32 / steps, "f64_flop_per_step": f64 / steps, "valu_insts_per_step": tot["SQ_INSTS_VALU"] / steps,
+                            "steps": steps, "note": "64 x wave-instructions (masked-off lanes counted as active: an upper bound), FMA = 2"}
     json.dump(res, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
     for j in ("bench_trace.json", "bench_pmc_write.json"):
         p = os.path.join(out, j)
