@@ -88,6 +88,7 @@ struct CarSoA {
     // ---- car-car contacts (players == 2)
     int contacts_enabled;
     float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
+    float *wsnap;           // [12][M] wheel transforms (cx, cy, angle) the step starts from, for car_sensor_kernel
     float *sleep;           // [5][M] b2Body::m_sleepTime of hull, wheels 0-3
     int32_t *coupled;       // [n] 1 = the two cars are solved together this step
     int32_t *coupled_list;  // [n] the coupled envs of this step, compacted (any order), and
@@ -147,6 +148,7 @@ void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t 
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
+void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
                      int max_episode_steps, bool car0_only, hipStream_t st);

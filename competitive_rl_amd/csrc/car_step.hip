@@ -130,7 +130,6 @@ static constexpr int kNearCap = 32;
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
                                                       float *__restrict__ rew_out, uint8_t *__restrict__ done_car, int sub,
                                                       int repeat) {
-    __shared__ int16_t near_list[kNearCap][64];  // per lane: tiles whose AABB meets the car's (sensor broadphase)
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= M) return;
@@ -160,7 +159,8 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         for (int k = 0; k < kWheelSlots; k++) wt[w][k] = s.wtiles[(w * kWheelSlots + k) * M + ci];
     }
     double reward = s.reward[ci], prev_reward = s.prev_reward[ci];
-    int visited_count = s.visited_count[ci], last_block = s.last_block[ci], done = s.done[ci];
+    const int visited_count = s.visited_count[ci];
+    int done = s.done[ci];
     int step_count = s.step_count[ci];
     const int ntiles = s.ntiles[env];
 
@@ -235,7 +235,71 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         if (step_count > 1000) done = 1;
     }
 
-    // ---- world.Step: Collide (sensor contacts at the transforms the step starts from)
+    // ---- world.Step's Collide (sensor contacts -> tile rewards) does not feed this step's solve: it runs in
+    // car_sensor_kernel NEXT TO the island solve, on the wheel transforms the step starts from, handed over here
+    // (the solve overwrites the bodies)
+#pragma unroll
+    for (int w = 0; w < 4; w++) s.wsnap[(3 * w + 0) * M + ci] = Wb[w].cx, s.wsnap[(3 * w + 1) * M + ci] = Wb[w].cy, s.wsnap[(3 * w + 2) * M + ci] = Wb[w].a;
+
+    // ---- world.Step's island solve happens in car_solve_kernel (cars on their own) or
+    // car_coupled_kernel (cars whose fixtures may touch): this kernel only decides which, and hands
+    // over the tyre forces and the joint motor targets.  Bodies and joint impulses are not modified
+    // here, so both lanes of an env read the same pre-solve poses of both cars.
+    bool coupled = false;
+    if (s.players == 2 && s.contacts_enabled) {
+        const int64_t c0 = env, c1 = s.n + env;
+        coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
+                            s.body[2 * M + c1]);
+        if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
+    if (car == 0 && s.players == 2) {
+        s.coupled[env] = coupled ? 1 : 0;
+        if (coupled) s.coupled_list[atomicAdd(s.coupled_count, 1)] = (int32_t)env;
+        else s.n_contact[env] = 0;
+    }
+    step_count += 1;
+
+    // ---- store (wheel attributes, sensor contacts, bookkeeping; the motor targets for the solver)
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        s.jspeed[w * M + ci] = motor_speed[w];
+        s.wgas[w * M + ci] = gas[w], s.womega[w * M + ci] = omega[w], s.wphase[w * M + ci] = phase[w];
+    }
+    s.reward[ci] = reward, s.prev_reward[ci] = prev_reward;
+    s.done[ci] = done;
+    s.step_count[ci] = step_count;
+    if (rew_out) {
+        // step_rewards accumulate over the repeats in f64 (crmp:584); the running sum is kept in prev_step
+        const double acc = (sub == 0 ? 0.0 : s.step_acc[ci]) + step_reward;
+        s.step_acc[ci] = acc;
+        rew_out[env * s.players + car] = (float)acc;
+    }
+    if (done_car) done_car[env * s.players + car] = (uint8_t)done;
+}
+
+// world.Step's Collide for the wheel sensors (FrictionDetector, crmp:111-153): Begin / EndContact of every wheel with the
+// track tiles at the transforms the step STARTS from (car_step_kernel's snapshot), tile rewards, road_visited.  Nothing in
+// here feeds this step's solve, so the kernel runs beside car_solve_kernel / car_coupled_kernel on a stream of its own.
+__global__ __launch_bounds__(64) void car_sensor_kernel(CarSoA s, CarConsts K) {
+    __shared__ int16_t near_list[kNearCap][64];  // per lane: tiles whose AABB meets the car's (sensor broadphase)
+    const int64_t M = (int64_t)s.players * s.n;
+    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= M) return;
+    const int car = ci >= s.n ? 1 : 0;
+    const int64_t env = ci - car * s.n;
+    Body Wb[4];
+    int16_t wt[4][kWheelSlots];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        Wb[w].cx = s.wsnap[(3 * w + 0) * M + ci], Wb[w].cy = s.wsnap[(3 * w + 1) * M + ci], Wb[w].a = s.wsnap[(3 * w + 2) * M + ci];
+#pragma unroll
+        for (int k = 0; k < kWheelSlots; k++) wt[w][k] = s.wtiles[(w * kWheelSlots + k) * M + ci];
+    }
+    double reward = s.reward[ci];
+    int visited_count = s.visited_count[ci], last_block = s.last_block[ci];
+    const int ntiles = s.ntiles[env];
     {
         const float R = 0.02f + 10.0f * 1.1920929e-07f;
         V2 wp[4][4];
@@ -349,44 +413,12 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         }
     }
 
-    // ---- world.Step's island solve happens in car_solve_kernel (cars on their own) or
-    // car_coupled_kernel (cars whose fixtures may touch): this kernel only decides which, and hands
-    // over the tyre forces and the joint motor targets.  Bodies and joint impulses are not modified
-    // here, so both lanes of an env read the same pre-solve poses of both cars.
-    bool coupled = false;
-    if (s.players == 2 && s.contacts_enabled) {
-        const int64_t c0 = env, c1 = s.n + env;
-        coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
-                            s.body[2 * M + c1]);
-        if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
-    }
 #pragma unroll
-    for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
-    if (car == 0 && s.players == 2) {
-        s.coupled[env] = coupled ? 1 : 0;
-        if (coupled) s.coupled_list[atomicAdd(s.coupled_count, 1)] = (int32_t)env;
-        else s.n_contact[env] = 0;
-    }
-    step_count += 1;
-
-    // ---- store (wheel attributes, sensor contacts, bookkeeping; the motor targets for the solver)
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        s.jspeed[w * M + ci] = motor_speed[w];
-        s.wgas[w * M + ci] = gas[w], s.womega[w * M + ci] = omega[w], s.wphase[w * M + ci] = phase[w];
+    for (int w = 0; w < 4; w++)
 #pragma unroll
         for (int k = 0; k < kWheelSlots; k++) s.wtiles[(w * kWheelSlots + k) * M + ci] = wt[w][k];
-    }
-    s.reward[ci] = reward, s.prev_reward[ci] = prev_reward;
-    s.visited_count[ci] = visited_count, s.last_block[ci] = last_block, s.done[ci] = done;
-    s.step_count[ci] = step_count;
-    if (rew_out) {
-        // step_rewards accumulate over the repeats in f64 (crmp:584); the running sum is kept in prev_step
-        const double acc = (sub == 0 ? 0.0 : s.step_acc[ci]) + step_reward;
-        s.step_acc[ci] = acc;
-        rew_out[env * s.players + car] = (float)acc;
-    }
-    if (done_car) done_car[env * s.players + car] = (uint8_t)done;
+    s.reward[ci] = reward;
+    s.visited_count[ci] = visited_count, s.last_block[ci] = last_block;
 }
 
 // Env-level bookkeeping after the physics: gym TimeLimit (max_episode_steps = 1000,
@@ -414,6 +446,11 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
     const int64_t M = (int64_t)s.players * s.n;
     if (s.coupled_count) hipMemsetAsync(s.coupled_count, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car, sub, repeat);
+}
+
+void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st) {
+    const int64_t M = (int64_t)s.players * s.n;
+    hipLaunchKernelGGL(car_sensor_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
 }
 
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {

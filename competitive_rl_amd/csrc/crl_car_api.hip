@@ -29,6 +29,8 @@ struct crl_car_ctx {
     // side stream next to the raster; slow_env = pipeline class per env (car_post_kernel)
     uint8_t *slow_env = nullptr;
     hipStream_t side = nullptr;
+    hipStream_t sens = nullptr;  // the wheel-sensor contacts of a step, beside its solve
+    hipEvent_t ev_sens = nullptr;
     hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
     hipEvent_t ev_reset = nullptr;
     hipEvent_t ev_walk = nullptr;  // recorded behind every walk-ahead launch: no new one is queued while it is pending
@@ -156,7 +158,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
 #undef A
@@ -185,6 +187,8 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
     c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sens, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->gen, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming) != hipSuccess ||
@@ -205,6 +209,8 @@ void crl_car_destroy(crl_car_ctx *c) {
     hipDeviceSynchronize();
     if (getenv("CRL_CAR_DEBUG") && (atoi(getenv("CRL_CAR_DEBUG")) & 64)) crl::car_raster_print_ticks();
     if (c->side) hipStreamDestroy(c->side);
+    if (c->sens) hipStreamDestroy(c->sens);
+    if (c->ev_sens) hipEventDestroy(c->ev_sens);
     if (c->gen) hipStreamDestroy(c->gen);
     if (c->ev_reset) hipEventDestroy(c->ev_reset);
     if (c->ev_walk) hipEventDestroy(c->ev_walk);
@@ -294,9 +300,10 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     const bool fork = c->overlap && obs_dev != nullptr;
     crl_timer_begin(tm, 0, st);
     for (int sub = 0; sub < c->repeat; sub++) {  // action repetition: Car.step + world.Step per repeat (crmp:576-603)
-        // Car.step, rewards, done flags, sensor contacts; decides which cars are solved together
+        // Car.step, rewards, done flags; decides which cars are solved together
         launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, sub, c->repeat, st);
         if (fork && sub == c->repeat - 1) break;  // the last world.Step is forked below
+        launch_car_sensors(c->s, c->K_, st);  // world.Step: Collide (wheel sensors), then Solve
         launch_car_solve(c->s, c->K_, st);
         launch_car_coupled(c->s, c->K_, st);
     }
@@ -323,7 +330,13 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side, c->ev_fork, 0);
         launch_car_coupled(c->s, c->K_, c->side);  // the few coupled envs: next to the per-car solve AND the frames
         hipEventRecord(c->ev_coupled, c->side);
+        // the wheel sensors (tile rewards, road_visited) read the transforms the step started from and feed nothing
+        // into its solve: a third stream, beside the latency-bound per-car solve (two wavefronts per CU)
+        hipStreamWaitEvent(c->sens, c->ev_fork, 0);
+        launch_car_sensors(c->s, c->K_, c->sens);
+        hipEventRecord(c->ev_sens, c->sens);
         launch_car_solve(c->s, c->K_, st);
+        hipStreamWaitEvent(st, c->ev_sens, 0);  // the frames show the reward; everything later on `st` sees the contacts
         crl_timer_end(tm, 0, st);
         crl_timer_begin(tm, 1, st);
         launch_car_raster(c->s, c->K_, target, st, c->slow_env, 0);
