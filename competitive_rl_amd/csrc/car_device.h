@@ -89,6 +89,7 @@ struct CarSoA {
     int contacts_enabled;
     float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
     float *wsnap;           // [12][M] wheel transforms (cx, cy, angle) the step starts from, for car_sensor_kernel
+    uint8_t *sensor_ovf;    // [M] 1 = car_sensor_kernel's lists overflowed for this car: car_sensor_serial_kernel redoes it
     float *sleep;           // [5][M] b2Body::m_sleepTime of hull, wheels 0-3
     int32_t *coupled;       // [n] 1 = the two cars are solved together this step
     int32_t *coupled_list;  // [n] the coupled envs of this step, compacted (any order), and

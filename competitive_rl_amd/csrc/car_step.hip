@@ -5,6 +5,8 @@
 // track tiles (Begin/EndContact -> tile rewards) -> island solve (180 velocity iterations over
 // 4 revolute joints, <= 60 position iterations) entirely in registers.  Bound by the sequential
 // Gauss-Seidel chain (VALU latency), not by HBM: ~1.3 KB of state per car per step.
+#include <stdlib.h>
+
 #include "car_solver.h"
 
 namespace crl {
@@ -124,8 +126,6 @@ __global__ __launch_bounds__(64) void car_solve_kernel(CarSoA s, CarConsts K) {
     store_car(s, M, ci, cr);
     s.first_step[ci] = 0;
 }
-
-static constexpr int kNearCap = 32;
 
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
                                                       float *__restrict__ rew_out, uint8_t *__restrict__ done_car, int sub,
@@ -282,143 +282,243 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
 // world.Step's Collide for the wheel sensors (FrictionDetector, crmp:111-153): Begin / EndContact of every wheel with the
 // track tiles at the transforms the step STARTS from (car_step_kernel's snapshot), tile rewards, road_visited.  Nothing in
 // here feeds this step's solve, so the kernel runs beside car_solve_kernel / car_coupled_kernel on a stream of its own.
-__global__ __launch_bounds__(64) void car_sensor_kernel(CarSoA s, CarConsts K) {
-    __shared__ int16_t near_list[kNearCap][64];  // per lane: tiles whose AABB meets the car's (sensor broadphase)
+//
+// One lane per WHEEL (4 lanes = a car, 16 cars per wavefront).  (1) broadphase: the car's four lanes scan a quarter of the
+// track each (ascending ranges) against all four wheel boxes and file the hits in the OWNER wheel's sub-list for that
+// quarter, so an owner reads its near tiles in ascending order; (2) narrow phase: every wheel walks its own few tiles
+// (polygon distance, the expensive part: one wheel per lane instead of four per lane); its BeginContacts are noted;
+// (3) the car's first lane replays the BeginContacts of the four wheels in the order Box2D raises them here (tile
+// ascending, wheel ascending): road_visited, the 50-tile rule, the reward.  A list that overflows sends the whole car
+// through the plain serial loop (never seen in practice; CRL_CAR_SENSOR_SERIAL=1 forces it, for the tests).
+static constexpr int kSubCap = 6, kBeginCap = 8;
+
+struct SensorBooks {
+    double reward;
+    int visited_count, last_block;
+};
+
+// BeginContact -> FrictionDetector._contact (crmp:111-153) for one (wheel, tile) pair, bookkeeping part
+__device__ inline void tile_begin(const CarSoA &s, int64_t M, int64_t ci, int ntiles, int t, SensorBooks &b) {
+    uint32_t *vw = s.visited + (int64_t)(t >> 5) * M + ci;
+    const uint32_t bit = 1u << (t & 31), cur = *vw;
+    if (!(cur & bit)) {
+        const int last_blk = b.last_block < 0 ? 0 : b.last_block;
+        if (t - last_blk < 50) {
+            b.last_block = t;
+            b.reward += 1000.0 / ntiles;
+        }
+        *vw = cur | bit;
+        b.visited_count += 1;
+    }
+}
+
+__device__ inline void wheel_shape(const CarConsts &K, float cx, float cy, float a, V2 (&wp)[4], float4 &box) {
+    float qs, qc;
+    crl_sincosf(a, &qs, &qc);
+    box = make_float4(3.4e38f, 3.4e38f, -3.4e38f, -3.4e38f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        wp[k] = rotv(qs, qc, mk(K.wheel_poly[k][0], K.wheel_poly[k][1])) + mk(cx, cy);
+        box.x = fminf(box.x, wp[k].x), box.y = fminf(box.y, wp[k].y), box.z = fmaxf(box.z, wp[k].x), box.w = fmaxf(box.w, wp[k].y);
+    }
+}
+
+__device__ inline bool box_near(const float4 &wb, const float4 &bb) {  // the wheel's box against a tile's, grown by 0.05
+    return !(wb.x > bb.z + 0.05f || wb.z < bb.x - 0.05f || wb.y > bb.w + 0.05f || wb.w < bb.y - 0.05f);
+}
+
+__device__ inline void load_tile_poly(const CarSoA &s, int64_t env, int t, V2 (&tp)[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        tp[k] = mk(s.tile_poly[((int64_t)t * 10 + 2 * k) * s.n + env], s.tile_poly[((int64_t)t * 10 + 2 * k + 1) * s.n + env]);
+}
+
+// Overflow path: the whole car in one lane, tile by tile.  A kernel of its own (launched behind car_sensor_kernel, exits at
+// once for every car that did not overflow) so that its run-time-indexed arrays cost the main kernel neither scratch
+// memory nor registers.
+__global__ __launch_bounds__(64) void car_sensor_serial_kernel(CarSoA s, CarConsts K) {
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ci >= M) return;
+    if (ci >= M || !s.sensor_ovf[ci]) return;
     const int car = ci >= s.n ? 1 : 0;
     const int64_t env = ci - car * s.n;
-    Body Wb[4];
+    const int ntiles = s.ntiles[env];
+    SensorBooks b;
+    b.reward = s.reward[ci], b.visited_count = s.visited_count[ci], b.last_block = s.last_block[ci];
+    const float R = 0.02f + 10.0f * 1.1920929e-07f;
+    V2 wp[4][4];
+    float4 wb[4];
     int16_t wt[4][kWheelSlots];
-#pragma unroll
     for (int w = 0; w < 4; w++) {
-        Wb[w].cx = s.wsnap[(3 * w + 0) * M + ci], Wb[w].cy = s.wsnap[(3 * w + 1) * M + ci], Wb[w].a = s.wsnap[(3 * w + 2) * M + ci];
-#pragma unroll
+        wheel_shape(K, s.wsnap[(3 * w + 0) * M + ci], s.wsnap[(3 * w + 1) * M + ci], s.wsnap[(3 * w + 2) * M + ci], wp[w], wb[w]);
         for (int k = 0; k < kWheelSlots; k++) wt[w][k] = s.wtiles[(w * kWheelSlots + k) * M + ci];
     }
-    double reward = s.reward[ci];
-    int visited_count = s.visited_count[ci], last_block = s.last_block[ci];
-    const int ntiles = s.ntiles[env];
-    {
-        const float R = 0.02f + 10.0f * 1.1920929e-07f;
-        V2 wp[4][4];
-        float wx0[4], wy0[4], wx1[4], wy1[4];
-        float cx0 = 3.4e38f, cy0 = 3.4e38f, cx1 = -3.4e38f, cy1 = -3.4e38f;
-#pragma unroll
+#pragma unroll 1
+    for (int t = 0; t < ntiles; t++) {
+        const float4 bb = s.tile_aabb[(int64_t)t * s.n + env];
+        bool any = false;
         for (int w = 0; w < 4; w++) {
-            float qs, qc;
-            crl_sincosf(Wb[w].a, &qs, &qc);
-            wx0[w] = wy0[w] = 3.4e38f, wx1[w] = wy1[w] = -3.4e38f;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                wp[w][k] = rotv(qs, qc, mk(K.wheel_poly[k][0], K.wheel_poly[k][1])) + mk(Wb[w].cx, Wb[w].cy);
-                wx0[w] = fminf(wx0[w], wp[w][k].x), wy0[w] = fminf(wy0[w], wp[w][k].y);
-                wx1[w] = fmaxf(wx1[w], wp[w][k].x), wy1[w] = fmaxf(wy1[w], wp[w][k].y);
-            }
-            cx0 = fminf(cx0, wx0[w]), cy0 = fminf(cy0, wy0[w]), cx1 = fmaxf(cx1, wx1[w]), cy1 = fmaxf(cy1, wy1[w]);
+            any = any || box_near(wb[w], bb);
+            for (int k = 0; k < kWheelSlots; k++) any = any || wt[w][k] == t;
         }
-        // touched tiles lie in [tmin, tmax]: two compares rule out "was touching" for most tiles
-        int tmin = 1 << 30, tmax = -1;
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-#pragma unroll
-            for (int k = 0; k < kWheelSlots; k++)
-                if (wt[w][k] >= 0) tmin = min(tmin, (int)wt[w][k]), tmax = max(tmax, (int)wt[w][k]);
-        // Broadphase over the track, then the narrow phase -- in two separate loops.  Every lane has
-        // its own track and position, so the tiles near its car sit at unrelated indices; testing them
-        // inside the scan would make the wavefront run the expensive body for the union of all lanes'
-        // tiles (nearly every iteration).  The scan only records the tile indices (ascending, which is
-        // also the order the Begin/End events are raised in) in a per-lane LDS list; the second loop
-        // walks the k-th entry of every lane together.
-        int cnt = 0;
-#pragma unroll 1
-        for (int t0 = 0; t0 < ntiles; t0 += 8) {
-            float4 bbs[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) bbs[j] = s.tile_aabb[(int64_t)min(t0 + j, ntiles - 1) * s.n + env];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int t = t0 + j;
-                const float4 bb = bbs[j];
-                const bool near_car = !(cx0 > bb.z + 0.05f || cx1 < bb.x - 0.05f || cy0 > bb.w + 0.05f || cy1 < bb.y - 0.05f);
-                bool was_any = false;
-                if (t >= tmin && t <= tmax) {
-#pragma unroll
-                    for (int w = 0; w < 4; w++)
-#pragma unroll
-                        for (int k = 0; k < kWheelSlots; k++) was_any = was_any || wt[w][k] == t;
-                }
-                if (t < ntiles && (near_car || was_any)) {
-                    if (cnt < kNearCap) near_list[cnt][threadIdx.x] = (int16_t)t;
-                    cnt++;
-                }
-            }
-        }
-        auto narrow = [&](int t) {
-            const float4 bb = s.tile_aabb[(int64_t)t * s.n + env];
-            V2 tp[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++)
-                tp[k] = mk(s.tile_poly[((int64_t)t * 10 + 2 * k) * s.n + env], s.tile_poly[((int64_t)t * 10 + 2 * k + 1) * s.n + env]);
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                bool was = false;
-#pragma unroll
-                for (int k = 0; k < kWheelSlots; k++) was = was || wt[w][k] == t;
-                bool now = false;
-                if (!(wx0[w] > bb.z + 0.05f || wx1[w] < bb.x - 0.05f || wy0[w] > bb.w + 0.05f || wy1[w] < bb.y - 0.05f))
-                    now = poly_dist2(wp[w], tp) < R * R;
-                if (now && !was) {  // BeginContact -> FrictionDetector._contact (crmp:111-153)
-                    bool placed = false;
-#pragma unroll
-                    for (int k = 0; k < kWheelSlots; k++)
-                        if (!placed && wt[w][k] < 0) wt[w][k] = (int16_t)t, placed = true;
-                    uint32_t *vw = s.visited + (int64_t)(t >> 5) * M + ci;
-                    const uint32_t bit = 1u << (t & 31), cur = *vw;
-                    if (!(cur & bit)) {
-                        const int last_blk = last_block < 0 ? 0 : last_block;
-                        if (t - last_blk < 50) {
-                            last_block = t;
-                            reward += 1000.0 / ntiles;
-                        }
-                        *vw = cur | bit;
-                        visited_count += 1;
-                    }
-                } else if (!now && was) {  // EndContact
-#pragma unroll
-                    for (int k = 0; k < kWheelSlots; k++)
-                        if (wt[w][k] == t) wt[w][k] = -1;
-                }
-            }
-        };
-#pragma unroll 1
-        for (int k = 0; k < kNearCap; k++) {
-            if (!__any(k < cnt)) break;
-            if (k < cnt) narrow(near_list[k][threadIdx.x]);
-        }
-        if (cnt > kNearCap) {  // more near tiles than list slots (not seen in practice): finish in order
-            const int last = near_list[kNearCap - 1][threadIdx.x];
-#pragma unroll 1
-            for (int t = last + 1; t < ntiles; t++) {
-                const float4 bb = s.tile_aabb[(int64_t)t * s.n + env];
-                const bool near_car = !(cx0 > bb.z + 0.05f || cx1 < bb.x - 0.05f || cy0 > bb.w + 0.05f || cy1 < bb.y - 0.05f);
-                bool was_any = false;
-#pragma unroll
-                for (int w = 0; w < 4; w++)
-#pragma unroll
-                    for (int k = 0; k < kWheelSlots; k++) was_any = was_any || wt[w][k] == t;
-                if (near_car || was_any) narrow(t);
+        if (!any) continue;
+        V2 tp[5];
+        load_tile_poly(s, env, t, tp);
+        for (int w = 0; w < 4; w++) {
+            bool was = false;
+            for (int k = 0; k < kWheelSlots; k++) was = was || wt[w][k] == t;
+            bool now = false;
+            if (box_near(wb[w], bb)) now = poly_dist2(wp[w], tp) < R * R;
+            if (now && !was) {
+                bool placed = false;
+                for (int k = 0; k < kWheelSlots; k++)
+                    if (!placed && wt[w][k] < 0) wt[w][k] = (int16_t)t, placed = true;
+                tile_begin(s, M, ci, ntiles, t, b);
+            } else if (!now && was) {
+                for (int k = 0; k < kWheelSlots; k++)
+                    if (wt[w][k] == t) wt[w][k] = -1;
             }
         }
     }
-
-#pragma unroll
     for (int w = 0; w < 4; w++)
-#pragma unroll
         for (int k = 0; k < kWheelSlots; k++) s.wtiles[(w * kWheelSlots + k) * M + ci] = wt[w][k];
-    s.reward[ci] = reward;
-    s.visited_count[ci] = visited_count, s.last_block[ci] = last_block;
+    s.reward[ci] = b.reward;
+    s.visited_count[ci] = b.visited_count, s.last_block[ci] = b.last_block;
+}
+
+// (one wavefront per workgroup and at most 128 registers: the kernel has to fit on SIMDs next to the register-heavy solve)
+__global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K, int force_serial) {
+    __shared__ int16_t sub[kSubCap][4][64];  // [entry][quarter of the track][owner lane]
+    __shared__ uint8_t subcnt[4][64];
+    __shared__ int16_t beg[kBeginCap][64];   // an owner's BeginContacts of this step, ascending
+    __shared__ uint8_t begcnt[64], ovf_l[64];
+    const int tid = threadIdx.x, w = tid & 3, q0 = tid & ~3;
+    const int64_t M = (int64_t)s.players * s.n;
+    const int64_t ci_raw = ((int64_t)blockIdx.x * 64 + tid) >> 2;
+    const bool valid = ci_raw < M;
+    const int64_t ci = valid ? ci_raw : M - 1;
+    const int car = ci >= s.n ? 1 : 0;
+    const int64_t env = ci - car * s.n;
+    const float R = 0.02f + 10.0f * 1.1920929e-07f;
+    const int ntiles = s.ntiles[env];
+
+    // ---- this lane's wheel: polygon, box, the tiles it touches (and whether each of those is still near)
+    V2 wp[4];
+    float4 wb;
+    wheel_shape(K, s.wsnap[(3 * w + 0) * M + ci], s.wsnap[(3 * w + 1) * M + ci], s.wsnap[(3 * w + 2) * M + ci], wp, wb);
+    int wt[kWheelSlots];
+    bool slot_near[kWheelSlots];
+#pragma unroll
+    for (int k = 0; k < kWheelSlots; k++) wt[k] = s.wtiles[(w * kWheelSlots + k) * M + ci];
+#pragma unroll
+    for (int k = 0; k < kWheelSlots; k++) {
+        const float4 bb = s.tile_aabb[(int64_t)max(wt[k], 0) * s.n + env];
+        slot_near[k] = wt[k] >= 0 && wt[k] < ntiles && box_near(wb, bb);
+    }
+
+    // ---- (1) broadphase: quarter w of the track against the car's four wheel boxes
+    float4 qb[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+        qb[o] = make_float4(__shfl(wb.x, q0 + o, 64), __shfl(wb.y, q0 + o, 64), __shfl(wb.z, q0 + o, 64), __shfl(wb.w, q0 + o, 64));
+    const int per = (ntiles + 3) >> 2, tbeg = w * per, tend = min(tbeg + per, ntiles);
+    int c4[4] = {0, 0, 0, 0};
+    bool ovf = (force_serial & 1) != 0;  // bits 2, 4, 8: timing ablations (wrong results): no polygon distance / no polygon loads / no scan
+#pragma unroll 1
+    for (int t0 = tbeg; t0 < tend && !(force_serial & 8); t0 += 8) {
+        float4 bbs[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) bbs[j] = s.tile_aabb[(int64_t)min(t0 + j, tend - 1) * s.n + env];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int t = t0 + j;
+            if (t >= tend) continue;
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if (box_near(qb[o], bbs[j])) {
+                    if (c4[o] < kSubCap) sub[c4[o]][w][q0 + o] = (int16_t)t;
+                    else ovf = true;
+                    c4[o]++;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++) subcnt[w][q0 + o] = (uint8_t)min(c4[o], kSubCap);
+    __syncthreads();
+
+    // ---- (2) narrow phase over this wheel's near tiles, ascending; tiles it touched that are no longer near end as
+    // their index is passed (the order only matters for which slot a BeginContact finds free)
+    const int n0 = subcnt[0][tid], n1 = n0 + subcnt[1][tid], n2 = n1 + subcnt[2][tid], n3 = n2 + subcnt[3][tid];
+    int nb = 0;
+#pragma unroll 1
+    for (int f = 0; __any(f < n3); f++) {
+        if (f >= n3) continue;
+        const int q = (f >= n0) + (f >= n1) + (f >= n2);
+        const int t = sub[f - (q == 0 ? 0 : q == 1 ? n0 : q == 2 ? n1 : n2)][q][tid];
+        V2 tp[5];
+        if (!(force_serial & 4)) load_tile_poly(s, env, t, tp);
+        else
+            for (int k = 0; k < 5; k++) tp[k] = mk((float)(t + k), (float)k * wb.x);
+        bool was = false;
+#pragma unroll
+        for (int k = 0; k < kWheelSlots; k++) {
+            if (wt[k] >= 0 && wt[k] < t && !slot_near[k]) wt[k] = -1;  // EndContact of a tile left behind
+            was = was || wt[k] == t;
+        }
+        const bool now = (force_serial & 2) ? tp[0].x < wb.x : poly_dist2(wp, tp) < R * R;
+        if (now && !was) {
+            bool placed = false;
+#pragma unroll
+            for (int k = 0; k < kWheelSlots; k++)
+                if (!placed && wt[k] < 0) wt[k] = t, slot_near[k] = true, placed = true;
+            if (nb < kBeginCap) beg[nb][tid] = (int16_t)t;
+            else ovf = true;
+            nb++;
+        } else if (!now && was) {
+#pragma unroll
+            for (int k = 0; k < kWheelSlots; k++)
+                if (wt[k] == t) wt[k] = -1;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kWheelSlots; k++)
+        if (wt[k] >= 0 && !slot_near[k]) wt[k] = -1;
+    begcnt[tid] = (uint8_t)min(nb, kBeginCap);
+    ovf_l[tid] = ovf ? 1 : 0;
+    __syncthreads();
+
+    // ---- (3) per car: the BeginContacts of its wheels in Box2D's order here (tile, then wheel)
+    const bool car_ovf = ovf_l[q0] | ovf_l[q0 + 1] | ovf_l[q0 + 2] | ovf_l[q0 + 3];
+    if (valid && !car_ovf) {
+#pragma unroll
+        for (int k = 0; k < kWheelSlots; k++) s.wtiles[(w * kWheelSlots + k) * M + ci] = (int16_t)wt[k];
+    }
+    if (valid && w == 0) s.sensor_ovf[ci] = car_ovf ? 1 : 0;  // car_sensor_serial_kernel redoes the car from scratch
+    if (valid && w == 0 && !car_ovf) {
+        SensorBooks b;
+        b.reward = s.reward[ci], b.visited_count = s.visited_count[ci], b.last_block = s.last_block[ci];
+        {
+            int ix[4] = {0, 0, 0, 0};
+            const int cn[4] = {begcnt[q0], begcnt[q0 + 1], begcnt[q0 + 2], begcnt[q0 + 3]};
+#pragma unroll 1
+            for (int it = 0; it < 4 * kBeginCap; it++) {
+                int best = 1 << 30, bo = -1;
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const int t = ix[o] < cn[o] ? (int)beg[min(ix[o], kBeginCap - 1)][q0 + o] : (1 << 30);
+                    if (t < best) best = t, bo = o;
+                }
+                if (bo < 0) break;
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    if (o == bo) ix[o]++;
+                tile_begin(s, M, ci, ntiles, best, b);
+            }
+        }
+        s.reward[ci] = b.reward;
+        s.visited_count[ci] = b.visited_count, s.last_block[ci] = b.last_block;
+    }
 }
 
 // Env-level bookkeeping after the physics: gym TimeLimit (max_episode_steps = 1000,
@@ -450,7 +550,9 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
 
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st) {
     const int64_t M = (int64_t)s.players * s.n;
-    hipLaunchKernelGGL(car_sensor_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
+    static const int force_serial = getenv("CRL_CAR_SENSOR_SERIAL") ? atoi(getenv("CRL_CAR_SENSOR_SERIAL")) : 0;
+    hipLaunchKernelGGL(car_sensor_kernel, dim3((unsigned)((4 * M + 63) / 64)), dim3(64), 0, st, s, k, force_serial);
+    hipLaunchKernelGGL(car_sensor_serial_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
 }
 
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
