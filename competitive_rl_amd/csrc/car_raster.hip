@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
     __shared__ int car_box[2][4];                  // per car: screen box of all its polygons
     __shared__ __attribute__((aligned(16))) int poly_row0[20];  // first scanline work item of each car polygon (+ total)
     __shared__ int ind_y0;
+    __shared__ float cam[8];  // sin, cos, centre of the view; hull angle, velocity, spin (for the indicators)
     __shared__ __attribute__((aligned(16))) uint32_t tile32[96 * 96 / 4];
     const int64_t n = s.n, M = (int64_t)s.players * n;
     const int64_t env = blockIdx.x / s.players;
@@ -132,17 +133,27 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         text_row_pre = s.text_bits[idx * CRL_CAR_TEXT_ROWS + (tid >> 5)];
     }
 
-    // ---- camera_update("rgb_array") for the viewer (uniform across the workgroup)
-    const float h_cx = s.body[0 * M + me], h_cy = s.body[1 * M + me], h_a = s.body[2 * M + me];
-    const float h_vx = s.body[3 * M + me], h_vy = s.body[4 * M + me], h_w = s.body[5 * M + me];
-    double angle = (double)h_a;
-    const double vx = (double)h_vx, vy = (double)h_vy;
-    if (vx * vx + vy * vy > 0.5 * 0.5) angle = atan2(-vx, vy);
-    const float af = (float)angle;
-    float sn, cs, hs, hc;
-    crl_sincosf(af, &sn, &cs), crl_sincosf(h_a, &hs, &hc);
-    const V2 hp = mk(h_cx, h_cy) - rotv(hs, hc, mk(K.hull_lc[0], K.hull_lc[1]));
-    const V2 off = hp + mk(cs * 0.0f - sn * 16.0f, sn * 0.0f + cs * 16.0f);
+    // ---- camera_update("rgb_array") for the viewer: uniform across the workgroup, so ONE wavefront does the
+    // double-precision part (atan2 of the velocity) and hands the result over through LDS; the other three only
+    // wait for their tile boxes meanwhile
+    if (wave == 0) {
+        const float h_cx = s.body[0 * M + me], h_cy = s.body[1 * M + me], h_a = s.body[2 * M + me];
+        const float h_vx = s.body[3 * M + me], h_vy = s.body[4 * M + me], h_w = s.body[5 * M + me];
+        double angle = (double)h_a;
+        const double vx = (double)h_vx, vy = (double)h_vy;
+        if (vx * vx + vy * vy > 0.5 * 0.5) angle = atan2(-vx, vy);
+        const float af = (float)angle;
+        float sn_, cs_, hs, hc;
+        crl_sincosf(af, &sn_, &cs_), crl_sincosf(h_a, &hs, &hc);
+        const V2 hp = mk(h_cx, h_cy) - rotv(hs, hc, mk(K.hull_lc[0], K.hull_lc[1]));
+        const V2 off_ = hp + mk(cs_ * 0.0f - sn_ * 16.0f, sn_ * 0.0f + cs_ * 16.0f);
+        if (lane == 0) cam[0] = sn_, cam[1] = cs_, cam[2] = off_.x, cam[3] = off_.y, cam[4] = h_a, cam[5] = h_vx, cam[6] = h_vy, cam[7] = h_w;
+    }
+    __syncthreads();
+    const float sn = cam[0], cs = cam[1];
+    const V2 off = mk(cam[2], cam[3]);
+    const float h_a = cam[4], h_w = cam[7];
+    const double vx = (double)cam[5], vy = (double)cam[6];
     const double obs_scale = (10 / (100 / sqrt(96.0))) * 1.8;
     const float inv_scale = (float)(1.0 / obs_scale), scale_f = (float)obs_scale;
     const float kf = (float)(CAR_PLAYFIELD / 20.0), inv_kf = 1.0f / kf;
@@ -224,9 +235,10 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         cand_cells[tid] = any ? (uint16_t)(cx0 | (cx1 << 4) | (cy0 << 8) | (cy1 << 12)) : (uint16_t)0xFFFF;
     }
 
-    // ---- (2) car polygons (threads 0..15) and indicator rectangles (threads 16..23)
-    if (tid < 8 * s.players) {
-        const int k = tid >> 3, part = tid & 7;  // car k; parts 0..3 wheels, 4..7 hull fixtures
+    // ---- (2) car polygons (wavefront 2) and indicator rectangles (wavefront 3), next to the candidate records (0, 1)
+    if (tid >= 128 && tid < 128 + 8 * s.players) {
+        const int ct_ = tid - 128;
+        const int k = ct_ >> 3, part = ct_ & 7;  // car k; parts 0..3 wheels, 4..7 hull fixtures
         const int64_t ci = k * n + env;
         const int o = part < 4 ? 6 + 6 * part : 0;
         const float bx = s.body[(o + 0) * M + ci], by = s.body[(o + 1) * M + ci], ba = s.body[(o + 2) * M + ci];
@@ -251,9 +263,9 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             }
         }
         q.gray = part < 4 ? 0 : (k == viewer ? G_OWN : G_OTHER);
-        cars[tid] = q;
-    } else if (tid >= 16 && tid < 24) {
-        const int r = tid - 16;
+        cars[ct_] = q;
+    } else if (tid >= 192 && tid < 200) {
+        const int r = tid - 192;
         const double S = 96 / 40.0, Hh = 96 / 40.0;
         IndRect q;
         if (r == 0) q = make_rect(0, 96 - 4 * Hh, 96, 4 * Hh * 1000, 0);

@@ -30,7 +30,7 @@ struct crl_car_ctx {
     uint8_t *slow_env = nullptr;
     hipStream_t side = nullptr;
     hipStream_t sens = nullptr;  // the wheel-sensor contacts of a step, beside its solve
-    hipEvent_t ev_sens = nullptr;
+    hipEvent_t ev_sens = nullptr, ev_c1 = nullptr;
     hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
     hipEvent_t ev_reset = nullptr;
     hipEvent_t ev_walk = nullptr;  // recorded behind every walk-ahead launch: no new one is queued while it is pending
@@ -189,6 +189,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->gen, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming) != hipSuccess ||
@@ -211,6 +212,7 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->side) hipStreamDestroy(c->side);
     if (c->sens) hipStreamDestroy(c->sens);
     if (c->ev_sens) hipEventDestroy(c->ev_sens);
+    if (c->ev_c1) hipEventDestroy(c->ev_c1);
     if (c->gen) hipStreamDestroy(c->gen);
     if (c->ev_reset) hipEventDestroy(c->ev_reset);
     if (c->ev_walk) hipEventDestroy(c->ev_walk);
@@ -335,6 +337,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->sens, c->ev_fork, 0);
         launch_car_sensors(c->s, c->K_, c->sens);
         hipEventRecord(c->ev_sens, c->sens);
+        hipStreamWaitEvent(c->side, c->ev_sens, 0);  // (the frames show the reward)
+        launch_car_raster(c->s, c->K_, target, c->side, c->slow_env, 1);  // coupled envs' frames, beside the tail of the big launch
+        hipEventRecord(c->ev_c1, c->side);
         launch_car_solve(c->s, c->K_, st);
         hipStreamWaitEvent(st, c->ev_sens, 0);  // the frames show the reward; everything later on `st` sees the contacts
         crl_timer_end(tm, 0, st);
@@ -347,7 +352,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_reset(c->s, c->K_, c->src, true, c->done_env, c->side);
         hipEventRecord(c->ev_join, c->side);
         queue_walk_ahead(c, c->side);
-        launch_car_raster(c->s, c->K_, target, st, c->slow_env, 1);
+        hipStreamWaitEvent(st, c->ev_c1, 0);
         hipStreamWaitEvent(st, c->ev_join, 0);
         launch_car_raster(c->s, c->K_, target, st, c->slow_env, 2);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
