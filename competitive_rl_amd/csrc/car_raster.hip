@@ -26,8 +26,11 @@
 
 namespace crl {
 
+#ifndef CRL_CAR_RASTER_WAVES
+#define CRL_CAR_RASTER_WAVES 5  // wavefronts per SIMD the register allocation aims at (= workgroups per CU; LDS allows 5)
+#endif
 static constexpr int kMaxCand = 128;
-static constexpr int kRankCap = 2048;  // pixels of one car's screen box handled by the patch pass
+static constexpr int kRankCap = 1024;  // pixels of one car's screen box handled by the patch pass (a car spans ~10 x 10)
 
 #define G_GRASS 161
 #define G_LIGHT 176
@@ -39,13 +42,31 @@ static constexpr int kRankCap = 2048;  // pixels of one car's screen box handled
 #define G_ABS_REAR 44
 #define G_GREEN 149
 
+// 96 bytes per candidate: VERTICES, not edges -- an edge vector is the difference of the same two floats wherever it is
+// formed, so expanding the record in registers gives the values the edge form would have stored (LDS is what limits
+// the workgroups per CU here: 12 KB of candidates instead of 23.5)
 struct CandTile {
-    float4 edge[5];   // tile edges (ax, ay, bx-ax, by-ay), counter-clockwise
-    float4 bedge[4];  // border quad edges, same form
-    float4 bb;        // world AABB of the tile polygon
-    float4 bb_all;    // world AABB of tile + border
-    int idx, border;
+    float4 v01, v23, v4b0;  // tile polygon p0..p4 (counter-clockwise), then border quad b0
+    float4 b12, b3m;        // b1, b2, b3; m.z = tile index | border kind << 16 (bits), m.w unused
+    float4 bb_all;          // world AABB of tile + border
 };
+
+// edges as (ax, ay, bx-ax, by-ay)
+__device__ inline void cand_expand(const CandTile &ct, float4 (&te)[5], float4 (&be)[4], float4 &ba, int &idx, int &border) {
+    const float4 a = ct.v01, b = ct.v23, c = ct.v4b0, d = ct.b12, e = ct.b3m;
+    ba = ct.bb_all;
+    te[0] = make_float4(a.x, a.y, a.z - a.x, a.w - a.y);
+    te[1] = make_float4(a.z, a.w, b.x - a.z, b.y - a.w);
+    te[2] = make_float4(b.x, b.y, b.z - b.x, b.w - b.y);
+    te[3] = make_float4(b.z, b.w, c.x - b.z, c.y - b.w);
+    te[4] = make_float4(c.x, c.y, a.x - c.x, a.y - c.y);
+    be[0] = make_float4(c.z, c.w, d.x - c.z, d.y - c.w);
+    be[1] = make_float4(d.x, d.y, d.z - d.x, d.w - d.y);
+    be[2] = make_float4(d.z, d.w, e.x - d.z, e.y - d.w);
+    be[3] = make_float4(e.x, e.y, c.z - e.x, c.w - e.y);
+    const int m = __float_as_int(e.z);
+    idx = m & 0xFFFF, border = m >> 16;
+}
 
 // inside test against precomputed edges: (bx-ax)*(y-ay) - (by-ay)*(x-ax) >= 0 for every edge
 __device__ inline bool in_edges(const float4 *e, int nv, float x, float y) {
@@ -91,7 +112,7 @@ __device__ unsigned long long g_car_ticks[24];
         tick_acc[Kk] += (unsigned)(now_ - tick_prev);                            \
         tick_prev = now_;                                                        \
     }
-__global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
+__global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
                                                          const uint8_t *__restrict__ only_env, int want) {
     __shared__ CandTile cand[kMaxCand];
     __shared__ __attribute__((aligned(8))) CarPoly cars[16];
@@ -205,12 +226,10 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         // unconditional (the slots of tiles without a border hold zeros): a load that waits for the flag is a second
         // exposed round trip
         for (int k = 0; k < 8; k++) bv[k] = s.border_poly_em[(env * kCarMaxTiles + t) * 8 + k];
-        for (int i = 0; i < 5; i++) {
-            const int j = i + 1 < 5 ? i + 1 : 0;
-            c.edge[i] = make_float4(pv[2 * i], pv[2 * i + 1], pv[2 * j] - pv[2 * i], pv[2 * j + 1] - pv[2 * i + 1]);
-        }
-        c.bb = bb, c.bb_all = bb;
-        c.idx = t, c.border = border;
+        c.v01 = make_float4(pv[0], pv[1], pv[2], pv[3]), c.v23 = make_float4(pv[4], pv[5], pv[6], pv[7]);
+        c.v4b0 = make_float4(pv[8], pv[9], bv[0], bv[1]), c.b12 = make_float4(bv[2], bv[3], bv[4], bv[5]);
+        c.b3m = make_float4(bv[6], bv[7], __int_as_float(t | (border << 16)), 0.0f);
+        float4 bb_all = bb;
         float sx0 = 1e30f, sy0 = 1e30f, sx1 = -1e30f, sy1 = -1e30f;  // conservative screen box of tile + border
         auto grow = [&](float wx, float wy) {
             const V2 tt = rotv(-sn, cs, mk(wx, wy) - off);
@@ -221,13 +240,12 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         if (border) {
             float x0 = bb.x, y0 = bb.y, x1 = bb.z, y1 = bb.w;
             for (int i = 0; i < 4; i++) {
-                const int j = i + 1 < 4 ? i + 1 : 0;
-                c.bedge[i] = make_float4(bv[2 * i], bv[2 * i + 1], bv[2 * j] - bv[2 * i], bv[2 * j + 1] - bv[2 * i + 1]);
                 x0 = fminf(x0, bv[2 * i]), y0 = fminf(y0, bv[2 * i + 1]), x1 = fmaxf(x1, bv[2 * i]), y1 = fmaxf(y1, bv[2 * i + 1]);
                 grow(bv[2 * i], bv[2 * i + 1]);
             }
-            c.bb_all = make_float4(x0, y0, x1, y1);
+            bb_all = make_float4(x0, y0, x1, y1);
         }
+        c.bb_all = bb_all;
         // culling cells the screen box (+1.5 px) meets
         const int cx0 = max((int)floorf(sx0 - 1.5f), 0) >> kCellShift, cx1 = min((int)ceilf(sx1 + 1.5f), 95) >> kCellShift;
         const int cy0 = max((int)floorf(sy0 - 1.5f), 0) >> kCellShift, cy1 = min((int)ceilf(sy1 + 1.5f), 95) >> kCellShift;
@@ -350,27 +368,27 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
         const int jy = (int)(((float)j + 0.5f) * (1.0f / (float)cw));
         const int cxi = bx0 + (j - jy * cw), cyi = by0 + jy, cell = cyi * kCellsPerRow + cxi;
         const int cx0 = cxi * kCell, cy0 = cyi * kCell;
-        const CandTile &ct = cand[c];
+        float4 te[5], be[4], ba_;
+        int idx_, border_;
+        cand_expand(cand[c], te, be, ba_, idx_, border_);  // back-to-back LDS reads, no early-out chain
+        (void)ba_, (void)idx_;
         const float px0 = (float)cx0 + 0.25f, px1 = (float)(cx0 + kCell) - 0.25f, py0 = (float)cy0 + 0.25f, py1 = (float)(cy0 + kCell) - 0.25f;
-        auto may_cover = [&](const float4 *e, int nv) {
-            float4 q[5];
-#pragma unroll
-            for (int i = 0; i < 5; i++) q[i] = e[i < nv ? i : nv - 1];  // back-to-back LDS reads, no early-out chain
-            bool may = true;
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const V2 ta = rotv(-sn, cs, mk(q[i].x, q[i].y) - off), tb = rotv(-sn, cs, mk(q[i].x + q[i].z, q[i].y + q[i].w) - off);
-                const float ax = 48.0f - scale_f * ta.x, ay = 48.0f - scale_f * ta.y;
-                const float dx = (48.0f - scale_f * tb.x) - ax, dy = (48.0f - scale_f * tb.y) - ay;
-                const float tol = -0.25f * (fabsf(dx) + fabsf(dy));
-                const float c00 = dx * (py0 - ay) - dy * (px0 - ax), c10 = dx * (py0 - ay) - dy * (px1 - ax);
-                const float c01 = dx * (py1 - ay) - dy * (px0 - ax), c11 = dx * (py1 - ay) - dy * (px1 - ax);
-                if (fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) < tol) may = false;  // every pixel centre is outside this edge
-            }
-            return may;
+        auto edge_rejects = [&](const float4 &q) {  // every pixel centre of the cell is outside this edge
+            const V2 ta = rotv(-sn, cs, mk(q.x, q.y) - off), tb = rotv(-sn, cs, mk(q.x + q.z, q.y + q.w) - off);
+            const float ax = 48.0f - scale_f * ta.x, ay = 48.0f - scale_f * ta.y;
+            const float dx = (48.0f - scale_f * tb.x) - ax, dy = (48.0f - scale_f * tb.y) - ay;
+            const float tol = -0.25f * (fabsf(dx) + fabsf(dy));
+            const float c00 = dx * (py0 - ay) - dy * (px0 - ax), c10 = dx * (py0 - ay) - dy * (px1 - ax);
+            const float c01 = dx * (py1 - ay) - dy * (px0 - ax), c11 = dx * (py1 - ay) - dy * (px1 - ax);
+            return fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) < tol;
         };
-        if (may_cover(ct.edge, 5)) atomicOr(&cell_tmask[cell][c >> 5], 1u << (c & 31));
-        if (ct.border && may_cover(ct.bedge, 4)) atomicOr(&cell_bmask[cell][c >> 5], 1u << (c & 31));
+        bool may_t = true, may_b = true;
+#pragma unroll
+        for (int i = 0; i < 5; i++) may_t = may_t && !edge_rejects(te[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) may_b = may_b && !edge_rejects(be[i]);
+        if (may_t) atomicOr(&cell_tmask[cell][c >> 5], 1u << (c & 31));
+        if (border_ && may_b) atomicOr(&cell_bmask[cell][c >> 5], 1u << (c & 31));
     }
     __syncthreads();
     CAR_TICK(4)
@@ -409,17 +427,12 @@ __global__ __launch_bounds__(256) void car_raster_kernel(CarSoA s, CarConsts K, 
             todo &= todo - 1u;
             const int c = wd * 32 + bit;
             const bool do_tile = (tm >> bit) & 1u, do_border = (bmk >> bit) & 1u;
-            const CandTile &ct = cand[c];
             // everything the candidate needs comes in with back-to-back LDS reads (no data-dependent
             // early-out between them: a chain of dependent ~100-cycle reads costs more than the
             // arithmetic it would save)
-            const float4 ba = ct.bb_all;
-            float4 te[5], be[4];
-#pragma unroll
-            for (int i = 0; i < 5; i++) te[i] = ct.edge[i];
-#pragma unroll
-            for (int i = 0; i < 4; i++) be[i] = ct.bedge[i];
-            const int border = ct.border, tidx = ct.idx;
+            float4 te[5], be[4], ba;
+            int border, tidx;
+            cand_expand(cand[c], te, be, ba, tidx, border);
             if (ax0 > ba.z || ax1 < ba.x || ay0 > ba.w || ay1 < ba.y) continue;
             if (do_border) {  // the border quad is drawn right after its tile, so it is tested first
                 unsigned in = open;
