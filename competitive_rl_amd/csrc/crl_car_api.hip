@@ -181,7 +181,10 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         uint32_t *tb = nullptr;
         rc = calloc_dev(c, &tb, (size_t)CRL_CAR_TEXT_STRINGS * CRL_CAR_TEXT_ROWS);
         if (rc) { crl_car_destroy(c); return rc; }
-        hipMemcpy(tb, text_bits_host, (size_t)CRL_CAR_TEXT_STRINGS * CRL_CAR_TEXT_ROWS * 4, hipMemcpyHostToDevice);
+        if (hipMemcpy(tb, text_bits_host, (size_t)CRL_CAR_TEXT_STRINGS * CRL_CAR_TEXT_ROWS * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            crl_car_destroy(c);
+            return crl_fail(CRL_EHIP, "car create: reward text upload");
+        }
         c->s.text_bits = tb;
     }
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;

@@ -39,6 +39,45 @@ __device__ inline uint32_t span_bits(int a, int b) {
 
 __device__ inline uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
 
+// The 16 bytes of chunk q (0 .. views * kFrameChunks - 1) of one env's frames: THE pixel function of this file, shared by
+// the three work splits below.  dbg: 1 = constants only, 2 = no score-band loads (profiling).
+__device__ __forceinline__ uint4 raw_chunk(const Frame &f, int q, const uint4 *__restrict__ atlas_rgb, int ink_row0, int ink_row1, int dbg) {
+    const bool blank = f.sl == 255;
+    const uint32_t bg = blank ? 0u : 0xFFFFFFFFu;
+    const int view = q >= kFrameChunks;
+    const int c = q - view * kFrameChunks;
+    const int row = c / kRowChunks;
+    const int cc = c - row * kRowChunks;
+    const bool mirror = view && row >= CRL_PONG_MIRROR_ROW;
+    const int sc = mirror ? (kRowChunks - 1 - cc) : cc;  // source chunk in the unmirrored row
+    uint4 v = make_uint4(bg, bg, bg, bg);
+    if (!blank && !(dbg & 1)) {
+        if (row < CRL_PONG_TOP) {
+            if (row >= ink_row0 && row < ink_row1 && !(dbg & 2)) v = atlas_rgb[(int64_t)((f.sl * 22 + f.sr) * CRL_PONG_TOP + row) * kRowChunks + sc];
+        } else if (row < CRL_PONG_BOTTOM) {
+            const int lo = sc * 16;
+            uint32_t m = 0;
+            if (row >= f.y && row < f.y + CRL_PONG_BALL) m |= span_bits(3 * f.x - lo, 3 * (f.x + CRL_PONG_BALL) - lo);
+            if (row >= f.bl && row < f.bl + CRL_PONG_BAT_H)
+                m |= span_bits(3 * CRL_PONG_BATL_X - lo, 3 * (CRL_PONG_BATL_X + CRL_PONG_BAT_W) - lo);
+            if (row >= f.br && row < f.br + CRL_PONG_BAT_H)
+                m |= span_bits(3 * CRL_PONG_BATR_X - lo, 3 * (CRL_PONG_BATR_X + CRL_PONG_BAT_W) - lo);
+            v = make_uint4(nibble_to_bytes(m & 15u), nibble_to_bytes((m >> 4) & 15u), nibble_to_bytes((m >> 8) & 15u),
+                           nibble_to_bytes((m >> 12) & 15u));
+        }
+        if (mirror) v = make_uint4(bswap32(v.w), bswap32(v.z), bswap32(v.y), bswap32(v.x));
+    }
+    return v;
+}
+
+// of two neighbouring envs' descriptors, the one chunk index q (relative to the first) falls into
+__device__ __forceinline__ Frame pick_frame(const Frame &f0, const Frame &f1, bool second) {
+    Frame f;
+    f.x = second ? f1.x : f0.x, f.y = second ? f1.y : f0.y, f.bl = second ? f1.bl : f0.bl, f.br = second ? f1.br : f0.br;
+    f.sl = second ? f1.sl : f0.sl, f.sr = second ? f1.sr : f0.sr;
+    return f;
+}
+
 __global__ __launch_bounds__(256) void pong_raster_raw_kernel(const uint64_t *__restrict__ frames,
                                                               const uint4 *__restrict__ atlas_rgb, int ink_row0,
                                                               int ink_row1, uint4 *__restrict__ obs, int views, int dbg) {
@@ -46,36 +85,7 @@ __global__ __launch_bounds__(256) void pong_raster_raw_kernel(const uint64_t *__
     const uint64_t packed = frames[env];  // wave-uniform -> scalar load
     const Frame f = unpack_frame(packed);
     uint4 *__restrict__ out = obs + env * (int64_t)(views * kFrameChunks);
-    const bool blank = f.sl == 255;
-    const uint4 *__restrict__ band = atlas_rgb + (int64_t)((blank ? 0 : f.sl * 22 + f.sr) * CRL_PONG_TOP) * kRowChunks;
-    const uint32_t bg = blank ? 0u : 0xFFFFFFFFu;
-
-    for (int q = threadIdx.x; q < views * kFrameChunks; q += 256) {
-        const int view = q >= kFrameChunks;
-        const int c = q - view * kFrameChunks;
-        const int row = c / kRowChunks;
-        const int cc = c - row * kRowChunks;
-        const bool mirror = view && row >= CRL_PONG_MIRROR_ROW;
-        const int sc = mirror ? (kRowChunks - 1 - cc) : cc;  // source chunk in the unmirrored row
-        uint4 v = make_uint4(bg, bg, bg, bg);
-        if (!blank && !dbg) {
-            if (row < CRL_PONG_TOP) {
-                if (row >= ink_row0 && row < ink_row1) v = band[row * kRowChunks + sc];
-            } else if (row < CRL_PONG_BOTTOM) {
-                const int lo = sc * 16;
-                uint32_t m = 0;
-                if (row >= f.y && row < f.y + CRL_PONG_BALL) m |= span_bits(3 * f.x - lo, 3 * (f.x + CRL_PONG_BALL) - lo);
-                if (row >= f.bl && row < f.bl + CRL_PONG_BAT_H)
-                    m |= span_bits(3 * CRL_PONG_BATL_X - lo, 3 * (CRL_PONG_BATL_X + CRL_PONG_BAT_W) - lo);
-                if (row >= f.br && row < f.br + CRL_PONG_BAT_H)
-                    m |= span_bits(3 * CRL_PONG_BATR_X - lo, 3 * (CRL_PONG_BATR_X + CRL_PONG_BAT_W) - lo);
-                v = make_uint4(nibble_to_bytes(m & 15u), nibble_to_bytes((m >> 4) & 15u), nibble_to_bytes((m >> 8) & 15u),
-                               nibble_to_bytes((m >> 12) & 15u));
-            }
-            if (mirror) v = make_uint4(bswap32(v.w), bswap32(v.z), bswap32(v.y), bswap32(v.x));
-        }
-        out[q] = v;
-    }
+    for (int q = threadIdx.x; q < views * kFrameChunks; q += 256) out[q] = raw_chunk(f, q, atlas_rgb, ink_row0, ink_row1, dbg);
 }
 
 // Address-linear kernel, workgroup-contiguous (production until the sweep variant below): workgroup b writes chunks [b * 512, (b + 1) * 512) of
@@ -108,35 +118,7 @@ __global__ __launch_bounds__(THREADS) void pong_raster_raw_linear_kernel(const u
         int q = q0 + i * THREADS + (int)threadIdx.x;
         const bool second = q >= per_env;
         q -= second ? per_env : 0;
-        Frame f;
-        f.x = second ? f1.x : f0.x, f.y = second ? f1.y : f0.y, f.bl = second ? f1.bl : f0.bl, f.br = second ? f1.br : f0.br;
-        f.sl = second ? f1.sl : f0.sl, f.sr = second ? f1.sr : f0.sr;
-        const bool blank = f.sl == 255;
-        const uint32_t bg = blank ? 0u : 0xFFFFFFFFu;
-        const int view = q >= kFrameChunks;
-        const int c = q - view * kFrameChunks;
-        const int row = c / kRowChunks;
-        const int cc = c - row * kRowChunks;
-        const bool mirror = view && row >= CRL_PONG_MIRROR_ROW;
-        const int sc = mirror ? (kRowChunks - 1 - cc) : cc;  // source chunk in the unmirrored row
-        uint4 v = make_uint4(bg, bg, bg, bg);
-        if (!blank && !(dbg & 1)) {
-            if (row < CRL_PONG_TOP) {
-                if (row >= ink_row0 && row < ink_row1 && !(dbg & 2)) v = atlas_rgb[(int64_t)((f.sl * 22 + f.sr) * CRL_PONG_TOP + row) * kRowChunks + sc];
-            } else if (row < CRL_PONG_BOTTOM) {
-                const int lo = sc * 16;
-                uint32_t m = 0;
-                if (row >= f.y && row < f.y + CRL_PONG_BALL) m |= span_bits(3 * f.x - lo, 3 * (f.x + CRL_PONG_BALL) - lo);
-                if (row >= f.bl && row < f.bl + CRL_PONG_BAT_H)
-                    m |= span_bits(3 * CRL_PONG_BATL_X - lo, 3 * (CRL_PONG_BATL_X + CRL_PONG_BAT_W) - lo);
-                if (row >= f.br && row < f.br + CRL_PONG_BAT_H)
-                    m |= span_bits(3 * CRL_PONG_BATR_X - lo, 3 * (CRL_PONG_BATR_X + CRL_PONG_BAT_W) - lo);
-                v = make_uint4(nibble_to_bytes(m & 15u), nibble_to_bytes((m >> 4) & 15u), nibble_to_bytes((m >> 8) & 15u),
-                               nibble_to_bytes((m >> 12) & 15u));
-            }
-            if (mirror) v = make_uint4(bswap32(v.w), bswap32(v.z), bswap32(v.y), bswap32(v.x));
-        }
-        obs[g] = v;
+        obs[g] = raw_chunk(pick_frame(f0, f1, second), q, atlas_rgb, ink_row0, ink_row1, dbg);
     }
 }
 
@@ -169,35 +151,7 @@ __global__ __launch_bounds__(256) void pong_raster_raw_sweep_kernel(const uint64
         int q = q0[i] + (int)threadIdx.x;
         const bool second = q >= per_env;
         q -= second ? per_env : 0;
-        Frame f;
-        f.x = second ? f1[i].x : f0[i].x, f.y = second ? f1[i].y : f0[i].y, f.bl = second ? f1[i].bl : f0[i].bl, f.br = second ? f1[i].br : f0[i].br;
-        f.sl = second ? f1[i].sl : f0[i].sl, f.sr = second ? f1[i].sr : f0[i].sr;
-        const bool blank = f.sl == 255;
-        const uint32_t bg = blank ? 0u : 0xFFFFFFFFu;
-        const int view = q >= kFrameChunks;
-        const int c = q - view * kFrameChunks;
-        const int row = c / kRowChunks;
-        const int cc = c - row * kRowChunks;
-        const bool mirror = view && row >= CRL_PONG_MIRROR_ROW;
-        const int sc = mirror ? (kRowChunks - 1 - cc) : cc;  // source chunk in the unmirrored row
-        uint4 v = make_uint4(bg, bg, bg, bg);
-        if (!blank && !(dbg & 1)) {
-            if (row < CRL_PONG_TOP) {
-                if (row >= ink_row0 && row < ink_row1 && !(dbg & 2)) v = atlas_rgb[(int64_t)((f.sl * 22 + f.sr) * CRL_PONG_TOP + row) * kRowChunks + sc];
-            } else if (row < CRL_PONG_BOTTOM) {
-                const int lo = sc * 16;
-                uint32_t m = 0;
-                if (row >= f.y && row < f.y + CRL_PONG_BALL) m |= span_bits(3 * f.x - lo, 3 * (f.x + CRL_PONG_BALL) - lo);
-                if (row >= f.bl && row < f.bl + CRL_PONG_BAT_H)
-                    m |= span_bits(3 * CRL_PONG_BATL_X - lo, 3 * (CRL_PONG_BATL_X + CRL_PONG_BAT_W) - lo);
-                if (row >= f.br && row < f.br + CRL_PONG_BAT_H)
-                    m |= span_bits(3 * CRL_PONG_BATR_X - lo, 3 * (CRL_PONG_BATR_X + CRL_PONG_BAT_W) - lo);
-                v = make_uint4(nibble_to_bytes(m & 15u), nibble_to_bytes((m >> 4) & 15u), nibble_to_bytes((m >> 8) & 15u),
-                               nibble_to_bytes((m >> 12) & 15u));
-            }
-            if (mirror) v = make_uint4(bswap32(v.w), bswap32(v.z), bswap32(v.y), bswap32(v.x));
-        }
-        obs[g] = v;
+        obs[g] = raw_chunk(pick_frame(f0[i], f1[i], second), q, atlas_rgb, ink_row0, ink_row1, dbg);
     }
 }
 

@@ -222,7 +222,7 @@ def test_full_size_car_properties():
     env.close()
 
 
-def _two_gpu_worker(rank, world, port, out_dir):
+def _two_gpu_worker(rank, world, port, out_dir, backend="nccl"):
     import os
     import sys
 
@@ -233,18 +233,26 @@ def _two_gpu_worker(rank, world, port, out_dir):
 
     import competitive_rl_amd as crl
 
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+    # "nccl": one GPU per rank, RCCL moves the packed message.  "gloo": both ranks on GPU 0 (a one-GPU box), the HIP
+    # shards' outputs are staged to the host and the same packed collective runs over gloo.
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo")
     total, steps = 512, 60
     sh = crl.shard_of(total, world, rank)
-    env = crl.HipPongVecEnv(sh.count, seed=21, mode="wrapped", resized_dim=42, frame_stack=1, env_id_base=sh.base, device=f"cuda:{rank}")
+    env = crl.HipPongVecEnv(sh.count, seed=21, mode="wrapped", resized_dim=42, frame_stack=1, env_id_base=sh.base, device=f"cuda:{dev}")
     env.reset()
     acts = torch.as_tensor(np.random.RandomState(5).randint(0, 3, (steps, total, 2)).astype(np.int32)).cuda()
     g = crl.StepGather(overlap=True)
     got = []
     for t in range(steps):
         out = env.step_device(acts[t, sh.base:sh.base + sh.count].contiguous())
-        g.launch(out)                       # ONE packed RCCL all-gather on a side stream ...
+        if backend != "nccl":
+            out = tuple(x.cpu() for x in out)
+        g.launch(out)                       # ONE packed all-gather (on a side stream when it runs on the GPU) ...
         if t + 1 < steps:
             pass                            # ... while the next step could already be simulated
         got.append([x.cpu().numpy().copy() for x in g.wait()])
@@ -256,23 +264,9 @@ def _two_gpu_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
-    """BASELINE config #5 in small: two HIP shards on two GPUs + the single packed RCCL all-gather == one unsharded HIP batch.
-    Needs two visible GPUs (the driver's multi-GPU node); skipped on a one-GPU box."""
-    _need_gpu()
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs")
-    import socket
-
-    import torch.multiprocessing as mp
-
+def _check_against_one_batch(tmp_path):
     import competitive_rl_amd as crl
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.start_processes(_two_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     got = np.load(tmp_path / "g.npz")
     total, steps = 512, 60
     env = crl.HipPongVecEnv(total, seed=21, mode="wrapped", resized_dim=42, frame_stack=1)
@@ -283,6 +277,38 @@ def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
         assert np.array_equal(got["obs"][t], buf.cpu().numpy()) and np.array_equal(got["rew"][t], rew.cpu().numpy())
         assert np.array_equal(got["done"][t], done.cpu().numpy()), t
     env.close()
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_hip_shards_on_one_gpu_plus_packed_gather_equal_one_batch(tmp_path):
+    """HIP + sharding together on a ONE-GPU box: two processes, each a HIP shard on GPU 0 (RNG keyed by the global env id
+    through env_id_base), their step outputs exchanged by the single packed all-gather (gloo) == one unsharded HIP batch."""
+    _need_gpu()
+    import torch.multiprocessing as mp
+
+    mp.start_processes(_two_gpu_worker, args=(2, _free_port(), str(tmp_path), "gloo"), nprocs=2, join=True, start_method="spawn")
+    _check_against_one_batch(tmp_path)
+
+
+def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
+    """BASELINE config #5 in small: two HIP shards on two GPUs + the single packed RCCL all-gather == one unsharded HIP batch.
+    Needs two visible GPUs (the driver's multi-GPU node); skipped on a one-GPU box."""
+    _need_gpu()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import torch.multiprocessing as mp
+
+    mp.start_processes(_two_gpu_worker, args=(2, _free_port(), str(tmp_path), "nccl"), nprocs=2, join=True, start_method="spawn")
+    _check_against_one_batch(tmp_path)
 
 
 def test_address_linear_gray_writer_is_bit_exact_too():
