@@ -404,7 +404,7 @@ static constexpr int kMTiles = kME * kPos / 16;     // 50 tiles of 16 conv2 posi
 static constexpr int kMWaves = CRL_MFMA_WAVES;                    // wavefronts per workgroup: two per SIMD (one gathers / converts while the other's MFMAs run)
 static constexpr int kMThreads = 64 * kMWaves;
 static constexpr int kMBuf = kME * CRL_POLICY_STACK * kPlanePad;  // 56 832 bytes per staging buffer
-static constexpr int kMLdsRest = (3 * 1600 + kME * kPos * 3 + kME * 12 + kME * 3 + 4) * 4;
+static constexpr int kMLdsRest = (3 * 1600 + 2 * kME * kPos * 3 + 4) * 4;
 static constexpr int kMLds = 2 * kMBuf + kMLdsRest;
 
 __device__ inline void group_request_m(uint8_t *shbuf, const uint8_t *__restrict__ ring, int head, const uint8_t *__restrict__ frame,
@@ -435,20 +435,28 @@ struct PolicyWeightsM {
     const float *w1, *b1, *w2, *b2, *wa, *ba;  // torch layouts: conv1 [16][4][4][4], conv2 [16][16][2][2], actor [3][1600]
 };
 
+// BF = true: conv1 on the bf16 matrix instruction at fp32 accuracy.  The inputs are integers 0..255 -- exact in bf16 -- and
+// each weight (pre-divided by 255) is the sum of three bf16 terms (8 + 8 + 8 mantissa bits), so the three products per tap
+// are exact and v_mfma_f32_16x16x32_bf16 accumulates them in fp32: 6 instructions x 16 cycles per parity class instead
+// of 16 x 32, and the patch conversion shrinks from 36 correctly rounded x / 255 to 48 byte -> bf16 conversions.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline uint32_t pk_bf16(float a, float b) {
+    const bf2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+template <bool BF>
 __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWeightsM W, uint8_t *__restrict__ ring, int head,
                                                                   const uint8_t *__restrict__ frame, int64_t frame_stride,
                                                                   int32_t *__restrict__ actions, int64_t action_stride,
-                                                                  float *__restrict__ logits_out, int64_t n, unsigned *__restrict__ ticket, int dbg,
-                                                                  int nbuf) {
-    // nbuf = 2: the next group streams into the other staging buffer during the convolutions; nbuf = 1 (hybrid mode, where
-    // the packed-FMA kernel shares the CU and its LDS): one buffer, refilled after the tile loop
+                                                                  float *__restrict__ logits_out, int64_t n, unsigned *__restrict__ ticket, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *sh_buf = smem;                                             // [nbuf][kME][4][kPlanePad]
-    float *sh_wa = reinterpret_cast<float *>(smem + nbuf * kMBuf);      // [3][1600]
-    float *sh_part = sh_wa + 3 * 1600;                                  // [kME * 100][3]
-    float *sh_grp = sh_part + kME * kPos * 3;                           // [kME][3][4]
-    float *sh_logit = sh_grp + kME * 12;                                // [kME][3]
-    unsigned *sh_ticket = reinterpret_cast<unsigned *>(sh_logit + kME * 3);
+    uint8_t *sh_buf = smem;                                             // [2][kME][4][kPlanePad]
+    float *sh_wa = reinterpret_cast<float *>(smem + 2 * kMBuf);         // [3][1600]
+    float *sh_part = sh_wa + 3 * 1600;                                  // [2][kME * 100][3]: a group's partial logits, double-buffered
+    unsigned *sh_ticket = reinterpret_cast<unsigned *>(sh_part + 2 * kME * kPos * 3);  // [2]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lj = lane & 15, lk = lane >> 4;
     const int64_t ngroups = (n + kME - 1) / kME;
@@ -456,8 +464,25 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
     for (int i = tid; i < 3 * 1600; i += kMThreads) sh_wa[i] = W.wa[i];
     // the wavefront's weights, once: A operands of every MFMA step
     float w1[16], w2[4][4];
+    bf8 wA[3][2];  // BF: A[oc = lj][k = 32 i + 8 lk + j], k = ic * 16 + ky * 4 + kx (torch's own order), as three bf16 terms
+    if constexpr (BF) {
 #pragma unroll
-    for (int s = 0; s < 16; s++) w1[s] = W.w1[lj * 64 + lk * 16 + s];                      // W1[oc = lj][ic = lk][ky = s / 4][kx = s % 4]
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float w = W.w1[lj * 64 + 32 * i + 8 * lk + j] / 255.0f;
+                const __bf16 h1 = (__bf16)w;
+                const float r1 = w - (float)h1;  // exact
+                const __bf16 h2 = (__bf16)r1;
+                const float r2 = r1 - (float)h2;  // exact
+                wA[0][i][j] = h1, wA[1][i][j] = h2, wA[2][i][j] = (__bf16)r2;
+            }
+#pragma unroll
+        for (int s = 0; s < 16; s++) w1[s] = 0.f;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; s++) w1[s] = W.w1[lj * 64 + lk * 16 + s];                  // W1[oc = lj][ic = lk][ky = s / 4][kx = s % 4]
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -469,8 +494,19 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
     // Every load above must have RETURNED before the first LDS-DMA request is issued: the compiler waits for a load at its
     // first use with a vmcnt(N) that counts only the loads it knows of -- inside the tile loop that wait would also drain
     // the next group's LDS-DMA transfers (inline asm, invisible to it) and serialise staging with the convolutions.
+    if constexpr (BF) {
 #pragma unroll
-    for (int s = 0; s < 16; s++) asm volatile("" : "+v"(w1[s]));
+        for (int t = 0; t < 3; t++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                u32x4 bits = __builtin_bit_cast(u32x4, wA[t][i]);
+                asm volatile("" : "+v"(bits));
+                wA[t][i] = __builtin_bit_cast(bf8, bits);
+            }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; s++) asm volatile("" : "+v"(w1[s]));
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -480,18 +516,51 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
 
     // Three groups are in play: g (being computed), g1 (streaming into the other buffer) and the ticket for the one after
     // (a returning global atomic takes microseconds: it is requested at the top of an iteration and read at its end).
-    int64_t g = blockIdx.x, g1 = ngroups;
-    int cur = 0;
+    int64_t g = blockIdx.x, g1 = ngroups, gprev = -1;
+    int cur = 0;  // parity of the group being computed: staging buffer, partial buffer; the ticket lands in slot cur ^ 1
     if (g < ngroups) {
         const int64_t env0 = g * kME;
-        if (tid == 0) *sh_ticket = atomicAdd(ticket, 1u);
+        if (tid == 0) sh_ticket[0] = atomicAdd(ticket, 1u);
         group_request_m(sh_buf, ring, head, frame, frame_stride, env0, (int)((n - env0) < kME ? (n - env0) : kME), wave, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        g1 = (int64_t)gridDim.x + *sh_ticket;
-        __syncthreads();
+        g1 = (int64_t)gridDim.x + sh_ticket[0];
     }
-    long long tk[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    // A finished group's 100 partial logits per env and action are summed in a fixed shape (lane j: positions j, j + 32, j + 64,
+    // j + 96; then a 32-lane butterfly) by ONE wavefront per env, at the top of the NEXT group's iteration -- beside the other
+    // wavefronts' matrix work instead of between two workgroup barriers.
+    auto finish_group = [&](int64_t gp, int par) {
+        const int64_t e0 = gp * kME;
+        const int envs = (int)((n - e0) < kME ? (n - e0) : kME);
+        const float *part = sh_part + par * (kME * kPos * 3);
+        for (int pe = wave; pe < envs; pe += kMWaves) {
+            const int j = lane & 31;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int pos = j + 32 * m;
+                if (pos < kPos) {
+                    const float *pp = part + (pe * kPos + pos) * 3;
+                    s0 += pp[0], s1 += pp[1], s2 += pp[2];
+                }
+            }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) s0 += __shfl_xor(s0, d), s1 += __shfl_xor(s1, d), s2 += __shfl_xor(s2, d);
+            if (lane == 0) {
+                const float a0 = ba0 + s0, a1 = ba1 + s1, a2 = ba2 + s2;
+                int best = 0;  // argmax, first index wins ties (torch.argmax)
+                float bv = a0;
+                if (a1 > bv) best = 1, bv = a1;
+                if (a2 > bv) best = 2;
+                actions[(e0 + pe) * action_stride] = best;
+                if (logits_out) {
+                    float *lo = logits_out + (e0 + pe) * 3;
+                    lo[0] = a0, lo[1] = a1, lo[2] = a2;
+                }
+            }
+        }
+    };
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     const long long tstart = tprev;
 #define MTICK(K)                                                \
     if (dbg & 4) {                                              \
@@ -502,12 +571,17 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
     while (g < ngroups) {
         const int64_t env0 = g * kME;
         const int envs_here = (int)((n - env0) < kME ? (n - env0) : kME);
-        uint8_t *buf = sh_buf + (nbuf == 2 ? cur : 0) * kMBuf;
-        if (tid == 0) *sh_ticket = atomicAdd(ticket, 1u);
-        if (nbuf == 2 && g1 < ngroups) {  // the next group streams into the other buffer during the convolutions
+        uint8_t *buf = sh_buf + cur * kMBuf;
+        float *part_out = sh_part + cur * (kME * kPos * 3);
+        if (tid == 0) sh_ticket[cur ^ 1] = atomicAdd(ticket, 1u);
+        MTICK(3)
+        if (gprev >= 0) finish_group(gprev, cur ^ 1);
+        MTICK(4)
+        if (g1 < ngroups) {  // the next group streams into the other buffer during the convolutions
             const int64_t e1 = g1 * kME;
             group_request_m(sh_buf + (cur ^ 1) * kMBuf, ring, head, frame, frame_stride, e1, (int)((n - e1) < kME ? (n - e1) : kME), wave, lane);
         }
+        MTICK(5)
         // the new frame also replaces plane `head` of the ring in HBM
         for (int i = tid; i < envs_here * kPlaneChunks; i += kMThreads) {
             const int fe = i / kPlaneChunks, c = i - fe * kPlaneChunks;
@@ -539,8 +613,35 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
                 }
             }
         };
+        // BF: lane (position lj, k-block lk) needs, of planes lk >> 1 and 2 + (lk >> 1), rows 4 y2 + 2 (lk & 1) + 0..3 and the six
+        // columns from 4 x2 on: the B operand of (class (ky0, kx0), K half i) is rows 2 ky0, 2 ky0 + 1 of that window, columns
+        // 2 kx0 .. 2 kx0 + 3, of plane 2 i + (lk >> 1) -- eight bf16 in k order.  Same aligned-dword trick as above.
+        auto gather_bf = [&](int t, bf8 (&bx)[4][2]) {
+            const int q = 16 * t + lj, e = q / kPos, pos = q - e * kPos, y2 = pos / 10, x2 = pos - y2 * 10;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int plane = 2 * i + (lk >> 1);
+                const uint8_t *base = buf + (e * CRL_POLICY_STACK + ((head + 1 + plane) & 3)) * kPlanePad + (4 * y2 + 2 * (lk & 1)) * kDim + 4 * x2;
+                uint32_t pk[4][3];  // per window row: columns (0,1) (2,3) (4,5) as bf16 pairs
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(base + rr * kDim - 2 * (rr & 1));
+                    uint32_t w0 = p32[0], w1_ = p32[1];
+                    if (rr & 1) w0 = (w0 >> 16) | (w1_ << 16), w1_ >>= 16;
+                    pk[rr][0] = pk_bf16((float)(w0 & 255u), (float)((w0 >> 8) & 255u));
+                    pk[rr][1] = pk_bf16((float)((w0 >> 16) & 255u), (float)(w0 >> 24));
+                    pk[rr][2] = pk_bf16((float)(w1_ & 255u), (float)((w1_ >> 8) & 255u));
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int ky0 = c >> 1, kx0 = c & 1;
+                    const u32x4 v = {pk[2 * ky0][kx0], pk[2 * ky0][kx0 + 1], pk[2 * ky0 + 1][kx0], pk[2 * ky0 + 1][kx0 + 1]};
+                    bx[c][i] = __builtin_bit_cast(bf8, v);
+                }
+            }
+        };
         float xnext[6][6];
-        if (!CRL_MFMA_PREFETCH) {
+        if (!CRL_MFMA_PREFETCH || BF) {
         } else if (dbg & 1) {  // ablation: no gather
 #pragma unroll
             for (int r = 0; r < 6; r++)
@@ -550,7 +651,20 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
         for (int t = wave; t < kMTiles; t += kMWaves) {
             const int q = 16 * t + lj, e = q / kPos, pos = q - e * kPos;
             float xin[6][6];
-            if (CRL_MFMA_PREFETCH) {
+            bf8 bx[4][2];
+            if constexpr (BF) {
+                if (dbg & 1) {  // ablation: no gather
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+#pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            const u32x4 v = {0x3f803f80u + (unsigned)lk, 0x40004000u, 0x3f803f80u, 0x40004000u + (unsigned)c};
+                            bx[c][i] = __builtin_bit_cast(bf8, v);
+                        }
+                } else {
+                    gather_bf(t, bx);
+                }
+            } else if (CRL_MFMA_PREFETCH) {
 #pragma unroll
                 for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -561,11 +675,20 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
             }
             // ---- conv1: four parity classes, 16 MFMAs each (independent accumulator chains)
             f4 d1[4] = {bias1, bias1, bias1, bias1};
+            if constexpr (BF) {
 #pragma unroll
-            for (int s = 0; s < 16; s++)
+                for (int tm = 2; tm >= 0; tm--)  // smallest weight term first
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    d1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], xin[2 * (c >> 1) + (s >> 2)][2 * (c & 1) + (s & 3)], d1[c], 0, 0, 0);
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) d1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[tm][i], bx[c][i], d1[c], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; s++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        d1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s], xin[2 * (c >> 1) + (s >> 2)][2 * (c & 1) + (s & 3)], d1[c], 0, 0, 0);
+            }
             // ---- conv2: the accumulators are the B operands as they stand
             f4 d2a = bias2, d2b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -577,7 +700,7 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
                     else d2a = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[c][r], hval, d2a, 0, 0, 0);
                 }
             if (dbg & 2) {  // ablation: no actor / cross-lane sums
-                if (lk == 0) sh_part[q * 3] = d2a[0] + d2b[1];
+                if (lk == 0) part_out[q * 3] = d2a[0] + d2b[1], part_out[q * 3 + 1] = 0.f, part_out[q * 3 + 2] = 0.f;
                 continue;
             }
             // ---- actor: lane (position lj, channels 4 lk + r)
@@ -593,55 +716,22 @@ __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWe
             // the four channel groups of a position sit 16 lanes apart: (g0 + g1) + (g2 + g3), a fixed order
             l0 += __shfl_xor(l0, 16), l1 += __shfl_xor(l1, 16), l2 += __shfl_xor(l2, 16);
             l0 += __shfl_xor(l0, 32), l1 += __shfl_xor(l1, 32), l2 += __shfl_xor(l2, 32);
-            if (lk == 0) sh_part[q * 3 + 0] = l0, sh_part[q * 3 + 1] = l1, sh_part[q * 3 + 2] = l2;
+            if (lk == 0) part_out[q * 3 + 0] = l0, part_out[q * 3 + 1] = l1, part_out[q * 3 + 2] = l2;
         }
         MTICK(1)
-        __syncthreads();
-        MTICK(2)
-        if (nbuf == 1 && g1 < ngroups) {  // single buffer: every tile of this group has been read
-            const int64_t e1 = g1 * kME;
-            group_request_m(sh_buf, ring, head, frame, frame_stride, e1, (int)((n - e1) < kME ? (n - e1) : kME), wave, lane);
-        }
-        // fixed-shape sum over the 100 positions of an env (4 groups of 25, then the 4 groups)
-        if (tid < kME * 12) {
-            const int pe = tid / 12, r = tid - pe * 12, a = r >> 2, grp = r & 3;
-            float s = 0.f;
-#pragma unroll
-            for (int p = 0; p < 25; p++) s += sh_part[(pe * kPos + grp * 25 + p) * 3 + a];
-            sh_grp[(pe * 3 + a) * 4 + grp] = s;
-        }
-        __syncthreads();
-        if (tid < kME * 3) {
-            const int pe = tid / 3, a = tid - pe * 3;
-            const float *gp = sh_grp + (pe * 3 + a) * 4;
-            sh_logit[pe * 3 + a] = (a == 0 ? ba0 : a == 1 ? ba1 : ba2) + ((gp[0] + gp[1]) + (gp[2] + gp[3]));
-        }
-        __syncthreads();
-        if (tid < envs_here) {
-            const float a0 = sh_logit[tid * 3], a1 = sh_logit[tid * 3 + 1], a2 = sh_logit[tid * 3 + 2];
-            int best = 0;  // argmax, first index wins ties (torch.argmax)
-            float bv = a0;
-            if (a1 > bv) best = 1, bv = a1;
-            if (a2 > bv) best = 2;
-            actions[(env0 + tid) * action_stride] = best;
-            if (logits_out) {
-                float *lo = logits_out + (env0 + tid) * 3;
-                lo[0] = a0, lo[1] = a1, lo[2] = a2;
-            }
-        }
-        MTICK(3)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's share of the next group has landed (and the ticket is back)
-        __syncthreads();                                    // ... everybody's has; this group's LDS scratch is free again
-        MTICK(4)
-        cur ^= 1;
+        __syncthreads();                                    // ... everybody's has, and every tile of this group is in part_out
+        MTICK(2)
+        gprev = g;
         g = g1;
-        g1 = (int64_t)gridDim.x + *sh_ticket;
-        __syncthreads();                                    // everyone has read the ticket before lane 0 overwrites it
+        g1 = (int64_t)gridDim.x + sh_ticket[cur ^ 1];
+        cur ^= 1;
     }
+    if (gprev >= 0) finish_group(gprev, cur ^ 1);
     if ((dbg & 4) && logits_out && lane == 0 && blockIdx.x < 64) {  // profiling: cycles per phase of every wavefront of the first workgroups
-        float *o = logits_out + (blockIdx.x * kMWaves + wave) * 6;
-        for (int k = 0; k < 5; k++) o[k] = (float)tk[k];
-        o[5] = (float)(__builtin_readcyclecounter() - tstart);
+        float *o = logits_out + (blockIdx.x * kMWaves + wave) * 8;
+        for (int k = 0; k < 7; k++) o[k] = (float)tk[k];
+        o[7] = (float)(__builtin_readcyclecounter() - tstart);
     }
 #undef MTICK
 }
@@ -678,8 +768,6 @@ struct crl_policy {
     uint8_t *ring = nullptr;
     unsigned *ticket = nullptr;  // next group to hand out (reset before every launch)
     PolicyWeights W{};
-    hipStream_t side = nullptr;  // hybrid mode: the MFMA kernel's stream, forked from / joined to the caller's
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *raw = nullptr;        // the checkpoint tensors in torch layout (MFMA kernel): w1 1024 | b1 16 | w2 1024 | b2 16 | wa 4800 | ba 3
     PolicyWeightsM WM{};
 };
@@ -722,10 +810,8 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
         memcpy(raw.data() + 2064, conv2_b, 16 * 4), memcpy(raw.data() + 2080, actor_w, 4800 * 4), memcpy(raw.data() + 6880, actor_b, 3 * 4);
         e = hipMalloc(&p->raw, raw.size() * sizeof(float));
         if (e == hipSuccess) e = hipMemcpy(p->raw, raw.data(), raw.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(pong_policy_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMLds);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(pong_policy_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMLds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(pong_policy_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMLds);
         if (e != hipSuccess) {
             crl_policy_destroy(p);
             return crl_fail(CRL_EHIP, "crl_policy_create (mfma weights): %s", hipGetErrorString(e));
@@ -744,9 +830,6 @@ void crl_policy_destroy(crl_policy *p) {
     (void)hipSetDevice(p->device);
     if (p->weights) (void)hipFree(p->weights);
     if (p->raw) (void)hipFree(p->raw);
-    if (p->side) (void)hipStreamDestroy(p->side);
-    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->ring) (void)hipFree(p->ring);
     if (p->ticket) (void)hipFree(p->ticket);
     delete p;
@@ -770,43 +853,21 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     static const int per_cu = getenv("CRL_POLICY_WGS") ? atoi(getenv("CRL_POLICY_WGS")) : 2;  // tuning experiments only
     const unsigned grid = (unsigned)(groups < per_cu * p->cus ? groups : per_cu * p->cus);  // persistent: two workgroups per CU
     HIP_TRY(hipMemsetAsync(p->ticket, 0, sizeof(unsigned), (hipStream_t)stream));
-    // CRL_POLICY_MFMA: 0 (default) = the packed-FMA kernel, 1 = the fp32-MFMA kernel, 2 = both side by side on two streams,
-    // the envs split CRL_POLICY_SPLIT % / rest (the matrix and the vector pipe of a SIMD are separate).  Measured at 65 536
-    // envs: 725-761 us, 732-774 us, 747-837 us -- the MFMA kernel is exact and correct but keeps its pipe only
-    // ~65 % busy (in-order wavefronts, arbitration favouring the older half), and the two kernels do not overlap in practice.
-    static const int use_mfma = getenv("CRL_POLICY_MFMA") ? atoi(getenv("CRL_POLICY_MFMA")) : 0;
-    static const int split_pct = getenv("CRL_POLICY_SPLIT") ? atoi(getenv("CRL_POLICY_SPLIT")) : 50;
+    // CRL_POLICY_MFMA: 3 (default) = matrix-pipe kernel, conv1 as three exact bf16 products per tap; 1 = the same kernel with
+    // conv1 on the fp32 matrix instruction; 0 = the packed-FMA kernel of round 1.  Measured at 65 536 envs:
+    // 430 us, 757 us, 725-805 us.
+    static const int use_mfma = getenv("CRL_POLICY_MFMA") ? atoi(getenv("CRL_POLICY_MFMA")) : 3;
     static const int mdbg = getenv("CRL_POLICY_MFMA_DEBUG") ? atoi(getenv("CRL_POLICY_MFMA_DEBUG")) : 0;  // profiling only (wrong outputs)
     hipStream_t main_st = (hipStream_t)stream;
-    if (use_mfma == 1 && !dbg) {
+    if ((use_mfma == 1 || use_mfma == 3) && !dbg) {
         const int64_t mgroups = (p->n + kME - 1) / kME;
         const unsigned mgrid = (unsigned)(mgroups < p->cus ? mgroups : p->cus);  // persistent: one workgroup per CU
-        hipLaunchKernelGGL(pong_policy_mfma_kernel, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
-                           frame_stride, actions_dev, action_stride, logits_dev, p->n, p->ticket, mdbg, 2);
-        HIP_TRY(hipGetLastError());
-        p->head = (p->head + 1) & 3;
-        return CRL_OK;
-    }
-    if (use_mfma == 2 && !dbg && p->n >= 4096 && p->side) {
-        int64_t nm = p->n * split_pct / 100 / kME * kME;  // envs [0, nm) on the matrix pipe, [nm, n) on the vector pipe
-        nm = nm < kME ? kME : nm;
-        const int64_t nv = p->n - nm;
-        HIP_TRY(hipMemsetAsync(p->ticket + 16, 0, sizeof(unsigned), main_st));
-        HIP_TRY(hipEventRecord(p->ev_fork, main_st));
-        HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-        const int64_t mgroups = nm / kME;
-        const unsigned mgrid = (unsigned)(mgroups < p->cus ? mgroups : p->cus);
-        hipLaunchKernelGGL(pong_policy_mfma_kernel, dim3(mgrid), dim3(kMThreads), kMBuf + kMLdsRest, p->side, p->WM, p->ring, p->head,
-                           frame_dev, frame_stride, actions_dev, action_stride, logits_dev, nm, p->ticket + 16, 0, 1);
-        HIP_TRY(hipEventRecord(p->ev_join, p->side));
-        if (nv > 0) {
-            const int64_t vgroups = (nv + kEnvsPerWg - 1) / kEnvsPerWg;
-            const unsigned vgrid = (unsigned)(vgroups < p->cus ? vgroups : p->cus);  // one packed-FMA workgroup per CU beside the MFMA one
-            hipLaunchKernelGGL(pong_policy_light_kernel<0>, dim3(vgrid), dim3(kPolicyThreads), 0, main_st, p->W, p->ring + nm * (int64_t)kRingBytes,
-                               p->head, frame_dev + nm * frame_stride, frame_stride, actions_dev + nm * action_stride, action_stride,
-                               logits_dev ? logits_dev + nm * 3 : nullptr, nv, 0, phase, p->ticket);
-        }
-        HIP_TRY(hipStreamWaitEvent(main_st, p->ev_join, 0));
+        if (use_mfma == 3)
+            hipLaunchKernelGGL(pong_policy_mfma_kernel<true>, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
+                               frame_stride, actions_dev, action_stride, logits_dev, p->n, p->ticket, mdbg);
+        else
+            hipLaunchKernelGGL(pong_policy_mfma_kernel<false>, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
+                               frame_stride, actions_dev, action_stride, logits_dev, p->n, p->ticket, mdbg);
         HIP_TRY(hipGetLastError());
         p->head = (p->head + 1) & 3;
         return CRL_OK;

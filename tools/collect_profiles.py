@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = {"raw": "pong_raster_raw_sweep_kernel", "fused84": "pong_raster_gray", "fused84_newest": "pong_raster_gray", "fused84_f32": "pong_raster_gray",
-            "car": "car_raster_kernel", "tournament": "pong_policy_light_kernel"}
+            "car": "car_raster_kernel", "tournament": "pong_policy_mfma_kernel"}
 
 
 def main():
