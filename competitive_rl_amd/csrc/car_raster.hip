@@ -107,11 +107,13 @@ __device__ inline IndRect make_rect(double x, double y, double w, double h, int 
 // CRL_CAR_DEBUG & 64: cycle counter (s_memtime) at every workgroup barrier, summed per phase over all workgroups
 __device__ unsigned long long g_car_ticks[24];
 #define CAR_TICK(Kk)                                                             \
-    if ((dbg & 64) && tid == 0) {                                                \
+    if (TICKS && (dbg & 64) && tid == 0) {                                       \
         const long long now_ = __builtin_readcyclecounter();                     \
         tick_acc[Kk] += (unsigned)(now_ - tick_prev);                            \
         tick_prev = now_;                                                        \
     }
+// TICKS: the instance with the cycle stamps (their accumulators cost a dozen registers -- in the production instance they were spills)
+template <bool TICKS>
 __global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
                                                          const uint8_t *__restrict__ only_env, int want) {
     __shared__ CandTile cand[kMaxCand];
@@ -129,12 +131,19 @@ __global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(C
     __shared__ float cam[8];  // sin, cos, centre of the view; hull angle, velocity, spin (for the indicators)
     __shared__ __attribute__((aligned(16))) uint32_t tile32[96 * 96 / 4];
     const int64_t n = s.n, M = (int64_t)s.players * n;
-    const int64_t env = blockIdx.x / s.players;
-    const int viewer = blockIdx.x - env * s.players;
+    // XCD-aware order: workgroup b runs on XCD b % 8, so the two views of an env are blocks b and b + 8 -- same XCD, dispatched
+    // together: the second view finds the env's track (tile boxes, polygons: most of what this kernel fetches) in that XCD's L2
+    int64_t env = blockIdx.x;
+    int viewer = 0;
+    if (s.players == 2) {
+        const int r = (int)(blockIdx.x & 15);
+        env = (int64_t)(blockIdx.x >> 4) * 8 + (r & 7), viewer = r >> 3;
+    }
+    if (env >= n) return;
     if (only_env && only_env[env] != want) return;  // env subset: finished envs / one class of the step pipeline
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t me = viewer * n + env;
-    long long tick_prev = (dbg & 64) ? __builtin_readcyclecounter() : 0;
+    long long tick_prev = (TICKS && (dbg & 64)) ? __builtin_readcyclecounter() : 0;
     unsigned tick_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // Loads that do not depend on the camera go out first (tile AABBs: unconditional, the slots past the
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(C
             if (tid + 256 * i < 96 * 96 / 16) out[tid + 256 * i] = ov[i];
     }
     CAR_TICK(11)
-    if ((dbg & 64) && tid == 0) {
+    if (TICKS && (dbg & 64) && tid == 0) {
         for (int i = 0; i < 12; i++) atomicAdd(&g_car_ticks[i], (unsigned long long)tick_acc[i]);
         atomicAdd(&g_car_ticks[23], 1ull);
     }
@@ -677,7 +686,9 @@ void car_raster_print_ticks() {
 
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env, int want) {
     static const int dbg = getenv("CRL_CAR_DEBUG") ? atoi(getenv("CRL_CAR_DEBUG")) : 0;
-    hipLaunchKernelGGL(car_raster_kernel, dim3((unsigned)(s.players * s.n)), dim3(256), 0, st, s, k, obs, dbg, only_env, want);
+    const unsigned grid = s.players == 2 ? (unsigned)((s.n + 7) / 8 * 16) : (unsigned)s.n;  // two views x groups of 8 envs (see the kernel)
+    if (dbg & 64) hipLaunchKernelGGL(car_raster_kernel<true>, dim3(grid), dim3(256), 0, st, s, k, obs, dbg, only_env, want);
+    else hipLaunchKernelGGL(car_raster_kernel<false>, dim3(grid), dim3(256), 0, st, s, k, obs, dbg, only_env, want);
 }
 
 }  // namespace crl
