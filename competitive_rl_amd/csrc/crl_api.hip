@@ -726,6 +726,19 @@ int crl_set_replay(crl_ctx *c, const double *u, const uint8_t *bx, const uint8_t
 int crl_kernel_timing(crl_ctx *c, int enable) {
     if (!c) return fail(CRL_EINVAL, "null ctx");
     c->tm.on = enable != 0;
+    // the event pairs of the first few hundred timed launches are created HERE, not inside the caller's timed loop
+    // (later ones come back through the pool when crl_kernel_time_ms reads them out)
+    if (c->tm.on && c->tm.pool.empty() && c->tm.ev[0].empty() && c->tm.ev[1].empty()) {
+        for (int i = 0; i < 512; i++) {
+            crl_event_pair p;
+            if (hipEventCreate(&p.a) != hipSuccess) break;
+            if (hipEventCreate(&p.b) != hipSuccess) {
+                hipEventDestroy(p.a);
+                break;
+            }
+            c->tm.pool.push_back(p);
+        }
+    }
     return CRL_OK;
 }
 
