@@ -341,3 +341,21 @@ print("sweep ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRL_GRAY_SWEEP="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sweep ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_wheel_sensor_overflow_path_gives_the_same_results():
+    """car_sensor_kernel sends a car whose per-wheel tile lists overflow through car_sensor_serial_kernel (one lane walks the whole
+    track); CRL_CAR_SENSOR_SERIAL=1 forces every car that way.  The step-bookkeeping fixture recorded from the reference, the
+    teacher-forced oracle comparison, action repeat and the free-running comparison must pass unchanged (child process: the
+    switch is read once)."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "tests/test_hip_car_step_golden.py",
+                        "tests/test_hip_car_parity.py", "-k",
+                        "bookkeeping or teacher_forced or action_repeat or free_running or single_car"],
+                       cwd=root, env=dict(os.environ, CRL_CAR_SENSOR_SERIAL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
