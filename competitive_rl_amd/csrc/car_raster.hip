@@ -9,8 +9,11 @@
 // cars and indicator bars follow pygame's integer polygon fill rule.  Parity with real
 // pygame is unpinned; the CPU checker under tests/ uses the same definition.
 //
-// Per workgroup: (1) the tiles whose AABB meets the camera's view box are compacted IN ORDER
-// into LDS (draw order matters: lower tile index is drawn later and wins), (2) the 16 car
+// Workgroup b draws (env, viewer) = the two views of env 8 (b / 16) + b % 8 in blocks 16 k + j and 16 k + 8 + j: same XCD
+// (b % 8), dispatched together, so the env's track is fetched from HBM once.
+// Per workgroup: (0) the camera (one wavefront, f64 atan2) goes through LDS, (1) the tiles whose AABB meets the camera's view
+// box are compacted IN ORDER into LDS as 80-byte vertex records (draw order matters: lower tile index is drawn later and
+// wins), (2) the 16 car
 // polygons and 8 indicator rectangles are projected once into LDS, and every 8x8-pixel cell
 // gets bit masks of the candidates that can cover it (separating-edge test in screen space),
 // (3) the background is resolved 4 pixels per lane into an LDS tile (a wavefront per 16x16

@@ -1,10 +1,13 @@
-// car_step.hip -- one cCarRacingDouble step, one lane per CAR INSTANCE (2 lanes per env).
-//
-// The two cars of an env only interact through contacts; unless their oriented boxes overlap
-// (then car_contact.hip solves them together) each car is an independent Box2D island: wheel model (f64) -> sensor overlap with the
-// track tiles (Begin/EndContact -> tile rewards) -> island solve (180 velocity iterations over
-// 4 revolute joints, <= 60 position iterations) entirely in registers.  Bound by the sequential
-// Gauss-Seidel chain (VALU latency), not by HBM: ~1.3 KB of state per car per step.
+// car_step.hip -- the dynamics of one cCarRacingDouble step, split over three kernels:
+//   car_step_kernel    one lane per CAR INSTANCE (2 lanes per env): controls, wheel model (f64), reward / done rules, hand-off
+//                      decision (do the two cars' fixtures come near each other?), snapshot of the wheel transforms;
+//   car_sensor_kernel  one lane per WHEEL: world.Step's Collide for the wheel sensors (Begin/EndContact with the track tiles ->
+//                      tile rewards), on a stream of its own beside the solve -- it feeds nothing into this step's solve;
+//   car_solve_kernel   one lane per car instance that is an island of its own: Box2D island solve (180 velocity iterations over 4
+//                      revolute joints, <= 60 position iterations) entirely in registers.  (Cars whose fixtures may touch are
+//                      solved together by car_contact.hip.)
+// Nothing here is HBM-bound (~1.3 KB of state per car per step): the solve is the issue rate of one wavefront per SIMD over a
+// sequential Gauss-Seidel chain, the sensors are a latency chain of small loads.
 #include <stdlib.h>
 
 #include "car_solver.h"
