@@ -90,6 +90,9 @@ struct CarSoA {
     float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
     float *wsnap;           // [12][M] wheel transforms (cx, cy, angle) the step starts from, for car_sensor_kernel
     uint8_t *sensor_ovf;    // [M] 1 = car_sensor_kernel's lists overflowed for this car: car_sensor_serial_kernel redoes it
+    // this struct and the body constants once more in device memory (the raster reads the context through pointers)
+    const struct CarSoA *self_dev;
+    const struct CarConsts *consts_dev;
     float *sleep;           // [5][M] b2Body::m_sleepTime of hull, wheels 0-3
     int32_t *coupled;       // [n] 1 = the two cars are solved together this step
     int32_t *coupled_list;  // [n] the coupled envs of this step, compacted (any order), and
@@ -152,10 +155,12 @@ void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
-                     int max_episode_steps, bool car0_only, hipStream_t st);
+                     int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 
 // only_env: draw env e iff only_env[e] == want; nullptr = every env
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
+void launch_car_raster_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
+                            int32_t *count_to_host, int64_t expected);
 void car_raster_print_ticks();  // CRL_CAR_DEBUG & 64
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
                       int players, hipStream_t st);

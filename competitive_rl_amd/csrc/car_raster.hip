@@ -117,8 +117,8 @@ __device__ unsigned long long g_car_ticks[24];
     }
 // TICKS: the instance with the cycle stamps (their accumulators cost a dozen registers -- in the production instance they were spills)
 template <bool TICKS>
-__global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
-                                                         const uint8_t *__restrict__ only_env, int want) {
+__device__ __forceinline__ void car_raster_tile(const CarSoA &s, const CarConsts &K, uint8_t *__restrict__ obs, int dbg, const int64_t env,
+                                                const int viewer) {
     __shared__ CandTile cand[kMaxCand];
     __shared__ __attribute__((aligned(8))) CarPoly cars[16];
     __shared__ __attribute__((aligned(16))) IndRect ind[8];
@@ -134,16 +134,6 @@ __global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(C
     __shared__ float cam[8];  // sin, cos, centre of the view; hull angle, velocity, spin (for the indicators)
     __shared__ __attribute__((aligned(16))) uint32_t tile32[96 * 96 / 4];
     const int64_t n = s.n, M = (int64_t)s.players * n;
-    // XCD-aware order: workgroup b runs on XCD b % 8, so the two views of an env are blocks b and b + 8 -- same XCD, dispatched
-    // together: the second view finds the env's track (tile boxes, polygons: most of what this kernel fetches) in that XCD's L2
-    int64_t env = blockIdx.x;
-    int viewer = 0;
-    if (s.players == 2) {
-        const int r = (int)(blockIdx.x & 15);
-        env = (int64_t)(blockIdx.x >> 4) * 8 + (r & 7), viewer = r >> 3;
-    }
-    if (env >= n) return;
-    if (only_env && only_env[env] != want) return;  // env subset: finished envs / one class of the step pipeline
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t me = viewer * n + env;
     long long tick_prev = (TICKS && (dbg & 64)) ? __builtin_readcyclecounter() : 0;
@@ -647,6 +637,54 @@ __global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(C
     }
 }
 
+// The kernels proper.  Tile slot b -> (position i = 8 (b / 16) + b % 8, viewer (b % 16) / 8) when there are two views: workgroup b
+// runs on XCD b % 8, so the two views of an env are slots b and b + 8 -- same XCD, dispatched together: the second view finds
+// the env's track (tile boxes, polygons: most of what this kernel fetches) in that XCD's L2.
+//   car_raster_kernel       position i = env i (all envs, or the subset only_env[env] == want: the big launch of a step);
+//   car_raster_list_kernel  position i = entry i of a compacted list whose length lives in device memory (the small env
+//                           classes of a step): a launch sized from the previous step's count that LOOPS if it falls short,
+//                           instead of 32 768 workgroups that each wait for a CU slot only to exit.  The tile is a real function
+//                           call there, the context read through pointers to its copy in device memory: inlined into the
+//                           loop, the ~100 scalar registers of context pointers stay live across it and spill (108 VGPRs of
+//                           spills), and by-value structs would be copied to every lane's private memory at the call -- a
+//                           20 % slower tile, which the big launch must not pay.
+template <bool TICKS>
+__global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, int dbg,
+                                                         const uint8_t *__restrict__ only_env, int want) {
+    int64_t env = blockIdx.x;
+    int viewer = 0;
+    if (s.players == 2) {
+        const int r = (int)(blockIdx.x & 15);
+        env = (int64_t)(blockIdx.x >> 4) * 8 + (r & 7), viewer = r >> 3;
+    }
+    if (env >= s.n) return;
+    if (only_env && only_env[env] != want) return;  // env subset: finished envs / one class of the step pipeline
+    car_raster_tile<TICKS>(s, K, obs, dbg, env, viewer);
+}
+
+__device__ __noinline__ void car_raster_tile_call(const CarSoA *__restrict__ sp, const CarConsts *__restrict__ Kp, uint8_t *__restrict__ obs,
+                                                  int dbg, int64_t env, int viewer) {
+    car_raster_tile<false>(*sp, *Kp, obs, dbg, env, viewer);
+}
+
+__global__ __launch_bounds__(256, CRL_CAR_RASTER_WAVES) void car_raster_list_kernel(const CarSoA *__restrict__ sp, const CarConsts *__restrict__ Kp,
+                                                              int players, uint8_t *__restrict__ obs, int dbg, const int32_t *__restrict__ list,
+                                                              const int32_t *__restrict__ list_count, int32_t *__restrict__ count_to_host) {
+    const int64_t positions = *list_count;
+    if (count_to_host && blockIdx.x == 0 && threadIdx.x == 0) *count_to_host = (int32_t)positions;
+    const int64_t slots = players == 2 ? (positions + 7) / 8 * 16 : positions;
+    for (int64_t b = blockIdx.x; b < slots; b += gridDim.x) {  // (gridDim.x is a multiple of 16)
+        int64_t i = b;
+        int viewer = 0;
+        if (players == 2) {
+            const int r = (int)(b & 15);
+            i = (b >> 4) * 8 + (r & 7), viewer = r >> 3;
+        }
+        if (i < positions) car_raster_tile_call(sp, Kp, obs, dbg, (int64_t)list[i], viewer);
+        if (b + gridDim.x < slots) __syncthreads();  // the next tile reuses the LDS
+    }
+}
+
 // MultipleFrameStack + FlattenMultiAgentObservation + WrapPyTorch (reference
 // utils/atari_wrappers.py:262-334, 12-37): per agent the last K frames, oldest first, agents
 // concatenated on the channel axis -> (N, 2K, 96, 96).  reset() fills all K slots with the first
@@ -692,6 +730,17 @@ void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStr
     const unsigned grid = s.players == 2 ? (unsigned)((s.n + 7) / 8 * 16) : (unsigned)s.n;  // two views x groups of 8 envs (see the kernel)
     if (dbg & 64) hipLaunchKernelGGL(car_raster_kernel<true>, dim3(grid), dim3(256), 0, st, s, k, obs, dbg, only_env, want);
     else hipLaunchKernelGGL(car_raster_kernel<false>, dim3(grid), dim3(256), 0, st, s, k, obs, dbg, only_env, want);
+}
+
+// the envs of a compacted list (its length in device memory); `expected` = the caller's guess of that length, only for the grid size
+void launch_car_raster_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
+                            int32_t *count_to_host, int64_t expected) {
+    static const int dbg = getenv("CRL_CAR_DEBUG") ? atoi(getenv("CRL_CAR_DEBUG")) : 0;
+    int64_t want = expected + expected / 4 + 32;  // slack: a launch that falls short loops, it does not miss tiles
+    want = want > s.n ? s.n : want;
+    const unsigned grid = (unsigned)((want + 7) / 8 * 16);
+    hipLaunchKernelGGL(car_raster_list_kernel, dim3(grid), dim3(256), 0, st, s.self_dev, s.consts_dev, s.players, obs, dbg & ~64, list, list_count,
+                       count_to_host);
 }
 
 }  // namespace crl

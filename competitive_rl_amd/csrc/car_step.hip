@@ -531,17 +531,35 @@ __global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K
 // crmp:578-579).  Also captures info["num_steps"] = CarRacing.step_count (crmp:616-620) before the auto-reset.
 __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *__restrict__ done_car,
                                                        uint8_t *__restrict__ done_env, uint8_t *__restrict__ slow_env,
-                                                       int32_t *__restrict__ info_steps, int max_episode_steps, int car0_only) {
+                                                       int32_t *__restrict__ info_steps, int max_episode_steps, int car0_only,
+                                                       int32_t *__restrict__ class_list, int32_t *__restrict__ class_count) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
-    const int el = s.elapsed[env] + 1;
-    bool d = el >= max_episode_steps;
-    for (int c = 0; c < (car0_only ? 1 : s.players); c++) d = d || done_car[s.players * env + c];
-    s.elapsed[env] = el;
-    done_env[env] = d ? 1 : 0;
-    if (info_steps) info_steps[env] = s.step_count[env];  // one world clock per env: both cars carry the same count
-    // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = after the reset
-    if (slow_env) slow_env[env] = d ? 2 : ((s.coupled && s.coupled[env]) ? 1 : 0);
+    int cls = 0;
+    if (env < s.n) {
+        const int el = s.elapsed[env] + 1;
+        bool d = el >= max_episode_steps;
+        for (int c = 0; c < (car0_only ? 1 : s.players); c++) d = d || done_car[s.players * env + c];
+        s.elapsed[env] = el;
+        done_env[env] = d ? 1 : 0;
+        if (info_steps) info_steps[env] = s.step_count[env];  // one world clock per env: both cars carry the same count
+        // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = after the reset
+        cls = d ? 2 : ((s.coupled && s.coupled[env]) ? 1 : 0);
+        if (slow_env) slow_env[env] = (uint8_t)cls;
+    }
+    // the two small classes also as compacted lists (any order): their frames are drawn by launches sized to the lists.
+    // One atomic per wavefront and class, not per env (thousands of them on two addresses took 20 us).
+    if (class_list) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 1; k <= 2; k++) {
+            const unsigned long long m = __ballot(cls == k);
+            if (!m) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&class_count[k - 1], (int)__popcll(m));
+            base = __shfl(base, 0);
+            if (cls == k) class_list[(int64_t)(k - 1) * s.n + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
+        }
+    }
 }
 
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
@@ -564,9 +582,10 @@ void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
 }
 
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
-                     int max_episode_steps, bool car0_only, hipStream_t st) {
+                     int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list, int32_t *class_count) {
+    if (class_count) hipMemsetAsync(class_count, 0, 2 * sizeof(int32_t), st);
     hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env, slow_env,
-                       info_steps, max_episode_steps, car0_only ? 1 : 0);
+                       info_steps, max_episode_steps, car0_only ? 1 : 0, class_list, class_count);
 }
 
 }  // namespace crl

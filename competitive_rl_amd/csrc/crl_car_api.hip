@@ -28,6 +28,9 @@ struct crl_car_ctx {
     // latency-bound part of a step (coupled solve, track generation for finished envs) runs on a
     // side stream next to the raster; slow_env = pipeline class per env (car_post_kernel)
     uint8_t *slow_env = nullptr;
+    int32_t *class_list = nullptr;   // [2][n] envs of class 1 (coupled) and class 2 (finished) of the current step, compacted
+    int32_t *class_count = nullptr;  // [2] their lengths
+    int32_t *class_count_host = nullptr, *class_count_hdev = nullptr;  // host-mapped copy (one step late): sizes the next step's launches
     hipStream_t side = nullptr;
     hipStream_t sens = nullptr;  // the wheel-sensor contacts of a step, beside its solve
     hipEvent_t ev_sens = nullptr, ev_c1 = nullptr;
@@ -165,6 +168,8 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
     if (!rc) rc = calloc_dev(c, &c->slow_env, n);
+    if (!rc) rc = calloc_dev(c, &c->class_list, 2 * n);
+    if (!rc) rc = calloc_dev(c, &c->class_count, 4);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     if (!rc) rc = calloc_dev(c, &c->info_steps, n);
     if (!rc) rc = calloc_dev(c, &c->term, (size_t)M * 96 * 96);
@@ -188,6 +193,12 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         c->s.text_bits = tb;
     }
     c->src.seed = opts->seed, c->src.env_id_base = opts->env_id_base;
+    if (hipHostMalloc((void **)&c->class_count_host, 4 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->class_count_hdev, c->class_count_host, 0) != hipSuccess) {
+        crl_car_destroy(c);
+        return crl_fail(CRL_EHIP, "car create: host-mapped counters");
+    }
+    c->class_count_host[0] = c->class_count_host[1] = (int32_t)std::min<int64_t>(n, 64);
     c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
@@ -203,6 +214,20 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         crl_car_destroy(c);
         return crl_fail(CRL_EHIP, "car create: side stream");
+    }
+    {  // device copies of the context struct and the constants (everything in them is final here)
+        CarSoA *sd = nullptr;
+        CarConsts *kd = nullptr;
+        if (calloc_dev(c, &sd, 1) || calloc_dev(c, &kd, 1)) {
+            crl_car_destroy(c);
+            return crl_fail(CRL_ENOMEM, "car create: context copy");
+        }
+        c->s.self_dev = sd, c->s.consts_dev = kd;
+        if (hipMemcpy(sd, &c->s, sizeof(CarSoA), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(kd, &c->K_, sizeof(CarConsts), hipMemcpyHostToDevice) != hipSuccess) {
+            crl_car_destroy(c);
+            return crl_fail(CRL_EHIP, "car create: context copy");
+        }
     }
     *out = c;
     return CRL_OK;
@@ -223,6 +248,7 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_coupled) hipEventDestroy(c->ev_coupled);
     if (c->ev_term) hipEventDestroy(c->ev_term);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->class_count_host) hipHostFree(c->class_count_host);
     for (void *p : c->allocs) hipFree(p);
     if (c->ru) hipFree(c->ru);
     if (c->rshuffle) hipFree(c->rshuffle);
@@ -312,7 +338,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, st);
         launch_car_coupled(c->s, c->K_, st);
     }
-    launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, c->info_steps, 1000, c->car0_only, st);
+    launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, c->info_steps, 1000, c->car0_only, st, c->class_list, c->class_count);
     if (!fork) {
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
         if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);
@@ -325,39 +351,41 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             crl_timer_end(tm, 1, st);
         }
     } else {
-        // Two streams.  Side: the latency-bound work only a few envs need (coupled solve, then track
-        // generation for finished envs; a handful of busy lanes each).  Main: the frames, in three
-        // classes as their inputs become final -- envs that neither touch nor finished (drawn next
-        // to the coupled solve), coupled envs, finished envs (terminal frame before the reset, first
-        // frame of the new episode after it).  The classes are disjoint sets of envs.
+        // Three streams, three disjoint classes of envs (car_post_kernel): envs that neither touch nor finished are solved and
+        // drawn on the caller's stream; coupled envs are solved on `side` and drawn on `sens` (behind the wheel sensors);
+        // finished envs get their terminal frame, their reset and the first frame of the new episode on `side`.
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
         hipEventRecord(c->ev_fork, st);
+        // side: the coupled solve (the few envs whose cars may touch), next to the per-car solve AND the frames
         hipStreamWaitEvent(c->side, c->ev_fork, 0);
-        launch_car_coupled(c->s, c->K_, c->side);  // the few coupled envs: next to the per-car solve AND the frames
+        launch_car_coupled(c->s, c->K_, c->side);
         hipEventRecord(c->ev_coupled, c->side);
-        // the wheel sensors (tile rewards, road_visited) read the transforms the step started from and feed nothing
-        // into its solve: a third stream, beside the latency-bound per-car solve (two wavefronts per CU)
+        // sens: the wheel sensors (tile rewards, road_visited) read the transforms the step started from and feed nothing
+        // into its solve; then the coupled envs' frames, beside the big launch
         hipStreamWaitEvent(c->sens, c->ev_fork, 0);
         launch_car_sensors(c->s, c->K_, c->sens);
         hipEventRecord(c->ev_sens, c->sens);
-        hipStreamWaitEvent(c->side, c->ev_sens, 0);  // (the frames show the reward)
-        launch_car_raster(c->s, c->K_, target, c->side, c->slow_env, 1);  // coupled envs' frames, beside the tail of the big launch
-        hipEventRecord(c->ev_c1, c->side);
+        hipStreamWaitEvent(c->sens, c->ev_coupled, 0);
+        launch_car_raster_list(c->s, c->K_, target, c->sens, c->class_list, c->class_count, c->class_count_hdev, c->class_count_host[0]);
+        hipEventRecord(c->ev_c1, c->sens);
+        // main: the per-car solve, then the frames of every env that neither touches nor finished (they show the reward: sensors first)
         launch_car_solve(c->s, c->K_, st);
-        hipStreamWaitEvent(st, c->ev_sens, 0);  // the frames show the reward; everything later on `st` sees the contacts
+        hipEventRecord(c->ev_term, st);  // (bodies of the non-coupled cars are final)
+        hipStreamWaitEvent(st, c->ev_sens, 0);
         crl_timer_end(tm, 0, st);
         crl_timer_begin(tm, 1, st);
         launch_car_raster(c->s, c->K_, target, st, c->slow_env, 0);
-        hipStreamWaitEvent(st, c->ev_coupled, 0);
-        launch_car_raster(c->s, c->K_, c->term, st, c->done_env, 1);  // info["terminal_observation"]
-        hipEventRecord(c->ev_term, st);
+        // side again: the finished envs from end to end -- terminal frame (info["terminal_observation"]), reset, first frame of the
+        // new episode -- beside the big launch instead of behind it
         hipStreamWaitEvent(c->side, c->ev_term, 0);
+        hipStreamWaitEvent(c->side, c->ev_sens, 0);
+        launch_car_raster_list(c->s, c->K_, c->term, c->side, c->class_list + c->n, c->class_count + 1, c->class_count_hdev + 1, c->class_count_host[1]);
         launch_car_reset(c->s, c->K_, c->src, true, c->done_env, c->side);
-        hipEventRecord(c->ev_join, c->side);
         queue_walk_ahead(c, c->side);
+        launch_car_raster_list(c->s, c->K_, target, c->side, c->class_list + c->n, c->class_count + 1, nullptr, c->class_count_host[1]);
+        hipEventRecord(c->ev_join, c->side);
         hipStreamWaitEvent(st, c->ev_c1, 0);
         hipStreamWaitEvent(st, c->ev_join, 0);
-        launch_car_raster(c->s, c->K_, target, st, c->slow_env, 2);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
         crl_timer_end(tm, 1, st);
     }
