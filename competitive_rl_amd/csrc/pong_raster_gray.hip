@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256) void pong_gray_header_kernel(const uint64_t *_
     memset(&h, 0, sizeof(h));
     if (fa.sl == 255) {  // both blank: plane erased by a done
         hdr[tile] = h;
+        reinterpret_cast<uint2 *>(hdr + n * tiles_per_env)[tile] = make_uint2(h.band_off, h.kind);
         return;
     }
     bool slow = false;
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(256) void pong_gray_header_kernel(const uint64_t *_
     }
     h.chunkmask = mask;
     hdr[tile] = h;
+    reinterpret_cast<uint2 *>(hdr + n * tiles_per_env)[tile] = make_uint2(h.band_off, h.kind);  // dense copy (skeleton experiment)
 }
 
 // One wavefront per 1-KiB-ALIGNED block of the output tensor (chunks [64 b, 64 b + 64) of the whole tensor), NB blocks per
@@ -702,6 +704,38 @@ __device__ inline int opaque_zero() {  // a zero the compiler must treat as per-
     int z;
     asm volatile("v_mov_b32 %0, 0" : "=v"(z));
     return z;
+}
+
+// Measurement only (CRL_GRAY_SWEEP=2, wrong pixels wherever a ball or bat is): the SKELETON of an address-linear writer with
+// real per-tile metadata -- tile index, one 16-byte header read, the template chunk, an aligned 1-KiB store -- and none of the
+// box path, i.e. what a writer that got its box pixels for free could at best cost.  NB blocks per wavefront, a grid apart.
+template <int NB>
+__global__ __launch_bounds__(256) void pong_gray_sweep_skeleton_kernel(const GrayTileHdr *__restrict__ hdrs, int n_tiles, GrayGeom q,
+                                                                       uint8_t *__restrict__ obs, int stride, int dense) {
+    constexpr int R = 84, chunks = R * R >> 4;
+    const int total = n_tiles * chunks;
+    const int bb = q.band_chunks;
+    const int zc0 = (q.zero_row0 * R + 15) >> 4, zc1 = (q.zero_row1 * R) >> 4;
+    const uint4 *__restrict__ band4 = reinterpret_cast<const uint4 *>(q.band);
+    const uint4 *__restrict__ rest4 = reinterpret_cast<const uint4 *>(q.rest);
+    int gl[NB], c[NB];
+    uint2 h[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        gl[i] = ((int)blockIdx.x * 256 + (int)threadIdx.x) + i * stride * 64;
+        const int gg = min(gl[i], total - 1), tile = gg / chunks;
+        c[i] = gg - tile * chunks;
+        h[i] = dense ? reinterpret_cast<const uint2 *>(hdrs + n_tiles)[tile] : *reinterpret_cast<const uint2 *>(hdrs + tile);  // band offset, kind
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((h[i].y & 255u) != 0) {
+            if (c[i] < bb) v = band4[h[i].x + c[i]];
+            else if (c[i] < zc0 || c[i] >= zc1) v = rest4[c[i]];
+        }
+        if (gl[i] < total) reinterpret_cast<uint4 *>(obs)[gl[i]] = v;
+    }
 }
 
 template <int RT, int NB>
@@ -874,6 +908,14 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         const int nb = wblocks < 8192 ? 1 : nb_env;
         const int stride = (int)(((wblocks + nb - 1) / nb + 3) / 4 * 4);  // blocks per round, a multiple of the 4 waves of a workgroup
         const dim3 grid((unsigned)(stride / 4));
+        static const int sweep_mode = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
+        if ((sweep_mode == 2 || sweep_mode == 3) && p.R == 84) {
+            const int dense = sweep_mode == 3;
+            if (nb == 1) hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<1>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);
+            else if (nb == 2) hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<2>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);
+            else hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<4>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);
+            return;
+        }
 #define CRL_SWEEP(RTv, NBv) hipLaunchKernelGGL((pong_raster_gray_sweep_kernel<RTv, NBv>), grid, dim3(256), 0, st, hdr, (int)tiles, g, q, p.obs, sdbg, p.ring, p.n, stride)
         if (p.R == 84) {
             if (nb == 1) CRL_SWEEP(84, 1);

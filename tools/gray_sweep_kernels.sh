@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/gray_sweep_kernels
 mkdir -p $OUT
-export CRL_GRAY_SWEEP=1
+export CRL_GRAY_SWEEP=${CRL_GRAY_SWEEP:-1}
 for v in ${SWEEP_SETTINGS:-0 1 5}; do
   export CRL_GRAY_SWEEP_DEBUG=$v
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --output-format csv -d $OUT/t$v -- python3 $REPO/bench.py --workload fused84 --steps 30 --warmup 5 --no-cpu-baseline > $OUT/b$v.json 2> $OUT/err$v)
