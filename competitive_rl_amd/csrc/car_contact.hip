@@ -306,8 +306,14 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
 #pragma unroll
         for (int w = 0; w < 4; w++) r.W[w].cx = mW[w].cx, r.W[w].cy = mW[w].cy, r.W[w].a = mW[w].a;
     };
-    if (nc == 0) {
-        // boxes overlap but nothing touches: two independent islands, as in the per-car kernel
+    // Envs whose boxes overlap but where nothing touches (most of this kernel's envs) are two independent islands, exactly as in the
+    // per-car kernel.  A wavefront that only holds such envs runs island_solve(); in a MIXED wavefront they ride along the contact
+    // path below instead of running island_solve() beside it (a divergent branch executes both sides one after the other: the
+    // per-car solve used to add its 0.24 ms to the ~1 ms contact path of nearly every wavefront).  Riding along is the same
+    // arithmetic: the LDS round trips copy values, the contact loops run zero times, and `iso` keeps the two places where one
+    // island differs from two -- when the position iterations stop, and who goes to sleep -- per car.
+    const bool iso = nc == 0;
+    if (!__any(nc != 0)) {
         island_solve(r, K, h, dt_ratio, slp);
     } else {
         JointTmp jt;
@@ -451,6 +457,7 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
         isl_integrate_pos(r, h);
         pos_to_lds();
         bool solved = false;
+        bool iso_done = false;  // iso: this car's own position iterations have converged (b2Island::Solve breaks out there)
 #pragma unroll 1
         for (int it = 0; it < 60; it++) {
             float minSep = 0.0f;
@@ -485,20 +492,26 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
             }
             const bool cok = minSep >= -3.0f * LINEAR_SLOP;  // (meaningful in the even lane)
             pos_from_lds();
-            const bool jok = isl_joints_pos(r, K);
+            bool jok = true;
+            if (!iso_done) jok = isl_joints_pos(r, K);  // (a converged island of its own is not iterated again)
             pos_to_lds();
-            // contactsOkay && jointsOkay of the whole island: combine the pair
-            const int mine = (me == 0 ? (cok ? 1 : 0) : 1) & (jok ? 1 : 0);
+            if (iso && jok) iso_done = true;
+            // contactsOkay && jointsOkay of the whole island: combine the pair (two islands: both have converged)
+            const int mine = iso ? (iso_done ? 1 : 0) : ((me == 0 ? (cok ? 1 : 0) : 1) & (jok ? 1 : 0));
             const int other = __shfl_xor(mine, 1);
             if (mine & other) {
                 solved = true;
                 break;
             }
         }
-        // one island: it sleeps only when all ten bodies have been still long enough
+        // one island: it sleeps only when all ten bodies have been still long enough; two islands: each on its own
         const float mm = isl_sleep_scan(r, slp, h);
         const float mo = __shfl_xor(mm, 1);
-        if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(r, slp);
+        if (iso) {
+            if (mm >= TIME_TO_SLEEP && iso_done) isl_put_to_sleep(r, slp);
+        } else if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) {
+            isl_put_to_sleep(r, slp);
+        }
     }
     for (int b = 0; b < 5; b++) s.sleep[b * M + me * s.n + env] = slp[b];
 
