@@ -148,6 +148,8 @@ struct CarTrackSrc {  // where reset draws come from
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st);
+void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, const int32_t *list, const int32_t *list_count,
+                           int64_t expected, hipStream_t st);
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st);
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st);

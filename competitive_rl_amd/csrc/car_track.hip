@@ -263,13 +263,30 @@ __device__ void gen_walk(const CarSoA &s, const CarTrackSrc &src, int64_t env, u
 // Reset of the finished envs.  The ~4.6 ms walk is normally already there (car_walk_ahead_kernel, tagged with
 // the episode it belongs to); then only the tiles are built and the cars placed.  Without a finished
 // walk-ahead (first episode, a reset right after a reset) the walk is done here, into its own scratch.
+__device__ inline void reset_one_env(CarSoA &s, const CarConsts &K, const CarTrackSrc &src, int64_t env, uint8_t *flag);
+
 __global__ __launch_bounds__(64) void car_reset_kernel(CarSoA s, CarConsts K, CarTrackSrc src, int only_done,
                                                        const uint8_t *__restrict__ done_env) {
     // one WAVEFRONT per env: the tiles are built one per lane; a missing walk is done by lane 0
     __shared__ uint8_t flag[kCarMaxTiles];
     const int64_t env = blockIdx.x;
-    const int lane = threadIdx.x;
     if (only_done && !done_env[env]) return;
+    reset_one_env(s, K, src, env, flag);
+}
+
+// the same over a compacted list of envs (the finished envs of a step: a handful of wavefronts instead of one per env that mostly exit)
+__global__ __launch_bounds__(64) void car_reset_list_kernel(CarSoA s, CarConsts K, CarTrackSrc src, const int32_t *__restrict__ list,
+                                                            const int32_t *__restrict__ list_count) {
+    __shared__ uint8_t flag[kCarMaxTiles];
+    const int count = *list_count;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        reset_one_env(s, K, src, (int64_t)list[i], flag);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
+__device__ inline void reset_one_env(CarSoA &s, const CarConsts &K, const CarTrackSrc &src, int64_t env, uint8_t *flag) {
+    const int lane = threadIdx.x;
     const uint32_t episode = __hip_atomic_load(&s.episode[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int len = 0, swap = 0, first = 0;
     const double *pts;
@@ -307,6 +324,13 @@ __global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSr
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st) {
     hipLaunchKernelGGL(car_reset_kernel, dim3((unsigned)s.n), dim3(64), 0, st, s, k, src, only_done ? 1 : 0, done_env);
+}
+
+void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, const int32_t *list, const int32_t *list_count,
+                           int64_t expected, hipStream_t st) {
+    int64_t want = expected + expected / 4 + 32;
+    want = want > s.n ? s.n : want;
+    hipLaunchKernelGGL(car_reset_list_kernel, dim3((unsigned)want), dim3(64), 0, st, s, k, src, list, list_count);
 }
 
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st) {

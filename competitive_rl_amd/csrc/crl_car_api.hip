@@ -380,7 +380,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side, c->ev_term, 0);
         hipStreamWaitEvent(c->side, c->ev_sens, 0);
         launch_car_raster_list(c->s, c->K_, c->term, c->side, c->class_list + c->n, c->class_count + 1, c->class_count_hdev + 1, c->class_count_host[1]);
-        launch_car_reset(c->s, c->K_, c->src, true, c->done_env, c->side);
+        launch_car_reset_list(c->s, c->K_, c->src, c->class_list + c->n, c->class_count + 1, c->class_count_host[1], c->side);
         queue_walk_ahead(c, c->side);
         launch_car_raster_list(c->s, c->K_, target, c->side, c->class_list + c->n, c->class_count + 1, nullptr, c->class_count_host[1]);
         hipEventRecord(c->ev_join, c->side);
