@@ -83,6 +83,7 @@ struct CarSoA {
     double *track_scratch;  // [2500][4][n] points (alpha, beta, x, y; f64) of the walk generated AHEAD for the env's next episode
     double *track_scratch_b;  // same shape: where a reset walks inline when no finished walk-ahead is there
     uint32_t *walk_tag;     // [n] episode index the stored walk belongs to (0xFFFFFFFF = none); written last, device-scope release
+    int32_t *walk_list, *walk_count;  // [n], [1]: the envs the current walk-ahead launch has to walk, compacted
     int32_t *walk_len, *walk_first, *walk_swap;  // [n] lap length, its first point, birth-place swap of the stored walk
     const uint32_t *text_bits;  // reward read-out bitmaps [CRL_CAR_TEXT_STRINGS][CRL_CAR_TEXT_ROWS] or nullptr
     // ---- car-car contacts (players == 2)

@@ -309,10 +309,31 @@ __device__ inline void reset_one_env(CarSoA &s, const CarConsts &K, const CarTra
 
 // Walk-ahead: for every env whose stored walk is not the one its next reset needs, generate it.  Runs on its
 // own stream beside the steps; a reset that comes before it has finished simply walks inline.
-__global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSrc src) {
+// Two kernels: the first lists the envs that need a walk (a few dozen of 16 384), the second walks them in DENSE wavefronts --
+// one lane per env directly would keep a 165-register wavefront resident for milliseconds on every CU that holds one such env, and
+// a frame workgroup needs a slot on all four SIMDs of its CU.
+__global__ __launch_bounds__(256) void car_walk_mark_kernel(CarSoA s, int32_t *__restrict__ list, int32_t *__restrict__ count) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= s.n) return;
-    // the index the env's next reset will use (acquire: pairs with the release at the end of car_reset_kernel)
+    bool need = false;
+    if (env < s.n) {
+        // the index the env's next reset will use (acquire: pairs with the release at the end of the reset)
+        const uint32_t episode = __hip_atomic_load(&s.episode[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        need = __hip_atomic_load(&s.walk_tag[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != episode;
+    }
+    const unsigned long long m = __ballot(need);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, (int)__popcll(m));
+    base = __shfl(base, 0);
+    if (need) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
+}
+
+__global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSrc src, const int32_t *__restrict__ list,
+                                                            const int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *count) return;
+    const int64_t env = list[i];
     const uint32_t episode = __hip_atomic_load(&s.episode[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == episode) return;
     int len, first, swap;
@@ -334,7 +355,9 @@ void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSr
 }
 
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st) {
-    hipLaunchKernelGGL(car_walk_ahead_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, src);
+    hipMemsetAsync(s.walk_count, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(car_walk_mark_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, s.walk_list, s.walk_count);
+    hipLaunchKernelGGL(car_walk_ahead_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, src, s.walk_list, s.walk_count);
 }
 
 }  // namespace crl

@@ -160,7 +160,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
-    A(walk_tag, n); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
+    A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
     A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
