@@ -359,3 +359,37 @@ def test_wheel_sensor_overflow_path_gives_the_same_results():
                         "bookkeeping or teacher_forced or action_repeat or free_running or single_car"],
                        cwd=root, env=dict(os.environ, CRL_CAR_SENSOR_SERIAL="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_small_class_launches_loop_when_the_class_is_larger_than_expected():
+    """The frames of a step's finished / coupled envs are drawn by launches sized from the PREVIOUS step's class counts; when a
+    class is suddenly much larger (here: 300 of 512 envs finish in one step after steps with none) the launch loops over its
+    list.  Every frame the step returns -- terminal observation, first frame of the new episode, the untouched envs -- must be
+    what one plain render of the same state gives."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 512
+    env = crl.HipCarVecEnv(n, seed=11)
+    env.reset()
+    acts = torch.zeros((n, 2, 2), device="cuda")
+    acts[:, :, 1] = 0.3
+    for _ in range(3):
+        env.step_device(acts)                      # steps without a finished env: the expected class sizes settle near zero
+    st = env.get_state()
+    out = np.arange(n) % 5 < 3                     # 308 envs: car 0 is put far outside the playfield
+    for body in ("hull", "wheel"):
+        st["car"][:, 0][body]["cx"][out] += 900.0
+    env.set_state(st)
+    before = env.render_current().clone()          # what the terminal observation of the finishing envs must show ... after one more step
+    obs, rew, done = env.step_device(acts)
+    obs = obs.clone()
+    assert np.array_equal(done.cpu().numpy().astype(bool), out)
+    assert torch.equal(obs, env.render_current())  # finished envs: first frame of the new episode; the others: their new state
+    idx = torch.nonzero(done).reshape(-1)
+    term = torch.stack(env.terminal_observation(idx))
+    assert term.shape[0] == int(out.sum()) and not torch.equal(term, obs[idx])
+    # a car 900 units off the track sees grass only, apart from the indicator strip: the terminal frames are drawn, not blank
+    assert int((term[:, 0, :80] == 161).sum() + (term[:, 0, :80] == 176).sum()) > 0.9 * term[:, 0, :80].numel()
+    del before
+    env.close()
