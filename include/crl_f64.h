@@ -1,0 +1,185 @@
+/*
+ * crl_f64.h -- the one double-precision sin / cos / atan2 of the CarRacing path.
+ *
+ * The reference computes in CPython floats: `_create_track` walks the track with math.cos / sin /
+ * atan2 (car_racing/car_racing_multi_players.py:262-452), `camera_update` takes
+ * math.atan2(-vx, vy) (:791-804) and pygame's `transform.rotate` takes sin / cos of the view
+ * angle in C doubles (pygame 1.9.6 transform.c, called at :786).  libm's last bit differs between
+ * glibc (the reference's hosts, the CPU oracle) and the GPU's device library, and every one of
+ * these values is later truncated to an integer or drives a comparison -- so both the HIP
+ * kernels (competitive_rl_amd/csrc/car_track.hip, car_obs.hip) and the CPU oracle
+ * (oracle/car_oracle.c) evaluate THESE functions and agree bit for bit by construction.
+ *
+ * Accuracy: evaluated in double-double arithmetic (two_sum / fma-based two_prod) to about 2^-95
+ * relative, then rounded once: the result is the correctly rounded double except when the exact
+ * value lies within ~2^-42 ulp of a rounding boundary (probability ~2^-41 per call).  glibc 2.35 is
+ * documented to < 1 ulp, not correctly rounded; tests/test_f64_math.py measures how often the two
+ * differ (and checks these against mpmath).  Built with -ffp-contract=off on both sides: only the
+ * fma() calls written below fuse.
+ *
+ * Domain: finite arguments, |x| < 2^30 for sin / cos; atan2 arguments of ordinary magnitude (no
+ * overflow of x*y products).  Outside it the functions return NaN rather than a wrong value.
+ */
+#ifndef CRL_F64_H_
+#define CRL_F64_H_
+
+#if defined(__HIPCC__)
+#define CRL_F64_FN __host__ __device__ static inline
+#else
+#define CRL_F64_FN static inline
+#endif
+
+typedef struct crl_dd { double h, l; } crl_dd;
+
+CRL_F64_FN crl_dd crl_dd_mk(double h, double l) { crl_dd r; r.h = h; r.l = l; return r; }
+CRL_F64_FN crl_dd crl_two_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return crl_dd_mk(s, (a - (s - bb)) + (b - bb));
+}
+CRL_F64_FN crl_dd crl_quick_two_sum(double a, double b) { /* |a| >= |b| */
+    const double s = a + b;
+    return crl_dd_mk(s, b - (s - a));
+}
+CRL_F64_FN crl_dd crl_two_prod(double a, double b) {
+    const double p = a * b;
+    return crl_dd_mk(p, __builtin_fma(a, b, -p));
+}
+CRL_F64_FN crl_dd crl_dd_add(crl_dd a, crl_dd b) {
+    crl_dd s = crl_two_sum(a.h, b.h);
+    const crl_dd t = crl_two_sum(a.l, b.l);
+    s.l += t.h;
+    s = crl_quick_two_sum(s.h, s.l);
+    s.l += t.l;
+    return crl_quick_two_sum(s.h, s.l);
+}
+CRL_F64_FN crl_dd crl_dd_add_d(crl_dd a, double b) {
+    crl_dd s = crl_two_sum(a.h, b);
+    s.l += a.l;
+    return crl_quick_two_sum(s.h, s.l);
+}
+CRL_F64_FN crl_dd crl_dd_neg(crl_dd a) { return crl_dd_mk(-a.h, -a.l); }
+CRL_F64_FN crl_dd crl_dd_mul(crl_dd a, crl_dd b) {
+    crl_dd p = crl_two_prod(a.h, b.h);
+    p.l += a.h * b.l + a.l * b.h;
+    return crl_quick_two_sum(p.h, p.l);
+}
+CRL_F64_FN crl_dd crl_dd_mul_d(crl_dd a, double b) {
+    crl_dd p = crl_two_prod(a.h, b);
+    p.l += a.l * b;
+    return crl_quick_two_sum(p.h, p.l);
+}
+CRL_F64_FN crl_dd crl_dd_div(crl_dd a, crl_dd b) {
+    const double q1 = a.h / b.h;
+    crl_dd r = crl_dd_add(a, crl_dd_neg(crl_dd_mul_d(b, q1)));
+    const double q2 = r.h / b.h;
+    r = crl_dd_add(r, crl_dd_neg(crl_dd_mul_d(b, q2)));
+    const double q3 = r.h / b.h;
+    crl_dd q = crl_quick_two_sum(q1, q2);
+    return crl_dd_add_d(q, q3);
+}
+
+/* sin and cos of r = rh + rl, |r| <= pi/4 (+ a little): Taylor series, the low-order terms in
+ * double-double, the tail (below 2^-50 of the result) in plain doubles. */
+CRL_F64_FN void crl_sincos_kernel(crl_dd r, crl_dd *sn, crl_dd *cs) {
+    const crl_dd z = crl_dd_mul(r, r);
+    const double zh = z.h;
+    /* (-1)^k / (2k+1)!, k = 1..13 */
+    const double ts = 0x1.952c77030ad4ap-49 +
+                      zh * (-0x1.2f49b46814157p-57 +
+                            zh * (0x1.71b8ef6dcf572p-66 + zh * (-0x1.761b41316381ap-75 + zh * (0x1.3f3ccdd165fa9p-84 + zh * -0x1.d1ab1c2dccea3p-94))));
+    crl_dd p = crl_dd_add_d(crl_dd_mk(-0x1.ae7f3e733b81fp-41, -0x1.1d8656b0ee8cbp-97), zh * ts);
+    p = crl_dd_add(crl_dd_mk(0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87), crl_dd_mul(z, p));
+    p = crl_dd_add(crl_dd_mk(-0x1.ae64567f544e4p-26, 0x1.c062e06d1f209p-80), crl_dd_mul(z, p));
+    p = crl_dd_add(crl_dd_mk(0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73), crl_dd_mul(z, p));
+    p = crl_dd_add(crl_dd_mk(-0x1.a01a01a01a01ap-13, -0x1.a01a01a01a01ap-73), crl_dd_mul(z, p));
+    p = crl_dd_add(crl_dd_mk(0x1.1111111111111p-7, 0x1.1111111111111p-63), crl_dd_mul(z, p));
+    p = crl_dd_add(crl_dd_mk(-0x1.5555555555555p-3, -0x1.5555555555555p-57), crl_dd_mul(z, p));
+    *sn = crl_dd_add(r, crl_dd_mul(r, crl_dd_mul(z, p)));
+    /* (-1)^k / (2k)!, k = 1..13 */
+    const double tc = -0x1.6827863b97d97p-53 +
+                      zh * (0x1.e542ba4020225p-62 +
+                            zh * (-0x1.0ce396db7f853p-70 + zh * (0x1.f2cf01972f578p-80 + zh * (-0x1.88e85fc6a4e5ap-89 + zh * 0x1.0a18a2635085dp-98))));
+    crl_dd q = crl_dd_add_d(crl_dd_mk(0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101), zh * tc);
+    q = crl_dd_add(crl_dd_mk(-0x1.93974a8c07c9dp-37, -0x1.05d6f8a2efd1fp-92), crl_dd_mul(z, q));
+    q = crl_dd_add(crl_dd_mk(0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83), crl_dd_mul(z, q));
+    q = crl_dd_add(crl_dd_mk(-0x1.27e4fb7789f5cp-22, -0x1.cbbc05b4fa99ap-76), crl_dd_mul(z, q));
+    q = crl_dd_add(crl_dd_mk(0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76), crl_dd_mul(z, q));
+    q = crl_dd_add(crl_dd_mk(-0x1.6c16c16c16c17p-10, 0x1.f49f49f49f49fp-65), crl_dd_mul(z, q));
+    q = crl_dd_add(crl_dd_mk(0x1.5555555555555p-5, 0x1.5555555555555p-59), crl_dd_mul(z, q));
+    q = crl_dd_add_d(crl_dd_mul(z, q), -0.5);
+    *cs = crl_dd_add_d(crl_dd_mul(z, q), 1.0);
+}
+
+/* sin and cos of x as double-doubles; returns 0 outside the domain */
+CRL_F64_FN int crl_sincos_dd(double x, crl_dd *sn, crl_dd *cs) {
+    if (!(x > -0x1p30 && x < 0x1p30)) return 0;
+    /* x = k * pi/2 + r, |r| <= pi/4 (+ rounding of the quotient): pi/2 in three doubles */
+    const double kf = __builtin_floor(x * 0x1.45f306dc9c883p-1 + 0.5);
+    const crl_dd p1 = crl_two_prod(kf, 0x1.921fb54442d18p+0);
+    const double a = x - p1.h; /* exact (Sterbenz) for k != 0 */
+    crl_dd r = crl_two_sum(a, -p1.l);
+    r = crl_dd_add(r, crl_dd_neg(crl_two_prod(kf, 0x1.1a62633145c07p-54)));
+    r = crl_dd_add_d(r, -(kf * -0x1.f1976b7ed8fbcp-110));
+    crl_dd s, c;
+    crl_sincos_kernel(r, &s, &c);
+    const long long k = (long long)kf;
+    const int n = (int)(k & 3);
+    *sn = n == 0 ? s : n == 1 ? c : n == 2 ? crl_dd_neg(s) : crl_dd_neg(c);
+    *cs = n == 0 ? c : n == 1 ? crl_dd_neg(s) : n == 2 ? crl_dd_neg(c) : s;
+    return 1;
+}
+
+CRL_F64_FN void crl_sincos(double x, double *sn, double *cs) {
+    crl_dd s, c;
+    if (!crl_sincos_dd(x, &s, &c)) {
+        *sn = *cs = __builtin_nan("");
+        return;
+    }
+    *sn = x == 0.0 ? x : s.h; /* keeps the sign of a zero */
+    *cs = c.h;
+}
+CRL_F64_FN double crl_sin(double x) {
+    double s, c;
+    crl_sincos(x, &s, &c);
+    return s;
+}
+CRL_F64_FN double crl_cos(double x) {
+    double s, c;
+    crl_sincos(x, &s, &c);
+    return c;
+}
+
+/* atan2(y, x): a first-quadrant estimate good to ~2e-8 (degree-17 Taylor after folding to
+ * |t| <= tan(pi/8)), then ONE Newton step theta = a + atan((|y| cos a - |x| sin a) / (|x| cos a + |y| sin a))
+ * with sin a, cos a as double-doubles, the quadrant fix-up in double-double, one final rounding. */
+CRL_F64_FN double crl_atan2(double y, double x) {
+    if (x != x || y != y) return __builtin_nan("");
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double pi_h = 0x1.921fb54442d18p+1, pi_l = 0x1.1a62633145c07p-53, pio2_h = 0x1.921fb54442d18p+0;
+    if (ay == 0.0) return __builtin_signbit(x) ? __builtin_copysign(pi_h, y) : __builtin_copysign(0.0, y);
+    if (ax == 0.0) return __builtin_copysign(pio2_h, y);
+    if (!(ax < 0x1p500 && ay < 0x1p500 && ax > 0x1p-500 && ay > 0x1p-500)) return __builtin_nan("");
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    double t = mn / mx, base = 0.0;
+    if (t > 0.41421356237309503) t = (mn - mx) / (mn + mx), base = 0x1.921fb54442d18p-1;
+    const double w = t * t;
+    const double pa = t * (1.0 + w * (-0x1.5555555555555p-2 +
+                                        w * (0x1.999999999999ap-3 +
+                                             w * (-0x1.2492492492492p-3 +
+                                                  w * (0x1.c71c71c71c71cp-4 +
+                                                       w * (-0x1.745d1745d1746p-4 + w * (0x1.3b13b13b13b14p-4 + w * (-0x1.1111111111111p-4 + w * 0x1.e1e1e1e1e1e1ep-5))))))));
+    double a = base + pa;          /* angle of (mx, mn) from the longer axis */
+    if (ay > ax) a = pio2_h - a;   /* angle of (|x|, |y|) from the +x axis, in (0, pi/2) */
+    crl_dd s, c;
+    crl_sincos_dd(a, &s, &c);
+    crl_dd num = crl_dd_add(crl_two_prod(ay, c.h), crl_dd_neg(crl_two_prod(ax, s.h)));
+    num = crl_dd_add_d(num, ay * c.l - ax * s.l);
+    const crl_dd den = crl_dd_add(crl_two_prod(ax, c.h), crl_two_prod(ay, s.h));
+    crl_dd d = crl_dd_div(num, den);
+    d = crl_dd_add_d(d, -(d.h * d.h * d.h) * 0x1.5555555555555p-2); /* atan(d) = d - d^3/3 (|d| < 1e-6) */
+    crl_dd th = crl_dd_add(crl_two_sum(a, d.h), crl_dd_mk(d.l, 0.0));
+    if (__builtin_signbit(x)) th = crl_dd_add(crl_dd_mk(pi_h, pi_l), crl_dd_neg(th));
+    return __builtin_copysign(th.h, y);
+}
+
+#endif /* CRL_F64_H_ */

@@ -2,39 +2,54 @@
  * crl_rot.h -- the one sine/cosine evaluation of the CarRacing float32 physics.
  *
  * Box2D builds a rotation as b2Rot(angle) = (sinf(angle), cosf(angle)) (b2Math.h), so the solver's
- * results depend on libm's last bit -- which differs between glibc (the reference's hosts, the CPU
- * oracle) and the GPU's device library.  Both the HIP kernels (competitive_rl_amd/csrc/car_*.hip)
- * and the CPU oracle (oracle/car_oracle.c) therefore evaluate THIS function: Cephes' single-precision
- * kernels (three-constant Cody-Waite reduction by pi/4, degree-7 / degree-8 polynomials, <= 2 ulp
- * for |x| < 8192), written as individual float multiplies and adds.  Both sides are compiled with
+ * results depend on libm's last bit -- which differs between glibc versions (the reference's hosts),
+ * other C libraries and the GPU's device library.  Both the HIP kernels (competitive_rl_amd/csrc/car_*.hip)
+ * and the CPU oracle (oracle/car_oracle.c, default build) therefore evaluate THIS function: the
+ * CORRECTLY ROUNDED float32 sine and cosine -- argument reduction and a Taylor polynomial in float64
+ * (relative error < 2^-52), rounded to float32 once, which is the correctly rounded result except when
+ * the exact value lies within ~2^-28 ulp of a float32 rounding boundary.  Both sides are compiled with
  * -ffp-contract=off, so every operation rounds once and the float32 state of a car is reproducible
- * bit for bit across CPU and GPU.  (Against any particular libm the difference is that libm's own
- * last-bit error; parity against real Box2D builds is unpinned either way)
+ * bit for bit across CPU and GPU.
+ *
+ * Distance to a particular libm = that libm's own rounding error: glibc 2.35's sinf / cosf return the
+ * neighbouring float in 1.3 % of calls (measured, tests/test_f64_math.py); rounds 1-2 used Cephes'
+ * float32 kernels here (<= 2 ulp, different from glibc in 14-17 % of calls).
+ * tests/test_oracle_libm_delta.py measures what that does to one world.Step.
  */
 #ifndef CRL_ROT_H_
 #define CRL_ROT_H_
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define CRL_ROT_FN __host__ __device__ static inline
 #else
 #define CRL_ROT_FN static inline
 #endif
 
+/* |x| < 2^20 * pi/2 (angles of a car: a few hundred radians at most) */
 CRL_ROT_FN void crl_sincosf(float x, float *sn, float *cs) {
-    const float ax = x < 0.0f ? -x : x;
-    int j = (int)(ax * 1.27323954473516f); /* 4/pi */
-    j = (j + 1) & ~1;                      /* nearest even octant: ax = j * pi/4 + r, |r| <= pi/4 */
-    const float y = (float)j;
-    const float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
-    const float z = r * r;
-    const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    const float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
-    const int q = (j >> 1) & 3;
-    float s = (q & 1) ? pc : ps, c = (q & 1) ? ps : pc;
-    if (q == 2 || q == 3) s = -s;
-    if (q == 1 || q == 2) c = -c;
-    *sn = x < 0.0f ? -s : s;
-    *cs = c;
+    if (x == 0.0f) { /* keeps the sign of a zero, like sinf */
+        *sn = x, *cs = 1.0f;
+        return;
+    }
+    const double xd = (double)x;
+    const double kf = __builtin_floor(xd * 0x1.45f306dc9c883p-1 + 0.5); /* nearest multiple of pi/2 */
+    /* pi/2 = HI (33 bits: kf * HI is exact) + LO */
+    const double r = (xd - kf * 0x1.921fb54400000p+0) - kf * 0x1.0b4611a626331p-34;
+    const double z = r * r;
+    const double ps = -0x1.5555555555555p-3 +
+                      z * (0x1.1111111111111p-7 +
+                           z * (-0x1.a01a01a01a01ap-13 +
+                                z * (0x1.71de3a556c734p-19 + z * (-0x1.ae64567f544e4p-26 + z * (0x1.6124613a86d09p-33 + z * -0x1.ae7f3e733b81fp-41)))));
+    const double pc = -0x1.0000000000000p-1 +
+                      z * (0x1.5555555555555p-5 +
+                           z * (-0x1.6c16c16c16c17p-10 +
+                                z * (0x1.a01a01a01a01ap-16 +
+                                     z * (-0x1.27e4fb7789f5cp-22 + z * (0x1.1eed8eff8d898p-29 + z * (-0x1.93974a8c07c9dp-37 + z * 0x1.ae7f3e733b81fp-45))))));
+    const double s = r + r * (z * ps), c = 1.0 + z * pc;
+    const int q = (int)((long long)kf & 3);
+    const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    *sn = (float)((q == 2 || q == 3) ? -so : so);
+    *cs = (float)((q == 1 || q == 2) ? -co : co);
 }
 
 #endif /* CRL_ROT_H_ */

@@ -10,7 +10,13 @@
  *     third-party dependency that is neither vendored nor installable; its published
  *     algorithm (Box2D 2.3 b2Island::Solve / b2RevoluteJoint / b2PolygonShape::ComputeMass)
  *     is restated here in float32 (joints, wheel-tile sensors, car-car contacts).  PARITY UNPINNED.
- *   - observation raster: analytic (no 10000x10000 pygame map), PARITY UNPINNED.
+ *   - observation raster: restated literally (pre-rastered palette map at reset, 192 x 192 crop,
+ *     pygame's nearest-neighbour rotate, blit, car polygons, indicator bars).  The reference's own
+ *     Python around the pygame calls is PINNED via tests/golden/car_obs.npz; pygame 1.9.6 itself
+ *     (third-party, not installable) is restated from its published source, UNPINNED.
+ *   - liboracle.so evaluates sin / cos / atan2 through include/crl_rot.h and include/crl_f64.h (shared
+ *     with the HIP kernels); liboracle_libm.so (-DCRL_LIBM) calls the host libm like the reference
+ *     does and is the build the reference-recorded fixtures are checked against bit for bit.
  *
  * Citations: car_racing/car_racing_multi_players.py = "crmp", car_racing/car_dynamics.py = "cd".
  * Build: -O2 -ffp-contract=off (f64 parts are CPython arithmetic, f32 parts Box2D's).
@@ -21,7 +27,24 @@
 #include <string.h>
 
 #include "car_oracle.h"
-#include "../include/crl_rot.h" /* the one sin/cos evaluation shared with the HIP kernels */
+/* Transcendentals.  Default build: the evaluations shared with the HIP kernels (include/crl_rot.h for
+ * Box2D's float32 b2Rot, include/crl_f64.h for CPython's math.sin / cos / atan2 and pygame's C doubles),
+ * so oracle and GPU agree bit for bit.  -DCRL_LIBM (liboracle_libm.so): the host's libm, i.e. what the
+ * reference itself calls -- that build is the one pinned bit for bit to the fixtures recorded from
+ * the reference's Python; tests/test_oracle_libm_delta.py measures the distance between the two. */
+#ifdef CRL_LIBM
+static inline void rot_sincosf(float a, float *s, float *c) { *s = sinf(a), *c = cosf(a); }
+#define m_sin sin
+#define m_cos cos
+#define m_atan2 atan2
+#else
+#include "../include/crl_f64.h"
+#include "../include/crl_rot.h"
+#define rot_sincosf crl_sincosf
+#define m_sin crl_sin
+#define m_cos crl_cos
+#define m_atan2 crl_atan2
+#endif
 
 /* ---- constants (crmp:54-88, cd:17-51) */
 #define SCALE 6.0
@@ -64,14 +87,14 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
             start_alpha = 2 * M_PI * (-0.5) / CHECKPOINTS;
             rad = 1.5 * TRACK_RAD;
         }
-        cp[c][0] = alpha, cp[c][1] = rad * cos(alpha), cp[c][2] = rad * sin(alpha);
+        cp[c][0] = alpha, cp[c][1] = rad * m_cos(alpha), cp[c][2] = rad * m_sin(alpha);
     }
     static __thread double tr[2600][4];
     double x = 1.5 * TRACK_RAD, y = 0, beta = 0;
     long dest_i = 0;
     int laps = 0, n = 0, no_freeze = 2500, visited_other_side = 0;
     for (;;) {
-        double alpha = atan2(y, x);
+        double alpha = m_atan2(y, x);
         if (visited_other_side && alpha > 0) laps++, visited_other_side = 0;
         if (alpha < 0) visited_other_side = 1, alpha += 2 * M_PI;
         double dest_alpha, dest_x, dest_y;
@@ -86,7 +109,7 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
             if (!failed) break;
             alpha -= 2 * M_PI;
         }
-        double r1x = cos(beta), r1y = sin(beta), p1x = -r1y, p1y = r1x;
+        double r1x = m_cos(beta), r1y = m_sin(beta), p1x = -r1y, p1y = r1x;
         double dest_dx = dest_x - x, dest_dy = dest_y - y;
         double proj = r1x * dest_dx + r1y * dest_dy;
         while (beta - alpha > 1.5 * M_PI) beta -= 2 * M_PI;
@@ -113,7 +136,7 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
     int len = (i2 - 1) - i1;
     if (len <= 0 || len > CAR_MAX_TILES) return 0;
     double(*t)[4] = &tr[i1];
-    double fb = t[0][1], fpx = cos(fb), fpy = sin(fb);
+    double fb = t[0][1], fpx = m_cos(fb), fpy = m_sin(fb);
     double a = fpx * (t[0][2] - t[len - 1][2]), b = fpy * (t[0][3] - t[len - 1][3]);
     double glued = sqrt(a * a + b * b);
     if (glued > TRACK_DETAIL_STEP) return 0;
@@ -139,21 +162,21 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
         const double *p1 = t[k], *p2 = t[((k - 1) % len + len) % len];
         double b1 = p1[1], x1 = p1[2], y1 = p1[3], b2 = p2[1], x2 = p2[2], y2 = p2[3];
         double v[5][2] = {
-            {x1 - TRACK_WIDTH * cos(b1), y1 - TRACK_WIDTH * sin(b1)},
-            {x1 - TRACK_WIDTH / 2 * cos(b1 - M_PI / 2), y1 - TRACK_WIDTH / 2 * sin(b1 - M_PI / 2)},
-            {x1 + TRACK_WIDTH * cos(b1), y1 + TRACK_WIDTH * sin(b1)},
-            {x2 + TRACK_WIDTH * cos(b2), y2 + TRACK_WIDTH * sin(b2)},
-            {x2 - TRACK_WIDTH * cos(b2), y2 - TRACK_WIDTH * sin(b2)},
+            {x1 - TRACK_WIDTH * m_cos(b1), y1 - TRACK_WIDTH * m_sin(b1)},
+            {x1 - TRACK_WIDTH / 2 * m_cos(b1 - M_PI / 2), y1 - TRACK_WIDTH / 2 * m_sin(b1 - M_PI / 2)},
+            {x1 + TRACK_WIDTH * m_cos(b1), y1 + TRACK_WIDTH * m_sin(b1)},
+            {x2 + TRACK_WIDTH * m_cos(b2), y2 + TRACK_WIDTH * m_sin(b2)},
+            {x2 - TRACK_WIDTH * m_cos(b2), y2 - TRACK_WIDTH * m_sin(b2)},
         };
         memcpy(out->tile[k], v, sizeof(v));
         out->border[k] = border[k];
         if (border[k]) {
             double side = sgn(b2 - b1);
             double bp[4][2] = {
-                {x1 + side * TRACK_WIDTH * cos(b1), y1 + side * TRACK_WIDTH * sin(b1)},
-                {x1 + side * (TRACK_WIDTH + BORDER) * cos(b1), y1 + side * (TRACK_WIDTH + BORDER) * sin(b1)},
-                {x2 + side * (TRACK_WIDTH + BORDER) * cos(b2), y2 + side * (TRACK_WIDTH + BORDER) * sin(b2)},
-                {x2 + side * TRACK_WIDTH * cos(b2), y2 + side * TRACK_WIDTH * sin(b2)},
+                {x1 + side * TRACK_WIDTH * m_cos(b1), y1 + side * TRACK_WIDTH * m_sin(b1)},
+                {x1 + side * (TRACK_WIDTH + BORDER) * m_cos(b1), y1 + side * (TRACK_WIDTH + BORDER) * m_sin(b1)},
+                {x2 + side * (TRACK_WIDTH + BORDER) * m_cos(b2), y2 + side * (TRACK_WIDTH + BORDER) * m_sin(b2)},
+                {x2 + side * TRACK_WIDTH * m_cos(b2), y2 + side * TRACK_WIDTH * m_sin(b2)},
             };
             memcpy(out->border_poly[k], bp, sizeof(bp));
         } else {
@@ -248,7 +271,7 @@ const car_consts *car_oracle_consts(void) {
 
 /* b2Body state <-> transform: xf.q = b2Rot(a); xf.p = c - q * localCenter */
 static void body_xf(const car_body *b, v2 lc, float *s, float *c, v2 *p) {
-    crl_sincosf(b->a, s, c);
+    rot_sincosf(b->a, s, c);
     *p = vsub(V(b->cx, b->cy), rot(*s, *c, lc));
 }
 
@@ -259,7 +282,7 @@ void car_oracle_place(car_state *car, double init_angle, double init_x, double i
     init_x -= birth_place_index % 2 * 5;
     init_y -= floor(birth_place_index / 2.0) * 10;
     float a = (float)init_angle, s, c;
-    crl_sincosf(a, &s, &c);
+    rot_sincosf(a, &s, &c);
     v2 p = V((float)init_x, (float)init_y);
     v2 com = vadd(p, rot(s, c, V(K.hull_lc[0], K.hull_lc[1])));
     car->hull.cx = com.x, car->hull.cy = com.y, car->hull.a = a;
@@ -428,7 +451,7 @@ static void isl_joints_init(car_state *car, joint_tmp *jt, float dt_ratio) {
         car_body *B = &car->wheel[w];
         joint_tmp *j = &jt[w];
         float sA, cA;
-        crl_sincosf(H->a, &sA, &cA);
+        rot_sincosf(H->a, &sA, &cA);
         j->rA = rot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA));
         j->rB = V(0, 0); /* rot(qB, localAnchorB - localCenterB) = 0 */
         v2 rA = j->rA, rB = j->rB;
@@ -548,7 +571,7 @@ static int isl_joints_pos(car_state *car) {
                 H->a -= iA * li, B->a += iB * li;
             }
             float sA, cA;
-            crl_sincosf(H->a, &sA, &cA);
+            rot_sincosf(H->a, &sA, &cA);
             v2 rA = rot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA)), rB = V(0, 0);
             v2 C = vsub(vsub(vadd(V(B->cx, B->cy), rB), V(H->cx, H->cy)), rA);
             float posErr = sqrtf(vdot(C, C));
@@ -658,7 +681,7 @@ static bref body_of(car_env *e, int car, int fixture) {
 }
 static xform xf_of(const bref *r) {
     xform t;
-    crl_sincosf(r->b->a, &t.s, &t.c);
+    rot_sincosf(r->b->a, &t.s, &t.c);
     t.p = vsub(V(r->b->cx, r->b->cy), rot(t.s, t.c, r->lc));
     return t;
 }
@@ -1026,7 +1049,7 @@ int car_oracle_reset(car_env *e, const double *u, int max_attempts, int shuffle_
 
 static void wheel_world_poly(const car_body *b, v2 *out) {
     float s, c;
-    crl_sincosf(b->a, &s, &c);
+    rot_sincosf(b->a, &s, &c);
     for (int k = 0; k < 4; k++) out[k] = vadd(rot(s, c, V(K.wheel_poly[k][0], K.wheel_poly[k][1])), V(b->cx, b->cy));
 }
 
@@ -1103,7 +1126,7 @@ void car_oracle_step_repeat(car_env *e, const double (*actions)[2], int repeat, 
                 double ms, f[2];
                 double ja = (double)(B->a - car->hull.a - 0.0f);
                 float qs, qc;
-                crl_sincosf(B->a, &qs, &qc);
+                rot_sincosf(B->a, &qs, &qc);
                 car_oracle_wheel(dt, car->steer[w], car->gas[w], car->brake[w], ja, (double)qs, (double)qc, (double)B->vx, (double)B->vy,
                                  car_oracle_wheel_on_road(e, c, w), &car->omega[w], &car->phase[w], &ms, f);
                 car->motor_speed[w] = (float)ms;
@@ -1152,13 +1175,29 @@ void car_oracle_hull_position(const car_env *e, int c, float out[3]) {
 int car_oracle_env_size(void) { return (int)sizeof(car_env); }
 
 /* ------------------------------------------------------------------ observation raster
- * CarRacing.get_observation (crmp:622-634): camera_update("rgb_array") :791-804, camera_view
- * :764-789, Car.draw_for_pygame (cd:284-298), render_indicators_for_pygame :645-670, then luma
- * 0.299R+0.587G+0.114B truncated to uint8.  The reference pre-rasterises a 10000x10000 map with
- * pygame and rotates a crop of it; neither is available here, so the background is classified
- * ANALYTICALLY at the pixel centre (point-in-polygon in world space).  Cars and indicator bars
- * follow pygame 1.9.6's integer polygon fill rule [from memory of its draw.c].  PARITY
- * UNPINNED; the 5-px reward text comes from pre-baked 1-bit strings (car_oracle_set_text). */
+ * CarRacing.get_observation (crmp:622-634), restated the way the reference computes it:
+ *   reset:  render_road_for_observation_map (:732-755, called at :519) pre-rasters grass, the
+ *           range(-20, 20, 2) squares and every road / border polygon with pygame.draw.polygon
+ *           into the 10000 x 10000 `observation_playground` at obs_scale px per world unit;
+ *   step:   camera_update("rgb_array") :791-804, camera_view :764-789 = 192 x 192 subsurface at the
+ *           int-truncated camera pixel -> pygame.transform.rotate (nearest neighbour, 16.16 fixed
+ *           point) -> blit so that the rotated centre lands on (48, 48); then Car.draw_for_pygame
+ *           (cd:284-298) for every car, render_indicators_for_pygame :645-670, and the luma
+ *           0.299 R + 0.587 G + 0.114 B truncated to uint8.
+ * pygame 1.9.6 (setup.py:7) is a third-party dependency that is neither vendored nor installable
+ * here: its draw_fillpoly / drawhorzlineclip (draw.c), surf_rotate / rotate / rotate90
+ * (transform.c), Rect and blit argument conversion (truncation toward zero) are restated from the
+ * published source [from memory]; PARITY AGAINST REAL pygame UNPINNED.  What IS pinned: the
+ * reference's own Python around those calls (which polygons, in which order and colours, the
+ * camera, the crop rectangle, the car transforms, the indicator geometry) through
+ * tests/golden/car_obs.npz, recorded from the reference's get_observation running over a
+ * pygame stand-in that implements the same restated primitives.
+ *
+ * The map is kept as a 7-colour palette (one byte per pixel here) of the WINDOW
+ * [org, org + w)^2 of the 10000^2 surface; everything outside the window is grass as long as no
+ * polygon leaves it (car_oracle_build_map returns the number of span pixels it had to drop:
+ * 0 for every track, tests assert it; org = 0, w = 10000 is the reference's whole surface).
+ * The 5-px reward text comes from pre-baked 1-bit strings (car_oracle_set_text). */
 #define G_GRASS 161
 #define G_LIGHT 176
 #define G_WHITE 255
@@ -1169,6 +1208,109 @@ int car_oracle_env_size(void) { return (int)sizeof(car_env); }
 #define G_ABS_REAR 44
 #define G_GREEN 149
 static const uint8_t G_ROAD[3] = {101, 103, 107};
+enum { P_GRASS = 0, P_LIGHT = 1, P_ROAD0 = 2, P_WHITE = 5, P_RED = 6 };
+/* luma of (102,204,102), (102,229,102), road 102 / 104 / 107, (255,255,255), (255,0,0): each
+ * 0.299 R + 0.587 G + 0.114 B in float64, truncated (crmp:631-633) */
+static const uint8_t PAL_GRAY[8] = {G_GRASS, G_LIGHT, 101, 103, 107, G_WHITE, G_RED, 0};
+#define MAP_SURFACE 10000 /* self.world_size (crmp:216) */
+
+typedef struct { uint8_t *px; int org, w; long dropped; } map_win;
+
+/* pygame draw.c drawhorzlineclip on the 10000^2 surface (clip rect = whole surface), restricted to the window */
+static void map_hline(map_win *m, int x1, int y, int x2, uint8_t v) {
+    if (y < 0 || y >= MAP_SURFACE) return;
+    if (x2 < x1) { int t = x1; x1 = x2; x2 = t; }
+    if (x1 < 0) x1 = 0;
+    if (x2 > MAP_SURFACE - 1) x2 = MAP_SURFACE - 1;
+    if (x2 < 0 || x1 >= MAP_SURFACE) return;
+    for (int x = x1; x <= x2; x++) {
+        const int wx = x - m->org, wy = y - m->org;
+        if (wx < 0 || wy < 0 || wx >= m->w || wy >= m->w) { m->dropped++; continue; }
+        m->px[(size_t)wy * m->w + wx] = v;
+    }
+}
+
+static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+/* pygame draw.c draw_fillpoly, scanline by scanline */
+static void map_fillpoly(map_win *m, const int *vx, const int *vy, int n, uint8_t v) {
+    int miny = vy[0], maxy = vy[0], xs[16];
+    for (int i = 1; i < n; i++) {
+        if (vy[i] < miny) miny = vy[i];
+        if (vy[i] > maxy) maxy = vy[i];
+    }
+    if (miny == maxy) { /* "Special case: polygon only 1 pixel high." */
+        int minx = vx[0], maxx = vx[0];
+        for (int i = 1; i < n; i++) {
+            if (vx[i] < minx) minx = vx[i];
+            if (vx[i] > maxx) maxx = vx[i];
+        }
+        map_hline(m, minx, miny, maxx, v);
+        return;
+    }
+    for (int y = miny; y <= maxy; y++) {
+        int ints = 0;
+        for (int i = 0; i < n; i++) {
+            const int ind1 = i ? i - 1 : n - 1, ind2 = i;
+            int y1 = vy[ind1], y2 = vy[ind2], x1, x2;
+            if (y1 < y2) x1 = vx[ind1], x2 = vx[ind2];
+            else if (y1 > y2) y2 = vy[ind1], y1 = vy[ind2], x2 = vx[ind1], x1 = vx[ind2];
+            else continue;
+            if ((y >= y1 && y < y2) || (y == maxy && y > y1 && y <= y2)) xs[ints++] = (y - y1) * (x2 - x1) / (y2 - y1) + x1;
+        }
+        qsort(xs, ints, sizeof(int), cmp_int);
+        for (int i = 0; i + 1 < ints; i += 2) map_hline(m, xs[i], y, xs[i + 1], v);
+    }
+}
+
+static double obs_scale(void) { return (10 / (100 / sqrt(96.0))) * 1.8; } /* crmp:214-215 */
+
+/* One vertex of a map polygon: (obs_scale * -v + world_size / 2) as a Python float, truncated by
+ * pygame's pg_TwoIntsFromObj (crmp:745-753) */
+static int map_coord(double v) { return (int)(obs_scale() * -v + MAP_SURFACE / 2.0); }
+
+/* render_road_for_observation_map (crmp:732-755) into map[w * w] (palette indices); returns the
+ * number of polygon pixels that fell outside the window */
+long car_oracle_build_map(const car_env *e, uint8_t *map, int org, int w) {
+    map_win m = {map, org, w, 0};
+    memset(map, P_GRASS, (size_t)w * w); /* screen.fill((0.4 * 255, 0.8 * 255, 0.4 * 255)) */
+    const double k = PLAYFIELD / 20.0;
+    for (int x = -20; x < 20; x += 2)
+        for (int y = -20; y < 20; y += 2) {
+            const double sq[4][2] = {{k * x + k, k * y + 0}, {k * x + 0, k * y + 0}, {k * x + 0, k * y + k}, {k * x + k, k * y + k}};
+            int vx[4], vy[4];
+            for (int i = 0; i < 4; i++) vx[i] = map_coord(sq[i][0]), vy[i] = map_coord(sq[i][1]);
+            map_fillpoly(&m, vx, vy, 4, P_LIGHT);
+        }
+    /* road_poly in the order _create_track appends it (crmp:400-441): for i = n-1 .. 0 the tile, then its border */
+    for (int i = e->trk.n - 1; i >= 0; i--) {
+        int vx[5], vy[5];
+        for (int j = 0; j < 5; j++) vx[j] = map_coord(e->trk.tile[i][j][0]), vy[j] = map_coord(e->trk.tile[i][j][1]);
+        map_fillpoly(&m, vx, vy, 5, (uint8_t)(P_ROAD0 + i % 3)); /* 255 * (0.4 + 0.01 * (i % 3)) -> 102, 104, 107 */
+        if (e->trk.border[i]) {
+            for (int j = 0; j < 4; j++) vx[j] = map_coord(e->trk.border_poly[i][j][0]), vy[j] = map_coord(e->trk.border_poly[i][j][1]);
+            map_fillpoly(&m, vx, vy, 4, i % 2 == 0 ? P_WHITE : P_RED);
+        }
+    }
+    return m.dropped;
+}
+
+/* integer map-space vertices of the polygons of build_map, for the HIP side's tests: out[i][0..4] tile, [5..8] border */
+void car_oracle_map_vertices(const car_env *e, int32_t *out /*[n][9][2]*/) {
+    for (int i = 0; i < e->trk.n; i++) {
+        for (int j = 0; j < 5; j++) out[(i * 9 + j) * 2] = map_coord(e->trk.tile[i][j][0]), out[(i * 9 + j) * 2 + 1] = map_coord(e->trk.tile[i][j][1]);
+        for (int j = 0; j < 4; j++) {
+            out[(i * 9 + 5 + j) * 2] = e->trk.border[i] ? map_coord(e->trk.border_poly[i][j][0]) : 0;
+            out[(i * 9 + 5 + j) * 2 + 1] = e->trk.border[i] ? map_coord(e->trk.border_poly[i][j][1]) : 0;
+        }
+    }
+}
+
+static uint8_t map_at(const uint8_t *map, int org, int w, int x, int y) {
+    const int wx = x - org, wy = y - org;
+    if (wx < 0 || wy < 0 || wx >= w || wy >= w) return P_GRASS;
+    return map[(size_t)wy * w + wx];
+}
 
 /* pygame draw_fillpoly membership test for one pixel */
 static int fillpoly_hit(const int *px, const int *py, int n, int x, int y) {
@@ -1210,44 +1352,31 @@ static void fill_rect(uint8_t *out, double x, double y, double w, double h, uint
 static const uint32_t *TEXT_BITS = 0; /* [3001][10] reward read-out bitmaps, or NULL */
 void car_oracle_set_text(const uint32_t *bits) { TEXT_BITS = bits; }
 
-void car_oracle_render(const car_env *e, int viewer, uint8_t *out) {
+typedef struct { double angle; float s, c; v2 off; double vx, vy; } camera;
+
+/* camera_update("rgb_array") (crmp:791-804) */
+static camera camera_of(const car_env *e, int viewer) {
     car_oracle_consts();
     const car_state *me = &e->car[viewer];
-    /* camera_update("rgb_array") */
-    double angle = (double)me->hull.a;
-    double vx = (double)me->hull.vx, vy = (double)me->hull.vy;
-    if (vx * vx + vy * vy > 0.5 * 0.5) angle = atan2(-vx, vy);
-    float af = (float)angle, s, c;
-    crl_sincosf(af, &s, &c);
+    camera cam;
+    cam.angle = (double)me->hull.a;
+    cam.vx = (double)me->hull.vx, cam.vy = (double)me->hull.vy;
+    if (cam.vx * cam.vx + cam.vy * cam.vy > 0.5 * 0.5) cam.angle = m_atan2(-cam.vx, cam.vy);
+    rot_sincosf((float)cam.angle, &cam.s, &cam.c); /* tmp.angle = angle: b2Rot(float32) */
     float hs, hc;
     v2 hp;
     body_xf(&me->hull, V(K.hull_lc[0], K.hull_lc[1]), &hs, &hc, &hp);
-    v2 off = vadd(hp, V(c * 0.0f - s * 16.0f, s * 0.0f + c * 16.0f));
-    const double obs_scale = (10 / (100 / sqrt(96.0))) * 1.8;
-    const float inv_scale = (float)(1.0 / obs_scale), scale_f = (float)obs_scale;
-    const float kf = (float)(PLAYFIELD / 20.0);
-    /* background */
-    for (int sy = 0; sy < 96; sy++)
-        for (int sx = 0; sx < 96; sx++) {
-            float dx = ((float)sx + 0.5f) - 48.0f, dy = ((float)sy + 0.5f) - 48.0f;
-            float rx = c * dx - s * dy, ry = s * dx + c * dy;
-            v2 pw = V(off.x - rx * inv_scale, off.y - ry * inv_scale);
-            float fx = floorf(pw.x / kf), fy = floorf(pw.y / kf);
-            int ix = (int)fx, iy = (int)fy;
-            int light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
-            uint8_t g = light ? G_LIGHT : G_GRASS;
-            for (int t = 0; t < e->trk.n; t++) {
-                const float *bb = e->tile_aabb[t];
-                if (e->trk.border[t]) {
-                    v2 bp[4];
-                    make_ccw(e->trk.border_poly[t], 4, 1.0, bp);
-                    if (point_in_convex(pw, bp, 4)) { g = (t % 2 == 0) ? G_WHITE : G_RED; break; }
-                }
-                if (pw.x < bb[0] || pw.x > bb[2] || pw.y < bb[1] || pw.y > bb[3]) continue;
-                if (point_in_convex(pw, (const v2 *)e->tile32[t], 5)) { g = G_ROAD[t % 3]; break; }
-            }
-            out[sy * 96 + sx] = g;
-        }
+    cam.off = vadd(hp, V(cam.c * 0.0f - cam.s * 16.0f, cam.s * 0.0f + cam.c * 16.0f)); /* hull.position + tmp * (0, 16) */
+    return cam;
+}
+
+/* cars (draw_for_pygame, cd:284-298), indicators (crmp:645-670), reward text: drawn over the background */
+static void draw_overlays(const car_env *e, int viewer, const camera *cam, uint8_t *out) {
+    const car_state *me = &e->car[viewer];
+    const float s = cam->s, c = cam->c;
+    const v2 off = cam->off;
+    const double vx = cam->vx, vy = cam->vy;
+    const float scale_f = (float)obs_scale();
     /* cars: car 0 then car 1; per car wheels then hull (cd:286-298) */
     for (int k = 0; k < 2; k++) {
         const car_state *car = &e->car[k];
@@ -1298,4 +1427,117 @@ void car_oracle_render(const car_env *e, int viewer, uint8_t *out) {
             for (int col = 0; col < 32; col++)
                 if ((TEXT_BITS[idx * 10 + row] >> col) & 1u) out[(91 + row) * 96 + col] = 255;
     }
+}
+
+/* camera_view(mode="rgb_array") (crmp:764-789): where each of the 96 x 96 screen pixels comes from.
+ * src_xy[2 * p] / [2 * p + 1] = map pixel (on the 10000^2 surface) shown at screen pixel p, or
+ * (-1, -1) where pygame's rotate writes its background colour (the subsurface's first pixel), or
+ * (-2, -2) where the blit does not reach; rect_xy = top-left corner of the 192 x 192 subsurface. */
+void car_oracle_view_sources(const car_env *e, int viewer, int32_t *src_xy, int32_t *rect_xy) {
+    const camera cam = camera_of(e, viewer);
+    const int W = 96, H = 96, SW = 2 * W, SH = 2 * H;
+    const double pos0 = obs_scale() * -(double)cam.off.x + MAP_SURFACE / 2.0, pos1 = obs_scale() * -(double)cam.off.y + MAP_SURFACE / 2.0;
+    const int rx = (int)(pos0 - W), ry = (int)(pos1 - H); /* pygame.Rect(pos[0] - width, pos[1] - height, 2 * width, 2 * height) */
+    rect_xy[0] = rx, rect_xy[1] = ry;
+    const float angle = (float)(57.295779513 * cam.angle); /* PyArg_ParseTuple "f" */
+    if (!fmod((double)angle, (double)90.0f)) {             /* surf_rotate: rotate90(surf, (int)angle) */
+        int numturns = ((int)angle / 90) % 4;
+        if (numturns < 0) numturns = 4 + numturns;
+        const int dw = (numturns % 2) ? SH : SW, dh = (numturns % 2) ? SW : SH;
+        const int cx = dw >> 1, cy = dh >> 1; /* camera_view.get_rect().center */
+        for (int Y = 0; Y < H; Y++)
+            for (int X = 0; X < W; X++) {
+                const int x = X - (-cx + W / 2), y = Y - (-cy + H / 2); /* screen.blit(camera_view, (-center[0] + width / 2, ...)) */
+                int sx, sy;
+                if (numturns == 0) sx = x, sy = y;
+                else if (numturns == 1) sx = SW - 1 - y, sy = x;
+                else if (numturns == 2) sx = SW - 1 - x, sy = SH - 1 - y;
+                else sx = y, sy = SH - 1 - x;
+                int32_t *o = src_xy + 2 * (Y * W + X);
+                if (x < 0 || y < 0 || x >= dw || y >= dh) o[0] = o[1] = -2;
+                else o[0] = rx + sx, o[1] = ry + sy;
+            }
+        return;
+    }
+    /* surf_rotate + rotate (pygame 1.9.6 transform.c) */
+    const double radangle = angle * .01745329251994329;
+    const double sangle = m_sin(radangle), cangle = m_cos(radangle);
+    const double x = SW, y = SH, cxd = cangle * x, cyd = cangle * y, sxd = sangle * x, syd = sangle * y;
+#define MAX2(a, b) ((a) > (b) ? (a) : (b))
+    const int nxmax = (int)(MAX2(MAX2(MAX2(fabs(cxd + syd), fabs(cxd - syd)), fabs(-cxd + syd)), fabs(-cxd - syd)));
+    const int nymax = (int)(MAX2(MAX2(MAX2(fabs(sxd + cyd), fabs(sxd - cyd)), fabs(-sxd + cyd)), fabs(-sxd - cyd)));
+#undef MAX2
+    const int dcy = nymax / 2;
+    const int xd = (SW - nxmax) * 32768, yd = (SH - nymax) * 32768; /* ((src->w - dst->w) << 15) */
+    const int isin = (int)(sangle * 65536), icos = (int)(cangle * 65536);
+    const int ax = (nxmax << 15) - (int)(cangle * ((nxmax - 1) << 15));
+    const int ay = (nymax << 15) - (int)(sangle * ((nxmax - 1) << 15));
+    const int xmaxval = (SW << 16) - 1, ymaxval = (SH << 16) - 1;
+    const int bx = -(nxmax >> 1) + W / 2, by = -(nymax >> 1) + H / 2; /* blit position of the rotated surface */
+    for (int Y = 0; Y < H; Y++)
+        for (int X = 0; X < W; X++) {
+            const int xx = X - bx, yy = Y - by; /* pixel of the rotated surface */
+            int32_t *o = src_xy + 2 * (Y * W + X);
+            if (xx < 0 || yy < 0 || xx >= nxmax || yy >= nymax) {
+                o[0] = o[1] = -2;
+                continue;
+            }
+            const int dx = (ax + (isin * (dcy - yy))) + xd + icos * xx; /* row start, then xx steps of (icos, isin) */
+            const int dy = (ay - (icos * (dcy - yy))) + yd + isin * xx;
+            if (dx < 0 || dy < 0 || dx > xmaxval || dy > ymaxval) o[0] = o[1] = -1;
+            else o[0] = rx + (dx >> 16), o[1] = ry + (dy >> 16);
+        }
+}
+
+/* the observation of `viewer` from a map built by car_oracle_build_map */
+void car_oracle_render(const car_env *e, const uint8_t *map, int org, int w, int viewer, uint8_t *out) {
+    int32_t *src = (int32_t *)malloc(sizeof(int32_t) * 96 * 96 * 2), rect[2];
+    car_oracle_view_sources(e, viewer, src, rect);
+    for (int p = 0; p < 96 * 96; p++) {
+        uint8_t pal;
+        if (src[2 * p] == -1) pal = map_at(map, org, w, rect[0], rect[1]); /* bgcolor = first pixel of the subsurface */
+        else if (src[2 * p] == -2) pal = 7;                                /* screen pixel the blit does not reach (black surface) */
+        else pal = map_at(map, org, w, src[2 * p], src[2 * p + 1]);
+        out[p] = PAL_GRAY[pal];
+    }
+    free(src);
+    const camera cam = camera_of(e, viewer);
+    draw_overlays(e, viewer, &cam, out);
+}
+
+/* Round-1/2 definition of the background, kept for comparison (tests report how many pixels it gets
+ * differently): every pixel centre classified ANALYTICALLY against the track polygons in world space. */
+void car_oracle_render_analytic(const car_env *e, int viewer, uint8_t *out) {
+    const camera cam = camera_of(e, viewer);
+    const float s = cam.s, c = cam.c;
+    const v2 off = cam.off;
+    const float inv_scale = (float)(1.0 / obs_scale());
+    const float kf = (float)(PLAYFIELD / 20.0);
+    for (int sy = 0; sy < 96; sy++)
+        for (int sx = 0; sx < 96; sx++) {
+            float dx = ((float)sx + 0.5f) - 48.0f, dy = ((float)sy + 0.5f) - 48.0f;
+            float rx = c * dx - s * dy, ry = s * dx + c * dy;
+            v2 pw = V(off.x - rx * inv_scale, off.y - ry * inv_scale);
+            float fx = floorf(pw.x / kf), fy = floorf(pw.y / kf);
+            int ix = (int)fx, iy = (int)fy;
+            int light = ix >= -20 && ix <= 18 && iy >= -20 && iy <= 18 && (ix & 1) == 0 && (iy & 1) == 0;
+            uint8_t g = light ? G_LIGHT : G_GRASS;
+            for (int t = 0; t < e->trk.n; t++) {
+                const float *bb = e->tile_aabb[t];
+                if (e->trk.border[t]) {
+                    v2 bp[4];
+                    make_ccw(e->trk.border_poly[t], 4, 1.0, bp);
+                    if (point_in_convex(pw, bp, 4)) { g = (t % 2 == 0) ? G_WHITE : G_RED; break; }
+                }
+                if (pw.x < bb[0] || pw.x > bb[2] || pw.y < bb[1] || pw.y > bb[3]) continue;
+                if (point_in_convex(pw, (const v2 *)e->tile32[t], 5)) { g = G_ROAD[t % 3]; break; }
+            }
+            out[sy * 96 + sx] = g;
+        }
+    draw_overlays(e, viewer, &cam, out);
+}
+
+/* the double-precision functions this build uses, for tests/test_f64_math.py */
+void car_oracle_f64(int fn, const double *a, const double *b, double *out, long n) {
+    for (long i = 0; i < n; i++) out[i] = fn == 0 ? m_sin(a[i]) : fn == 1 ? m_cos(a[i]) : m_atan2(a[i], b[i]);
 }

@@ -73,4 +73,14 @@ void car_oracle_contact_event(car_env *e, int c, int w, int t, int begin);
 int car_oracle_wheel_on_road(const car_env *e, int c, int w);
 void car_oracle_hull_position(const car_env *e, int c, float out[3]);
 int car_oracle_env_size(void);
+/* observation: palette map of the window [org, org + w)^2 of the 10000^2 surface, then the view */
+#define CAR_MAP_ORG 4392
+#define CAR_MAP_W 1216
+long car_oracle_build_map(const car_env *e, uint8_t *map, int org, int w);
+void car_oracle_map_vertices(const car_env *e, int32_t *out);
+void car_oracle_view_sources(const car_env *e, int viewer, int32_t *src_xy, int32_t *rect_xy);
+void car_oracle_render(const car_env *e, const uint8_t *map, int org, int w, int viewer, uint8_t *out);
+void car_oracle_render_analytic(const car_env *e, int viewer, uint8_t *out);
+void car_oracle_set_text(const uint32_t *bits);
+void car_oracle_f64(int fn, const double *a, const double *b, double *out, long n);
 #endif

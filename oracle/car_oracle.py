@@ -26,35 +26,50 @@ CONSTS_DT = np.dtype([("hull_poly", "<f4", (4, 8, 2)), ("hull_n", "<i4", (4,)), 
                       ("wheel_mass", "<f4"), ("wheel_inv_mass", "<f4"), ("wheel_I", "<f4"), ("wheel_inv_I", "<f4"),
                       ("anchor", "<f4", (4, 2))])
 
-_ready = False
+MAP_ORG, MAP_W = 4392, 1216  # window of the 10000 x 10000 observation map the oracle keeps (car_oracle.h)
+PAL_GRAY = np.array([161, 176, 101, 103, 107, 255, 76, 0], np.uint8)
+
+_libs = {}
 
 
-def lib():
-    global _ready
-    L = _po.lib()
-    if not _ready:
-        vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
-        L.car_oracle_create_track.argtypes = [vp, vp]
-        L.car_oracle_create_track.restype = i32
-        L.car_oracle_consts.restype = vp
-        L.car_oracle_process_action.argtypes = [vp, vp]
-        L.car_oracle_controls.argtypes = [vp, f64, f64, f64]
-        L.car_oracle_wheel.argtypes = [f64] * 9 + [i32, vp, vp, vp, vp]
-        L.car_oracle_place.argtypes = [vp, f64, f64, f64, i32]
-        L.car_oracle_reset.argtypes = [vp, vp, i32, i32]
-        L.car_oracle_reset.restype = i32
-        L.car_oracle_step.argtypes = [vp, vp, vp, vp]
-        L.car_oracle_step_repeat.argtypes = [vp, vp, i32, vp, vp]
-        L.car_oracle_contact_event.argtypes = [vp, i32, i32, i32, i32]
-        L.car_oracle_hull_position.argtypes = [vp, i32, vp]
-        L.car_oracle_wheel_on_road.argtypes = [vp, i32, i32]
-        L.car_oracle_wheel_on_road.restype = i32
-        L.car_oracle_render.argtypes = [vp, i32, vp]
-        L.car_oracle_set_text.argtypes = [vp]
-        L.car_oracle_env_size.restype = i32
-        assert L.car_oracle_env_size() == ENV_DT.itemsize, (L.car_oracle_env_size(), ENV_DT.itemsize)
-        _ready = True
+def _configure(L):
+    vp, i32, f64 = C.c_void_p, C.c_int, C.c_double
+    L.car_oracle_create_track.argtypes = [vp, vp]
+    L.car_oracle_create_track.restype = i32
+    L.car_oracle_consts.restype = vp
+    L.car_oracle_process_action.argtypes = [vp, vp]
+    L.car_oracle_controls.argtypes = [vp, f64, f64, f64]
+    L.car_oracle_wheel.argtypes = [f64] * 9 + [i32, vp, vp, vp, vp]
+    L.car_oracle_place.argtypes = [vp, f64, f64, f64, i32]
+    L.car_oracle_reset.argtypes = [vp, vp, i32, i32]
+    L.car_oracle_reset.restype = i32
+    L.car_oracle_step.argtypes = [vp, vp, vp, vp]
+    L.car_oracle_step_repeat.argtypes = [vp, vp, i32, vp, vp]
+    L.car_oracle_contact_event.argtypes = [vp, i32, i32, i32, i32]
+    L.car_oracle_hull_position.argtypes = [vp, i32, vp]
+    L.car_oracle_wheel_on_road.argtypes = [vp, i32, i32]
+    L.car_oracle_wheel_on_road.restype = i32
+    L.car_oracle_build_map.argtypes = [vp, vp, i32, i32]
+    L.car_oracle_build_map.restype = C.c_long
+    L.car_oracle_map_vertices.argtypes = [vp, vp]
+    L.car_oracle_view_sources.argtypes = [vp, i32, vp, vp]
+    L.car_oracle_render.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.car_oracle_render_analytic.argtypes = [vp, i32, vp]
+    L.car_oracle_set_text.argtypes = [vp]
+    L.car_oracle_f64.argtypes = [i32, vp, vp, vp, C.c_long]
+    L.car_oracle_env_size.restype = i32
+    assert L.car_oracle_env_size() == ENV_DT.itemsize, (L.car_oracle_env_size(), ENV_DT.itemsize)
     return L
+
+
+def lib(libm=False):
+    """liboracle.so (sin / cos / atan2 shared with the HIP kernels) or, libm=True, liboracle_libm.so (the
+    host libm, like the reference): same sources, see oracle/Makefile."""
+    key = bool(libm)
+    if key not in _libs:
+        L = _po.lib()  # builds both
+        _libs[key] = _configure(C.CDLL(_po.LIB_LIBM) if libm else L)
+    return _libs[key]
 
 
 def _p(a):
@@ -68,7 +83,17 @@ def set_text(bits):
     """Reward read-out bitmaps u32 [3001, 10] (kept alive here); None turns the text off."""
     global _text
     _text = None if bits is None else np.ascontiguousarray(bits, np.uint32)
-    lib().car_oracle_set_text(None if _text is None else _p(_text))
+    for libm in (False, True):
+        lib(libm).car_oracle_set_text(None if _text is None else _p(_text))
+
+
+def f64(fn, a, b=None, libm=False):
+    """sin (fn=0) / cos (1) / atan2(a, b) (2) as the chosen oracle build evaluates them."""
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.zeros_like(a) if b is None else np.ascontiguousarray(b, np.float64)
+    out = np.zeros_like(a)
+    lib(libm).car_oracle_f64(int(fn), _p(a), _p(b), _p(out), a.size)
+    return out
 
 
 def consts():
@@ -76,10 +101,10 @@ def consts():
     return np.frombuffer((C.c_char * CONSTS_DT.itemsize).from_address(ptr), CONSTS_DT)[0]
 
 
-def create_track(u24):
+def create_track(u24, libm=False):
     u = np.ascontiguousarray(u24, np.float64)
     trk = np.zeros(1, TRACK_DT)
-    ok = lib().car_oracle_create_track(_p(u), _p(trk))
+    ok = lib(libm).car_oracle_create_track(_p(u), _p(trk))
     return bool(ok), trk[0]
 
 
@@ -97,43 +122,83 @@ def wheel(dt, steer, gas, brake, joint_angle, q_sin, q_cos, vx, vy, on_road, ome
 
 
 class CarEnv:
-    """One cCarRacingDouble env (2 cars)."""
+    """One cCarRacingDouble env (2 cars).  libm=True: the build that calls the host libm (oracle/Makefile)."""
 
-    def __init__(self):
+    def __init__(self, libm=False):
         self.buf = np.zeros(1, ENV_DT)
         self.e = self.buf[0]
+        self.L = lib(libm)
+        self._map = None
+        self._map_key = None
 
     def reset(self, u, shuffle_swap=0):
         u = np.ascontiguousarray(u, np.float64).reshape(-1)
-        return lib().car_oracle_reset(_p(self.buf), _p(u), len(u) // 24, int(shuffle_swap))
+        self._map = None
+        return self.L.car_oracle_reset(_p(self.buf), _p(u), len(u) // 24, int(shuffle_swap))
 
     def step(self, actions):
         rew, done = np.zeros(2), np.zeros(2, np.int32)
         if actions is None:
-            lib().car_oracle_step(_p(self.buf), None, _p(rew), _p(done))
+            self.L.car_oracle_step(_p(self.buf), None, _p(rew), _p(done))
         else:
             a = np.ascontiguousarray(actions, np.float64).reshape(2, 2)
-            lib().car_oracle_step(_p(self.buf), _p(a), _p(rew), _p(done))
+            self.L.car_oracle_step(_p(self.buf), _p(a), _p(rew), _p(done))
         return rew, done
 
     def step_repeat(self, actions, repeat):
         rew, done = np.zeros(2), np.zeros(2, np.int32)
         a = np.ascontiguousarray(actions, np.float64).reshape(2, 2)
-        lib().car_oracle_step_repeat(_p(self.buf), _p(a), int(repeat), _p(rew), _p(done))
+        self.L.car_oracle_step_repeat(_p(self.buf), _p(a), int(repeat), _p(rew), _p(done))
         return rew, done
 
     def contact_event(self, c, w, t, begin):
-        lib().car_oracle_contact_event(_p(self.buf), c, w, t, int(begin))
+        self.L.car_oracle_contact_event(_p(self.buf), c, w, t, int(begin))
 
     def wheel_on_road(self, c, w):
-        return bool(lib().car_oracle_wheel_on_road(_p(self.buf), c, w))
+        return bool(self.L.car_oracle_wheel_on_road(_p(self.buf), c, w))
 
-    def render(self, viewer):
+    def build_map(self, org=MAP_ORG, w=MAP_W):
+        """render_road_for_observation_map: palette map (w, w) u8 of the window [org, org + w)^2 and the number
+        of polygon pixels that fell outside it."""
+        m = np.zeros((w, w), np.uint8)
+        dropped = self.L.car_oracle_build_map(_p(self.buf), _p(m), int(org), int(w))
+        return m, int(dropped)
+
+    def map(self):
+        """The windowed map of the current track (cached until the next reset / invalidate_map())."""
+        if self._map is None:
+            self._map, dropped = self.build_map()
+            assert dropped == 0, "a track polygon leaves the map window"
+        return self._map
+
+    def invalidate_map(self):
+        self._map = None
+
+    def map_vertices(self):
+        n = int(self.e["trk"]["n"])
+        out = np.zeros((n, 9, 2), np.int32)
+        self.L.car_oracle_map_vertices(_p(self.buf), _p(out))
+        return out
+
+    def view_sources(self, viewer):
+        src, rect = np.zeros((96, 96, 2), np.int32), np.zeros(2, np.int32)
+        self.L.car_oracle_view_sources(_p(self.buf), int(viewer), _p(src), _p(rect))
+        return src, rect
+
+    def render(self, viewer, map_=None, org=MAP_ORG):
+        """CarRacing.get_observation(viewer): (96, 96) u8"""
+        m = self.map() if map_ is None else map_
         out = np.zeros((96, 96), np.uint8)
-        lib().car_oracle_render(_p(self.buf), int(viewer), _p(out))
+        self.L.car_oracle_render(_p(self.buf), _p(m), int(org), int(m.shape[0]), int(viewer), _p(out))
+        return out
+
+    def render_analytic(self, viewer):
+        """rounds 1-2: background classified analytically at pixel centres (kept for comparison)"""
+        out = np.zeros((96, 96), np.uint8)
+        self.L.car_oracle_render_analytic(_p(self.buf), int(viewer), _p(out))
         return out
 
     def hull_position(self, c):
         out = np.zeros(3, np.float32)
-        lib().car_oracle_hull_position(_p(self.buf), c, _p(out))
+        self.L.car_oracle_hull_position(_p(self.buf), c, _p(out))
         return out

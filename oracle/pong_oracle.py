@@ -11,6 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "liboracle.so")
+LIB_LIBM = os.path.join(HERE, "liboracle_libm.so")  # same sources with -DCRL_LIBM: the host libm's sin / cos / atan2
 
 RAW, GRAY = 0, 1
 
@@ -26,9 +27,12 @@ assert STATE_DT.itemsize == 120 and FRAME_DT.itemsize == 8
 
 
 def build(force=False):
+    inc = os.path.join(os.path.dirname(HERE), "include")
     srcs = [os.path.join(HERE, f) for f in ("pong_oracle.c", "car_oracle.c", "car_oracle.h", "Makefile")]
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    srcs += [os.path.join(inc, f) for f in ("crl.h", "crl_rot.h", "crl_f64.h")]
+    for lib_ in (LIB, LIB_LIBM):
+        if force or not os.path.exists(lib_) or any(os.path.getmtime(lib_) < os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-C", HERE, "-B", os.path.basename(lib_)], stdout=subprocess.DEVNULL)
     return LIB
 
 
