@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(PKG, "libcrl_hip.so")
 CRL_ENV_PONG_DOUBLE, CRL_ENV_CAR_DOUBLE, CRL_ENV_PONG_SINGLE, CRL_ENV_CAR_SINGLE = 1, 2, 3, 4
 CRL_FLAG_STACK_REPLICATE = 1
 CAR_MAX_TILES = 512
+CAR_MAP_ORG, CAR_MAP_W = 4392, 1216  # include/crl.h CRL_CAR_MAP_*
 CRL_OBS_RAW_RGB, CRL_OBS_GRAY_RESIZED = 0, 1
 PONG_FRAME_BYTES = 210 * 160 * 3
 ATLAS_BYTES = 22 * 22 * 34 * 160
@@ -19,7 +20,7 @@ ATLAS_BYTES = 22 * 22 * 34 * 160
 SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "crl_render", "crl_info", "crl_copy_info",
            "crl_terminal_observation", "crl_get_state", "crl_set_state", "crl_set_replay", "crl_render_raw",
            "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version",
-           "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_set_replay",
+           "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_get_map", "crl_car_set_replay",
            "crl_policy_create", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
            "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update"]
 
@@ -108,6 +109,7 @@ def load():
     L.crl_car_set_state.argtypes = [vp, vp, i64, i64, vp]
     L.crl_car_get_track.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     L.crl_car_set_track.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp]
+    L.crl_car_get_map.argtypes = [vp, i64, vp, vp, vp]
     L.crl_car_set_replay.argtypes = [vp, vp, vp, i64]
     L.crl_policy_create.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.crl_policy_destroy.argtypes = [vp]

@@ -9,6 +9,8 @@
 //
 // A = a fixture of car 0, B = a fixture of car 1 (fixtures 0-3: hull polygons, 4-7: wheels; wheels do
 // not collide with wheels).  friction = sqrt(0.2*0.2), restitution = 0, polygonRadius = 0.01.
+#include <stdlib.h>
+
 #include "car_solver.h"
 
 namespace crl {
@@ -190,329 +192,497 @@ __device__ inline V2 rel_vel(const BRef &A, const BRef &B, V2 rA, V2 rB) {
     return ((bvel(*B.b) + scross(B.b->w, rB)) - bvel(*A.b)) - scross(A.b->w, rA);
 }
 
-__global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) {
-    // dense over the compacted list of coupled envs: a workgroup holds 111 KB of LDS, so the ones
-    // past the end of the list must leave at once (the frames of the other envs are being drawn
-    // on the same CUs meanwhile)
-    // TWO LANES PER ENV: lane 2p holds car 0 of pair p, lane 2p+1 car 1.  The joints of a car only couple its
-    // own hull and wheels, so each lane solves its car's joints in registers, both cars at once, exactly like
-    // the per-car kernel.  Only the contacts pick their bodies by fixture index at run time: they are solved
-    // by the even lane on the LDS copy of the two cars, and the lanes exchange velocities (positions in the
-    // position phase) with that copy around every contact pass.  LDS operations of a wavefront complete in
-    // order, so the pair needs no barrier.
+// ---- (1) narrow phase: ONE WAVEFRONT per coupled env, one lane per fixture pair (fa = lane / 8 of car 0, fb = lane % 8 of
+// car 1; the 16 wheel-wheel pairs do not collide).  b2CollidePolygons per lane, then the touching pairs are compacted in
+// (fa, fb) order -- the order the contacts are solved in -- with a ballot; at most kMaxContacts are kept.  Accumulated
+// impulses are carried over from last step's manifolds by contact id (warm starting).  The env goes to one of two lists:
+// `touch` (one island with contacts: car_touch_kernel) or `near` (the boxes overlap but nothing touches: two islands of
+// their own, car_near_kernel = the per-car solve).
+__global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts K) {
+    const int lane = threadIdx.x;
+    const int count = *s.coupled_count;
+    const int64_t M = 2 * s.n;
+    if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host) *s.coupled_to_host = count;
+    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        const int64_t env = s.coupled_list[slot];
+        const int fa = lane >> 3, fb = lane & 7;
+        const bool active = !(fa >= 4 && fb >= 4);
+        Contact c;
+        c.pair = fa * 8 + fb, c.type = 0, c.count = 0;
+        for (int i = 0; i < 2; i++) c.nimp[i] = c.timp[i] = 0.f, c.id[i] = 0u, c.pt[i][0] = c.pt[i][1] = 0.f;
+        c.ln[0] = c.ln[1] = c.lp[0] = c.lp[1] = 0.f;
+        if (active) {
+            XF xf[2];
+            float ccx[2], ccy[2], crad[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int f = k ? fb : fa;
+                const int64_t ci = k * s.n + env;
+                const int o = f < 4 ? 0 : 6 + 6 * (f - 4);
+                const float bx = s.body[(o + 0) * M + ci], by = s.body[(o + 1) * M + ci], ba = s.body[(o + 2) * M + ci];
+                crl_sincosf(ba, &xf[k].s, &xf[k].c);
+                const V2 lc = f < 4 ? mk(K.hull_lc[0], K.hull_lc[1]) : mk(0.f, 0.f);
+                xf[k].p = mk(bx, by) - rotv(xf[k].s, xf[k].c, lc);
+                // bounding circle of the fixture (world centre, radius): circles that do not overlap cannot be within the
+                // 0.02 contact margin -- rejects most pairs cheaply
+                const Shape sh = shape_of(K, f);
+                V2 ctr = mk(0.f, 0.f);
+                for (int i = 0; i < sh.n; i++) ctr = ctr + shape_vertex(sh, i);
+                ctr = (1.0f / sh.n) * ctr;
+                float r2 = 0.f;
+                for (int i = 0; i < sh.n; i++) r2 = fmaxf(r2, dot(shape_vertex(sh, i) - ctr, shape_vertex(sh, i) - ctr));
+                const V2 wc = xmul(xf[k], ctr);
+                ccx[k] = wc.x, ccy[k] = wc.y, crad[k] = sqrtf(r2) + 0.03f;
+            }
+            const float dx = ccx[0] - ccx[1], dy = ccy[0] - ccy[1], rr = crad[0] + crad[1];
+            if (!(dx * dx + dy * dy > rr * rr)) collide_polygons(c, shape_of(K, fa), xf[0], shape_of(K, fb), xf[1]);
+        }
+        const bool hit = active && c.count > 0;
+        const unsigned long long m = __ballot(hit);
+        const int rank = (int)__popcll(m & ((1ull << lane) - 1ull));
+        const int nc = min((int)__popcll(m), kMaxContacts);
+        if (hit && rank < kMaxContacts) {
+            const float *old = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
+            const int n_old = s.n_contact[env];
+            for (int k = 0; k < n_old; k++) {
+                const float *o = old + k * kContactWords;
+                if (__float_as_int(o[0]) != c.pair) continue;
+                const int ocount = __float_as_int(o[1]);
+                for (int i = 0; i < c.count; i++)
+                    for (int j = 0; j < ocount; j++)
+                        if (__float_as_uint(o[11 + j]) == c.id[i]) c.nimp[i] = o[13 + j], c.timp[i] = o[15 + j];
+            }
+            float *o = s.contact_new + (env * kMaxContacts + rank) * (int64_t)kContactWords;
+            o[0] = __int_as_float(c.pair), o[1] = __int_as_float(c.count), o[2] = __int_as_float(c.type);
+            o[3] = c.ln[0], o[4] = c.ln[1], o[5] = c.lp[0], o[6] = c.lp[1];
+            o[7] = c.pt[0][0], o[8] = c.pt[0][1], o[9] = c.pt[1][0], o[10] = c.pt[1][1];
+            o[11] = __uint_as_float(c.id[0]), o[12] = __uint_as_float(c.id[1]);
+            o[13] = c.nimp[0], o[14] = c.nimp[1], o[15] = c.timp[0], o[16] = c.timp[1];
+        }
+        if (lane == 0) {
+            s.nc_new[env] = nc;
+            // [1] near-only; touching by manifold count: [2] one, [3] two, [4] three or more
+            const int cls = nc == 0 ? 0 : nc >= 3 ? 3 : nc;
+            int32_t *lst = nc ? s.touch_list + (int64_t)(cls - 1) * s.n : s.near_list;
+            lst[atomicAdd(s.coupled_count + 1 + cls, 1)] = (int32_t)env;
+            if (nc) s.touch_all[atomicAdd(s.coupled_count + 5, 1)] = (int32_t)env;
+        }
+    }
+}
+
+// ---- (2) envs whose boxes overlap but where nothing touches: two islands of their own, exactly the per-car kernel,
+// two lanes per env over the compacted list
+__global__ __launch_bounds__(64) void car_near_kernel(CarSoA s, CarConsts K) {
+    const int64_t M = 2 * s.n;
+    const int count = s.coupled_count[1];
+    for (int slot = blockIdx.x * 32 + (threadIdx.x >> 1); slot < count; slot += gridDim.x * 32) {
+        const int64_t env = s.near_list[slot];
+        const int64_t ci = (int64_t)(threadIdx.x & 1) * s.n + env;
+        CarRegs cr;
+        load_car(s, M, ci, cr);
+#pragma unroll
+        for (int w = 0; w < 4; w++) cr.fx[w] = s.wforce[(2 * w + 0) * M + ci], cr.fy[w] = s.wforce[(2 * w + 1) * M + ci];
+        const float h = (float)(1.0 / CAR_FPS);
+        const float dt_ratio = s.first_step[ci] ? 0.0f : (1.0f / h) * h;
+        float slp[5];
+#pragma unroll
+        for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + ci];
+        island_solve(cr, K, h, dt_ratio, slp);
+#pragma unroll
+        for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = slp[b];
+        store_car(s, M, ci, cr);
+        s.first_step[ci] = 0;
+        if ((threadIdx.x & 1) == 0) s.n_contact[env] = 0;
+    }
+}
+
+// ---- (3) touching envs: one Box2D island of ten bodies, eight joints and nc contacts.
+// TWO LANES PER ENV: lane 2p holds car 0 of pair p ("A side"), lane 2p+1 car 1 ("B side"), state in registers.  The joints
+// of a car only couple its own hull and wheels: each lane solves its car's joints exactly like the per-car kernel, both
+// cars at once.  A contact couples ONE body of each car, picked by fixture index at run time: each lane selects its own
+// body's velocity (five candidates, v_cndmask), the two lanes swap those three values through DPP, BOTH lanes then solve
+// the contact -- same operands, same instructions, one pass of the wavefront -- and each lane writes its own body back.
+// Everything a contact needs in the 180 velocity iterations (constraint rows, accumulated impulses, manifold) lives in
+// registers for the first NK contacts; the narrow phase files the envs by manifold count (1, 2, >= 3: 94 % / 6 % / 0.2 % of the
+// touching envs), so a wavefront runs the instance for ITS count and the loop over contacts is unrolled.  Manifolds past
+// the third (not seen in 10^4 touching env-steps, possible) go through the same code from their LDS rows.
+struct TouchC {  // one contact's velocity-constraint rows in LDS (where InitializeVelocityConstraints leaves them)
+    float nimp0, nimp1, timp0, timp1;
+    float nx, ny, rA0x, rA0y;
+    float rB0x, rB0y, rA1x, rA1y;
+    float rB1x, rB1y, tm0, tm1;
+    float nm0, nm1, k00, k01;
+    float k10, k11, ik00, ik01;
+    float ik10, ik11;
+    int count, pair;
+};
+static_assert(sizeof(TouchC) == 112, "TouchC rows");
+
+struct KC {  // one contact in registers
+    float nimp0, nimp1, timp0, timp1;
+    float nx, ny, rA0x, rA0y, rB0x, rB0y, rA1x, rA1y, rB1x, rB1y, tm0, tm1, nm0, nm1, k00, k01, k10, k11, ik00, ik01, ik10, ik11;
+    int count;  // velocity-constraint points (the block solver may have dropped the second)
+    int bi;     // this lane's body of the contact: 0 = hull, 1..4 = wheels 0..3
+    float mA, iA, mB, iB;
+    bool ok;  // the env has this contact (k < nc)
+    int ccount, ctype;  // manifold (position pass)
+    float lnx, lny, lpx, lpy, pt0x, pt0y, pt1x, pt1y;
+};
+
+__device__ __forceinline__ float lane_swap(float x) {  // the value of the other lane of the pair (DPP quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+}
+
+// body `bi` of a car in registers: 0 = hull, 1..4 = wheels 0..3
+// (one v_cndmask per candidate: written as a sequence of simple selects -- a nested ?: chain comes out as branches)
+__device__ __forceinline__ float sel5(int bi, float h, float w0, float w1, float w2, float w3) {
+    float x = h;
+    x = bi == 1 ? w0 : x;
+    x = bi == 2 ? w1 : x;
+    x = bi == 3 ? w2 : x;
+    x = bi == 4 ? w3 : x;
+    return x;
+}
+#define CRL_SEL(field, bi) sel5(bi, r.H.field, r.W[0].field, r.W[1].field, r.W[2].field, r.W[3].field)
+#define CRL_PUT(field, bi, ok, val)                                                   \
+    {                                                                                 \
+        const int bj_ = (ok) ? (bi) : -1;                                             \
+        r.H.field = bj_ == 0 ? (val) : r.H.field;                                     \
+        r.W[0].field = bj_ == 1 ? (val) : r.W[0].field;                               \
+        r.W[1].field = bj_ == 2 ? (val) : r.W[1].field;                               \
+        r.W[2].field = bj_ == 3 ? (val) : r.W[2].field;                               \
+        r.W[3].field = bj_ == 4 ? (val) : r.W[3].field;                               \
+    }
+
+__device__ __forceinline__ KC kc_load(const TouchC &t, const Contact &c, int me, bool ok, const CarConsts &K) {
+    KC q;
+    q.nimp0 = t.nimp0, q.nimp1 = t.nimp1, q.timp0 = t.timp0, q.timp1 = t.timp1;
+    q.nx = t.nx, q.ny = t.ny, q.rA0x = t.rA0x, q.rA0y = t.rA0y, q.rB0x = t.rB0x, q.rB0y = t.rB0y, q.rA1x = t.rA1x, q.rA1y = t.rA1y;
+    q.rB1x = t.rB1x, q.rB1y = t.rB1y, q.tm0 = t.tm0, q.tm1 = t.tm1, q.nm0 = t.nm0, q.nm1 = t.nm1;
+    q.k00 = t.k00, q.k01 = t.k01, q.k10 = t.k10, q.k11 = t.k11, q.ik00 = t.ik00, q.ik01 = t.ik01, q.ik10 = t.ik10, q.ik11 = t.ik11;
+    q.count = t.count;
+    const int fA = t.pair >> 3, fB = t.pair & 7, f = me ? fB : fA;
+    q.bi = f < 4 ? 0 : f - 3;
+    q.mA = fA < 4 ? K.hull_inv_mass : K.wheel_inv_mass, q.iA = fA < 4 ? K.hull_inv_I : K.wheel_inv_I;
+    q.mB = fB < 4 ? K.hull_inv_mass : K.wheel_inv_mass, q.iB = fB < 4 ? K.hull_inv_I : K.wheel_inv_I;
+    q.ok = ok;
+    q.ccount = c.count, q.ctype = c.type, q.lnx = c.ln[0], q.lny = c.ln[1], q.lpx = c.lp[0], q.lpy = c.lp[1];
+    q.pt0x = c.pt[0][0], q.pt0y = c.pt[0][1], q.pt1x = c.pt[1][0], q.pt1y = c.pt[1][1];
+    return q;
+}
+
+// b2ContactSolver::SolveVelocityConstraints for one contact: friction per point, then the normal constraint (one point, or
+// the two-point block solver), in Box2D's order.  any1 / any2: some lane of the wavefront has a one- / two-point constraint.
+__device__ __forceinline__ void contact_vel(CarRegs &r, KC &q, const int me, const float friction, const bool any1, const bool any2) {
+    const int bi = q.bi;
+    const float ovx = CRL_SEL(vx, bi), ovy = CRL_SEL(vy, bi), ow = CRL_SEL(w, bi);
+    const float pvx = lane_swap(ovx), pvy = lane_swap(ovy), pw = lane_swap(ow);
+    V2 vA = me ? mk(pvx, pvy) : mk(ovx, ovy), vB = me ? mk(ovx, ovy) : mk(pvx, pvy);
+    float wA = me ? pw : ow, wB = me ? ow : pw;
+    const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
+    const V2 normal = mk(q.nx, q.ny), tangent = mk(normal.y, -normal.x);
+    const V2 rA0 = mk(q.rA0x, q.rA0y), rB0 = mk(q.rB0x, q.rB0y), rA1 = mk(q.rA1x, q.rA1y), rB1 = mk(q.rB1x, q.rB1y);
+    const int count = q.count;
+    auto relv = [&](V2 ra, V2 rb) { return ((vB + scross(wB, rb)) - vA) - scross(wA, ra); };
+    auto apply = [&](V2 ra, V2 rb, V2 P) {
+        vA.x -= mA * P.x, vA.y -= mA * P.y, wA -= iA * cross(ra, P);
+        vB.x += mB * P.x, vB.y += mB * P.y, wB += iB * cross(rb, P);
+    };
+    {  // friction, point 0 (every constraint has it)
+        const float vt = dot(relv(rA0, rB0), tangent);
+        float lambda = q.tm0 * (-vt);
+        const float maxF = friction * q.nimp0;
+        float ni = q.timp0 + lambda;
+        ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
+        lambda = ni - q.timp0, q.timp0 = ni;
+        apply(rA0, rB0, lambda * tangent);
+    }
+    if (any2) {
+        if (count == 2) {  // friction, point 1
+            const float vt = dot(relv(rA1, rB1), tangent);
+            float lambda = q.tm1 * (-vt);
+            const float maxF = friction * q.nimp1;
+            float ni = q.timp1 + lambda;
+            ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
+            lambda = ni - q.timp1, q.timp1 = ni;
+            apply(rA1, rB1, lambda * tangent);
+        }
+    }
+    if (any1) {
+        if (count == 1) {
+            const float vn = dot(relv(rA0, rB0), normal);
+            float lambda = -q.nm0 * (vn - 0.0f);
+            const float ni = fmaxf(q.nimp0 + lambda, 0.0f);
+            lambda = ni - q.nimp0, q.nimp0 = ni;
+            apply(rA0, rB0, lambda * normal);
+        }
+    }
+    if (any2) {
+        if (count == 2) {
+            const V2 a = mk(q.nimp0, q.nimp1);
+            float vn1 = dot(relv(rA0, rB0), normal), vn2 = dot(relv(rA1, rB1), normal);
+            V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
+            b = b - mk(q.k00 * a.x + q.k10 * a.y, q.k01 * a.x + q.k11 * a.y);
+            V2 x = mk(-(q.ik00 * b.x + q.ik10 * b.y), -(q.ik01 * b.x + q.ik11 * b.y));
+            bool solved = x.x >= 0.0f && x.y >= 0.0f;
+            if (!solved) {
+                x = mk(-q.nm0 * b.x, 0.0f);
+                vn2 = q.k01 * x.x + b.y;
+                solved = x.x >= 0.0f && vn2 >= 0.0f;
+            }
+            if (!solved) {
+                x = mk(0.0f, -q.nm1 * b.y);
+                vn1 = q.k10 * x.y + b.x;
+                solved = x.y >= 0.0f && vn1 >= 0.0f;
+            }
+            if (!solved) {
+                x = mk(0.0f, 0.0f);
+                solved = b.x >= 0.0f && b.y >= 0.0f;
+            }
+            if (solved) {
+                const V2 d = x - a;
+                const V2 P1 = d.x * normal, P2 = d.y * normal;
+                vA.x -= mA * (P1.x + P2.x), vA.y -= mA * (P1.y + P2.y);
+                wA -= iA * (cross(rA0, P1) + cross(rA1, P2));
+                vB.x += mB * (P1.x + P2.x), vB.y += mB * (P1.y + P2.y);
+                wB += iB * (cross(rB0, P1) + cross(rB1, P2));
+                q.nimp0 = x.x, q.nimp1 = x.y;
+            }
+        }
+    }
+    const float nvx = me ? vB.x : vA.x, nvy = me ? vB.y : vA.y, nw = me ? wB : wA;
+    CRL_PUT(vx, bi, q.ok, nvx) CRL_PUT(vy, bi, q.ok, nvy) CRL_PUT(w, bi, q.ok, nw)
+}
+
+// b2ContactSolver::SolvePositionConstraints for one contact (both manifold points)
+__device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const int me, const V2 hlc, float &minSep) {
+    const int bi = q.bi;
+    const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
+    const V2 mylc = bi == 0 ? hlc : mk(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const bool ok = q.ok && j < q.ccount;
+        // this lane's body (centre, angle) -> its transform; the partner's through DPP
+        const float ocx = CRL_SEL(cx, bi), ocy = CRL_SEL(cy, bi), oa = CRL_SEL(a, bi);
+        XF ox;
+        crl_sincosf(oa, &ox.s, &ox.c);
+        ox.p = mk(ocx, ocy) - rotv(ox.s, ox.c, mylc);
+        XF px;
+        px.s = lane_swap(ox.s), px.c = lane_swap(ox.c), px.p.x = lane_swap(ox.p.x), px.p.y = lane_swap(ox.p.y);
+        const float pcx = lane_swap(ocx), pcy = lane_swap(ocy), pa = lane_swap(oa);
+        const XF xa = me ? px : ox, xb = me ? ox : px;
+        V2 cA = me ? mk(pcx, pcy) : mk(ocx, ocy), cB = me ? mk(ocx, ocy) : mk(pcx, pcy);
+        float aA = me ? pa : oa, aB = me ? oa : pa;
+        const V2 lpt = j ? mk(q.pt1x, q.pt1y) : mk(q.pt0x, q.pt0y);
+        V2 normal, point;
+        float sep;
+        if (q.ctype == 0) {
+            normal = rotv(xa.s, xa.c, mk(q.lnx, q.lny));
+            const V2 plane = xmul(xa, mk(q.lpx, q.lpy)), clip = xmul(xb, lpt);
+            sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
+        } else {
+            normal = rotv(xb.s, xb.c, mk(q.lnx, q.lny));
+            const V2 plane = xmul(xb, mk(q.lpx, q.lpy)), clip = xmul(xa, lpt);
+            sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
+            normal = -1.0f * normal;
+        }
+        const V2 rA = point - cA, rB = point - cB;
+        if (ok && sep < minSep) minSep = sep;
+        const float C = fminf(fmaxf(0.2f * (sep + LINEAR_SLOP), -0.2f), 0.0f);
+        const float rnA = cross(rA, normal), rnB = cross(rB, normal);
+        const float Kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        const float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
+        const V2 P = impulse * normal;
+        cA.x -= mA * P.x, cA.y -= mA * P.y, aA -= iA * cross(rA, P);
+        cB.x += mB * P.x, cB.y += mB * P.y, aB += iB * cross(rB, P);
+        const float ncx = me ? cB.x : cA.x, ncy = me ? cB.y : cA.y, na = me ? aB : aA;
+        CRL_PUT(cx, bi, ok, ncx) CRL_PUT(cy, bi, ok, ncy) CRL_PUT(a, bi, ok, na)
+    }
+}
+
+// NK = contacts kept in registers (the list this wavefront serves holds envs with nc == NK, or nc >= 3 for NK == 3)
+template <int NK>
+__device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K, const int32_t *list, const int list_count,
+                                            CarRegs (*sh_car)[2], Contact (*sh_ct)[kMaxContacts], TouchC (*sh_tc)[kMaxContacts]) {
     const int pair = threadIdx.x >> 1, me = threadIdx.x & 1;
     const int slot = blockIdx.x * 32 + pair;
-    if (slot >= *s.coupled_count) return;
-    const int64_t env = s.coupled_list[slot];
+    const bool live = slot < list_count;
+    // (lanes past the end of the list ride along on the last env's data and store nothing: the DPP swaps and the uniform
+    // loop bounds below want every lane of the wavefront in step)
+    const int64_t env = list[live ? slot : list_count - 1];
     const int64_t M = 2 * s.n;
-    __shared__ CarRegs sh_car[32][2];
-    __shared__ Contact sh_ct[32][kMaxContacts];
-    __shared__ ContactVC sh_vc[32][kMaxContacts];
-    __shared__ int sh_nc[32];
     CarRegs(&car)[2] = sh_car[pair];
     {
         const int64_t ci = me * s.n + env;
         load_car(s, M, ci, car[me]);
         for (int w = 0; w < 4; w++) car[me].fx[w] = s.wforce[(2 * w + 0) * M + ci], car[me].fy[w] = s.wforce[(2 * w + 1) * M + ci];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int first_step = s.first_step[env];
     const float h = (float)(1.0 / CAR_FPS);
     const float dt_ratio = first_step ? 0.0f : (1.0f / h) * h;
-
-    // ---- Collide: manifolds of the 48 fixture pairs, impulses carried over by contact id
     Contact *ct = sh_ct[pair];
-    int nc = 0;
-    if (me == 0) {  // the even lane runs the narrow phase for the pair
-    // bounding circle of every fixture (world centre, radius): rejects most of the 48 pairs cheaply;
-    // circles that do not overlap cannot be within the 0.02 contact margin
-    float fcx[2][8], fcy[2][8], frad[2][8];
-    for (int k = 0; k < 2; k++)
-        for (int f = 0; f < 8; f++) {
-            const Shape sh = shape_of(K, f);
-            V2 ctr = mk(0.f, 0.f);
-            for (int i = 0; i < sh.n; i++) ctr = ctr + shape_vertex(sh, i);
-            ctr = (1.0f / sh.n) * ctr;
-            float r2 = 0.f;
-            for (int i = 0; i < sh.n; i++) r2 = fmaxf(r2, dot(shape_vertex(sh, i) - ctr, shape_vertex(sh, i) - ctr));
-            const V2 wc = xmul(xf_of(body_of(car[k], K, f)), ctr);
-            fcx[k][f] = wc.x, fcy[k][f] = wc.y, frad[k][f] = sqrtf(r2) + 0.03f;
+    TouchC *tc = sh_tc[pair];
+    const int nc = s.nc_new[env];
+    int nc_wave = nc;  // contacts past NK: the wavefront's loop runs to the largest count in it
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) nc_wave = max(nc_wave, __shfl_xor(nc_wave, d));
+    if (me == 0) {  // this step's manifolds, from the narrow phase
+        const float *in = s.contact_new + env * (int64_t)(kMaxContacts * kContactWords);
+        for (int k = 0; k < nc; k++) {
+            const float *o = in + k * kContactWords;
+            Contact &c = ct[k];
+            c.pair = __float_as_int(o[0]), c.count = __float_as_int(o[1]), c.type = __float_as_int(o[2]);
+            c.ln[0] = o[3], c.ln[1] = o[4], c.lp[0] = o[5], c.lp[1] = o[6];
+            c.pt[0][0] = o[7], c.pt[0][1] = o[8], c.pt[1][0] = o[9], c.pt[1][1] = o[10];
+            c.id[0] = __float_as_uint(o[11]), c.id[1] = __float_as_uint(o[12]);
+            c.nimp[0] = o[13], c.nimp[1] = o[14], c.timp[0] = o[15], c.timp[1] = o[16];
         }
-    {
-        float *old = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
-        const int n_old = s.n_contact[env];
-        for (int fa = 0; fa < 8; fa++)
-            for (int fb = 0; fb < 8; fb++) {
-                if (fa >= 4 && fb >= 4) continue;
-                {
-                    const float dx = fcx[0][fa] - fcx[1][fb], dy = fcy[0][fa] - fcy[1][fb], rr = frad[0][fa] + frad[1][fb];
-                    if (dx * dx + dy * dy > rr * rr) continue;
-                }
-                const BRef A = body_of(car[0], K, fa), B = body_of(car[1], K, fb);
-                Contact c;
-                c.pair = fa * 8 + fb, c.type = 0;
-                for (int i = 0; i < 2; i++) c.nimp[i] = c.timp[i] = 0.f, c.id[i] = 0u, c.pt[i][0] = c.pt[i][1] = 0.f;
-                c.ln[0] = c.ln[1] = c.lp[0] = c.lp[1] = 0.f;
-                collide_polygons(c, shape_of(K, fa), xf_of(A), shape_of(K, fb), xf_of(B));
-                if (c.count == 0 || nc >= kMaxContacts) continue;
-                for (int k = 0; k < n_old; k++) {
-                    const float *o = old + k * kContactWords;
-                    if (__float_as_int(o[0]) != c.pair) continue;
-                    const int ocount = __float_as_int(o[1]);
-                    for (int i = 0; i < c.count; i++)
-                        for (int j = 0; j < ocount; j++)
-                            if (__float_as_uint(o[11 + j]) == c.id[i]) c.nimp[i] = o[13 + j], c.timp[i] = o[15 + j];
-                }
-                ct[nc++] = c;
-            }
-    }
-
-        sh_nc[pair] = nc;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    nc = sh_nc[pair];
 
     float slp[5];  // b2Body::m_sleepTime of this lane's car
     for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + me * s.n + env];
-    // The joints always couple the hull with wheel w, so they are solved on REGISTER copies of the two
-    // cars (r0, r1), exactly like the per-car kernel; only the contacts pick their bodies by fixture index
-    // at run time, and they work on the LDS copy.  Velocities (positions in the position phase) are
-    // exchanged between the two copies around every contact pass: 30 independent LDS accesses each way
-    // instead of every joint access being a dependent LDS round trip.
     CarRegs r = car[me];
     Body &mH = car[me].H;
     Body(&mW)[4] = car[me].W;
-    auto vel_to_lds = [&]() {
+    JointTmp jt;
+    isl_integrate_vel(r, K, h);
+    {  // b2ContactSolver::InitializeVelocityConstraints + WarmStart, once per step: even lane, on an LDS copy of both cars
         mH.vx = r.H.vx, mH.vy = r.H.vy, mH.w = r.H.w;
 #pragma unroll
         for (int w = 0; w < 4; w++) mW[w].vx = r.W[w].vx, mW[w].vy = r.W[w].vy, mW[w].w = r.W[w].w;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-    auto vel_from_lds = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (me == 0) {
+            for (int k = 0; k < nc; k++) {
+                Contact &c = ct[k];
+                ContactVC q;
+                const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
+                q.count = c.count;
+                const float mA = A.im, iA = A.ii, mB = B.im, iB = B.ii;
+                V2 pts[2];
+                pts[0] = pts[1] = mk(0.f, 0.f);
+                world_manifold(c, xf_of(A), xf_of(B), q.normal, pts);
+                const V2 cA = mk(A.b->cx, A.b->cy), cB = mk(B.b->cx, B.b->cy), tangent = mk(q.normal.y, -q.normal.x);
+                q.rA[0] = q.rA[1] = q.rB[0] = q.rB[1] = mk(0.f, 0.f);
+                q.nmass[0] = q.nmass[1] = q.tmass[0] = q.tmass[1] = 0.f;
+                q.K[0][0] = q.K[0][1] = q.K[1][0] = q.K[1][1] = q.invK[0][0] = q.invK[0][1] = q.invK[1][0] = q.invK[1][1] = 0.f;
+                for (int j = 0; j < c.count; j++) {
+                    c.nimp[j] *= dt_ratio, c.timp[j] *= dt_ratio;
+                    q.rA[j] = pts[j] - cA, q.rB[j] = pts[j] - cB;
+                    const float rnA = cross(q.rA[j], q.normal), rnB = cross(q.rB[j], q.normal);
+                    const float kN = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+                    q.nmass[j] = kN > 0.0f ? 1.0f / kN : 0.0f;
+                    const float rtA = cross(q.rA[j], tangent), rtB = cross(q.rB[j], tangent);
+                    const float kT = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+                    q.tmass[j] = kT > 0.0f ? 1.0f / kT : 0.0f;
+                }
+                if (q.count == 2) {
+                    const float rn1A = cross(q.rA[0], q.normal), rn1B = cross(q.rB[0], q.normal);
+                    const float rn2A = cross(q.rA[1], q.normal), rn2B = cross(q.rB[1], q.normal);
+                    const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B, k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
+                    const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
+                    if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
+                        q.K[0][0] = k11, q.K[0][1] = k12, q.K[1][0] = k12, q.K[1][1] = k22;
+                        float det = k11 * k22 - k12 * k12;
+                        if (det != 0.0f) det = 1.0f / det;
+                        q.invK[0][0] = det * k22, q.invK[1][0] = -det * k12, q.invK[0][1] = -det * k12, q.invK[1][1] = det * k11;
+                    } else {
+                        q.count = 1;
+                    }
+                }
+                TouchC &t = tc[k];
+                t.nimp0 = c.nimp[0], t.nimp1 = c.nimp[1], t.timp0 = c.timp[0], t.timp1 = c.timp[1];
+                t.nx = q.normal.x, t.ny = q.normal.y, t.rA0x = q.rA[0].x, t.rA0y = q.rA[0].y;
+                t.rB0x = q.rB[0].x, t.rB0y = q.rB[0].y, t.rA1x = q.rA[1].x, t.rA1y = q.rA[1].y;
+                t.rB1x = q.rB[1].x, t.rB1y = q.rB[1].y, t.tm0 = q.tmass[0], t.tm1 = q.tmass[1];
+                t.nm0 = q.nmass[0], t.nm1 = q.nmass[1], t.k00 = q.K[0][0], t.k01 = q.K[0][1];
+                t.k10 = q.K[1][0], t.k11 = q.K[1][1], t.ik00 = q.invK[0][0], t.ik01 = q.invK[0][1];
+                t.ik10 = q.invK[1][0], t.ik11 = q.invK[1][1], t.count = q.count, t.pair = c.pair;
+            }
+            for (int k = 0; k < nc; k++) {
+                const TouchC &t = tc[k];
+                const BRef A = body_of(car[0], K, t.pair >> 3), B = body_of(car[1], K, t.pair & 7);
+                const V2 normal = mk(t.nx, t.ny), tangent = mk(normal.y, -normal.x);
+                for (int j = 0; j < t.count; j++) {
+                    const V2 rA = j ? mk(t.rA1x, t.rA1y) : mk(t.rA0x, t.rA0y), rB = j ? mk(t.rB1x, t.rB1y) : mk(t.rB0x, t.rB0y);
+                    const V2 P = (j ? t.nimp1 : t.nimp0) * normal + (j ? t.timp1 : t.timp0) * tangent;
+                    A.b->w -= A.ii * cross(rA, P), A.b->vx -= A.im * P.x, A.b->vy -= A.im * P.y;
+                    B.b->w += B.ii * cross(rB, P), B.b->vx += B.im * P.x, B.b->vy += B.im * P.y;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the contact warm start changed the velocities)
         r.H.vx = mH.vx, r.H.vy = mH.vy, r.H.w = mH.w;
 #pragma unroll
         for (int w = 0; w < 4; w++) r.W[w].vx = mW[w].vx, r.W[w].vy = mW[w].vy, r.W[w].w = mW[w].w;
-    };
-    auto pos_to_lds = [&]() {
-        mH.cx = r.H.cx, mH.cy = r.H.cy, mH.a = r.H.a;
+    }
+    isl_joints_init(r, jt, K, dt_ratio);
+    const float friction = sqrtf(0.2f * 0.2f);
+    // the first NK contacts into registers (rows past the env's count: contact 0's, switched off)
+    KC kc[NK];
+    bool any1 = false, any2 = false;
 #pragma unroll
-        for (int w = 0; w < 4; w++) mW[w].cx = r.W[w].cx, mW[w].cy = r.W[w].cy, mW[w].a = r.W[w].a;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-    auto pos_from_lds = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        r.H.cx = mH.cx, r.H.cy = mH.cy, r.H.a = mH.a;
-#pragma unroll
-        for (int w = 0; w < 4; w++) r.W[w].cx = mW[w].cx, r.W[w].cy = mW[w].cy, r.W[w].a = mW[w].a;
-    };
-    // Envs whose boxes overlap but where nothing touches (most of this kernel's envs) are two independent islands, exactly as in the
-    // per-car kernel.  A wavefront that only holds such envs runs island_solve(); in a MIXED wavefront they ride along the contact
-    // path below instead of running island_solve() beside it (a divergent branch executes both sides one after the other: the
-    // per-car solve used to add its 0.24 ms to the ~1 ms contact path of nearly every wavefront).  Riding along is the same
-    // arithmetic: the LDS round trips copy values, the contact loops run zero times, and `iso` keeps the two places where one
-    // island differs from two -- when the position iterations stop, and who goes to sleep -- per car.
-    const bool iso = nc == 0;
-    if (!__any(nc != 0)) {
-        island_solve(r, K, h, dt_ratio, slp);
-    } else {
-        JointTmp jt;
-        ContactVC *vc = sh_vc[pair];
-        isl_integrate_vel(r, K, h);
-        vel_to_lds();
-        if (me == 0) {  // contact constraints and warm start: even lane, LDS copy
-        // b2ContactSolver::InitializeVelocityConstraints, then WarmStart
-        for (int k = 0; k < nc; k++) {
-            Contact &c = ct[k];
-            ContactVC &q = vc[k];
-            const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
-            q.count = c.count;
-            const float mA = A.im, iA = A.ii, mB = B.im, iB = B.ii;
-            V2 pts[2];
-            world_manifold(c, xf_of(A), xf_of(B), q.normal, pts);
-            const V2 cA = mk(A.b->cx, A.b->cy), cB = mk(B.b->cx, B.b->cy), tangent = mk(q.normal.y, -q.normal.x);
-            for (int j = 0; j < c.count; j++) {
-                c.nimp[j] *= dt_ratio, c.timp[j] *= dt_ratio;
-                q.rA[j] = pts[j] - cA, q.rB[j] = pts[j] - cB;
-                const float rnA = cross(q.rA[j], q.normal), rnB = cross(q.rB[j], q.normal);
-                const float kN = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
-                q.nmass[j] = kN > 0.0f ? 1.0f / kN : 0.0f;
-                const float rtA = cross(q.rA[j], tangent), rtB = cross(q.rB[j], tangent);
-                const float kT = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
-                q.tmass[j] = kT > 0.0f ? 1.0f / kT : 0.0f;
-            }
-            if (q.count == 2) {
-                const float rn1A = cross(q.rA[0], q.normal), rn1B = cross(q.rB[0], q.normal);
-                const float rn2A = cross(q.rA[1], q.normal), rn2B = cross(q.rB[1], q.normal);
-                const float k11 = mA + mB + iA * rn1A * rn1A + iB * rn1B * rn1B, k22 = mA + mB + iA * rn2A * rn2A + iB * rn2B * rn2B;
-                const float k12 = mA + mB + iA * rn1A * rn2A + iB * rn1B * rn2B;
-                if (k11 * k11 < 1000.0f * (k11 * k22 - k12 * k12)) {
-                    q.K[0][0] = k11, q.K[0][1] = k12, q.K[1][0] = k12, q.K[1][1] = k22;
-                    float det = k11 * k22 - k12 * k12;
-                    if (det != 0.0f) det = 1.0f / det;
-                    q.invK[0][0] = det * k22, q.invK[1][0] = -det * k12, q.invK[0][1] = -det * k12, q.invK[1][1] = det * k11;
-                } else {
-                    q.count = 1;
-                }
-            }
-        }
-        for (int k = 0; k < nc; k++) {
-            const Contact &c = ct[k];
-            const ContactVC &q = vc[k];
-            const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
-            const V2 tangent = mk(q.normal.y, -q.normal.x);
-            for (int j = 0; j < q.count; j++) {
-                const V2 P = c.nimp[j] * q.normal + c.timp[j] * tangent;
-                A.b->w -= A.ii * cross(q.rA[j], P), A.b->vx -= A.im * P.x, A.b->vy -= A.im * P.y;
-                B.b->w += B.ii * cross(q.rB[j], P), B.b->vx += B.im * P.x, B.b->vy += B.im * P.y;
-            }
-        }
-        }
-        vel_from_lds();  // (the contact warm start changed the velocities)
-        isl_joints_init(r, jt, K, dt_ratio);
-        const float friction = sqrtf(0.2f * 0.2f);
+    for (int k = 0; k < NK; k++) {
+        const bool ok = k < nc;
+        kc[k] = kc_load(tc[ok ? k : 0], ct[ok ? k : 0], me, ok, K);
+        any1 = any1 || __any(kc[k].count == 1), any2 = any2 || __any(kc[k].count == 2);
+    }
+    bool tail1 = false, tail2 = false;  // contacts past NK (NK == 3 only)
+    for (int k = NK; k < nc_wave; k++) tail1 = tail1 || __any(k < nc && tc[k < nc ? k : 0].count == 1), tail2 = tail2 || __any(k < nc && tc[k < nc ? k : 0].count == 2);
 #pragma unroll 1
-        for (int it = 0; it < 180; it++) {
-            isl_joints_vel(r, jt, K, h);
-            vel_to_lds();
-            if (me == 0)
-            for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolveVelocityConstraints
-                // The two bodies' velocities, the constraint data and the accumulated impulses come into
-                // registers with back-to-back LDS reads, the whole contact (friction per point, then the
-                // normal constraint) is solved there in Box2D's order, and everything goes back once.
-                Contact &c = ct[k];
-                const ContactVC &q = vc[k];
-                const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
-                V2 vA = mk(A.b->vx, A.b->vy), vB = mk(B.b->vx, B.b->vy);
-                float wA = A.b->w, wB = B.b->w;
-                const float mA = A.im, iA = A.ii, mB = B.im, iB = B.ii;
-                const V2 normal = q.normal, tangent = mk(normal.y, -normal.x);
-                const int count = q.count;
-                const V2 rA0 = q.rA[0], rB0 = q.rB[0], rA1 = q.rA[1], rB1 = q.rB[1];
-                const float tm0 = q.tmass[0], tm1 = q.tmass[1], nm0 = q.nmass[0], nm1 = q.nmass[1];
-                const float k00 = q.K[0][0], k01 = q.K[0][1], k10 = q.K[1][0], k11 = q.K[1][1];
-                const float ik00 = q.invK[0][0], ik01 = q.invK[0][1], ik10 = q.invK[1][0], ik11 = q.invK[1][1];
-                float nimp0 = c.nimp[0], nimp1 = c.nimp[1], timp0 = c.timp[0], timp1 = c.timp[1];
-                auto relv = [&](V2 ra, V2 rb) { return ((vB + scross(wB, rb)) - vA) - scross(wA, ra); };
-                auto apply = [&](V2 ra, V2 rb, V2 P) {
-                    vA.x -= mA * P.x, vA.y -= mA * P.y, wA -= iA * cross(ra, P);
-                    vB.x += mB * P.x, vB.y += mB * P.y, wB += iB * cross(rb, P);
-                };
+    for (int it = 0; it < 180; it++) {
+        isl_joints_vel(r, jt, K, h);
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    if (j < count) {
-                        const V2 ra = j ? rA1 : rA0, rb = j ? rB1 : rB0;
-                        float &timp = j ? timp1 : timp0;
-                        const float vt = dot(relv(ra, rb), tangent);
-                        float lambda = (j ? tm1 : tm0) * (-vt);
-                        const float maxF = friction * (j ? nimp1 : nimp0);
-                        float ni = timp + lambda;
-                        ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
-                        lambda = ni - timp, timp = ni;
-                        apply(ra, rb, lambda * tangent);
-                    }
-                }
-                if (count == 1) {
-                    const float vn = dot(relv(rA0, rB0), normal);
-                    float lambda = -nm0 * (vn - 0.0f);
-                    const float ni = fmaxf(nimp0 + lambda, 0.0f);
-                    lambda = ni - nimp0, nimp0 = ni;
-                    apply(rA0, rB0, lambda * normal);
-                } else if (count == 2) {
-                    const V2 a = mk(nimp0, nimp1);
-                    float vn1 = dot(relv(rA0, rB0), normal), vn2 = dot(relv(rA1, rB1), normal);
-                    V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
-                    b = b - mk(k00 * a.x + k10 * a.y, k01 * a.x + k11 * a.y);
-                    V2 x = mk(-(ik00 * b.x + ik10 * b.y), -(ik01 * b.x + ik11 * b.y));
-                    bool solved = x.x >= 0.0f && x.y >= 0.0f;
-                    if (!solved) {
-                        x = mk(-nm0 * b.x, 0.0f);
-                        vn2 = k01 * x.x + b.y;
-                        solved = x.x >= 0.0f && vn2 >= 0.0f;
-                    }
-                    if (!solved) {
-                        x = mk(0.0f, -nm1 * b.y);
-                        vn1 = k10 * x.y + b.x;
-                        solved = x.y >= 0.0f && vn1 >= 0.0f;
-                    }
-                    if (!solved) {
-                        x = mk(0.0f, 0.0f);
-                        solved = b.x >= 0.0f && b.y >= 0.0f;
-                    }
-                    if (solved) {
-                        const V2 d = x - a;
-                        const V2 P1 = d.x * normal, P2 = d.y * normal;
-                        vA.x -= mA * (P1.x + P2.x), vA.y -= mA * (P1.y + P2.y);
-                        wA -= iA * (cross(rA0, P1) + cross(rA1, P2));
-                        vB.x += mB * (P1.x + P2.x), vB.y += mB * (P1.y + P2.y);
-                        wB += iB * (cross(rB0, P1) + cross(rB1, P2));
-                        nimp0 = x.x, nimp1 = x.y;
-                    }
-                }
-                A.b->vx = vA.x, A.b->vy = vA.y, A.b->w = wA, B.b->vx = vB.x, B.b->vy = vB.y, B.b->w = wB;
-                c.nimp[0] = nimp0, c.nimp[1] = nimp1, c.timp[0] = timp0, c.timp[1] = timp1;
-            }
-            vel_from_lds();
-        }
-        isl_integrate_pos(r, h);
-        pos_to_lds();
-        bool solved = false;
-        bool iso_done = false;  // iso: this car's own position iterations have converged (b2Island::Solve breaks out there)
+        for (int k = 0; k < NK; k++) contact_vel(r, kc[k], me, friction, any1, any2);
+        if (NK == 3) {
 #pragma unroll 1
-        for (int it = 0; it < 60; it++) {
-            float minSep = 0.0f;
-            if (me == 0)
-            for (int k = 0; k < nc; k++) {  // b2ContactSolver::SolvePositionConstraints
-                const Contact &c = ct[k];
-                const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
-                for (int j = 0; j < c.count; j++) {
-                    const XF xa = xf_of(A), xb = xf_of(B);
-                    V2 normal, point;
-                    float sep;
-                    if (c.type == 0) {
-                        normal = rotv(xa.s, xa.c, mk(c.ln[0], c.ln[1]));
-                        const V2 plane = xmul(xa, mk(c.lp[0], c.lp[1])), clip = xmul(xb, mk(c.pt[j][0], c.pt[j][1]));
-                        sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
-                    } else {
-                        normal = rotv(xb.s, xb.c, mk(c.ln[0], c.ln[1]));
-                        const V2 plane = xmul(xb, mk(c.lp[0], c.lp[1])), clip = xmul(xa, mk(c.pt[j][0], c.pt[j][1]));
-                        sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
-                        normal = -1.0f * normal;
-                    }
-                    const V2 rA = point - mk(A.b->cx, A.b->cy), rB = point - mk(B.b->cx, B.b->cy);
-                    if (sep < minSep) minSep = sep;
-                    const float C = fminf(fmaxf(0.2f * (sep + LINEAR_SLOP), -0.2f), 0.0f);
-                    const float rnA = cross(rA, normal), rnB = cross(rB, normal);
-                    const float Kn = A.im + B.im + A.ii * rnA * rnA + B.ii * rnB * rnB;
-                    const float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
-                    const V2 P = impulse * normal;
-                    A.b->cx -= A.im * P.x, A.b->cy -= A.im * P.y, A.b->a -= A.ii * cross(rA, P);
-                    B.b->cx += B.im * P.x, B.b->cy += B.im * P.y, B.b->a += B.ii * cross(rB, P);
-                }
+            for (int k = NK; k < nc_wave; k++) {
+                const bool ok = k < nc;
+                KC q = kc_load(tc[ok ? k : 0], ct[ok ? k : 0], me, ok, K);
+                contact_vel(r, q, me, friction, tail1, tail2);
+                if (ok && me == 0) tc[k].nimp0 = q.nimp0, tc[k].nimp1 = q.nimp1, tc[k].timp0 = q.timp0, tc[k].timp1 = q.timp1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            const bool cok = minSep >= -3.0f * LINEAR_SLOP;  // (meaningful in the even lane)
-            pos_from_lds();
-            bool jok = true;
-            if (!iso_done) jok = isl_joints_pos(r, K);  // (a converged island of its own is not iterated again)
-            pos_to_lds();
-            if (iso && jok) iso_done = true;
-            // contactsOkay && jointsOkay of the whole island: combine the pair (two islands: both have converged)
-            const int mine = iso ? (iso_done ? 1 : 0) : ((me == 0 ? (cok ? 1 : 0) : 1) & (jok ? 1 : 0));
-            const int other = __shfl_xor(mine, 1);
-            if (mine & other) {
-                solved = true;
-                break;
-            }
-        }
-        // one island: it sleeps only when all ten bodies have been still long enough; two islands: each on its own
-        const float mm = isl_sleep_scan(r, slp, h);
-        const float mo = __shfl_xor(mm, 1);
-        if (iso) {
-            if (mm >= TIME_TO_SLEEP && iso_done) isl_put_to_sleep(r, slp);
-        } else if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) {
-            isl_put_to_sleep(r, slp);
         }
     }
+    if (me == 0) {
+#pragma unroll
+        for (int k = 0; k < NK; k++)
+            if (k < nc) ct[k].nimp[0] = kc[k].nimp0, ct[k].nimp[1] = kc[k].nimp1, ct[k].timp[0] = kc[k].timp0, ct[k].timp[1] = kc[k].timp1;
+        for (int k = NK; k < nc; k++) ct[k].nimp[0] = tc[k].nimp0, ct[k].nimp[1] = tc[k].nimp1, ct[k].timp[0] = tc[k].timp0, ct[k].timp[1] = tc[k].timp1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    isl_integrate_pos(r, h);
+    bool solved = false;
+    const V2 hlc = mk(K.hull_lc[0], K.hull_lc[1]);
+#pragma unroll 1
+    for (int it = 0; it < 60; it++) {
+        float minSep = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NK; k++) contact_pos(r, kc[k], me, hlc, minSep);
+        if (NK == 3) {
+#pragma unroll 1
+            for (int k = NK; k < nc_wave; k++) {
+                const bool ok = k < nc;
+                const KC q = kc_load(tc[ok ? k : 0], ct[ok ? k : 0], me, ok, K);
+                contact_pos(r, q, me, hlc, minSep);
+            }
+        }
+        const bool cok = minSep >= -3.0f * LINEAR_SLOP;
+        const bool jok = isl_joints_pos(r, K);
+        // contactsOkay && jointsOkay of the whole island: combine the pair
+        const int mine = (cok ? 1 : 0) & (jok ? 1 : 0);
+        const int other = __shfl_xor(mine, 1);
+        if (mine & other) {  // (both lanes of the pair leave together; the wavefront goes on for the other islands)
+            solved = true;
+            break;
+        }
+    }
+    // one island: it sleeps only when all ten bodies have been still long enough
+    const float mm = isl_sleep_scan(r, slp, h);
+    const float mo = __shfl_xor(mm, 1);
+    if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(r, slp);
+    if (!live) return;
     for (int b = 0; b < 5; b++) s.sleep[b * M + me * s.n + env] = slp[b];
 
     // ---- store bodies, joints and the manifolds with their impulses
@@ -531,10 +701,37 @@ __global__ __launch_bounds__(64) void car_coupled_kernel(CarSoA s, CarConsts K) 
         o[13] = c.nimp[0], o[14] = c.nimp[1], o[15] = c.timp[0], o[16] = c.timp[1];
     }
 }
+#undef CRL_SEL
+#undef CRL_PUT
 
-void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st) {
+// one instance per manifold-count class; blockIdx.y = class (0: nc == 1, 1: nc == 2, 2: nc >= 3)
+__global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K) {
+    const int cls = blockIdx.y;
+    const int count = s.coupled_count[2 + cls];
+    if ((int)blockIdx.x * 32 >= count) return;
+    __shared__ __attribute__((aligned(16))) CarRegs sh_car[32][2];
+    __shared__ __attribute__((aligned(16))) Contact sh_ct[32][kMaxContacts];
+    __shared__ __attribute__((aligned(16))) TouchC sh_tc[32][kMaxContacts];
+    const int32_t *list = s.touch_list + (int64_t)cls * s.n;
+    if (cls == 0) touch_solve<1>(s, K, list, count, sh_car, sh_ct, sh_tc);
+    else if (cls == 1) touch_solve<2>(s, K, list, count, sh_car, sh_ct, sh_tc);
+    else touch_solve<3>(s, K, list, count, sh_car, sh_ct, sh_tc);
+}
+
+// world.Step of the coupled envs.  `near_st` (may equal `st`): where the near-only envs are solved, beside the touching ones.
+void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st, hipEvent_t ev_narrow, hipEvent_t ev_near) {
     if (s.players != 2 || !s.contacts_enabled) return;
-    hipLaunchKernelGGL(car_coupled_kernel, dim3((unsigned)((s.n + 31) / 32)), dim3(64), 0, st, s, k);
+    if (!near_st) near_st = st;
+    const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
+    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k);
+    if (near_st != st) {
+        hipEventRecord(ev_narrow, st);
+        hipStreamWaitEvent(near_st, ev_narrow, 0);
+    }
+    hipLaunchKernelGGL(car_near_kernel, dim3((unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512)), dim3(64), 0, near_st, s, k);
+    if (near_st != st) hipEventRecord(ev_near, near_st);
+    hipLaunchKernelGGL(car_touch_kernel, dim3((unsigned)((s.n + 31) / 32), 3), dim3(64), 0, st, s, k);
+    if (near_st != st) hipStreamWaitEvent(st, ev_near, 0);
 }
 
 }  // namespace crl

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/crl.h"
+#include "../../include/crl_f64.h"
 #include "../../include/crl_rot.h"
 
 namespace crl {
@@ -25,6 +26,21 @@ namespace crl {
 static constexpr int kCarMaxTiles = CRL_CAR_MAX_TILES;  // 512
 static constexpr int kWheelSlots = 6;                   // tiles one wheel can touch at once
 static constexpr int kMaxContacts = 8, kContactWords = 20;
+
+// ---- observation map (car_obs.hip): the window [kMapOrg, kMapOrg + kMapW)^2 of the reference's 10000 x 10000
+// `observation_playground` (car_racing_multi_players.py:216-222, 732-755) as a 7-colour palette, 4 bits per pixel,
+// in 16 x 16-pixel blocks of 128 bytes (one L2 line): block (by, bx) at ((by * kMapBlocks + bx) * 128), row r of a
+// block at + 8 r, pixel x of that row in nibble (x & 1) of byte (x >> 1).  A rotated 96 x 96 view touches ~50-64 blocks.
+static constexpr int kMapOrg = CRL_CAR_MAP_ORG, kMapW = CRL_CAR_MAP_W;      // 4392, 1216
+static constexpr int kMapBlocks = kMapW / 16;                                // 76 per row
+static constexpr int64_t kMapBytes = (int64_t)kMapBlocks * kMapBlocks * 128;  // 739 328 per env
+static constexpr int kMapSurface = 10000;
+#define CRL_CAR_OBS_SCALE 0x1.c37d6d52bdddbp+0  // (10 / (100 / sqrt(96))) * 1.8 (crmp:214-215)
+enum { kPalGrass = 0, kPalLight = 1, kPalRoad0 = 2, kPalWhite = 5, kPalRed = 6 };
+// per (env, viewer) tile, written by car_view_kernel and read by car_obs_kernel
+static constexpr int kViewWords = 20;     // struct ViewParams (16 words) + the float32 camera (sin, cos, offset x, y)
+static constexpr int kSpanSlots = 16;     // scanline spans one car polygon can produce (a polygon is <= 5.3 px across: <= 8)
+static constexpr int kViewRecWords = 16 * kSpanSlots;
 
 // constants of car_racing_multi_players.py:54-88 and car_dynamics.py:17-51
 #define CAR_SCALE 6.0
@@ -97,10 +113,37 @@ struct CarSoA {
     float *sleep;           // [5][M] b2Body::m_sleepTime of hull, wheels 0-3
     int32_t *coupled;       // [n] 1 = the two cars are solved together this step
     int32_t *coupled_list;  // [n] the coupled envs of this step, compacted (any order), and
-    int32_t *coupled_count; // [1] how many: the coupled kernel launches dense wavefronts over the list
+    int32_t *coupled_count; // [8] how many: [0] coupled (car_step_kernel), then the narrow phase's split: [1] near-only, [2..4] touching
+                            //     with one / two / three-or-more manifolds
+    int32_t *near_list, *touch_list;  // [n], [3][n]
+    int32_t *touch_all;     // [n] every touching env (any manifold count), [5] of coupled_count: their frames
+    int32_t *coupled_to_host;  // host-mapped word: the step's coupled-env count, read by the host one step late (sizes the list launches)
+    int32_t *zero_next;     // [16] the OTHER step parity's counter block (coupled_count[8] + class counts): car_step_kernel clears it for the next step
+    int32_t *nc_new;        // [n] this step's manifold count (car_narrow_kernel)
+    float *contact_new;     // [n][kMaxContacts][kContactWords] this step's manifolds with the carried-over impulses
     int32_t *n_contact;     // [n] touching car-car contacts carried to the next step (warm start)
     float *contact;         // [n][16][kContactWords] persisted manifolds + impulses
+    // ---- observations as the reference computes them (car_obs.hip)
+    uint8_t *obs_map;       // [n][kMapBytes] pre-rastered palette map of the env's track (built at reset)
+    uint32_t *map_vtx;      // [n][512][9] map-space vertices (x | y << 16, int16 each, window coordinates) of tile i (5) and its border (4)
+    uint32_t *map_yr;       // [n][512] first | last << 16 map row (int16 each) that tile i or its border touches
+    int32_t *map_overflow;  // [n] polygon vertices that fell outside the window at the last reset (0 for every track)
+    uint32_t *map_lightx, *map_lighty;  // [kMapW / 32] bit masks: columns / rows of the window covered by the lighter squares
+    int32_t *view;          // [tiles][kViewWords] ViewParams
+    uint8_t *view_cnt;      // [tiles][16] spans per car polygon
+    uint32_t *view_rec;     // [tiles][16][kSpanSlots] spans: y | xl << 8 | xr << 16
 };
+
+struct ViewParams {  // one (env, viewer) tile: where its 96 x 96 pixels come from, and what is drawn over them
+    // source of screen pixel (X, Y) in 16.16 fixed point, in WINDOW coordinates of the map (the crop rectangle folded in):
+    //   dx = dx00 + icos * X - isin * Y,  dy = dy00 + isin * X + icos * Y;  map pixel = (dx >> 16, dy >> 16)
+    int32_t dx00, dy00, isin, icos;
+    int32_t rx, ry;         // top-left corner of the 192 x 192 crop, window coordinates
+    int32_t flags;          // bit 0: every source pixel lies inside the window; bit 1: no pixel takes rotate()'s background colour
+    int32_t text_idx;       // row of the reward read-out bitmaps, -1 = none
+    uint32_t rect[8];       // indicator rectangles, clipped: x0 | x1 << 8 | y0 << 16 | y1 << 24 (x0 > x1: empty)
+};
+static_assert(sizeof(ViewParams) == 16 * 4 && kViewWords >= 20, "ViewParams layout");
 
 struct V2 {
     float x, y;
@@ -156,7 +199,8 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
                      hipStream_t st);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
-void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st);
+void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st = nullptr, hipEvent_t ev_narrow = nullptr,
+                        hipEvent_t ev_near = nullptr);  // near_st == nullptr: everything on st
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
                      int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 
@@ -165,6 +209,14 @@ void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStr
 void launch_car_raster_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
                             int32_t *count_to_host, int64_t expected);
 void car_raster_print_ticks();  // CRL_CAR_DEBUG & 64
+// car_obs.hip: the reference's observation pipeline
+void launch_car_map_build(const CarSoA &s, hipStream_t st, const uint8_t *only_env = nullptr, int64_t first = 0, int64_t count = -1);  // envs [first, first + count), all or only_env[e] != 0
+void launch_car_map_build_list(const CarSoA &s, hipStream_t st, const int32_t *list, const int32_t *list_count, int64_t expected);
+void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
+void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
+                         int32_t *count_to_host, int64_t expected, const uint8_t *filter = nullptr, int want_cls = 0);
+void car_map_light_masks(uint32_t *lightx, uint32_t *lighty);  // host: the squares' columns / rows (kMapW / 32 words each)
+int car_map_coord(double v);                                     // host: (int)(obs_scale * -v + 5000), as the map polygons' vertices
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
                       int players, hipStream_t st);
 

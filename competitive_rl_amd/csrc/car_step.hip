@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
                                                       int repeat) {
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 16 && s.zero_next) s.zero_next[threadIdx.x] = 0;  // the NEXT step's counters (the other parity's block: nobody reads it now)
     if (ci >= M) return;
     const int car = ci >= s.n ? 1 : 0;
     const int64_t env = ci - car * s.n;
@@ -565,7 +566,6 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st) {
     const int64_t M = (int64_t)s.players * s.n;
-    if (s.coupled_count) hipMemsetAsync(s.coupled_count, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car, sub, repeat);
 }
 
@@ -583,7 +583,6 @@ void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
 
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
                      int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list, int32_t *class_count) {
-    if (class_count) hipMemsetAsync(class_count, 0, 2 * sizeof(int32_t), st);
     hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env, slow_env,
                        info_steps, max_episode_steps, car0_only ? 1 : 0, class_list, class_count);
 }

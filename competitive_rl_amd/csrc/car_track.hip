@@ -37,7 +37,7 @@ __device__ inline double sgnd(double v) { return (double)((v > 0) - (v < 0)); }
 // one iteration of the walk; returns the appended point
 __device__ inline void walk_step(const Checkpoints &cp, Walk &w, double out[4]) {
     const double PI = 3.141592653589793;
-    double alpha = atan2(w.y, w.x);
+    double alpha = crl_atan2(w.y, w.x);
     if (w.visited_other_side && alpha > 0) w.laps++, w.visited_other_side = 0;
     if (alpha < 0) w.visited_other_side = 1, alpha += 2 * PI;
     double dest_x = 0, dest_y = 0;
@@ -53,7 +53,7 @@ __device__ inline void walk_step(const Checkpoints &cp, Walk &w, double out[4]) 
         if (!failed) break;
         alpha -= 2 * PI;
     }
-    const double r1x = cos(w.beta), r1y = sin(w.beta), p1x = -r1y, p1y = r1x;
+    const double r1x = crl_cos(w.beta), r1y = crl_sin(w.beta), p1x = -r1y, p1y = r1x;
     const double dest_dx = dest_x - w.x, dest_dy = dest_y - w.y;
     double proj = r1x * dest_dx + r1y * dest_dy;
     while (w.beta - alpha > 1.5 * PI) w.beta -= 2 * PI;
@@ -85,7 +85,7 @@ __device__ int create_track(const double u[24], double *__restrict__ pts, int64_
         double rad = CAR_TRACK_RAD / 3 + (CAR_TRACK_RAD - CAR_TRACK_RAD / 3) * u[2 * c + 1];
         if (c == 0) alpha = 0, rad = 1.5 * CAR_TRACK_RAD;
         if (c == 11) alpha = 2 * PI * c / 12, cp.start_alpha = 2 * PI * (-0.5) / 12, rad = 1.5 * CAR_TRACK_RAD;
-        cp.a[c] = alpha, cp.x[c] = rad * cos(alpha), cp.y[c] = rad * sin(alpha);
+        cp.a[c] = alpha, cp.x[c] = rad * crl_cos(alpha), cp.y[c] = rad * crl_sin(alpha);
     }
     Walk w;
     walk_init(w);
@@ -108,7 +108,7 @@ __device__ int create_track(const double u[24], double *__restrict__ pts, int64_
     const int len = (i2 - 1) - i1;  // points i1 .. i2-2
     if (len <= 0 || len > kCarMaxTiles) return 0;
     const double *trk = pts + (int64_t)i1 * 4 * stride;
-    const double fb = trk[1 * stride], fpx = cos(fb), fpy = sin(fb);
+    const double fb = trk[1 * stride], fpx = crl_cos(fb), fpy = crl_sin(fb);
     const double a = fpx * (trk[2 * stride] - trk[((int64_t)(len - 1) * 4 + 2) * stride]);
     const double b = fpy * (trk[3 * stride] - trk[((int64_t)(len - 1) * 4 + 3) * stride]);
     if (sqrt(a * a + b * b) > CAR_TRACK_DETAIL_STEP) return 0;
@@ -141,7 +141,16 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
     const int64_t n = s.n, M = (int64_t)s.players * n;
     const int lane = threadIdx.x & 63;
     auto T = [&](int i, int q) { return trk[((int64_t)i * 4 + q) * n]; };
-    if (lane == 0) s.ntiles[env] = len;
+    if (lane == 0) s.ntiles[env] = len, s.map_overflow[env] = 0;
+    // one vertex of a polygon of render_road_for_observation_map (crmp:745-753): (obs_scale * -v + world_size / 2), truncated
+    // by pygame; kept in window coordinates as int16 (the window holds every track: map_overflow counts what does not fit)
+    int overflow = 0;
+    auto map_vertex = [&](const double *v) -> uint32_t {
+        const int mx = (int)(CRL_CAR_OBS_SCALE * -v[0] + kMapSurface / 2.0) - kMapOrg, my = (int)(CRL_CAR_OBS_SCALE * -v[1] + kMapSurface / 2.0) - kMapOrg;
+        if (mx < 0 || my < 0 || mx >= kMapW || my >= kMapW) overflow++;
+        const int cx = min(max(mx, -32768), 32767), cy = min(max(my, -32768), 32767);
+        return (uint32_t)(uint16_t)(int16_t)cx | ((uint32_t)(uint16_t)(int16_t)cy << 16);
+    };
     // red-white border on hard turns: 4 consecutive same-sign turns ...
     for (int i = lane; i < len; i += 64) {
         bool good = true;
@@ -166,13 +175,20 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         const double b1 = T(i, 1), x1 = T(i, 2), y1 = T(i, 3), b2 = T(j, 1), x2 = T(j, 2), y2 = T(j, 3);
         const double PI = 3.141592653589793;
         const double v[5][2] = {
-            {x1 - CAR_TRACK_WIDTH * cos(b1), y1 - CAR_TRACK_WIDTH * sin(b1)},
-            {x1 - CAR_TRACK_WIDTH / 2 * cos(b1 - PI / 2), y1 - CAR_TRACK_WIDTH / 2 * sin(b1 - PI / 2)},
-            {x1 + CAR_TRACK_WIDTH * cos(b1), y1 + CAR_TRACK_WIDTH * sin(b1)},
-            {x2 + CAR_TRACK_WIDTH * cos(b2), y2 + CAR_TRACK_WIDTH * sin(b2)},
-            {x2 - CAR_TRACK_WIDTH * cos(b2), y2 - CAR_TRACK_WIDTH * sin(b2)},
+            {x1 - CAR_TRACK_WIDTH * crl_cos(b1), y1 - CAR_TRACK_WIDTH * crl_sin(b1)},
+            {x1 - CAR_TRACK_WIDTH / 2 * crl_cos(b1 - PI / 2), y1 - CAR_TRACK_WIDTH / 2 * crl_sin(b1 - PI / 2)},
+            {x1 + CAR_TRACK_WIDTH * crl_cos(b1), y1 + CAR_TRACK_WIDTH * crl_sin(b1)},
+            {x2 + CAR_TRACK_WIDTH * crl_cos(b2), y2 + CAR_TRACK_WIDTH * crl_sin(b2)},
+            {x2 - CAR_TRACK_WIDTH * crl_cos(b2), y2 - CAR_TRACK_WIDTH * crl_sin(b2)},
         };
         float bb[4];
+        uint32_t *mv = s.map_vtx + (env * kCarMaxTiles + i) * 9;
+        int ylo = 32767, yhi = -32768;
+        for (int q = 0; q < 5; q++) {
+            const uint32_t w = map_vertex(v[q]);
+            mv[q] = w;
+            ylo = min(ylo, (int)(int16_t)(w >> 16)), yhi = max(yhi, (int)(int16_t)(w >> 16));
+        }
         store_poly_ccw(v, 5, s.tile_poly + (int64_t)i * 10 * n + env, n, bb);
         s.tile_aabb[(int64_t)i * n + env] = make_float4(bb[0], bb[1], bb[2], bb[3]);
         s.tile_aabb_em[env * kCarMaxTiles + i] = make_float4(bb[0], bb[1], bb[2], bb[3]);
@@ -181,18 +197,25 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         if (flag[i]) {
             const double side = sgnd(b2 - b1);
             const double bp[4][2] = {
-                {x1 + side * CAR_TRACK_WIDTH * cos(b1), y1 + side * CAR_TRACK_WIDTH * sin(b1)},
-                {x1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * cos(b1), y1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * sin(b1)},
-                {x2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * cos(b2), y2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * sin(b2)},
-                {x2 + side * CAR_TRACK_WIDTH * cos(b2), y2 + side * CAR_TRACK_WIDTH * sin(b2)},
+                {x1 + side * CAR_TRACK_WIDTH * crl_cos(b1), y1 + side * CAR_TRACK_WIDTH * crl_sin(b1)},
+                {x1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos(b1), y1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin(b1)},
+                {x2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos(b2), y2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin(b2)},
+                {x2 + side * CAR_TRACK_WIDTH * crl_cos(b2), y2 + side * CAR_TRACK_WIDTH * crl_sin(b2)},
             };
+            for (int q = 0; q < 4; q++) {
+                const uint32_t w = map_vertex(bp[q]);
+                mv[5 + q] = w;
+                ylo = min(ylo, (int)(int16_t)(w >> 16)), yhi = max(yhi, (int)(int16_t)(w >> 16));
+            }
             store_poly_ccw(bp, 4, s.border_poly + (int64_t)i * 8 * n + env, n, nullptr);
             bflag = (i % 2 == 0) ? 1 : 2;  // white / red
             for (int q = 0; q < 8; q++) s.border_poly_em[(env * kCarMaxTiles + i) * 8 + q] = s.border_poly[((int64_t)i * 8 + q) * n + env];
         }
         s.border[(int64_t)i * n + env] = bflag;
         s.border_em[env * kCarMaxTiles + i] = bflag;
+        s.map_yr[env * kCarMaxTiles + i] = (uint32_t)(uint16_t)(int16_t)ylo | ((uint32_t)(uint16_t)(int16_t)yhi << 16);
     }
+    if (overflow) atomicAdd(&s.map_overflow[env], overflow);
     const double ia = T(0, 1), ix = T(0, 2), iy = T(0, 3);
     if (lane == 0) s.start_pose[0 * n + env] = (float)ia, s.start_pose[1 * n + env] = (float)ix, s.start_pose[2 * n + env] = (float)iy;
     if (lane < s.players) {

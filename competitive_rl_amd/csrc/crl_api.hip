@@ -772,10 +772,14 @@ int crl_car_get_track(crl_ctx *c, int64_t env, int32_t *n, float *tile_poly, flo
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_get_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
 }
-int crl_car_set_track(crl_ctx *c, int64_t env, int32_t n, const float *tile_poly, const float *border_poly, const uint8_t *border,
+int crl_car_set_track(crl_ctx *c, int64_t env, int32_t n, const double *tile_poly, const double *border_poly, const uint8_t *border,
                       const float *start_pose, void *stream) {
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_set_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
+}
+int crl_car_get_map(crl_ctx *c, int64_t env, uint8_t *palette_host, int32_t *overflow, void *stream) {
+    if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
+    return crl_car_get_map_impl(c->car, env, palette_host, overflow, (hipStream_t)stream);
 }
 int crl_car_set_replay(crl_ctx *c, const double *u, const uint8_t *swap, int64_t attempts) {
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");

@@ -29,9 +29,14 @@ struct crl_car_ctx {
     // side stream next to the raster; slow_env = pipeline class per env (car_post_kernel)
     uint8_t *slow_env = nullptr;
     int32_t *class_list = nullptr;   // [2][n] envs of class 1 (coupled) and class 2 (finished) of the current step, compacted
-    int32_t *class_count = nullptr;  // [2] their lengths
+    int32_t *class_count = nullptr;  // [2] their lengths (inside `counters`)
+    int32_t *counters = nullptr;     // [2][16] per step parity: coupled_count[8], class_count[2]; a step's first kernel clears the other block
+    int parity = 0;
+    hipEvent_t ev_nearfr = nullptr;
     int32_t *class_count_host = nullptr, *class_count_hdev = nullptr;  // host-mapped copy (one step late): sizes the next step's launches
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;  // the near-only coupled envs (plain island solves), beside the touching ones on `side`
+    hipEvent_t ev_narrow = nullptr, ev_near = nullptr;
     hipStream_t sens = nullptr;  // the wheel-sensor contacts of a step, beside its solve
     hipEvent_t ev_sens = nullptr, ev_c1 = nullptr;
     hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
@@ -42,6 +47,7 @@ struct crl_car_ctx {
     bool car0_only = false;         // crl_opts.done_policy == CRL_CAR_DONE_CAR0
     hipEvent_t ev_fork = nullptr, ev_coupled = nullptr, ev_term = nullptr, ev_join = nullptr;
     bool overlap = true;
+    bool analytic = false;  // CRL_CAR_OBS_ANALYTIC=1: rounds 1-2' analytic raster (car_raster.hip) instead of map + gather, for A/B
 };
 
 namespace crl {
@@ -161,15 +167,18 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(coupled_count, 4); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
+    A(obs_map, (size_t)kMapBytes * n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
+    A(map_lightx, kMapW / 32); A(map_lighty, kMapW / 32);
+    A(view, (size_t)kViewWords * M); A(view_cnt, (size_t)16 * M); A(view_rec, (size_t)kViewRecWords * M);
 #undef A
     if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
     if (!rc) rc = calloc_dev(c, &c->slow_env, n);
     if (!rc) rc = calloc_dev(c, &c->class_list, 2 * n);
-    if (!rc) rc = calloc_dev(c, &c->class_count, 4);
+    if (!rc) rc = calloc_dev(c, &c->counters, 2 * 16);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     if (!rc) rc = calloc_dev(c, &c->info_steps, n);
     if (!rc) rc = calloc_dev(c, &c->term, (size_t)M * 96 * 96);
@@ -199,8 +208,24 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         return crl_fail(CRL_EHIP, "car create: host-mapped counters");
     }
     c->class_count_host[0] = c->class_count_host[1] = (int32_t)std::min<int64_t>(n, 64);
+    c->s.coupled_to_host = c->class_count_hdev;
+    c->s.coupled_count = c->counters, c->class_count = c->counters + 8, c->s.zero_next = c->counters + 16;
     c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
+    c->analytic = getenv("CRL_CAR_OBS_ANALYTIC") && atoi(getenv("CRL_CAR_OBS_ANALYTIC")) != 0;
+    {
+        uint32_t lx[kMapW / 32], ly[kMapW / 32];
+        car_map_light_masks(lx, ly);
+        if (hipMemcpy(c->s.map_lightx, lx, sizeof(lx), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->s.map_lighty, ly, sizeof(ly), hipMemcpyHostToDevice) != hipSuccess) {
+            crl_car_destroy(c);
+            return crl_fail(CRL_EHIP, "car create: map constants");
+        }
+    }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_narrow, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_near, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_nearfr, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess ||
@@ -238,6 +263,10 @@ void crl_car_destroy(crl_car_ctx *c) {
     hipDeviceSynchronize();
     if (getenv("CRL_CAR_DEBUG") && (atoi(getenv("CRL_CAR_DEBUG")) & 64)) crl::car_raster_print_ticks();
     if (c->side) hipStreamDestroy(c->side);
+    if (c->side2) hipStreamDestroy(c->side2);
+    if (c->ev_narrow) hipEventDestroy(c->ev_narrow);
+    if (c->ev_near) hipEventDestroy(c->ev_near);
+    if (c->ev_nearfr) hipEventDestroy(c->ev_nearfr);
     if (c->sens) hipStreamDestroy(c->sens);
     if (c->ev_sens) hipEventDestroy(c->ev_sens);
     if (c->ev_c1) hipEventDestroy(c->ev_c1);
@@ -283,13 +312,25 @@ void crl_car_seed(crl_car_ctx *c, uint64_t seed) {
 }
 int64_t crl_car_obs_bytes(const crl_car_ctx *c) { return (int64_t)c->s.players * c->K * CRL_CAR_OBS * CRL_CAR_OBS; }
 
+// frames of every env, or of the envs with only_env[e] == want
+static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1) {
+    if (c->analytic) launch_car_raster(c->s, c->K_, dst, st, only_env, want);
+    else launch_car_obs(c->s, c->K_, dst, st, only_env, want);
+}
+// frames of the envs of a compacted list
+static void frames_list(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const int32_t *list, const int32_t *list_count, int32_t *count_to_host,
+                        int64_t expected) {
+    if (c->analytic) launch_car_raster_list(c->s, c->K_, dst, st, list, list_count, count_to_host, expected);
+    else launch_car_obs_list(c->s, c->K_, dst, st, list, list_count, count_to_host, expected);
+}
+
 // newest frames -> obs_dev, through the frame stack when K > 1
 static void draw(crl_car_ctx *c, uint8_t *obs_dev, bool fill_all, hipStream_t st) {
     if (c->K == 1) {
-        launch_car_raster(c->s, c->K_, obs_dev, st);
+        frames(c, obs_dev, st);
         return;
     }
-    launch_car_raster(c->s, c->K_, c->frame, st);
+    frames(c, c->frame, st);
     launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, fill_all, c->K, c->n, c->s.players, st);
 }
 
@@ -302,6 +343,7 @@ int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         launch_car_walk_ahead(c->s, c->src, st);
     }
     launch_car_reset(c->s, c->K_, c->src, false, nullptr, st);
+    launch_car_map_build(c->s, st);  // render_road_for_observation_map (crmp:519)
     queue_walk_ahead(c, st, true);
     if (obs_dev) draw(c, obs_dev, true, st);
     hipError_t e = hipGetLastError();
@@ -316,7 +358,7 @@ int crl_car_players(const crl_car_ctx *c) { return c->s.players; }
 
 int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
     if (c->K > 1) return crl_fail(CRL_ESTATE, "crl_render on a stacked CarRacing context would advance the stack");
-    launch_car_raster(c->s, c->K_, obs_dev, st);
+    frames(c, obs_dev, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car render: %s", hipGetErrorString(e));
     return CRL_OK;
@@ -330,7 +372,13 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     // world.Step, crmp:576-603), so the env-level bookkeeping does not wait for the coupled solve.
     const bool fork = c->overlap && obs_dev != nullptr;
     crl_timer_begin(tm, 0, st);
+    auto next_counters = [&]() {  // this sub-step's counter block; car_step_kernel clears the other one for the next
+        c->parity ^= 1;
+        c->s.coupled_count = c->counters + 16 * c->parity, c->class_count = c->s.coupled_count + 8;
+        c->s.zero_next = c->counters + 16 * (c->parity ^ 1);
+    };
     for (int sub = 0; sub < c->repeat; sub++) {  // action repetition: Car.step + world.Step per repeat (crmp:576-603)
+        next_counters();
         // Car.step, rewards, done flags; decides which cars are solved together
         launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, sub, c->repeat, st);
         if (fork && sub == c->repeat - 1) break;  // the last world.Step is forked below
@@ -341,8 +389,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, c->info_steps, 1000, c->car0_only, st, c->class_list, c->class_count);
     if (!fork) {
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
-        if (obs_dev) launch_car_raster(c->s, c->K_, c->term, st, c->done_env);
+        if (obs_dev) frames(c, c->term, st, c->done_env);
         launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
+        launch_car_map_build(c->s, st, c->done_env);
         queue_walk_ahead(c, st);
         crl_timer_end(tm, 0, st);
         if (obs_dev) {
@@ -351,40 +400,49 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             crl_timer_end(tm, 1, st);
         }
     } else {
-        // Three streams, three disjoint classes of envs (car_post_kernel): envs that neither touch nor finished are solved and
-        // drawn on the caller's stream; coupled envs are solved on `side` and drawn on `sens` (behind the wheel sensors);
-        // finished envs get their terminal frame, their reset and the first frame of the new episode on `side`.
+        // Four streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished):
+        //   st     per-car solve -> frames of class 0 (the big launch)
+        //   sens   wheel sensors (tile rewards, road_visited: they read the transforms the step started from and feed nothing into
+        //          its solve; every frame shows the reward, so every frame launch waits for them)
+        //   side   narrow phase of the coupled envs -> the touching ones' island solve -> their frames; then the finished envs
+        //          from end to end: terminal frame (info["terminal_observation"]), reset, map, first frame of the new episode
+        //   side2  the coupled envs where nothing touches (two islands of their own) -> their frames
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
+        const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
         hipEventRecord(c->ev_fork, st);
-        // side: the coupled solve (the few envs whose cars may touch), next to the per-car solve AND the frames
         hipStreamWaitEvent(c->side, c->ev_fork, 0);
-        launch_car_coupled(c->s, c->K_, c->side);
-        hipEventRecord(c->ev_coupled, c->side);
-        // sens: the wheel sensors (tile rewards, road_visited) read the transforms the step started from and feed nothing
-        // into its solve; then the coupled envs' frames, beside the big launch
         hipStreamWaitEvent(c->sens, c->ev_fork, 0);
         launch_car_sensors(c->s, c->K_, c->sens);
         hipEventRecord(c->ev_sens, c->sens);
-        hipStreamWaitEvent(c->sens, c->ev_coupled, 0);
-        launch_car_raster_list(c->s, c->K_, target, c->sens, c->class_list, c->class_count, c->class_count_hdev, c->class_count_host[0]);
-        hipEventRecord(c->ev_c1, c->sens);
-        // main: the per-car solve, then the frames of every env that neither touches nor finished (they show the reward: sensors first)
+        launch_car_coupled(c->s, c->K_, c->side, c->side2, c->ev_narrow, c->ev_near);  // (side ends up behind side2's solve too)
+        if (c->s.players == 2 && c->s.contacts_enabled) {
+            hipStreamWaitEvent(c->side2, c->ev_sens, 0);
+            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled);
+            else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
+            hipEventRecord(c->ev_nearfr, c->side2);
+        }
+        hipEventRecord(c->ev_coupled, c->side);
+        // main: the per-car solve, then the frames of every env that is neither coupled nor finished
         launch_car_solve(c->s, c->K_, st);
         hipEventRecord(c->ev_term, st);  // (bodies of the non-coupled cars are final)
         hipStreamWaitEvent(st, c->ev_sens, 0);
         crl_timer_end(tm, 0, st);
         crl_timer_begin(tm, 1, st);
-        launch_car_raster(c->s, c->K_, target, st, c->slow_env, 0);
-        // side again: the finished envs from end to end -- terminal frame (info["terminal_observation"]), reset, first frame of the
-        // new episode -- beside the big launch instead of behind it
-        hipStreamWaitEvent(c->side, c->ev_term, 0);
+        frames(c, target, st, c->slow_env, 0);
+        // side again: frames of the touching envs, then the finished envs
         hipStreamWaitEvent(c->side, c->ev_sens, 0);
-        launch_car_raster_list(c->s, c->K_, c->term, c->side, c->class_list + c->n, c->class_count + 1, c->class_count_hdev + 1, c->class_count_host[1]);
-        launch_car_reset_list(c->s, c->K_, c->src, c->class_list + c->n, c->class_count + 1, c->class_count_host[1], c->side);
+        if (c->s.players == 2 && c->s.contacts_enabled) {
+            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
+            else launch_car_obs_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
+        }
+        hipStreamWaitEvent(c->side, c->ev_term, 0);
+        frames_list(c, c->term, c->side, c->class_list + c->n, c->class_count + 1, c->class_count_hdev + 1, exp_done);
+        launch_car_reset_list(c->s, c->K_, c->src, c->class_list + c->n, c->class_count + 1, exp_done, c->side);
+        launch_car_map_build_list(c->s, c->side, c->class_list + c->n, c->class_count + 1, exp_done);
         queue_walk_ahead(c, c->side);
-        launch_car_raster_list(c->s, c->K_, target, c->side, c->class_list + c->n, c->class_count + 1, nullptr, c->class_count_host[1]);
+        frames_list(c, target, c->side, c->class_list + c->n, c->class_count + 1, nullptr, exp_done);
         hipEventRecord(c->ev_join, c->side);
-        hipStreamWaitEvent(st, c->ev_c1, 0);
+        if (c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(st, c->ev_nearfr, 0);
         hipStreamWaitEvent(st, c->ev_join, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
         crl_timer_end(tm, 1, st);
@@ -543,33 +601,84 @@ int crl_car_get_track_impl(crl_car_ctx *c, int64_t env, int32_t *n_out, float *t
     return CRL_OK;
 }
 
-int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const float *tile_poly, const float *border_poly,
+// Track of one env from the reference's float64 polygons (road_poly, crmp:400-441): tile i = (road1_l, road_m, road1_r,
+// road2_r, road2_l), border quad (b1_l, b1_r, b2_r, b2_l).  Derives what the kernels keep: counter-clockwise float32 polygons
+// (b2PolygonShape), their boxes, the integer map-space vertices of render_road_for_observation_map -- and rebuilds the map.
+int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const double *tile_poly, const double *border_poly,
                            const uint8_t *border, const float *start_pose, hipStream_t st) {
     if (env < 0 || env >= c->n || nt <= 0 || nt > kCarMaxTiles || !tile_poly) return crl_fail(CRL_EINVAL, "bad track");
     const int64_t n = c->n;
     std::vector<float4> aabb(nt);
+    std::vector<float> tp((size_t)nt * 10), bp((size_t)nt * 8, 0.0f);
+    std::vector<uint32_t> mv((size_t)nt * 9, 0u), yr(nt);
+    std::vector<uint8_t> bflag(nt, 0);
+    int32_t overflow = 0;
+    auto map_vertex = [&](const double *v) -> uint32_t {
+        const int mx = car_map_coord(v[0]) - kMapOrg, my = car_map_coord(v[1]) - kMapOrg;
+        if (mx < 0 || my < 0 || mx >= kMapW || my >= kMapW) overflow++;
+        const int cx = std::min(std::max(mx, -32768), 32767), cy = std::min(std::max(my, -32768), 32767);
+        return (uint32_t)(uint16_t)(int16_t)cx | ((uint32_t)(uint16_t)(int16_t)cy << 16);
+    };
     for (int t = 0; t < nt; t++) {
         float x0 = 3.4e38f, y0 = 3.4e38f, x1 = -3.4e38f, y1 = -3.4e38f;
+        float tmp[5][2];
+        ccw(reinterpret_cast<const double(*)[2]>(tile_poly + (size_t)t * 10), 5, 1.0, tmp);
+        int ylo = 32767, yhi = -32768;
         for (int k = 0; k < 5; k++) {
-            const float x = tile_poly[t * 10 + 2 * k], y = tile_poly[t * 10 + 2 * k + 1];
-            x0 = fminf(x0, x), y0 = fminf(y0, y), x1 = fmaxf(x1, x), y1 = fmaxf(y1, y);
+            tp[t * 10 + 2 * k] = tmp[k][0], tp[t * 10 + 2 * k + 1] = tmp[k][1];
+            x0 = fminf(x0, tmp[k][0]), y0 = fminf(y0, tmp[k][1]), x1 = fmaxf(x1, tmp[k][0]), y1 = fmaxf(y1, tmp[k][1]);
+            const uint32_t w = mv[t * 9 + k] = map_vertex(tile_poly + (size_t)t * 10 + 2 * k);
+            ylo = std::min(ylo, (int)(int16_t)(w >> 16)), yhi = std::max(yhi, (int)(int16_t)(w >> 16));
         }
         aabb[t] = make_float4(x0, y0, x1, y1);
+        if (border && border[t] && border_poly) {
+            float tb[4][2];
+            ccw(reinterpret_cast<const double(*)[2]>(border_poly + (size_t)t * 8), 4, 1.0, tb);
+            for (int k = 0; k < 4; k++) {
+                bp[t * 8 + 2 * k] = tb[k][0], bp[t * 8 + 2 * k + 1] = tb[k][1];
+                const uint32_t w = mv[t * 9 + 5 + k] = map_vertex(border_poly + (size_t)t * 8 + 2 * k);
+                ylo = std::min(ylo, (int)(int16_t)(w >> 16)), yhi = std::max(yhi, (int)(int16_t)(w >> 16));
+            }
+            bflag[t] = border[t];
+        }
+        yr[t] = (uint32_t)(uint16_t)(int16_t)ylo | ((uint32_t)(uint16_t)(int16_t)yhi << 16);
     }
     hipMemcpyAsync(c->s.ntiles + env, &nt, 4, hipMemcpyHostToDevice, st);
-    hipMemcpy2DAsync(c->s.tile_poly + env, n * 4, tile_poly, 4, 4, (size_t)nt * 10, hipMemcpyHostToDevice, st);
+    hipMemcpy2DAsync(c->s.tile_poly + env, n * 4, tp.data(), 4, 4, (size_t)nt * 10, hipMemcpyHostToDevice, st);
     hipMemcpy2DAsync(c->s.tile_aabb + env, n * 16, aabb.data(), 16, 16, (size_t)nt, hipMemcpyHostToDevice, st);
-    if (border_poly) hipMemcpy2DAsync(c->s.border_poly + env, n * 4, border_poly, 4, 4, (size_t)nt * 8, hipMemcpyHostToDevice, st);
-    if (border) hipMemcpy2DAsync(c->s.border + env, n, border, 1, 1, (size_t)nt, hipMemcpyHostToDevice, st);
+    hipMemcpy2DAsync(c->s.border_poly + env, n * 4, bp.data(), 4, 4, (size_t)nt * 8, hipMemcpyHostToDevice, st);
+    hipMemcpy2DAsync(c->s.border + env, n, bflag.data(), 1, 1, (size_t)nt, hipMemcpyHostToDevice, st);
     if (start_pose) hipMemcpy2DAsync(c->s.start_pose + env, n * 4, start_pose, 4, 4, 3, hipMemcpyHostToDevice, st);
-    // env-major copies read by the raster
-    hipMemcpyAsync(c->s.tile_poly_em + env * kCarMaxTiles * 10, tile_poly, (size_t)nt * 40, hipMemcpyHostToDevice, st);
+    // env-major copies (analytic raster, map build)
+    hipMemcpyAsync(c->s.tile_poly_em + env * kCarMaxTiles * 10, tp.data(), (size_t)nt * 40, hipMemcpyHostToDevice, st);
     hipMemcpyAsync(c->s.tile_aabb_em + env * kCarMaxTiles, aabb.data(), (size_t)nt * 16, hipMemcpyHostToDevice, st);
-    if (border_poly) hipMemcpyAsync(c->s.border_poly_em + env * kCarMaxTiles * 8, border_poly, (size_t)nt * 32, hipMemcpyHostToDevice, st);
-    if (border) hipMemcpyAsync(c->s.border_em + env * kCarMaxTiles, border, (size_t)nt, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(c->s.border_poly_em + env * kCarMaxTiles * 8, bp.data(), (size_t)nt * 32, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(c->s.border_em + env * kCarMaxTiles, bflag.data(), (size_t)nt, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(c->s.map_vtx + env * kCarMaxTiles * 9, mv.data(), (size_t)nt * 36, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(c->s.map_yr + env * kCarMaxTiles, yr.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(c->s.map_overflow + env, &overflow, 4, hipMemcpyHostToDevice, st);
+    launch_car_map_build(c->s, st, nullptr, env, 1);
     hipStreamSynchronize(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "set_track: %s", hipGetErrorString(e));
+    return CRL_OK;
+}
+
+// The env's pre-rastered map as one palette index per pixel, [CRL_CAR_MAP_W][CRL_CAR_MAP_W] (tests); *overflow = polygon
+// vertices that fell outside the window at the last reset / set_track
+int crl_car_get_map_impl(crl_car_ctx *c, int64_t env, uint8_t *palette_host, int32_t *overflow, hipStream_t st) {
+    if (env < 0 || env >= c->n || !palette_host) return crl_fail(CRL_EINVAL, "bad argument");
+    std::vector<uint8_t> raw((size_t)kMapBytes);
+    hipMemcpyAsync(raw.data(), c->s.obs_map + env * kMapBytes, (size_t)kMapBytes, hipMemcpyDeviceToHost, st);
+    int32_t ov = 0;
+    hipMemcpyAsync(&ov, c->s.map_overflow + env, 4, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return crl_fail(CRL_EHIP, "get_map: copy failed");
+    if (overflow) *overflow = ov;
+    for (int y = 0; y < kMapW; y++)
+        for (int x = 0; x < kMapW; x++) {
+            const uint8_t b = raw[(size_t)((y >> 4) * kMapBlocks + (x >> 4)) * 128 + (y & 15) * 8 + ((x & 15) >> 1)];
+            palette_host[(size_t)y * kMapW + x] = (b >> ((x & 1) * 4)) & 15;
+        }
     return CRL_OK;
 }
 

@@ -41,8 +41,9 @@ int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first
 int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t first, int64_t count, hipStream_t st);
 int crl_car_get_track_impl(crl_car_ctx *c, int64_t env, int32_t *n_out, float *tile_poly, float *border_poly, uint8_t *border,
                            float *start_pose, hipStream_t st);
-int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const float *tile_poly, const float *border_poly,
+int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const double *tile_poly, const double *border_poly,
                            const uint8_t *border, const float *start_pose, hipStream_t st);
+int crl_car_get_map_impl(crl_car_ctx *c, int64_t env, uint8_t *palette_host, int32_t *overflow, hipStream_t st);
 int crl_car_set_replay_impl(crl_car_ctx *c, const double *u, const uint8_t *swap, int64_t attempts);
 
 namespace crl {

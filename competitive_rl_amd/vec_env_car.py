@@ -242,13 +242,24 @@ class HipCarVecEnv(VecEnv):
         return dict(n=k, tile_poly=tiles[:k], border_poly=bpoly[:k], border=border[:k], start_pose=pose)
 
     def set_track(self, env, tile_poly, border_poly, border, start_pose):
-        tile_poly = np.ascontiguousarray(tile_poly, np.float32)
-        border_poly = np.ascontiguousarray(border_poly, np.float32)
+        """Replace one env's track: float64 polygons in the reference's vertex order (road_poly, _create_track
+        car_racing_multi_players.py:400-441): tiles [n, 5, 2], border quads [n, 4, 2], border u8 [n] (0 none, 1 white, 2 red)."""
+        tile_poly = np.ascontiguousarray(tile_poly, np.float64)
+        border_poly = np.ascontiguousarray(border_poly, np.float64)
         border = np.ascontiguousarray(border, np.uint8)
+        assert tile_poly.shape[1:] == (5, 2) and border_poly.shape == (len(tile_poly), 4, 2) and border.shape == (len(tile_poly),)
         start_pose = np.ascontiguousarray(start_pose, np.float32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         N.check(self._L.crl_car_set_track(self._h, int(env), len(tile_poly), p(tile_poly), p(border_poly), p(border), p(start_pose),
                                           self._stream()))
+
+    def get_map(self, env):
+        """The env's pre-rastered observation map (render_road_for_observation_map): palette indices (1216, 1216) u8, and
+        the number of polygon vertices that did not fit the window (0 for every track)."""
+        m = np.zeros((N.CAR_MAP_W, N.CAR_MAP_W), np.uint8)
+        ov = C.c_int32()
+        N.check(self._L.crl_car_get_map(self._h, int(env), m.ctypes.data_as(C.c_void_p), C.byref(ov), self._stream()))
+        return m, ov.value
 
     def set_replay(self, u, swap):
         """u: [N, attempts, 24] uniforms of _create_track attempts; swap: [N, attempts] birth-place bits."""

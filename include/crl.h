@@ -72,6 +72,12 @@ enum crl_env_kind {
 /* ---- cCarRacingDouble-v0 (car_racing/car_racing_multi_players.py:54-88) */
 #define CRL_CAR_MAX_TILES 512 /* tiles of one track (reference tracks: 230-380) */
 #define CRL_CAR_OBS 96        /* STATE_W = STATE_H = 96 */
+/* The pre-rastered observation map (render_road_for_observation_map, car_racing_multi_players.py:732-755):
+   the reference draws into a 10000 x 10000 surface; everything that is not grass lies inside the window
+   [CRL_CAR_MAP_ORG, CRL_CAR_MAP_ORG + CRL_CAR_MAP_W)^2 of it (1.7636 px per world unit, origin at 5000),
+   which is what a context keeps per env: 7-colour palette, 4 bits per pixel, 739 328 bytes. */
+#define CRL_CAR_MAP_ORG 4392
+#define CRL_CAR_MAP_W 1216
 /* reward read-out of the indicator strip: bitmaps of "%05.0f" % r for r = -999..2000 plus "-0000",
    10 rows of 32 bits each (competitive_rl_amd/assets/car_reward_text.npz) */
 #define CRL_CAR_TEXT_STRINGS 3001
@@ -276,12 +282,21 @@ typedef struct crl_car_env_state {
 
 int crl_car_get_state(crl_ctx *ctx, crl_car_env_state *state_host, int64_t first, int64_t count, void *stream);
 int crl_car_set_state(crl_ctx *ctx, const crl_car_env_state *state_host, int64_t first, int64_t count, void *stream);
-/* Track of env `env`: n tiles; tile_poly float32 [n][5][2] (counter-clockwise), border_poly
- * float32 [n][4][2], border u8 [n] (0 none, 1 white, 2 red), start_pose = track[0] (beta, x, y). */
+/* Track of env `env` as the physics keeps it: n tiles; tile_poly float32 [n][5][2] (counter-clockwise, as
+ * b2PolygonShape stores them), border_poly float32 [n][4][2], border u8 [n] (0 none, 1 white, 2 red),
+ * start_pose = track[0] (beta, x, y). */
 int crl_car_get_track(crl_ctx *ctx, int64_t env, int32_t *n, float *tile_poly, float *border_poly, uint8_t *border,
                       float *start_pose, void *stream);
-int crl_car_set_track(crl_ctx *ctx, int64_t env, int32_t n, const float *tile_poly, const float *border_poly,
+/* Replaces the track of env `env` (parity tests: a track built elsewhere).  The polygons are the reference's
+ * road_poly entries in float64 and in its vertex order (_create_track, car_racing_multi_players.py:400-441):
+ * tile i = (road1_l, road_m, road1_r, road2_r, road2_l), border quad (b1_l, b1_r, b2_r, b2_l) where border[i] != 0.
+ * Derives the float32 sensors and re-rasters the env's observation map (render_road_for_observation_map, :732-755). */
+int crl_car_set_track(crl_ctx *ctx, int64_t env, int32_t n, const double *tile_poly, const double *border_poly,
                       const uint8_t *border, const float *start_pose, void *stream);
+/* The env's pre-rastered observation map, one palette index per pixel (0 grass, 1 lighter square, 2-4 road
+ * 102 / 104 / 107, 5 white, 6 red): palette_host u8 [CRL_CAR_MAP_W][CRL_CAR_MAP_W]; *overflow (optional) = polygon
+ * vertices that fell outside the window at the env's last reset (0 for every track). */
+int crl_car_get_map(crl_ctx *ctx, int64_t env, uint8_t *palette_host, int32_t *overflow, void *stream);
 /* Replay mode for CarRacing.reset's randomness: per env `attempts` rows of 24 uniforms (the
  * np_random.uniform draws of one _create_track attempt) and one birth-place swap bit each. */
 int crl_car_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *swap_host, int64_t attempts);

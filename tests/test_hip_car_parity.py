@@ -1,10 +1,11 @@
 """cCarRacingDouble: HIP path (through the C ABI) against the CPU oracle.
 
-Bar (north_star: within 1e-5 on CarRacing float state): since both sides evaluate one shared sin/cos
-(include/crl_rot.h) and neither contracts multiply-adds, the float32 physics is BIT-IDENTICAL -- bodies, joint and
-contact impulses, with and without car-car contacts, teacher-forced and free-running -- and the tests below assert
-exactly that (tolerance 0).  Only the procedural track (float64 sin/cos/atan2 of the device library vs glibc) is
-compared with a tolerance (2e-4); the physics tests therefore push the oracle's tracks into the HIP env."""
+Bar (north_star: within 1e-5 on CarRacing float state): both sides evaluate the same sin / cos / atan2
+(include/crl_rot.h for Box2D's float32 b2Rot, include/crl_f64.h for the float64 track walk and camera) and neither
+contracts multiply-adds, so the float32 physics, the procedural tracks, the pre-rastered maps and the frames are
+BIT-IDENTICAL -- teacher-forced and free-running, with and without car-car contacts -- and the tests below assert
+exactly that (tolerance 0).  The distance from this oracle build to the one that calls the host libm, like the
+reference does, is measured on the CPU in tests/test_oracle_libm_delta.py."""
 import ctypes as C
 import os
 
@@ -49,42 +50,25 @@ def oracle_to_hip_state(envs):
 
 
 def push_tracks(hip, envs):
-    from oracle import car_oracle as co
-
+    """the oracle's tracks into the HIP env, as the reference's float64 road_poly entries"""
     for i, env in enumerate(envs):
         e = env.e
         n = int(e["trk"]["n"])
-        bp = np.zeros((n, 4, 2), np.float32)
-        border = np.zeros(n, np.uint8)
-        for t in range(n):
-            if e["trk"]["border"][t]:
-                p = e["trk"]["border_poly"][t]
-                area = sum(p[k][0] * p[(k + 1) % 4][1] - p[(k + 1) % 4][0] * p[k][1] for k in range(4))
-                bp[t] = p if area > 0 else p[::-1]
-                border[t] = 1 if t % 2 == 0 else 2
+        border = np.where(e["trk"]["border"][:n] > 0, np.where(np.arange(n) % 2 == 0, 1, 2), 0).astype(np.uint8)
         pose = e["trk"]["track"][0][1:4].astype(np.float32)
-        hip.set_track(i, e["tile32"][:n], bp, border, pose)
+        hip.set_track(i, e["trk"]["tile"][:n], e["trk"]["border_poly"][:n], border, pose)
 
 
-def make_oracle_envs(n, seed0=0):
-    from oracle import car_oracle as co
-
-    g = np.load(os.path.join(G, "car_track.npz"))
-    draws = [g[f"{j}/draws"] for j in range(int(g["count"]))]
-    envs = []
-    for i in range(n):
-        u = np.concatenate([draws[(seed0 + i * 3 + k) % len(draws)] for k in range(6)])
-        e = co.CarEnv()
-        assert e.reset(u, i % 2) > 0
-        e.e["contacts_enabled"] = 1
-        e.step(None)
-        envs.append(e)
-    return envs
+from tests.car_scenarios import make_oracle_envs  # noqa: E402,F401
 
 
 def test_track_generation_matches_oracle():
+    """GPU reset (replayed draws) against the oracle: both walk the track with the same float64 sin / cos / atan2
+    (include/crl_f64.h), so tiles, borders, start poses, the integer map vertices, the pre-rastered map and the first
+    frames are IDENTICAL -- no tolerance."""
     _need_gpu()
     import competitive_rl_amd as crl
+    from competitive_rl_amd import _native as N
     from oracle import car_oracle as co
 
     g = np.load(os.path.join(G, "car_track.npz"))
@@ -96,10 +80,11 @@ def test_track_generation_matches_oracle():
         for a in range(A):
             u[i, a] = draws[(2 * i + a) % len(draws)]
             swap[i, a] = (i + a) % 2
+    co.set_text(N.load_car_text())
     env = crl.HipCarVecEnv(n)
     env.set_replay(u, swap)
-    obs = env.reset()
-    assert tuple(obs.shape) == (n, 2, 96, 96)
+    obs = env.reset().cpu().numpy()
+    assert obs.shape == (n, 2, 96, 96)
     st = env.get_state()
     for i in range(n):
         o = co.CarEnv()
@@ -107,14 +92,21 @@ def test_track_generation_matches_oracle():
         assert att > 0
         sw = int(swap[i, att - 1])
         o.reset(u[i].reshape(-1), sw)
+        o.step(None)
         tr = env.get_track(i)
         nt = int(o.e["trk"]["n"])
         assert tr["n"] == nt, i
-        assert np.allclose(tr["tile_poly"], o.e["tile32"][:nt], atol=2e-4), i
+        assert np.array_equal(tr["tile_poly"], o.e["tile32"][:nt]), i
         assert np.array_equal(tr["border"] > 0, o.e["trk"]["border"][:nt] > 0), i
         for c in range(2):
             for f in ("cx", "cy", "a"):
-                assert abs(float(st[i]["car"][c]["hull"][f]) - float(o.e["car"][c]["hull"][f])) < 2e-4, (i, c, f)
+                assert float(st[i]["car"][c]["hull"][f]) == float(o.e["car"][c]["hull"][f]), (i, c, f)
+        if i < 8:  # the map (1.5 M pixels per env) and the first frames
+            m, overflow = env.get_map(i)
+            assert overflow == 0 and np.array_equal(m, o.map()), (i, int((m != o.map()).sum()))
+            for v in range(2):
+                assert np.array_equal(obs[i, v], o.render(v)), (i, v, int((obs[i, v] != o.render(v)).sum()))
+    co.set_text(None)
     env.close()
 
 
@@ -161,52 +153,98 @@ def test_step_teacher_forced_matches_oracle():
     hip.close()
 
 
-def test_free_running_stays_close_and_render_matches():
+def test_free_running_stays_identical_and_render_matches():
+    """120 steps with NO re-synchronisation: the HIP env and the oracle start from one state and are compared on the way
+    (bodies bit for bit, every frame pixel for pixel against the oracle's literal restatement of get_observation)."""
     _need_gpu()
     import competitive_rl_amd as crl
     from oracle import car_oracle as co
 
     from competitive_rl_amd import _native as N
 
-    L = co.lib()
-    L.car_oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     co.set_text(N.load_car_text())
     n, steps = 8, 120
     envs = make_oracle_envs(n, seed0=11)
     hip = crl.HipCarVecEnv(n)
     hip.reset()
     push_tracks(hip, envs)
+    for i, e in enumerate(envs):  # set_track re-rasters the env's map
+        m, overflow = hip.get_map(i)
+        assert overflow == 0 and np.array_equal(m, e.map()), i
     hip.set_state(oracle_to_hip_state(envs))
     rs = np.random.RandomState(9)
-    mism = []
+    frames = 0
     for t in range(steps):
         acts = np.stack([np.stack([[0.3 * np.sin(t / 15 + i), 0.8], [rs.uniform(-0.2, 0.2), 0.5]]) for i in range(n)]).astype(np.float32)
         obs, rew, done = hip.step_device(torch.as_tensor(acts).cuda())
         for i, e in enumerate(envs):
             e.step(acts[i].astype(np.float64))
-        if t % 20 == 19:
-            # render parity from synchronised state
-            hip.set_state(oracle_to_hip_state(envs))
-            got = hip.render_current().cpu().numpy()
+        if t % 10 == 9:
+            hs = hip.get_state()
+            got = obs.cpu().numpy()
             for i, e in enumerate(envs):
+                for c in range(2):
+                    for f in ("cx", "cy", "a", "vx", "vy", "w"):
+                        assert hs[i]["car"][c]["hull"][f] == e.e["car"][c]["hull"][f], (t, i, c, f)
+                        assert np.array_equal(hs[i]["car"][c]["wheel"][f], e.e["car"][c]["wheel"][f]), (t, i, c, f)
                 for v in range(2):
-                    want = np.zeros((96, 96), np.uint8)
-                    L.car_oracle_render(e.buf.ctypes.data, v, want.ctypes.data)
-                    mism.append(float((got[i, v] != want).mean()))
-    hs = hip.get_state()
-    for i, e in enumerate(envs):
-        for c in range(2):
-            # free-running for 120 steps (re-synchronised only by the oracle's own state every 20): still the same bits
-            for f in ("cx", "cy", "a", "vx", "vy", "w"):
-                assert hs[i]["car"][c]["hull"][f] == e.e["car"][c]["hull"][f], (i, c, f)
-    print("render mismatch fractions: max", max(mism), "mean", np.mean(mism))
-    # identical definition on both sides; the bar leaves room for a pixel or two per frame flipping on a
-    # polygon edge through the last bit of the device's sinf/cosf (observed: exactly 0)
-    assert max(mism) < 2.5e-4, mism
+                    want = e.render(v)
+                    assert np.array_equal(got[i, v], want), (t, i, v, int((got[i, v] != want).sum()))
+                    frames += 1
+    assert frames == 12 * n * 2
     palette = {0, 29, 44, 60, 76, 101, 103, 107, 149, 161, 176, 255}
     assert set(np.unique(got).tolist()) <= palette
     assert (got[:, :, 91:, :16] == 255).any()  # the reward read-out is there
     co.set_text(None)
+    hip.close()
+
+
+def test_observations_equal_the_reference_recording():
+    """tests/golden/car_obs.npz: frames returned by the reference's own CarRacing.get_observation (pygame / Box2D stand-ins,
+    every line around them the reference's).  The HIP env is put into each recorded state and must draw the same pixels --
+    rotate90 view angles, signed indicator bars and the reward read-out included."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from competitive_rl_amd import _native as N
+    from oracle import car_oracle as co
+
+    g = np.load(os.path.join(G, "car_obs.npz"))
+    S = int(g["scenarios"])
+    envs = []
+    for sc in range(S):
+        e = co.CarEnv()
+        u = g[f"{sc}/draws"]
+        assert e.reset(u, 0) == len(u) // 24
+        e.e["contacts_enabled"] = 1
+        e.step(None)
+        envs.append(e)
+    idx = [np.flatnonzero(g["scenario"] == sc) for sc in range(S)]
+    F = max(len(k) for k in idx)
+    n = S * F  # one HIP env per recorded frame
+    owner = [envs[i // F] for i in range(n)]
+    hip = crl.HipCarVecEnv(n)
+    hip.reset()
+    twins = []
+    for i in range(n):
+        sc, k = i // F, min(i % F, len(idx[i // F]) - 1)
+        tw = co.CarEnv()
+        tw.buf[:] = envs[sc].buf
+        tw.e = tw.buf[0]
+        tw.e["car"] = g["cars"][idx[sc][k]]
+        tw.e["reward"] = g["reward"][idx[sc][k]]
+        twins.append(tw)
+    push_tracks(hip, twins)
+    hip.set_state(oracle_to_hip_state(twins))
+    got = hip.render_current().cpu().numpy()
+    bad = []
+    for i in range(n):
+        sc, k = i // F, min(i % F, len(idx[i // F]) - 1)
+        want = g["obs"][idx[sc][k]]
+        for v in range(2):
+            d = int((got[i, v] != want[v]).sum())
+            if d:
+                bad.append((str(g["tag"][idx[sc][k]]), v, d))
+    assert not bad, bad[:10]
     hip.close()
 
 
