@@ -156,6 +156,87 @@ __device__ void collide_polygons(Contact &c, const Shape &pa, const XF &xa, cons
     c.count = n;
 }
 
+// ---- the same b2CollidePolygons on polygons whose vertices and edge normals are already in WORLD space (the narrow-phase
+// kernel transforms each lane's two fixtures once into LDS: the nested separation search then reads 16 values instead of
+// re-transforming a vertex per inner iteration).  Local-space quantities of the manifold (localNormal, localPoint, the
+// incident points) are computed from the untransformed vertices exactly as in collide_polygons above.
+struct WPoly {
+    V2 w[8], n[8];  // world vertices, world edge normals
+    int cnt;
+};
+__device__ inline float max_separation_w(int &edge, const WPoly &p1, const WPoly &p2) {
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int i = 0; i < p1.cnt; i++) {
+        const V2 n = p1.n[i], v1 = p1.w[i];
+        float si = 3.4e38f;
+        for (int j = 0; j < p2.cnt; j++) {
+            const float sij = dot(n, p2.w[j] - v1);
+            if (sij < si) si = sij;
+        }
+        if (si > best) best = si, bi = i;
+    }
+    edge = bi;
+    return best;
+}
+// nl: local edge normals of every fixture shape (table in LDS, [fixture][edge]), as shape_normal computes them
+__device__ void collide_polygons_w(Contact &c, const Shape &pa, const XF &xa, const WPoly &wa, const V2 *nla, const Shape &pb, const XF &xb,
+                                   const WPoly &wb, const V2 *nlb) {
+    c.count = 0;
+    const float totalRadius = 0.02f;
+    int edgeA, edgeB;
+    const float sepA = max_separation_w(edgeA, wa, wb);
+    if (sepA > totalRadius) return;
+    const float sepB = max_separation_w(edgeB, wb, wa);
+    if (sepB > totalRadius) return;
+    const bool flip = sepB > 0.98f * sepA + 0.001f;
+    const Shape &p1 = flip ? pb : pa, &p2 = flip ? pa : pb;
+    const XF &x1 = flip ? xb : xa, &x2 = flip ? xa : xb;
+    const WPoly &w1 = flip ? wb : wa, &w2 = flip ? wa : wb;
+    const V2 *nl2 = flip ? nla : nlb;
+    const int edge1 = flip ? edgeB : edgeA;
+    c.type = flip ? 1 : 0;
+    ClipV inc[2];
+    {
+        const V2 n1 = qmulT(x2, w1.n[edge1]);
+        int idx = 0;
+        float mind = 3.4e38f;
+        for (int i = 0; i < p2.n; i++) {
+            const float d = dot(n1, nl2[i]);
+            if (d < mind) mind = d, idx = i;
+        }
+        const int i1 = idx, i2 = i1 + 1 < p2.n ? i1 + 1 : 0;
+        inc[0].v = w2.w[i1], inc[0].id = mkid((uint32_t)edge1, (uint32_t)i1, 1u, 0u);
+        inc[1].v = w2.w[i2], inc[1].id = mkid((uint32_t)edge1, (uint32_t)i2, 1u, 0u);
+    }
+    const int iv1 = edge1, iv2 = edge1 + 1 < p1.n ? edge1 + 1 : 0;
+    V2 v11 = shape_vertex(p1, iv1), v12 = shape_vertex(p1, iv2);
+    V2 lt = v12 - v11;
+    lt = (1.0f / sqrtf(dot(lt, lt))) * lt;
+    const V2 ln = mk(lt.y, -lt.x), planePoint = 0.5f * (v11 + v12);
+    const V2 tangent = rotv(x1.s, x1.c, lt), normal = mk(tangent.y, -tangent.x);
+    v11 = w1.w[iv1], v12 = w1.w[iv2];
+    const float frontOffset = dot(normal, v11);
+    const float side1 = -dot(tangent, v11) + totalRadius, side2 = dot(tangent, v12) + totalRadius;
+    ClipV c1[2], c2[2];
+    if (clip_segment(c1, inc, -1.0f * tangent, side1, iv1) < 2) return;
+    if (clip_segment(c2, c1, tangent, side2, iv2) < 2) return;
+    c.ln[0] = ln.x, c.ln[1] = ln.y, c.lp[0] = planePoint.x, c.lp[1] = planePoint.y;
+    int n = 0;
+    for (int i = 0; i < 2; i++) {
+        const float sep = dot(normal, c2[i].v) - frontOffset;
+        if (sep <= totalRadius) {
+            const V2 lpt = xmulT(x2, c2[i].v);
+            c.pt[n][0] = lpt.x, c.pt[n][1] = lpt.y;
+            uint32_t id = c2[i].id;
+            if (flip) id = mkid((id >> 8) & 255u, id & 255u, (id >> 24) & 255u, (id >> 16) & 255u);
+            c.id[n] = id;
+            n++;
+        }
+    }
+    c.count = n;
+}
+
 struct ContactVC {
     V2 normal, rA[2], rB[2];
     float nmass[2], tmass[2], K[2][2], invK[2][2];
@@ -198,8 +279,29 @@ __device__ inline V2 rel_vel(const BRef &A, const BRef &B, V2 rA, V2 rB) {
 // impulses are carried over from last step's manifolds by contact id (warm starting).  The env goes to one of two lists:
 // `touch` (one island with contacts: car_touch_kernel) or `near` (the boxes overlap but nothing touches: two islands of
 // their own, car_near_kernel = the per-car solve).
-__global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts K) {
+__global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) {
+    // (the fixture tables are indexed per lane at run time: a by-value kernel argument would first be copied to every lane's
+    // scratch, and reading them from device memory makes every vertex a dependent ~200-cycle load: stage them in LDS)
+    __shared__ CarConsts Ks;
     const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);  // on the step's critical path (narrow phase -> touching solve -> their frames), beside bulk kernels
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(s.consts_dev);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&Ks);
+        for (int i = lane; i < (int)(sizeof(CarConsts) / 4); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const CarConsts &K = Ks;
+    (void)Kv;
+    // local edge normals of the five distinct shapes (hull polygons 0-3, wheel box): one lane per edge, once per workgroup
+    __shared__ V2 nl[8][8];
+    if (lane < 40) {
+        const int f = lane >> 3, e = lane & 7;  // f = 4: every wheel
+        const Shape sh = shape_of(K, f);
+        if (e < sh.n) nl[f][e] = shape_normal(sh, e);
+    }
+    __syncthreads();
+    __shared__ WPoly wp[64][2];
     const int count = *s.coupled_count;
     const int64_t M = 2 * s.n;
     if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host) *s.coupled_to_host = count;
@@ -235,7 +337,17 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts K) {
                 ccx[k] = wc.x, ccy[k] = wc.y, crad[k] = sqrtf(r2) + 0.03f;
             }
             const float dx = ccx[0] - ccx[1], dy = ccy[0] - ccy[1], rr = crad[0] + crad[1];
-            if (!(dx * dx + dy * dy > rr * rr)) collide_polygons(c, shape_of(K, fa), xf[0], shape_of(K, fb), xf[1]);
+            if (!(dx * dx + dy * dy > rr * rr)) {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {  // both fixtures into world space once: vertices, and normals as rotv(q, local normal)
+                    const int f = k ? fb : fa;
+                    const Shape sh = shape_of(K, f);
+                    WPoly &w = wp[lane][k];
+                    w.cnt = sh.n;
+                    for (int i = 0; i < sh.n; i++) w.w[i] = xmul(xf[k], shape_vertex(sh, i)), w.n[i] = rotv(xf[k].s, xf[k].c, nl[f < 4 ? f : 4][i]);
+                }
+                collide_polygons_w(c, shape_of(K, fa), xf[0], wp[lane][0], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[lane][1], nl[fb < 4 ? fb : 4]);
+            }
         }
         const bool hit = active && c.count > 0;
         const unsigned long long m = __ballot(hit);
@@ -709,6 +821,7 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K) {
     const int cls = blockIdx.y;
     const int count = s.coupled_count[2 + cls];
     if ((int)blockIdx.x * 32 >= count) return;
+    __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) CarRegs sh_car[32][2];
     __shared__ __attribute__((aligned(16))) Contact sh_ct[32][kMaxContacts];
     __shared__ __attribute__((aligned(16))) TouchC sh_tc[32][kMaxContacts];

@@ -200,9 +200,9 @@ __device__ inline uint32_t pack_rect(double x, double y, double w, double h) {
 
 // One lane per tile: camera_update("rgb_array") and camera_view's crop / rotation constants -- the double-precision part
 // (atan2, sin, cos in double-double), 64 tiles per wavefront.
-__device__ void car_camera_tile(const CarSoA &s, const CarConsts &K, int64_t env, int viewer) {
+__device__ __forceinline__ void camera_compute(const CarSoA &s, const CarConsts &K, int64_t env, int viewer, ViewParams &vp, float4 &cam) {
     const int64_t n = s.n, M = (int64_t)s.players * n;
-    const int64_t me = viewer * n + env, tile = env * s.players + viewer;
+    const int64_t me = viewer * n + env;
     const float h_cx = s.body[0 * M + me], h_cy = s.body[1 * M + me], h_a = s.body[2 * M + me];
     const float h_vx = s.body[3 * M + me], h_vy = s.body[4 * M + me];
     double angle = (double)h_a;
@@ -213,7 +213,6 @@ __device__ void car_camera_tile(const CarSoA &s, const CarConsts &K, int64_t env
     const V2 hp = mk(h_cx, h_cy) - rotv(hs, hc, mk(K.hull_lc[0], K.hull_lc[1]));
     const V2 off = hp + mk(cs * 0.0f - sn * 16.0f, sn * 0.0f + cs * 16.0f);
     // ---- camera_view(mode="rgb_array"): crop rectangle, then surf_rotate's constants (pygame 1.9.6 transform.c)
-    ViewParams vp;
     const int W = 96, H = 96, SW = 192, SH = 192;
     const double pos0 = CRL_CAR_OBS_SCALE * -(double)off.x + kMapSurface / 2.0, pos1 = CRL_CAR_OBS_SCALE * -(double)off.y + kMapSurface / 2.0;
     const double rxd = pos0 - W, ryd = pos1 - H;
@@ -267,18 +266,24 @@ __device__ void car_camera_tile(const CarSoA &s, const CarConsts &K, int64_t env
         if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
         vp.text_idx = min(max(idx, 0), CRL_CAR_TEXT_STRINGS - 1);
     }
-    int32_t *dst = s.view + tile * kViewWords;
+    cam = make_float4(sn, cs, off.x, off.y);  // the float32 camera for the car polygons (Car.draw_for_pygame's tmp transform and offset)
+}
+__device__ void car_camera_tile(const CarSoA &s, const CarConsts &K, int64_t env, int viewer) {
+    ViewParams vp;
+    float4 cam;
+    camera_compute(s, K, env, viewer, vp, cam);
+    int32_t *dst = s.view + (env * s.players + viewer) * kViewWords;
     const int32_t *src = reinterpret_cast<const int32_t *>(&vp);
     for (int i = 0; i < 8; i++) dst[i] = src[i];
-    // the float32 camera for the car polygons (Car.draw_for_pygame's tmp transform and offset)
-    reinterpret_cast<float4 *>(dst)[4] = make_float4(sn, cs, off.x, off.y);
+    reinterpret_cast<float4 *>(dst)[4] = cam;
 }
 
 // 16 lanes per tile: lane q = car polygon q of the draw order -> its scanline spans; lanes 0-7 also one indicator rectangle each.
-__device__ void car_poly_tile(const CarSoA &s, const CarConsts &K, int64_t env, int viewer, int q) {
+// rect_out: the eight indicator rectangles (lane q < 8 writes [q]); rec: the polygon's span slots; returns the span count
+__device__ __forceinline__ int poly_compute(const CarSoA &s, const CarConsts &K, int64_t env, int viewer, int q, const float4 cam, uint32_t *rect_out,
+                                            uint32_t *rec) {
     const int64_t n = s.n, M = (int64_t)s.players * n;
-    const int64_t me = viewer * n + env, tile = env * s.players + viewer;
-    const float4 cam = reinterpret_cast<const float4 *>(s.view + tile * kViewWords)[4];
+    const int64_t me = viewer * n + env;
     const float sn = cam.x, cs = cam.y;
     const V2 off = mk(cam.z, cam.w);
     const float scale_f = (float)CRL_CAR_OBS_SCALE;
@@ -293,11 +298,10 @@ __device__ void car_poly_tile(const CarSoA &s, const CarConsts &K, int64_t env, 
         } else if (q < 6) r = pack_rect((7 + (q - 2)) * S, 96 - Hh, S, Hh * (-0.01 * s.womega[(q - 2) * M + me]));
         else if (q == 6) r = pack_rect(20 * S, 96 - 2 * Hh, S * (10.0 * (double)(s.body[(6 + 2) * M + me] - h_a - 0.0f)), 2 * Hh);
         else r = pack_rect(30 * S, 96 - 2 * Hh, S * (0.8 * (double)s.body[5 * M + me]), 2 * Hh);
-        reinterpret_cast<uint32_t *>(s.view + tile * kViewWords)[8 + q] = r;
+        rect_out[q] = r;
     }
     // ---- Car.draw_for_pygame: lane q = polygon q of the draw order (car 0: wheels 0-3, hull fixtures 0-3; then car 1)
     int cnt = 0;
-    uint32_t *rec = s.view_rec + (tile * 16 + q) * kSpanSlots;
     const int k = q >> 3, part = q & 7;
     if (k < s.players) {
         const int64_t ci = k * n + env;
@@ -366,7 +370,13 @@ __device__ void car_poly_tile(const CarSoA &s, const CarConsts &K, int64_t env, 
         }
     }
     // (a polygon is at most 5.3 px across: <= 8 spans; a count above the slots would be a bug and shows up as a missing span)
-    s.view_cnt[tile * 16 + q] = (uint8_t)min(cnt, kSpanSlots);
+    return min(cnt, kSpanSlots);
+}
+__device__ void car_poly_tile(const CarSoA &s, const CarConsts &K, int64_t env, int viewer, int q) {
+    const int64_t tile = env * s.players + viewer;
+    const float4 cam = reinterpret_cast<const float4 *>(s.view + tile * kViewWords)[4];
+    s.view_cnt[tile * 16 + q] = (uint8_t)poly_compute(s, K, env, viewer, q, cam, reinterpret_cast<uint32_t *>(s.view + tile * kViewWords) + 8,
+                                                      s.view_rec + (tile * 16 + q) * kSpanSlots);
 }
 
 // `filter` (optional): the env is handled only if filter[env] == want
@@ -384,25 +394,6 @@ __global__ __launch_bounds__(64) void car_poly_kernel(CarSoA s, CarConsts K, con
     if (filter && filter[env] != want) return;
     car_poly_tile(s, K, env, (int)(t % s.players), threadIdx.x & 15);
 }
-__global__ __launch_bounds__(64) void car_camera_list_kernel(CarSoA s, CarConsts K, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count,
-                                                             const uint8_t *__restrict__ filter, int want) {
-    const int64_t tiles = (int64_t)(*list_count) * s.players;
-    for (int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x; t < tiles; t += (int64_t)gridDim.x * 64) {
-        const int64_t env = list[t / s.players];
-        if (filter && filter[env] != want) continue;
-        car_camera_tile(s, K, env, (int)(t % s.players));
-    }
-}
-__global__ __launch_bounds__(64) void car_poly_list_kernel(CarSoA s, CarConsts K, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count,
-                                                           const uint8_t *__restrict__ filter, int want) {
-    const int64_t tiles = (int64_t)(*list_count) * s.players;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4); t < tiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t env = list[t / s.players];
-        if (filter && filter[env] != want) continue;
-        car_poly_tile(s, K, env, (int)(t % s.players), threadIdx.x & 15);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ the tile
 static constexpr int kPitch = 28;  // dwords per tile row in LDS (96 B of pixels + 16 B: the 4-row patch stores spread over the banks)
 
@@ -455,10 +446,11 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
     }
 }
 
-__device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restrict__ obs, const int64_t env, const int viewer, uint32_t *tile) {
+// vp: ViewParams words; rec / cnt: the car polygons' spans (global memory from the camera / polygon kernels, or LDS in the fused kernel)
+__device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restrict__ obs, const int64_t env, const int viewer, uint32_t *tile,
+                                             const int32_t *vp, const uint32_t *rec, const uint8_t *cnt) {
     const int lane = threadIdx.x;
     const int64_t t = env * s.players + viewer;
-    const int32_t *vp = s.view + t * kViewWords;
     const int dx00 = vp[0], dy00 = vp[1], isin = vp[2], icos = vp[3], rx = vp[4], ry = vp[5], flags = vp[6], text_idx = vp[7];
     const uint8_t *map = s.obs_map + env * kMapBytes;
     uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile);
@@ -472,8 +464,6 @@ __device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restric
     }
     // ---- cars.  Draw order: car 0 wheels (black), car 0 hull, car 1 wheels, car 1 hull; within a layer every span has the
     // same colour, and LDS operations of ONE wavefront execute in program order, so a later layer simply overwrites
-    const uint32_t *rec = s.view_rec + t * kViewRecWords;
-    const uint8_t *cnt = s.view_cnt + t * 16;
     const uint32_t *cnt32 = reinterpret_cast<const uint32_t *>(cnt);  // one byte per polygon, one word per layer
     const uint32_t cnt_all[4] = {cnt32[0], cnt32[1], cnt32[2], cnt32[3]};
 #pragma unroll
@@ -531,26 +521,38 @@ __global__ __launch_bounds__(64) void car_obs_kernel(CarSoA s, uint8_t *__restri
     }
     if (env >= s.n) return;
     if (only_env && only_env[env] != want) return;
-    car_obs_tile(s, obs, env, viewer, tile);
+    const int64_t t = env * s.players + viewer;
+    car_obs_tile(s, obs, env, viewer, tile, s.view + t * kViewWords, s.view_rec + t * kViewRecWords, s.view_cnt + t * 16);
 }
 
-__global__ __launch_bounds__(64) void car_obs_list_kernel(CarSoA s, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
+// The envs of a compacted list (the small env classes of a step): camera, polygons and tile in ONE launch, one wavefront per
+// tile -- every lane computes the (uniform) camera, lanes 0-15 the polygons, everything handed over through LDS.  Three
+// dependent launches of a few hundred wavefronts each cost three launch latencies at the end of a step.
+__global__ __launch_bounds__(64) void car_obs_list_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
                                                           const int32_t *__restrict__ list_count, int32_t *__restrict__ count_to_host,
                                                           const uint8_t *__restrict__ filter, int want) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[96 * kPitch];
+    __shared__ __attribute__((aligned(16))) int32_t vp_s[16];
+    __shared__ __attribute__((aligned(16))) uint32_t rec_s[kViewRecWords];
+    __shared__ __attribute__((aligned(16))) uint8_t cnt_s[16];
+    const int lane = threadIdx.x;
     const int64_t positions = *list_count;
-    if (count_to_host && blockIdx.x == 0 && threadIdx.x == 0) *count_to_host = (int32_t)positions;
-    const int64_t slots = s.players == 2 ? (positions + 7) / 8 * 16 : positions;
-    for (int64_t b = blockIdx.x; b < slots; b += gridDim.x) {  // (gridDim.x is a multiple of 16)
-        int64_t i = b;
-        int viewer = 0;
-        if (s.players == 2) {
-            const int r = (int)(b & 15);
-            i = (b >> 4) * 8 + (r & 7), viewer = r >> 3;
-        }
-        if (i < positions) {
-            const int64_t env = list[i];
-            if (!filter || filter[env] == want) car_obs_tile(s, obs, env, viewer, tile);
+    if (count_to_host && blockIdx.x == 0 && lane == 0) *count_to_host = (int32_t)positions;
+    const int64_t tiles = positions * s.players;
+    for (int64_t b = blockIdx.x; b < tiles; b += gridDim.x) {
+        const int64_t env = list[b / s.players];
+        const int viewer = (int)(b % s.players);
+        if (!filter || filter[env] == want) {
+            ViewParams vp;
+            float4 cam;
+            camera_compute(s, K, env, viewer, vp, cam);
+            if (lane == 0) {
+                const int32_t *src = reinterpret_cast<const int32_t *>(&vp);
+                for (int i = 0; i < 8; i++) vp_s[i] = src[i];
+            }
+            if (lane < 16) cnt_s[lane] = (uint8_t)poly_compute(s, K, env, viewer, lane, cam, reinterpret_cast<uint32_t *>(vp_s) + 8, rec_s + lane * kSpanSlots);
+            __syncthreads();
+            car_obs_tile(s, obs, env, viewer, tile, vp_s, rec_s, cnt_s);
         }
         __syncthreads();  // the next tile reuses the LDS
     }
@@ -564,16 +566,13 @@ void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream
     hipLaunchKernelGGL(car_obs_kernel, dim3(grid), dim3(64), 0, st, s, obs, only_env, want);
 }
 
-// the envs of a compacted list (its length in device memory; `expected` = the caller's guess of it, only for the grid sizes),
+// the envs of a compacted list (its length in device memory; `expected` = the caller's guess of it, only for the grid size),
 // optionally only those with filter[env] == want
 void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
                          int32_t *count_to_host, int64_t expected, const uint8_t *filter, int want_cls) {
     int64_t want = expected + expected / 4 + 32;  // slack: a launch that falls short loops, it does not miss tiles
     want = want > s.n ? s.n : want;
-    hipLaunchKernelGGL(car_camera_list_kernel, dim3((unsigned)((want * s.players + 63) / 64)), dim3(64), 0, st, s, k, list, list_count, filter, want_cls);
-    hipLaunchKernelGGL(car_poly_list_kernel, dim3((unsigned)((want * s.players + 3) / 4)), dim3(64), 0, st, s, k, list, list_count, filter, want_cls);
-    const unsigned grid = (unsigned)((want + 7) / 8 * 16);
-    hipLaunchKernelGGL(car_obs_list_kernel, dim3(grid), dim3(64), 0, st, s, obs, list, list_count, count_to_host, filter, want_cls);
+    hipLaunchKernelGGL(car_obs_list_kernel, dim3((unsigned)(want * s.players)), dim3(64), 0, st, s, k, obs, list, list_count, count_to_host, filter, want_cls);
 }
 
 }  // namespace crl

@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K
 // CarRacingWrapper (make_competitive_car_racing.py:24-33: `d[0]`; a finished opponent just stays frozen,
 // crmp:578-579).  Also captures info["num_steps"] = CarRacing.step_count (crmp:616-620) before the auto-reset.
 __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *__restrict__ done_car,
-                                                       uint8_t *__restrict__ done_env, uint8_t *__restrict__ slow_env,
+                                                       uint8_t *__restrict__ done_env, uint8_t *__restrict__ done_out, uint8_t *__restrict__ slow_env,
                                                        int32_t *__restrict__ info_steps, int max_episode_steps, int car0_only,
                                                        int32_t *__restrict__ class_list, int32_t *__restrict__ class_count) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
         for (int c = 0; c < (car0_only ? 1 : s.players); c++) d = d || done_car[s.players * env + c];
         s.elapsed[env] = el;
         done_env[env] = d ? 1 : 0;
+        if (done_out) done_out[env] = d ? 1 : 0;  // the caller's done tensor (was a device-to-device copy at the end of the step)
         if (info_steps) info_steps[env] = s.step_count[env];  // one world clock per env: both cars carry the same count
         // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = after the reset
         cls = d ? 2 : ((s.coupled && s.coupled[env]) ? 1 : 0);
@@ -581,9 +582,9 @@ void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
     hipLaunchKernelGGL(car_solve_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
 }
 
-void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *slow_env, int32_t *info_steps,
+void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
                      int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list, int32_t *class_count) {
-    hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env, slow_env,
+    hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env, done_out, slow_env,
                        info_steps, max_episode_steps, car0_only ? 1 : 0, class_list, class_count);
 }
 

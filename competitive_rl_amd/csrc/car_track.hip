@@ -37,7 +37,7 @@ __device__ inline double sgnd(double v) { return (double)((v > 0) - (v < 0)); }
 // one iteration of the walk; returns the appended point
 __device__ inline void walk_step(const Checkpoints &cp, Walk &w, double out[4]) {
     const double PI = 3.141592653589793;
-    double alpha = crl_atan2(w.y, w.x);
+    double alpha = crl_atan2_fast(w.y, w.x);
     if (w.visited_other_side && alpha > 0) w.laps++, w.visited_other_side = 0;
     if (alpha < 0) w.visited_other_side = 1, alpha += 2 * PI;
     double dest_x = 0, dest_y = 0;
@@ -53,7 +53,7 @@ __device__ inline void walk_step(const Checkpoints &cp, Walk &w, double out[4]) 
         if (!failed) break;
         alpha -= 2 * PI;
     }
-    const double r1x = crl_cos(w.beta), r1y = crl_sin(w.beta), p1x = -r1y, p1y = r1x;
+    const double r1x = crl_cos_fast(w.beta), r1y = crl_sin_fast(w.beta), p1x = -r1y, p1y = r1x;
     const double dest_dx = dest_x - w.x, dest_dy = dest_y - w.y;
     double proj = r1x * dest_dx + r1y * dest_dy;
     while (w.beta - alpha > 1.5 * PI) w.beta -= 2 * PI;
@@ -85,7 +85,7 @@ __device__ int create_track(const double u[24], double *__restrict__ pts, int64_
         double rad = CAR_TRACK_RAD / 3 + (CAR_TRACK_RAD - CAR_TRACK_RAD / 3) * u[2 * c + 1];
         if (c == 0) alpha = 0, rad = 1.5 * CAR_TRACK_RAD;
         if (c == 11) alpha = 2 * PI * c / 12, cp.start_alpha = 2 * PI * (-0.5) / 12, rad = 1.5 * CAR_TRACK_RAD;
-        cp.a[c] = alpha, cp.x[c] = rad * crl_cos(alpha), cp.y[c] = rad * crl_sin(alpha);
+        cp.a[c] = alpha, cp.x[c] = rad * crl_cos_fast(alpha), cp.y[c] = rad * crl_sin_fast(alpha);
     }
     Walk w;
     walk_init(w);
@@ -108,7 +108,7 @@ __device__ int create_track(const double u[24], double *__restrict__ pts, int64_
     const int len = (i2 - 1) - i1;  // points i1 .. i2-2
     if (len <= 0 || len > kCarMaxTiles) return 0;
     const double *trk = pts + (int64_t)i1 * 4 * stride;
-    const double fb = trk[1 * stride], fpx = crl_cos(fb), fpy = crl_sin(fb);
+    const double fb = trk[1 * stride], fpx = crl_cos_fast(fb), fpy = crl_sin_fast(fb);
     const double a = fpx * (trk[2 * stride] - trk[((int64_t)(len - 1) * 4 + 2) * stride]);
     const double b = fpy * (trk[3 * stride] - trk[((int64_t)(len - 1) * 4 + 3) * stride]);
     if (sqrt(a * a + b * b) > CAR_TRACK_DETAIL_STEP) return 0;
@@ -175,11 +175,11 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         const double b1 = T(i, 1), x1 = T(i, 2), y1 = T(i, 3), b2 = T(j, 1), x2 = T(j, 2), y2 = T(j, 3);
         const double PI = 3.141592653589793;
         const double v[5][2] = {
-            {x1 - CAR_TRACK_WIDTH * crl_cos(b1), y1 - CAR_TRACK_WIDTH * crl_sin(b1)},
-            {x1 - CAR_TRACK_WIDTH / 2 * crl_cos(b1 - PI / 2), y1 - CAR_TRACK_WIDTH / 2 * crl_sin(b1 - PI / 2)},
-            {x1 + CAR_TRACK_WIDTH * crl_cos(b1), y1 + CAR_TRACK_WIDTH * crl_sin(b1)},
-            {x2 + CAR_TRACK_WIDTH * crl_cos(b2), y2 + CAR_TRACK_WIDTH * crl_sin(b2)},
-            {x2 - CAR_TRACK_WIDTH * crl_cos(b2), y2 - CAR_TRACK_WIDTH * crl_sin(b2)},
+            {x1 - CAR_TRACK_WIDTH * crl_cos_fast(b1), y1 - CAR_TRACK_WIDTH * crl_sin_fast(b1)},
+            {x1 - CAR_TRACK_WIDTH / 2 * crl_cos_fast(b1 - PI / 2), y1 - CAR_TRACK_WIDTH / 2 * crl_sin_fast(b1 - PI / 2)},
+            {x1 + CAR_TRACK_WIDTH * crl_cos_fast(b1), y1 + CAR_TRACK_WIDTH * crl_sin_fast(b1)},
+            {x2 + CAR_TRACK_WIDTH * crl_cos_fast(b2), y2 + CAR_TRACK_WIDTH * crl_sin_fast(b2)},
+            {x2 - CAR_TRACK_WIDTH * crl_cos_fast(b2), y2 - CAR_TRACK_WIDTH * crl_sin_fast(b2)},
         };
         float bb[4];
         uint32_t *mv = s.map_vtx + (env * kCarMaxTiles + i) * 9;
@@ -197,10 +197,10 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         if (flag[i]) {
             const double side = sgnd(b2 - b1);
             const double bp[4][2] = {
-                {x1 + side * CAR_TRACK_WIDTH * crl_cos(b1), y1 + side * CAR_TRACK_WIDTH * crl_sin(b1)},
-                {x1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos(b1), y1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin(b1)},
-                {x2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos(b2), y2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin(b2)},
-                {x2 + side * CAR_TRACK_WIDTH * crl_cos(b2), y2 + side * CAR_TRACK_WIDTH * crl_sin(b2)},
+                {x1 + side * CAR_TRACK_WIDTH * crl_cos_fast(b1), y1 + side * CAR_TRACK_WIDTH * crl_sin_fast(b1)},
+                {x1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos_fast(b1), y1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin_fast(b1)},
+                {x2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos_fast(b2), y2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin_fast(b2)},
+                {x2 + side * CAR_TRACK_WIDTH * crl_cos_fast(b2), y2 + side * CAR_TRACK_WIDTH * crl_sin_fast(b2)},
             };
             for (int q = 0; q < 4; q++) {
                 const uint32_t w = map_vertex(bp[q]);

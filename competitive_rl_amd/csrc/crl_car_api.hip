@@ -221,7 +221,9 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
             return crl_fail(CRL_EHIP, "car create: map constants");
         }
     }
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (numerically lower = higher priority)
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||  // the touching envs: the step's critical path
         hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_narrow, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_near, hipEventDisableTiming) != hipSuccess ||
@@ -386,7 +388,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, st);
         launch_car_coupled(c->s, c->K_, st);
     }
-    launch_car_post(c->s, c->done_car, c->done_env, c->slow_env, c->info_steps, 1000, c->car0_only, st, c->class_list, c->class_count);
+    launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, 1000, c->car0_only, st, c->class_list, c->class_count);
     if (!fork) {
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
         if (obs_dev) frames(c, c->term, st, c->done_env);
@@ -447,7 +449,6 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
         crl_timer_end(tm, 1, st);
     }
-    if (done_dev) hipMemcpyAsync(done_dev, c->done_env, c->n, hipMemcpyDeviceToDevice, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car step: %s", hipGetErrorString(e));
     return CRL_OK;

@@ -182,4 +182,79 @@ CRL_F64_FN double crl_atan2(double y, double x) {
     return __builtin_copysign(th.h, y);
 }
 
+
+/* ---- fast variants for the track walk (_create_track takes an atan2, a sin and a cos per step of a 2 500-step walk, for
+ * every attempt of every reset): plain double arithmetic, no tables in memory, error <= 3 ulp (sin / cos <= 2; measured in
+ * tests/test_f64_math.py) -- not correctly rounded, but the SAME bits on the GPU and in the CPU oracle, which is what
+ * the walk needs.  The double-double functions above (a few hundred operations each) stay for the once-per-frame camera. */
+CRL_F64_FN void crl_sincos_fast(double x, double *sn, double *cs) {
+    if (!(x > -0x1p20 && x < 0x1p20)) {
+        *sn = *cs = __builtin_nan("");
+        return;
+    }
+    const double kf = __builtin_floor(x * 0x1.45f306dc9c883p-1 + 0.5);
+    /* pi/2 = P1 + P2 + P3 with 33-bit P1, P2: kf * P1 and kf * P2 are exact */
+    const double r = ((x - kf * 0x1.921fb54400000p+0) - kf * 0x1.0b4611a600000p-34) - kf * 0x1.3198a2e037073p-69;
+    const double z = r * r;
+    const double ps = -0x1.5555555555555p-3 +
+                      z * (0x1.1111111111111p-7 +
+                           z * (-0x1.a01a01a01a01ap-13 +
+                                z * (0x1.71de3a556c734p-19 +
+                                     z * (-0x1.ae64567f544e4p-26 + z * (0x1.6124613a86d09p-33 + z * (-0x1.ae7f3e733b81fp-41 + z * 0x1.952c77030ad4ap-49))))));
+    const double pc = 0x1.5555555555555p-5 +
+                      z * (-0x1.6c16c16c16c17p-10 +
+                           z * (0x1.a01a01a01a01ap-16 +
+                                z * (-0x1.27e4fb7789f5cp-22 + z * (0x1.1eed8eff8d898p-29 + z * (-0x1.93974a8c07c9dp-37 + z * (0x1.ae7f3e733b81fp-45 + z * -0x1.6827863b97d97p-53))))));
+    const double s = r + r * (z * ps);
+    const double hz = 0.5 * z, w = 1.0 - hz; /* cos = 1 - z/2 + z^2 pc, with the rounding of (1 - z/2) put back (fdlibm's __kernel_cos) */
+    const double c = w + (((1.0 - w) - hz) + z * (z * pc));
+    const int q = (int)((long long)kf & 3);
+    const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    *sn = x == 0.0 ? x : ((q == 2 || q == 3) ? -so : so);
+    *cs = (q == 1 || q == 2) ? -co : co;
+}
+CRL_F64_FN double crl_sin_fast(double x) {
+    double s, c;
+    crl_sincos_fast(x, &s, &c);
+    return s;
+}
+CRL_F64_FN double crl_cos_fast(double x) {
+    double s, c;
+    crl_sincos_fast(x, &s, &c);
+    return c;
+}
+/* atan2: u = min / max in [0, 1]; atan(u) = atan(i / 8) + atan((u - i/8) / (1 + u i/8)), i = nearest eighth: the
+ * remainder is below 1/16, an eight-term Taylor series; atan(i / 8) as hi + lo */
+CRL_F64_FN double crl_atan2_fast(double y, double x) {
+    if (x != x || y != y) return __builtin_nan("");
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double pi_h = 0x1.921fb54442d18p+1, pi_l = 0x1.1a62633145c07p-53, pio2_h = 0x1.921fb54442d18p+0, pio2_l = 0x1.1a62633145c07p-54;
+    if (ay == 0.0) return __builtin_signbit(x) ? __builtin_copysign(pi_h, y) : __builtin_copysign(0.0, y);
+    if (ax == 0.0) return __builtin_copysign(pio2_h, y);
+    if (!(ax < 0x1p500 && ay < 0x1p500 && ax > 0x1p-500 && ay > 0x1p-500)) return __builtin_nan("");
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const double u = mn / mx;
+    const int i = (int)(u * 8.0 + 0.5);
+    const double c = (double)i * 0.125;
+    const double v = (u - c) / (1.0 + u * c);
+    double th = 0.0, tl = 0.0;
+    th = i == 1 ? 0x1.fd5ba9aac2f6ep-4 : th, tl = i == 1 ? -0x1.cd37686760c17p-59 : tl;
+    th = i == 2 ? 0x1.f5b75f92c80ddp-3 : th, tl = i == 2 ? 0x1.8ab6e3cf7afbdp-57 : tl;
+    th = i == 3 ? 0x1.6f61941e4def1p-2 : th, tl = i == 3 ? -0x1.c63aae6f6e918p-56 : tl;
+    th = i == 4 ? 0x1.dac670561bb4fp-2 : th, tl = i == 4 ? 0x1.a2b7f222f65e2p-56 : tl;
+    th = i == 5 ? 0x1.1e00babdefeb4p-1 : th, tl = i == 5 ? -0x1.928df287a668fp-58 : tl;
+    th = i == 6 ? 0x1.4978fa3269ee1p-1 : th, tl = i == 6 ? 0x1.2419a87f2a458p-56 : tl;
+    th = i == 7 ? 0x1.700a7c5784634p-1 : th, tl = i == 7 ? -0x1.8c34d25aadef6p-56 : tl;
+    th = i == 8 ? 0x1.921fb54442d18p-1 : th, tl = i == 8 ? 0x1.1a62633145c07p-55 : tl;
+    const double w = v * v;
+    const double pv = v + v * (w * (-0x1.5555555555555p-2 +
+                                    w * (0x1.999999999999ap-3 +
+                                         w * (-0x1.2492492492492p-3 +
+                                              w * (0x1.c71c71c71c71cp-4 + w * (-0x1.745d1745d1746p-4 + w * (0x1.3b13b13b13b14p-4 + w * -0x1.1111111111111p-4)))))));
+    double a = th + (tl + pv);                       /* angle of (mx, mn) from the longer axis, in [0, pi/4] */
+    if (ay > ax) a = pio2_h - (a - pio2_l);          /* from the +x axis */
+    if (__builtin_signbit(x)) a = pi_h - (a - pi_l); /* second quadrant */
+    return __builtin_copysign(a, y);
+}
+
 #endif /* CRL_F64_H_ */

@@ -37,13 +37,19 @@ static inline void rot_sincosf(float a, float *s, float *c) { *s = sinf(a), *c =
 #define m_sin sin
 #define m_cos cos
 #define m_atan2 atan2
+#define t_sin sin
+#define t_cos cos
+#define t_atan2 atan2
 #else
 #include "../include/crl_f64.h"
 #include "../include/crl_rot.h"
 #define rot_sincosf crl_sincosf
-#define m_sin crl_sin
+#define m_sin crl_sin /* camera, pygame's rotate: the correctly rounded double-double evaluations */
 #define m_cos crl_cos
 #define m_atan2 crl_atan2
+#define t_sin crl_sin_fast /* _create_track's walk: the plain-double evaluations (<= 3 ulp), as the GPU walks it */
+#define t_cos crl_cos_fast
+#define t_atan2 crl_atan2_fast
 #endif
 
 /* ---- constants (crmp:54-88, cd:17-51) */
@@ -87,14 +93,14 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
             start_alpha = 2 * M_PI * (-0.5) / CHECKPOINTS;
             rad = 1.5 * TRACK_RAD;
         }
-        cp[c][0] = alpha, cp[c][1] = rad * m_cos(alpha), cp[c][2] = rad * m_sin(alpha);
+        cp[c][0] = alpha, cp[c][1] = rad * t_cos(alpha), cp[c][2] = rad * t_sin(alpha);
     }
     static __thread double tr[2600][4];
     double x = 1.5 * TRACK_RAD, y = 0, beta = 0;
     long dest_i = 0;
     int laps = 0, n = 0, no_freeze = 2500, visited_other_side = 0;
     for (;;) {
-        double alpha = m_atan2(y, x);
+        double alpha = t_atan2(y, x);
         if (visited_other_side && alpha > 0) laps++, visited_other_side = 0;
         if (alpha < 0) visited_other_side = 1, alpha += 2 * M_PI;
         double dest_alpha, dest_x, dest_y;
@@ -109,7 +115,7 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
             if (!failed) break;
             alpha -= 2 * M_PI;
         }
-        double r1x = m_cos(beta), r1y = m_sin(beta), p1x = -r1y, p1y = r1x;
+        double r1x = t_cos(beta), r1y = t_sin(beta), p1x = -r1y, p1y = r1x;
         double dest_dx = dest_x - x, dest_dy = dest_y - y;
         double proj = r1x * dest_dx + r1y * dest_dy;
         while (beta - alpha > 1.5 * M_PI) beta -= 2 * M_PI;
@@ -136,7 +142,7 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
     int len = (i2 - 1) - i1;
     if (len <= 0 || len > CAR_MAX_TILES) return 0;
     double(*t)[4] = &tr[i1];
-    double fb = t[0][1], fpx = m_cos(fb), fpy = m_sin(fb);
+    double fb = t[0][1], fpx = t_cos(fb), fpy = t_sin(fb);
     double a = fpx * (t[0][2] - t[len - 1][2]), b = fpy * (t[0][3] - t[len - 1][3]);
     double glued = sqrt(a * a + b * b);
     if (glued > TRACK_DETAIL_STEP) return 0;
@@ -162,21 +168,21 @@ int car_oracle_create_track(const double *u /*24 draws*/, car_track *out) {
         const double *p1 = t[k], *p2 = t[((k - 1) % len + len) % len];
         double b1 = p1[1], x1 = p1[2], y1 = p1[3], b2 = p2[1], x2 = p2[2], y2 = p2[3];
         double v[5][2] = {
-            {x1 - TRACK_WIDTH * m_cos(b1), y1 - TRACK_WIDTH * m_sin(b1)},
-            {x1 - TRACK_WIDTH / 2 * m_cos(b1 - M_PI / 2), y1 - TRACK_WIDTH / 2 * m_sin(b1 - M_PI / 2)},
-            {x1 + TRACK_WIDTH * m_cos(b1), y1 + TRACK_WIDTH * m_sin(b1)},
-            {x2 + TRACK_WIDTH * m_cos(b2), y2 + TRACK_WIDTH * m_sin(b2)},
-            {x2 - TRACK_WIDTH * m_cos(b2), y2 - TRACK_WIDTH * m_sin(b2)},
+            {x1 - TRACK_WIDTH * t_cos(b1), y1 - TRACK_WIDTH * t_sin(b1)},
+            {x1 - TRACK_WIDTH / 2 * t_cos(b1 - M_PI / 2), y1 - TRACK_WIDTH / 2 * t_sin(b1 - M_PI / 2)},
+            {x1 + TRACK_WIDTH * t_cos(b1), y1 + TRACK_WIDTH * t_sin(b1)},
+            {x2 + TRACK_WIDTH * t_cos(b2), y2 + TRACK_WIDTH * t_sin(b2)},
+            {x2 - TRACK_WIDTH * t_cos(b2), y2 - TRACK_WIDTH * t_sin(b2)},
         };
         memcpy(out->tile[k], v, sizeof(v));
         out->border[k] = border[k];
         if (border[k]) {
             double side = sgn(b2 - b1);
             double bp[4][2] = {
-                {x1 + side * TRACK_WIDTH * m_cos(b1), y1 + side * TRACK_WIDTH * m_sin(b1)},
-                {x1 + side * (TRACK_WIDTH + BORDER) * m_cos(b1), y1 + side * (TRACK_WIDTH + BORDER) * m_sin(b1)},
-                {x2 + side * (TRACK_WIDTH + BORDER) * m_cos(b2), y2 + side * (TRACK_WIDTH + BORDER) * m_sin(b2)},
-                {x2 + side * TRACK_WIDTH * m_cos(b2), y2 + side * TRACK_WIDTH * m_sin(b2)},
+                {x1 + side * TRACK_WIDTH * t_cos(b1), y1 + side * TRACK_WIDTH * t_sin(b1)},
+                {x1 + side * (TRACK_WIDTH + BORDER) * t_cos(b1), y1 + side * (TRACK_WIDTH + BORDER) * t_sin(b1)},
+                {x2 + side * (TRACK_WIDTH + BORDER) * t_cos(b2), y2 + side * (TRACK_WIDTH + BORDER) * t_sin(b2)},
+                {x2 + side * TRACK_WIDTH * t_cos(b2), y2 + side * TRACK_WIDTH * t_sin(b2)},
             };
             memcpy(out->border_poly[k], bp, sizeof(bp));
         } else {
@@ -1539,5 +1545,6 @@ void car_oracle_render_analytic(const car_env *e, int viewer, uint8_t *out) {
 
 /* the double-precision functions this build uses, for tests/test_f64_math.py */
 void car_oracle_f64(int fn, const double *a, const double *b, double *out, long n) {
-    for (long i = 0; i < n; i++) out[i] = fn == 0 ? m_sin(a[i]) : fn == 1 ? m_cos(a[i]) : m_atan2(a[i], b[i]);
+    for (long i = 0; i < n; i++)
+        out[i] = fn == 0 ? m_sin(a[i]) : fn == 1 ? m_cos(a[i]) : fn == 2 ? m_atan2(a[i], b[i]) : fn == 3 ? t_sin(a[i]) : fn == 4 ? t_cos(a[i]) : t_atan2(a[i], b[i]);
 }

@@ -26,6 +26,19 @@ def test_crl_f64_is_correctly_rounded_on_a_sample():
         assert float(mp.atan2(mp.mpf(float(y[i])), mp.mpf(float(z[i])))) == a[i], (y[i], z[i], a[i])
 
 
+def test_fast_variants_stay_within_three_ulp():
+    """crl_*_fast (the track walk): plain-double evaluations, compared with the correctly rounded ones"""
+    x, y, z = _args(400000, 3)
+    worst = {}
+    for fn, name in ((0, "sin"), (1, "cos"), (2, "atan2")):
+        a = co.f64(fn + 3, x if fn < 2 else y, None if fn < 2 else z)
+        b = co.f64(fn, x if fn < 2 else y, None if fn < 2 else z)
+        ulp = np.spacing(np.abs(b))
+        worst[name] = (float((np.abs(a - b) / ulp).max()), float((a != b).mean()))
+    print("fast vs correctly rounded: (max ulp, fraction differing)", worst)
+    assert all(v[0] <= 3.0 for v in worst.values()), worst
+
+
 def test_special_arguments():
     assert co.f64(0, [0.0, -0.0]).tolist() == [0.0, -0.0] and np.signbit(co.f64(0, [-0.0]))[0]
     assert co.f64(1, [0.0])[0] == 1.0
