@@ -212,6 +212,7 @@ void car_raster_print_ticks();  // CRL_CAR_DEBUG & 64
 // car_obs.hip: the reference's observation pipeline
 void launch_car_map_build(const CarSoA &s, hipStream_t st, const uint8_t *only_env = nullptr, int64_t first = 0, int64_t count = -1);  // envs [first, first + count), all or only_env[e] != 0
 void launch_car_map_build_list(const CarSoA &s, hipStream_t st, const int32_t *list, const int32_t *list_count, int64_t expected);
+void launch_car_view(const CarSoA &s, const CarConsts &k, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
                          int32_t *count_to_host, int64_t expected, const uint8_t *filter = nullptr, int want_cls = 0);

@@ -558,10 +558,13 @@ __global__ __launch_bounds__(64) void car_obs_list_kernel(CarSoA s, CarConsts K,
     }
 }
 
-void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env, int want) {
+// camera + car polygons of every env (or of the envs with only_env[e] == want): what launch_car_obs reads
+void launch_car_view(const CarSoA &s, const CarConsts &k, hipStream_t st, const uint8_t *only_env, int want) {
     const int64_t tiles = s.n * s.players;
     hipLaunchKernelGGL(car_camera_kernel, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, st, s, k, only_env, want);
     hipLaunchKernelGGL(car_poly_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(64), 0, st, s, k, only_env, want);
+}
+void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env, int want) {
     const unsigned grid = s.players == 2 ? (unsigned)((s.n + 7) / 8 * 16) : (unsigned)s.n;
     hipLaunchKernelGGL(car_obs_kernel, dim3(grid), dim3(64), 0, st, s, obs, only_env, want);
 }

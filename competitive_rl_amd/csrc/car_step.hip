@@ -544,8 +544,10 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
         done_env[env] = d ? 1 : 0;
         if (done_out) done_out[env] = d ? 1 : 0;  // the caller's done tensor (was a device-to-device copy at the end of the step)
         if (info_steps) info_steps[env] = s.step_count[env];  // one world clock per env: both cars carry the same count
-        // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = after the reset
-        cls = d ? 2 : ((s.coupled && s.coupled[env]) ? 1 : 0);
+        // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = finished (terminal frame, reset, first
+        // frame), 3 = finished and coupled (the same, after the coupled solve)
+        const bool cp = s.coupled && s.coupled[env];
+        cls = d ? (cp ? 3 : 2) : (cp ? 1 : 0);
         if (slow_env) slow_env[env] = (uint8_t)cls;
     }
     // the two small classes also as compacted lists (any order): their frames are drawn by launches sized to the lists.
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
     if (class_list) {
         const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int k = 1; k <= 2; k++) {
+        for (int k = 1; k <= 3; k++) {
             const unsigned long long m = __ballot(cls == k);
             if (!m) continue;
             int base = 0;

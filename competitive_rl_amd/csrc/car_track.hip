@@ -174,12 +174,15 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         const int j = ((i - 1) % len + len) % len;
         const double b1 = T(i, 1), x1 = T(i, 2), y1 = T(i, 3), b2 = T(j, 1), x2 = T(j, 2), y2 = T(j, 3);
         const double PI = 3.141592653589793;
+        // (each angle's sine and cosine once: the reference evaluates math.cos / math.sin of the same argument again and again)
+        double s1, c1, s2, c2, sm, cm;
+        crl_sincos_fast(b1, &s1, &c1), crl_sincos_fast(b2, &s2, &c2), crl_sincos_fast(b1 - PI / 2, &sm, &cm);
         const double v[5][2] = {
-            {x1 - CAR_TRACK_WIDTH * crl_cos_fast(b1), y1 - CAR_TRACK_WIDTH * crl_sin_fast(b1)},
-            {x1 - CAR_TRACK_WIDTH / 2 * crl_cos_fast(b1 - PI / 2), y1 - CAR_TRACK_WIDTH / 2 * crl_sin_fast(b1 - PI / 2)},
-            {x1 + CAR_TRACK_WIDTH * crl_cos_fast(b1), y1 + CAR_TRACK_WIDTH * crl_sin_fast(b1)},
-            {x2 + CAR_TRACK_WIDTH * crl_cos_fast(b2), y2 + CAR_TRACK_WIDTH * crl_sin_fast(b2)},
-            {x2 - CAR_TRACK_WIDTH * crl_cos_fast(b2), y2 - CAR_TRACK_WIDTH * crl_sin_fast(b2)},
+            {x1 - CAR_TRACK_WIDTH * c1, y1 - CAR_TRACK_WIDTH * s1},
+            {x1 - CAR_TRACK_WIDTH / 2 * cm, y1 - CAR_TRACK_WIDTH / 2 * sm},
+            {x1 + CAR_TRACK_WIDTH * c1, y1 + CAR_TRACK_WIDTH * s1},
+            {x2 + CAR_TRACK_WIDTH * c2, y2 + CAR_TRACK_WIDTH * s2},
+            {x2 - CAR_TRACK_WIDTH * c2, y2 - CAR_TRACK_WIDTH * s2},
         };
         float bb[4];
         uint32_t *mv = s.map_vtx + (env * kCarMaxTiles + i) * 9;
@@ -197,10 +200,10 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         if (flag[i]) {
             const double side = sgnd(b2 - b1);
             const double bp[4][2] = {
-                {x1 + side * CAR_TRACK_WIDTH * crl_cos_fast(b1), y1 + side * CAR_TRACK_WIDTH * crl_sin_fast(b1)},
-                {x1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos_fast(b1), y1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin_fast(b1)},
-                {x2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_cos_fast(b2), y2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * crl_sin_fast(b2)},
-                {x2 + side * CAR_TRACK_WIDTH * crl_cos_fast(b2), y2 + side * CAR_TRACK_WIDTH * crl_sin_fast(b2)},
+                {x1 + side * CAR_TRACK_WIDTH * c1, y1 + side * CAR_TRACK_WIDTH * s1},
+                {x1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * c1, y1 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * s1},
+                {x2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * c2, y2 + side * (CAR_TRACK_WIDTH + CAR_BORDER) * s2},
+                {x2 + side * CAR_TRACK_WIDTH * c2, y2 + side * CAR_TRACK_WIDTH * s2},
             };
             for (int q = 0; q < 4; q++) {
                 const uint32_t w = map_vertex(bp[q]);

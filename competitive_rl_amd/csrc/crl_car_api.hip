@@ -28,11 +28,13 @@ struct crl_car_ctx {
     // latency-bound part of a step (coupled solve, track generation for finished envs) runs on a
     // side stream next to the raster; slow_env = pipeline class per env (car_post_kernel)
     uint8_t *slow_env = nullptr;
-    int32_t *class_list = nullptr;   // [2][n] envs of class 1 (coupled) and class 2 (finished) of the current step, compacted
-    int32_t *class_count = nullptr;  // [2] their lengths (inside `counters`)
+    int32_t *class_list = nullptr;   // [3][n] envs of class 1 (coupled), 2 (finished, cars on their own) and 3 (finished and coupled) of the current step, compacted
+    int32_t *class_count = nullptr;  // [3] their lengths (inside `counters`)
     int32_t *counters = nullptr;     // [2][16] per step parity: coupled_count[8], class_count[2]; a step's first kernel clears the other block
     int parity = 0;
     hipEvent_t ev_nearfr = nullptr;
+    hipEvent_t ev_fin3 = nullptr;
+    hipEvent_t ev_fin = nullptr;
     int32_t *class_count_host = nullptr, *class_count_hdev = nullptr;  // host-mapped copy (one step late): sizes the next step's launches
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;  // the near-only coupled envs (plain island solves), beside the touching ones on `side`
@@ -177,7 +179,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
     if (!rc) rc = calloc_dev(c, &c->slow_env, n);
-    if (!rc) rc = calloc_dev(c, &c->class_list, 2 * n);
+    if (!rc) rc = calloc_dev(c, &c->class_list, 3 * n);
     if (!rc) rc = calloc_dev(c, &c->counters, 2 * 16);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     if (!rc) rc = calloc_dev(c, &c->info_steps, n);
@@ -228,10 +230,13 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_narrow, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_near, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nearfr, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fin3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->gen, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own
+
         hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming) != hipSuccess ||
         hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t)) != hipSuccess ||
@@ -269,6 +274,8 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_narrow) hipEventDestroy(c->ev_narrow);
     if (c->ev_near) hipEventDestroy(c->ev_near);
     if (c->ev_nearfr) hipEventDestroy(c->ev_nearfr);
+    if (c->ev_fin3) hipEventDestroy(c->ev_fin3);
+    if (c->ev_fin) hipEventDestroy(c->ev_fin);
     if (c->sens) hipStreamDestroy(c->sens);
     if (c->ev_sens) hipEventDestroy(c->ev_sens);
     if (c->ev_c1) hipEventDestroy(c->ev_c1);
@@ -315,9 +322,18 @@ void crl_car_seed(crl_car_ctx *c, uint64_t seed) {
 int64_t crl_car_obs_bytes(const crl_car_ctx *c) { return (int64_t)c->s.players * c->K * CRL_CAR_OBS * CRL_CAR_OBS; }
 
 // frames of every env, or of the envs with only_env[e] == want
-static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1) {
-    if (c->analytic) launch_car_raster(c->s, c->K_, dst, st, only_env, want);
-    else launch_car_obs(c->s, c->K_, dst, st, only_env, want);
+// tm (optional): timer 1 brackets the frame kernel alone (car_obs_kernel / car_raster_kernel), for bench.py's roofline
+static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1, crl_timer *tm = nullptr) {
+    if (c->analytic) {
+        crl_timer_begin(tm, 1, st);
+        launch_car_raster(c->s, c->K_, dst, st, only_env, want);
+        crl_timer_end(tm, 1, st);
+        return;
+    }
+    launch_car_view(c->s, c->K_, st, only_env, want);
+    crl_timer_begin(tm, 1, st);
+    launch_car_obs(c->s, c->K_, dst, st, only_env, want);
+    crl_timer_end(tm, 1, st);
 }
 // frames of the envs of a compacted list
 static void frames_list(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const int32_t *list, const int32_t *list_count, int32_t *count_to_host,
@@ -402,13 +418,16 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             crl_timer_end(tm, 1, st);
         }
     } else {
-        // Four streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished):
+        // Four streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished, 3 finished and coupled):
         //   st     per-car solve -> frames of class 0 (the big launch)
         //   sens   wheel sensors (tile rewards, road_visited: they read the transforms the step started from and feed nothing into
-        //          its solve; every frame shows the reward, so every frame launch waits for them)
-        //   side   narrow phase of the coupled envs -> the touching ones' island solve -> their frames; then the finished envs
-        //          from end to end: terminal frame (info["terminal_observation"]), reset, map, first frame of the new episode
-        //   side2  the coupled envs where nothing touches (two islands of their own) -> their frames
+        //          its solve; every frame shows the reward, so every frame launch waits for them); then the finished envs: terminal
+        //          frame, reset, map, first frame of the new episode
+        //   side   narrow phase of the coupled envs -> the touching ones' island solve -> their frames
+        //   side2  the coupled envs where nothing touches (two islands of their own) -> their frames; then the few envs that are
+        //          finished AND coupled
+        // (no more streams than that: the runtime maps streams of one priority onto four hardware queues, and two streams
+        // that share one wait for each other's kernels; the milliseconds-long walk-ahead has a priority class of its own)
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
         hipEventRecord(c->ev_fork, st);
@@ -429,25 +448,37 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipEventRecord(c->ev_term, st);  // (bodies of the non-coupled cars are final)
         hipStreamWaitEvent(st, c->ev_sens, 0);
         crl_timer_end(tm, 0, st);
-        crl_timer_begin(tm, 1, st);
-        frames(c, target, st, c->slow_env, 0);
-        // side again: frames of the touching envs, then the finished envs
+        frames(c, target, st, c->slow_env, 0, tm);
+        // side again: frames of the touching envs (the finished-and-coupled envs' chain runs beside them, on side2)
         hipStreamWaitEvent(c->side, c->ev_sens, 0);
         if (c->s.players == 2 && c->s.contacts_enabled) {
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
         }
-        hipStreamWaitEvent(c->side, c->ev_term, 0);
-        frames_list(c, c->term, c->side, c->class_list + c->n, c->class_count + 1, c->class_count_hdev + 1, exp_done);
-        launch_car_reset_list(c->s, c->K_, c->src, c->class_list + c->n, c->class_count + 1, exp_done, c->side);
-        launch_car_map_build_list(c->s, c->side, c->class_list + c->n, c->class_count + 1, exp_done);
-        queue_walk_ahead(c, c->side);
-        frames_list(c, target, c->side, c->class_list + c->n, c->class_count + 1, nullptr, exp_done);
+        // the finished envs, end to end: terminal frame (info["terminal_observation"]), reset, map, first frame of the new episode.
+        // Class 2 (cars on their own: nearly all of them) on `sens`, as soon as the per-car solve and the sensors are in -- beside the
+        // big frame launch; class 3 (finished AND coupled: their terminal frame shows the coupled solve's result) on `side2`, last.
+        auto finish_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {
+            const int32_t *list = c->class_list + (int64_t)(cls - 1) * c->n, *cnt = c->class_count + (cls - 1);
+            frames_list(c, c->term, q, list, cnt, count_to_host, expected);
+            launch_car_reset_list(c->s, c->K_, c->src, list, cnt, expected, q);
+            launch_car_map_build_list(c->s, q, list, cnt, expected);
+            frames_list(c, target, q, list, cnt, nullptr, expected);
+        };
+        hipStreamWaitEvent(c->sens, c->ev_term, 0);
+        finish_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
+        hipEventRecord(c->ev_fin, c->sens);
+        hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // (recorded on side behind the touching AND the near-only solve)
+        hipStreamWaitEvent(c->side2, c->ev_sens, 0);
+        finish_chain(c->side2, 3, 8, nullptr);
+        hipEventRecord(c->ev_fin3, c->side2);
         hipEventRecord(c->ev_join, c->side);
+        queue_walk_ahead(c, c->sens);
         if (c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(st, c->ev_nearfr, 0);
+        hipStreamWaitEvent(st, c->ev_fin, 0);
+        hipStreamWaitEvent(st, c->ev_fin3, 0);
         hipStreamWaitEvent(st, c->ev_join, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
-        crl_timer_end(tm, 1, st);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "car step: %s", hipGetErrorString(e));
