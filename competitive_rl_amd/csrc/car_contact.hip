@@ -165,16 +165,23 @@ struct WPoly {
     int cnt;
 };
 __device__ inline float max_separation_w(int &edge, const WPoly &p1, const WPoly &p2) {
+    // both polygons' data comes in with back-to-back LDS reads and is indexed statically (8 x 8, entries past a polygon's
+    // count switched off): a rolled double loop is a chain of ~100-cycle LDS round trips
+    V2 n1[8], v1[8], w2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) n1[i] = p1.n[i], v1[i] = p1.w[i], w2[i] = p2.w[i];
+    const int c1 = p1.cnt, c2 = p2.cnt;
     float best = -3.4e38f;
     int bi = 0;
-    for (int i = 0; i < p1.cnt; i++) {
-        const V2 n = p1.n[i], v1 = p1.w[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
         float si = 3.4e38f;
-        for (int j = 0; j < p2.cnt; j++) {
-            const float sij = dot(n, p2.w[j] - v1);
-            if (sij < si) si = sij;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float sij = dot(n1[i], w2[j] - v1[i]);
+            if (j < c2 && sij < si) si = sij;
         }
-        if (si > best) best = si, bi = i;
+        if (i < c1 && si > best) best = si, bi = i;
     }
     edge = bi;
     return best;

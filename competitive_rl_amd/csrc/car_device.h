@@ -161,13 +161,15 @@ struct Body {
     float cx, cy, a, vx, vy, w;
 };
 
-// Conservative "could these two cars touch" test on the hull poses: oriented boxes that contain
-// hull + steered wheels (half extents 1.75 x 2.75 about the hull origin, + margin), separating
-// axis test.  Symmetric in its arguments' roles, evaluated identically by both lanes of an env.
-__host__ __device__ inline bool cars_near(const CarConsts &K, float x0, float y0, float a0, float x1, float y1, float a1) {
-    const float ex = 1.75f + 0.2f, ey = 2.75f + 0.2f;
+// Conservative "could these two cars touch" test on the hull poses: oriented boxes that contain hull + steered wheels
+// (half extents 1.75 x 2.75 about the hull origin, + margin), separating axis test.  Symmetric in its arguments' roles,
+// evaluated identically by both lanes of an env.  This only ROUTES the env (coupled solve or per-car solve: the same
+// arithmetic for cars that do not touch), so it may use the fast hardware sine / cosine (error ~1e-6, covered by the margin).
+__device__ inline void fast_sincosf(float a, float *s, float *c) { *s = __sinf(a), *c = __cosf(a); }
+__device__ inline bool cars_near(const CarConsts &K, float x0, float y0, float a0, float x1, float y1, float a1) {
+    const float ex = 1.75f + 0.21f, ey = 2.75f + 0.21f;
     float s0, c0, s1, c1;
-    crl_sincosf(a0, &s0, &c0), crl_sincosf(a1, &s1, &c1);
+    fast_sincosf(a0, &s0, &c0), fast_sincosf(a1, &s1, &c1);
     // box centres = hull origins (body origin = centre of mass - R * localCenter)
     const float ox0 = x0 - (c0 * K.hull_lc[0] - s0 * K.hull_lc[1]), oy0 = y0 - (s0 * K.hull_lc[0] + c0 * K.hull_lc[1]);
     const float ox1 = x1 - (c1 * K.hull_lc[0] - s1 * K.hull_lc[1]), oy1 = y1 - (s1 * K.hull_lc[0] + c1 * K.hull_lc[1]);

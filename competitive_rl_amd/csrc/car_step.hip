@@ -65,6 +65,7 @@ __device__ inline float poly_dist2(const V2 (&A)[4], const V2 (&B)[5]) {
 // Second-level "could the cars touch" test: world AABBs of the 8 fixtures of each car (4 hull
 // polygons, 4 wheels; wheels do not collide with wheels), grown by more than the polygon radii.
 // No overlapping pair => b2CollidePolygons would find no manifold point for this env.
+// (a routing decision like cars_near: hardware sine / cosine, and a margin of 0.04 where the contact margin is 0.02)
 __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_t M, int64_t c0, int64_t c1) {
     // (fully unrolled: the 16 boxes stay in registers)
     float bb[2][8][4];
@@ -76,7 +77,7 @@ __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_
             const int o = f < 4 ? 0 : 6 + 6 * (f - 4);
             const float cx = s.body[(o + 0) * M + ci], cy = s.body[(o + 1) * M + ci], a = s.body[(o + 2) * M + ci];
             float sn, cs;
-            crl_sincosf(a, &sn, &cs);
+            fast_sincosf(a, &sn, &cs);
             const V2 lc = f < 4 ? mk(K.hull_lc[0], K.hull_lc[1]) : mk(0.f, 0.f);
             const V2 p = mk(cx, cy) - rotv(sn, cs, lc);
             const int nv = f < 4 ? K.hull_n[f] : 4;
@@ -89,7 +90,7 @@ __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_
                     x0 = fminf(x0, wv.x), y0 = fminf(y0, wv.y), x1 = fmaxf(x1, wv.x), y1 = fmaxf(y1, wv.y);
                 }
             }
-            bb[k][f][0] = x0 - 0.03f, bb[k][f][1] = y0 - 0.03f, bb[k][f][2] = x1 + 0.03f, bb[k][f][3] = y1 + 0.03f;
+            bb[k][f][0] = x0 - 0.04f, bb[k][f][1] = y0 - 0.04f, bb[k][f][2] = x1 + 0.04f, bb[k][f][3] = y1 + 0.04f;
         }
     }
     bool any = false;
@@ -258,10 +259,21 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     }
 #pragma unroll
     for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
-    if (car == 0 && s.players == 2) {
-        s.coupled[env] = coupled ? 1 : 0;
-        if (coupled) s.coupled_list[atomicAdd(s.coupled_count, 1)] = (int32_t)env;
-        else s.n_contact[env] = 0;
+    if (s.players == 2) {
+        // one atomic per WAVEFRONT, not per coupled env: a tenth of 16 384 envs on one address took longer than the rest of the kernel
+        const bool mine = car == 0 && coupled;
+        const unsigned long long m = __ballot(mine);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(s.coupled_count, (int)__popcll(m));
+            base = __shfl(base, (int)__ffsll((long long)m) - 1);
+            if (mine) s.coupled_list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
+        }
+        if (car == 0) {
+            s.coupled[env] = coupled ? 1 : 0;
+            if (!coupled) s.n_contact[env] = 0;
+        }
     }
     step_count += 1;
 
@@ -555,7 +567,7 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
     if (class_list) {
         const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int k = 1; k <= 3; k++) {
+        for (int k = 2; k <= 3; k++) {  // (class 1, the coupled envs, is listed by the narrow phase: near-only and touching)
             const unsigned long long m = __ballot(cls == k);
             if (!m) continue;
             int base = 0;
