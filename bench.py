@@ -2,7 +2,7 @@
 """bench.py -- env-steps/sec of the cPongDouble hot path on N MI355X (one process per GPU).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|raw|fused84|fused84_f32|fused84_newest|car|tournament]
-                    [--envs E] [--gather none|scalars|obs] [--no-cpu-baseline]
+                    [--envs E] [--gather none|scalars|obs|descriptors] [--no-cpu-baseline]
 
 A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated, device-resident) random
 actions, auto-reset included, no host sync inside the timed loop.  The headline (``metric`` / ``value``) is
@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--workload", default="all",
                     choices=["all", "raw", "fused84", "fused84_f32", "fused84_newest", "car", "tournament"])
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
-    ap.add_argument("--gather", choices=["none", "scalars", "obs"], default="none")
+    ap.add_argument("--gather", choices=["none", "scalars", "obs", "descriptors"], default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -239,10 +239,19 @@ def run_workload(name, args, G):
     gather_state = G.get("gather")
 
     def step(i):
-        out = env.step_device(pool[i % 16])
+        if world > 1 and args.gather == "obs" and name != "car" and name != "tournament":
+            # the env draws straight into the collective's send buffer (two of them, alternating: gather(t) still reads one)
+            out = env.step_device(pool[i % 16], obs_out=gather_state.obs_slot(inner._obs[0].shape, inner._obs[0].dtype, dev))
+        else:
+            out = env.step_device(pool[i % 16])
         if world > 1 and args.gather != "none":
-            gather_state.wait(materialize=False)  # at most one collective in flight: gather(t) overlaps simulate(t+1)
-            gather_state.launch(out if args.gather == "obs" else out[1:])
+            if args.gather == "descriptors":
+                # 64 bytes of frame descriptors per env over the links; every rank then re-draws the GLOBAL batch (inside wait())
+                gather_state.wait(materialize=True)
+                gather_state.launch(out[1:], env=inner)
+            else:
+                gather_state.wait(materialize=False)  # at most one collective in flight: gather(t) overlaps simulate(t+1)
+                gather_state.launch(out if args.gather == "obs" else out[1:])
 
     for i in range(args.warmup):
         step(i)
@@ -260,7 +269,7 @@ def run_workload(name, args, G):
     for i in range(args.steps):
         step(i)
     if world > 1 and args.gather != "none":
-        gather_state.wait(materialize=False)
+        gather_state.wait(materialize=args.gather == "descriptors")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -359,7 +368,7 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
-        G["gather"] = crl.StepGather(overlap=True)
+        G["gather"] = crl.StepGather(overlap=True, mode="descriptors" if args.gather == "descriptors" else "obs")
     results = {}
     for nm in names:
         results[nm] = run_workload(nm, args, G)
@@ -375,7 +384,9 @@ def main():
         if "roofline_valu" in head:
             line["roofline_valu"] = head["roofline_valu"]
         if world > 1 and args.gather != "none":
-            line["config"]["gather"] = args.gather + " (one packed all_gather_into_tensor per step on a side stream, overlapped with the next step)"
+            line["config"]["gather"] = args.gather + (" (64 bytes of frame descriptors per env in one packed all_gather_into_tensor per step; every rank re-draws all shards' observations)"
+                                                      if args.gather == "descriptors" else
+                                                      " (one packed all_gather_into_tensor per step on a side stream, overlapped with the next step)")
         if names[0] in cpu:
             line["cpu_baseline"] = cpu[names[0]]
         if multi:

@@ -22,7 +22,8 @@ SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "cr
            "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version",
            "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_get_map", "crl_car_set_replay",
            "crl_policy_create", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
-           "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update"]
+           "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update", "crl_ctx_last_error",
+           "crl_obs_descriptors", "crl_render_frames_dev"]
 
 FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
                      ("score_l", "u1"), ("score_r", "u1")])
@@ -95,12 +96,14 @@ def load():
     L.crl_terminal_observation_dev.argtypes = [vp, vp, i64, vp, vp]
     L.crl_check.argtypes = [vp, vp]
     L.crl_car_info.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
-    L.crl_car_copy_info.argtypes = [vp, vp, vp, vp]
+    L.crl_car_copy_info.argtypes = [vp, vp, vp, vp, vp]
     L.crl_frame_stack_update.argtypes = [vp, vp, i32, i64, vp, i64, i32, i32, i64, vp]
     L.crl_get_state.argtypes = [vp, vp, i64, i64, vp]
     L.crl_set_state.argtypes = [vp, vp, i64, i64, vp]
     L.crl_set_replay.argtypes = [vp, vp, vp, vp, i64]
     L.crl_render_raw.argtypes = [vp, vp, i64, vp, vp]
+    L.crl_obs_descriptors.argtypes = [vp, vp, vp]
+    L.crl_render_frames_dev.argtypes = [vp, vp, i64, vp, vp]
     L.crl_obs_bytes_per_env.argtypes = [vp]
     L.crl_obs_bytes_per_env.restype = i64
     L.crl_kernel_timing.argtypes = [vp, i32]
@@ -119,10 +122,12 @@ def load():
     L.crl_policy_get_stack.argtypes = [vp, vp, vp]
     L.crl_policy_set_stack.argtypes = [vp, vp, vp]
     L.crl_last_error.restype = C.c_char_p
+    L.crl_ctx_last_error.restype = C.c_char_p
+    L.crl_ctx_last_error.argtypes = [vp]
     L.crl_version.restype = C.c_char_p
     for name in SYMBOLS:
         getattr(L, name)
-        if name not in ("crl_destroy", "crl_policy_destroy", "crl_obs_bytes_per_env", "crl_last_error", "crl_version"):
+        if name not in ("crl_destroy", "crl_policy_destroy", "crl_obs_bytes_per_env", "crl_last_error", "crl_ctx_last_error", "crl_version"):
             getattr(L, name).restype = i32
     _lib = L
     return L

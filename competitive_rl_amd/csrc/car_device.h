@@ -204,7 +204,7 @@ void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st = nullptr, hipEvent_t ev_narrow = nullptr,
                         hipEvent_t ev_near = nullptr);  // near_st == nullptr: everything on st
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
-                     int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
+                     int32_t *info_elapsed, int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 
 // only_env: draw env e iff only_env[e] == want; nullptr = every env
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K
 // crmp:578-579).  Also captures info["num_steps"] = CarRacing.step_count (crmp:616-620) before the auto-reset.
 __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *__restrict__ done_car,
                                                        uint8_t *__restrict__ done_env, uint8_t *__restrict__ done_out, uint8_t *__restrict__ slow_env,
-                                                       int32_t *__restrict__ info_steps, int max_episode_steps, int car0_only,
+                                                       int32_t *__restrict__ info_steps, int32_t *__restrict__ info_elapsed, int max_episode_steps, int car0_only,
                                                        int32_t *__restrict__ class_list, int32_t *__restrict__ class_count) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int cls = 0;
@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
         s.elapsed[env] = el;
         done_env[env] = d ? 1 : 0;
         if (done_out) done_out[env] = d ? 1 : 0;  // the caller's done tensor (was a device-to-device copy at the end of the step)
+        if (info_elapsed) info_elapsed[env] = el;  // gym TimeLimit._elapsed_steps after this step, before the auto-reset zeroes it
         if (info_steps) info_steps[env] = s.step_count[env];  // one world clock per env: both cars carry the same count
         // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = finished (terminal frame, reset, first
         // frame), 3 = finished and coupled (the same, after the coupled solve)
@@ -597,9 +598,9 @@ void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
 }
 
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
-                     int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list, int32_t *class_count) {
+                     int32_t *info_elapsed, int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list, int32_t *class_count) {
     hipLaunchKernelGGL(car_post_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, done_car, done_env, done_out, slow_env,
-                       info_steps, max_episode_steps, car0_only ? 1 : 0, class_list, class_count);
+                       info_steps, info_elapsed, max_episode_steps, car0_only ? 1 : 0, class_list, class_count);
 }
 
 }  // namespace crl

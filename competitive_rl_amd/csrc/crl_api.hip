@@ -27,7 +27,11 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
 
 using namespace crl;
 
+// Error text: per calling thread (crl_last_error: also covers crl_create, which has no context yet) and per context
+// (crl_ctx_last_error).  Every entry point that takes a context names it first (CRL_ENTER); crl_fail then files the
+// message under that context as well.
 static thread_local std::string g_err;
+static thread_local std::string *g_ctx_err = nullptr;
 
 int crl_fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -36,6 +40,7 @@ int crl_fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+    if (g_ctx_err) *g_ctx_err = buf;
     return code;
 }
 #define fail crl_fail
@@ -73,6 +78,7 @@ static AreaTab area_table(int ssize, int dsize) {
 
 
 struct crl_ctx {
+    std::string err;  // text of this context's most recent failing call (crl_ctx_last_error)
     crl_opts o;
     int64_t n;
     PongSoA s{};
@@ -290,10 +296,13 @@ static int setup_gray(crl_ctx *c) {
 
 extern "C" {
 
+#define CRL_ENTER(c) g_ctx_err = (c) ? &const_cast<crl_ctx *>(c)->err : nullptr
 const char *crl_last_error(void) { return g_err.c_str(); }
+const char *crl_ctx_last_error(const crl_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
 const char *crl_version(void) { return "crl-hip 0.1 (gfx950)"; }
 
 int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **out) {
+    g_ctx_err = nullptr;
     if (!opts || !out) return fail(CRL_EINVAL, "null argument");
     const bool is_car = opts->env_kind == CRL_ENV_CAR_DOUBLE || opts->env_kind == CRL_ENV_CAR_SINGLE;
     if (!score_atlas_host && !is_car) return fail(CRL_EINVAL, "null argument");
@@ -393,6 +402,7 @@ int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **
 }
 
 void crl_destroy(crl_ctx *c) {
+    g_ctx_err = nullptr;
     if (!c) return;
     hipSetDevice(c->o.device);
     hipDeviceSynchronize();
@@ -412,6 +422,7 @@ void crl_destroy(crl_ctx *c) {
 }
 
 int crl_seed(crl_ctx *c, uint64_t seed) {
+    CRL_ENTER(c);
     if (!c) return fail(CRL_EINVAL, "null ctx");
     if (c->car) crl_car_seed(c->car, seed);
     c->src.seed = seed;
@@ -449,22 +460,25 @@ static int pending_action_error(crl_ctx *c, bool clear) {
 }
 
 int crl_check(crl_ctx *c, void *stream) {
+    CRL_ENTER(c);
     if (!c) return fail(CRL_EINVAL, "null ctx");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return pending_action_error(c, true);
 }
 
 int crl_reset(crl_ctx *c, uint8_t *obs_dev, void *stream) {
+    CRL_ENTER(c);
     if (!c) return fail(CRL_EINVAL, "null ctx");
     hipStream_t st = (hipStream_t)stream;
     if (c->car) return crl_car_reset(c->car, obs_dev, st);
-    if (int rc = pending_action_error(c, false)) return rc;
+    if (int rc = pending_action_error(c, true)) return rc;  // reported ONCE, by the first call that sees it: the next call proceeds
     launch_pong_reset(c->s, c->src, c->n, pong_mode(c), st);
     HIP_TRY(hipGetLastError());
     return draw_obs(c, obs_dev, st);
 }
 
 int crl_render(crl_ctx *c, uint8_t *obs_dev, void *stream) {
+    CRL_ENTER(c);
     if (!c || !obs_dev) return fail(CRL_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
     if (c->car) return crl_car_render(c->car, obs_dev, st);
@@ -472,10 +486,11 @@ int crl_render(crl_ctx *c, uint8_t *obs_dev, void *stream) {
 }
 
 int crl_step(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, void *stream) {
+    CRL_ENTER(c);
     if (!c || !actions_void) return fail(CRL_EINVAL, "null ctx/actions");
     hipStream_t st = (hipStream_t)stream;
     if (c->car) return crl_car_step(c->car, (const float *)actions_void, obs_dev, rew_dev, done_dev, st, &c->tm);
-    if (int rc = pending_action_error(c, false)) return rc;
+    if (int rc = pending_action_error(c, true)) return rc;  // (reported once; this call did no work)
     const int32_t *actions_dev = (const int32_t *)actions_void;
     begin_timed(c, 0, st);
     launch_pong_dynamics(c->s, c->src, actions_dev, c->n, pong_mode(c), rew_dev, done_dev, st);
@@ -485,6 +500,7 @@ int crl_step(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_
 }
 
 int crl_info(crl_ctx *c, const float **real_reward_dev, const int32_t **num_steps_dev) {
+    CRL_ENTER(c);
     if (!c) return fail(CRL_EINVAL, "null ctx");
     if (c->car) return fail(CRL_ESTATE, "crl_info is a Pong entry point");
     if (real_reward_dev) *real_reward_dev = c->s.real_reward;
@@ -493,6 +509,7 @@ int crl_info(crl_ctx *c, const float **real_reward_dev, const int32_t **num_step
 }
 
 int crl_copy_info(crl_ctx *c, float *rr_out, int32_t *ns_out, void *stream) {
+    CRL_ENTER(c);
     if (!c) return fail(CRL_EINVAL, "null ctx");
     if (c->car) return fail(CRL_ESTATE, "crl_copy_info is a Pong entry point");
     hipStream_t st = (hipStream_t)stream;
@@ -502,22 +519,26 @@ int crl_copy_info(crl_ctx *c, float *rr_out, int32_t *ns_out, void *stream) {
 }
 
 int crl_car_info(crl_ctx *c, const uint8_t **done_car_dev, const int32_t **num_steps_dev) {
+    CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     if (done_car_dev) *done_car_dev = crl_car_done_flags(c->car);
     if (num_steps_dev) *num_steps_dev = crl_car_info_steps(c->car);
     return CRL_OK;
 }
 
-int crl_car_copy_info(crl_ctx *c, uint8_t *done_car_out, int32_t *num_steps_out, void *stream) {
+int crl_car_copy_info(crl_ctx *c, uint8_t *done_car_out, int32_t *num_steps_out, int32_t *elapsed_out, void *stream) {
+    CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     hipStream_t st = (hipStream_t)stream;
     const int64_t P = crl_car_players(c->car);
     if (done_car_out) HIP_TRY(hipMemcpyAsync(done_car_out, crl_car_done_flags(c->car), (size_t)(c->n * P), hipMemcpyDeviceToDevice, st));
     if (num_steps_out) HIP_TRY(hipMemcpyAsync(num_steps_out, crl_car_info_steps(c->car), (size_t)c->n * 4, hipMemcpyDeviceToDevice, st));
+    if (elapsed_out) HIP_TRY(hipMemcpyAsync(elapsed_out, crl_car_info_elapsed(c->car), (size_t)c->n * 4, hipMemcpyDeviceToDevice, st));
     return CRL_OK;
 }
 
 int64_t crl_obs_bytes_per_env(const crl_ctx *c) {
+    CRL_ENTER(c);
     if (!c) return 0;
     if (c->car) return crl_car_obs_bytes(c->car);
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) return pong_views(c) * (int64_t)CRL_PONG_FRAME_BYTES;
@@ -567,6 +588,7 @@ static int render_pairs(crl_ctx *c, const std::vector<uint64_t> &f0, const std::
 }
 
 int crl_terminal_observation_dev(crl_ctx *c, const int64_t *env_idx_dev, int64_t count, uint8_t *out_dev, void *stream) {
+    CRL_ENTER(c);
     if (!c || (count > 0 && (!env_idx_dev || !out_dev))) return fail(CRL_EINVAL, "null argument");
     if (count <= 0) return CRL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -583,6 +605,7 @@ int crl_terminal_observation_dev(crl_ctx *c, const int64_t *env_idx_dev, int64_t
 }
 
 int crl_terminal_observation(crl_ctx *c, const int64_t *env_idx_host, int64_t count, uint8_t *out_dev, void *stream) {
+    CRL_ENTER(c);
     if (!c || (count > 0 && (!env_idx_host || !out_dev))) return fail(CRL_EINVAL, "null argument");
     if (count <= 0) return CRL_OK;
     for (int64_t k = 0; k < count; k++)
@@ -600,7 +623,50 @@ int crl_terminal_observation(crl_ctx *c, const int64_t *env_idx_host, int64_t co
     return crl_terminal_observation_dev(c, c->idx_dev, count, out_dev, stream);
 }
 
+// The frame descriptors the CURRENT observation was drawn from, in the ring layout uint64 [8][N] (plane p of the stack, kept
+// frame s -> row 2p + s; raw contexts and K = 1 use the newest plane, rows 6 and 7): 64 bytes per env instead of its pixels.
+int crl_obs_descriptors(crl_ctx *c, crl_pong_frame *desc_out_dev, void *stream) {
+    CRL_ENTER(c);
+    if (!c || !desc_out_dev) return fail(CRL_EINVAL, "null argument");
+    if (c->car) return fail(CRL_ESTATE, "crl_obs_descriptors is a Pong entry point");
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t *out = reinterpret_cast<uint64_t *>(desc_out_dev);
+    if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
+        HIP_TRY(hipMemsetAsync(out, 0xFF, (size_t)6 * c->n * 8, st));  // (blank planes: never read)
+        HIP_TRY(hipMemcpyAsync(out + 6 * c->n, c->s.obs_frames, (size_t)2 * c->n * 8, hipMemcpyDeviceToDevice, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(out, c->s.ring, (size_t)8 * c->n * 8, hipMemcpyDeviceToDevice, st));
+    }
+    return CRL_OK;
+}
+
+// Draws `count` observations from descriptors in that layout (uint64 [8][count]) -- any envs, e.g. another shard's: out_dev as
+// crl_step's obs_dev for `count` envs.  A frame is a pure function of its descriptors, so a rank that holds every shard's
+// descriptors holds every shard's observation (BASELINE config #5 without moving pixels).
+int crl_render_frames_dev(crl_ctx *c, const crl_pong_frame *desc_dev, int64_t count, uint8_t *out_dev, void *stream) {
+    CRL_ENTER(c);
+    if (!c || (count > 0 && (!desc_dev || !out_dev))) return fail(CRL_EINVAL, "null argument");
+    if (c->car) return fail(CRL_ESTATE, "crl_render_frames_dev is a Pong entry point");
+    if (count <= 0) return CRL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t *ring = reinterpret_cast<const uint64_t *>(desc_dev);
+    if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
+        launch_pong_raster_raw(ring + 6 * count, count, c->atlas_rgb, c->ink_row0, c->ink_row1, out_dev, pong_views(c), st);
+    } else {
+        GrayParams p{};
+        p.ring = ring, p.n = count, p.R = c->o.resized_dim, p.K = c->o.frame_stack, p.views = pong_views(c);
+        p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
+        p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
+        p.obs = out_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32;
+        launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
+                                   c->band_chunks, c->tab_blob, c->tofs, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return CRL_OK;
+}
+
 int crl_render_raw(crl_ctx *c, const crl_pong_frame *frames_host, int64_t count, uint8_t *out_dev, void *stream) {
+    CRL_ENTER(c);
     if (!c || !frames_host || !out_dev) return fail(CRL_EINVAL, "null argument");
     if (c->car) return fail(CRL_ESTATE, "crl_render_raw is a Pong entry point");
     if (c->o.obs_mode != CRL_OBS_RAW_RGB) return fail(CRL_ESTATE, "crl_render_raw needs a RAW_RGB context");
@@ -638,6 +704,7 @@ static uint64_t from_frame(const crl_pong_frame &f) {
 extern "C" {
 
 int crl_get_state(crl_ctx *c, crl_pong_env_state *out, int64_t first, int64_t count, void *stream) {
+    CRL_ENTER(c);
     if (!c || !out || first < 0 || count < 0 || first + count > c->n) return fail(CRL_EINVAL, "bad range");
     if (c->car) return fail(CRL_ESTATE, "use crl_car_get_state for CarRacing contexts");
     hipStream_t st = (hipStream_t)stream;
@@ -669,6 +736,7 @@ int crl_get_state(crl_ctx *c, crl_pong_env_state *out, int64_t first, int64_t co
 }
 
 int crl_set_state(crl_ctx *c, const crl_pong_env_state *in, int64_t first, int64_t count, void *stream) {
+    CRL_ENTER(c);
     if (!c || !in || first < 0 || count < 0 || first + count > c->n) return fail(CRL_EINVAL, "bad range");
     if (c->car) return fail(CRL_ESTATE, "use crl_car_set_state for CarRacing contexts");
     hipStream_t st = (hipStream_t)stream;
@@ -705,6 +773,7 @@ int crl_set_state(crl_ctx *c, const crl_pong_env_state *in, int64_t first, int64
 }
 
 int crl_set_replay(crl_ctx *c, const double *u, const uint8_t *bx, const uint8_t *by, int64_t per_env) {
+    CRL_ENTER(c);
     if (!c) return fail(CRL_EINVAL, "null ctx");
     if (c->car) return fail(CRL_ESTATE, "use crl_car_set_replay for CarRacing contexts");
     HIP_TRY(hipDeviceSynchronize());
@@ -724,6 +793,7 @@ int crl_set_replay(crl_ctx *c, const double *u, const uint8_t *bx, const uint8_t
 }
 
 int crl_kernel_timing(crl_ctx *c, int enable) {
+    CRL_ENTER(c);
     if (!c) return fail(CRL_EINVAL, "null ctx");
     c->tm.on = enable != 0;
     // the event pairs of the first few hundred timed launches are created HERE, not inside the caller's timed loop
@@ -743,6 +813,7 @@ int crl_kernel_timing(crl_ctx *c, int enable) {
 }
 
 int crl_kernel_time_ms(crl_ctx *c, int which, double *total_ms, int64_t *launches) {
+    CRL_ENTER(c);
     if (!c || which < 0 || which > 1) return fail(CRL_EINVAL, "bad argument");
     crl_timer &t = c->tm;
     for (auto &p : t.ev[which]) {
@@ -760,28 +831,36 @@ int crl_kernel_time_ms(crl_ctx *c, int which, double *total_ms, int64_t *launche
 }
 
 int crl_car_get_state(crl_ctx *c, crl_car_env_state *out, int64_t first, int64_t count, void *stream) {
+    CRL_ENTER(c);
     if (!c || !c->car || !out) return fail(CRL_EINVAL, "not a CarRacing context / null argument");
     return crl_car_get_state_impl(c->car, out, first, count, (hipStream_t)stream);
 }
 int crl_car_set_state(crl_ctx *c, const crl_car_env_state *in, int64_t first, int64_t count, void *stream) {
+    CRL_ENTER(c);
     if (!c || !c->car || !in) return fail(CRL_EINVAL, "not a CarRacing context / null argument");
     return crl_car_set_state_impl(c->car, in, first, count, (hipStream_t)stream);
 }
 int crl_car_get_track(crl_ctx *c, int64_t env, int32_t *n, float *tile_poly, float *border_poly, uint8_t *border,
                       float *start_pose, void *stream) {
+    CRL_ENTER(c);
+    CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_get_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
 }
 int crl_car_set_track(crl_ctx *c, int64_t env, int32_t n, const double *tile_poly, const double *border_poly, const uint8_t *border,
                       const float *start_pose, void *stream) {
+    CRL_ENTER(c);
+    CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_set_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
 }
 int crl_car_get_map(crl_ctx *c, int64_t env, uint8_t *palette_host, int32_t *overflow, void *stream) {
+    CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_get_map_impl(c->car, env, palette_host, overflow, (hipStream_t)stream);
 }
 int crl_car_set_replay(crl_ctx *c, const double *u, const uint8_t *swap, int64_t attempts) {
+    CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_set_replay_impl(c->car, u, swap, attempts);
 }

@@ -46,6 +46,7 @@ struct crl_car_ctx {
     hipEvent_t ev_walk = nullptr;  // recorded behind every walk-ahead launch: no new one is queued while it is pending
     bool walk_pending = false;
     int32_t *info_steps = nullptr;  // [n] CarRacing.step_count after the step, before the auto-reset (info["num_steps"])
+    int32_t *info_elapsed = nullptr;  // [n] gym TimeLimit._elapsed_steps after the step, before the auto-reset (info["TimeLimit.truncated"])
     bool car0_only = false;         // crl_opts.done_policy == CRL_CAR_DONE_CAR0
     hipEvent_t ev_fork = nullptr, ev_coupled = nullptr, ev_term = nullptr, ev_join = nullptr;
     bool overlap = true;
@@ -183,6 +184,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     if (!rc) rc = calloc_dev(c, &c->counters, 2 * 16);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     if (!rc) rc = calloc_dev(c, &c->info_steps, n);
+    if (!rc) rc = calloc_dev(c, &c->info_elapsed, n);
     if (!rc) rc = calloc_dev(c, &c->term, (size_t)M * 96 * 96);
     c->K = opts->frame_stack < 1 ? 1 : opts->frame_stack;
     c->repeat = opts->action_repeat >= 1 ? opts->action_repeat : 1;
@@ -372,6 +374,7 @@ int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
 const uint8_t *crl_car_terminal_frames(const crl_car_ctx *c) { return c->term; }
 const uint8_t *crl_car_done_flags(const crl_car_ctx *c) { return c->done_car; }
 const int32_t *crl_car_info_steps(const crl_car_ctx *c) { return c->info_steps; }
+const int32_t *crl_car_info_elapsed(const crl_car_ctx *c) { return c->info_elapsed; }
 int crl_car_players(const crl_car_ctx *c) { return c->s.players; }
 
 int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
@@ -404,7 +407,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, st);
         launch_car_coupled(c->s, c->K_, st);
     }
-    launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, 1000, c->car0_only, st, c->class_list, c->class_count);
+    launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, st, c->class_list, c->class_count);
     if (!fork) {
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
         if (obs_dev) frames(c, c->term, st, c->done_env);

@@ -34,6 +34,7 @@ int crl_car_render(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st);
 const uint8_t *crl_car_terminal_frames(const crl_car_ctx *c);
 const uint8_t *crl_car_done_flags(const crl_car_ctx *c);
 const int32_t *crl_car_info_steps(const crl_car_ctx *c);
+const int32_t *crl_car_info_elapsed(const crl_car_ctx *c);
 int crl_car_players(const crl_car_ctx *c);
 int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, hipStream_t st,
                  crl_timer *tm);

@@ -236,9 +236,9 @@ class HipPongVecEnv(VecEnv):
     def reset(self):
         self._check_open()
         buf = self._obs[self._flip]
+        N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
         self._flip ^= 1
         self._serial += 1
-        N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
         return self._format_obs(buf)
 
     def step_async(self, actions):
@@ -267,11 +267,13 @@ class HipPongVecEnv(VecEnv):
     def step_wait(self):
         self._check_open()
         buf = self._obs[self._flip]
-        self._flip ^= 1
-        self._serial += 1
+        self.waiting = False
+        # (the library first: a refused call -- e.g. the report of an earlier out-of-range action -- has not stepped the envs,
+        # so the buffer flip and the serial that lazy infos check stay where they are)
         N.check(self._L.crl_step(self._h, C.c_void_p(self._actions.data_ptr()), C.c_void_p(buf.data_ptr()),
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
-        self.waiting = False
+        self._flip ^= 1
+        self._serial += 1
         done = self._done.bool()
         if self.dones_kind == "dummy":  # scalar done broadcast over the agents (dummy_vec_env.py:39-40)
             done_out = done[:, None].expand(-1, self.V)
@@ -403,18 +405,47 @@ class HipPongVecEnv(VecEnv):
                                        C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
-    def step_device(self, actions_i32, render=True):
+    def obs_descriptors(self, out=None):
+        """The frame descriptors the current observation was drawn from: int64 (8, N) on the device, 64 bytes per env (ring
+        layout of include/crl.h).  ``render_descriptors`` turns descriptors -- this shard's or any other's -- back into pixels."""
+        if out is None:
+            out = torch.empty((8, self.num_envs), dtype=torch.int64, device=self.device)
+        assert out.is_contiguous() and out.numel() == 8 * self.num_envs and out.element_size() == 8 and out.device == self.device
+        N.check(self._L.crl_obs_descriptors(self._h, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def render_descriptors(self, desc, out=None):
+        """Observations of ``count`` envs from their descriptors (int64 (8, count) on the device): same layout as step_device's
+        observation buffer, (count, V, ...)."""
+        assert desc.is_contiguous() and desc.element_size() == 8 and desc.device == self.device and desc.numel() % 8 == 0
+        count = desc.numel() // 8
+        if out is None:
+            out = torch.empty((count,) + tuple(self._obs_shape[1:]), dtype=self._buf_dtype, device=self.device)
+        assert out.is_contiguous() and out.device == self.device
+        N.check(self._L.crl_render_frames_dev(self._h, C.c_void_p(desc.data_ptr()), count, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def step_device(self, actions_i32, render=True, obs_out=None):
         """Hot-loop entry for training/bench code: `actions_i32` is an int32 (N, 2) tensor
-        already on the device; returns device tensors, no host work, no clones, no sync."""
+        already on the device; returns device tensors, no host work, no clones, no sync.  ``obs_out``: draw the observation
+        straight into the caller's tensor (e.g. a slice of a collective's send buffer) instead of the env's double buffer."""
         if not (actions_i32.is_contiguous() and actions_i32.dtype == torch.int32 and actions_i32.device == self.device):
             raise AssertionError("step_device needs a contiguous int32 tensor on the env's device")
+        if obs_out is not None:
+            if not (obs_out.is_contiguous() and obs_out.dtype == self._buf_dtype and obs_out.device == self.device
+                    and obs_out.numel() == self._obs[0].numel()):
+                raise AssertionError("obs_out must be a contiguous tensor of the observation buffer's size and dtype on the env's device")
+            N.check(self._L.crl_step(self._h, C.c_void_p(actions_i32.data_ptr()), C.c_void_p(obs_out.data_ptr()),
+                                     C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+            self._serial += 1
+            return obs_out.view(self._obs[0].shape), self._rew, self._done
         buf = self._obs[self._flip]
-        self._prev_buf = self._obs[self._flip ^ 1]
-        self._flip ^= 1
-        self._serial += 1
         N.check(self._L.crl_step(self._h, C.c_void_p(actions_i32.data_ptr()),
                                  C.c_void_p(buf.data_ptr()) if render else None,
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+        self._prev_buf = self._obs[self._flip ^ 1]  # (after the call: a refused call has not stepped the envs)
+        self._flip ^= 1
+        self._serial += 1
         return buf, self._rew, self._done
 
     def kernel_timing(self, enable=True):

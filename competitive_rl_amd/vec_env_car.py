@@ -105,7 +105,6 @@ class HipCarVecEnv(VecEnv):
         self._rew = torch.zeros((n, self.P), dtype=torch.float32, device=dev)
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
         self._actions = torch.zeros((n, self.P, 2), dtype=torch.float32, device=dev)
-        self._elapsed = torch.zeros((n,), dtype=torch.int32, device=dev)  # gym TimeLimit._elapsed_steps mirror (infos only)
         self._serial = 0
         self._prev_buf = self._obs[1]
         self.envs = _EnvList(self)
@@ -131,7 +130,6 @@ class HipCarVecEnv(VecEnv):
         self._flip ^= 1
         self._serial += 1
         N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
-        self._elapsed.zero_()
         return self._out(buf)
 
     def step_async(self, actions):
@@ -158,20 +156,21 @@ class HipCarVecEnv(VecEnv):
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
         return buf, self._rew, self._done
 
-    def _info_snapshot(self):
-        """Copies of the library's per-step info arrays: per-car done flags (N, P) u8, CarRacing.step_count (N,) i32."""
+    def _info_snapshot(self, elapsed=False):
+        """Copies of the library's per-step info arrays: per-car done flags (N, P) u8, CarRacing.step_count (N,) i32 and, on
+        request, gym TimeLimit's step count after the step (N,) i32 -- the device keeps that counter (it is part of the state)."""
         dc = torch.empty((self.num_envs, self.P), dtype=torch.uint8, device=self.device)
         ns = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
-        N.check(self._L.crl_car_copy_info(self._h, C.c_void_p(dc.data_ptr()), C.c_void_p(ns.data_ptr()), self._stream()))
-        return dc, ns
+        el = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device) if elapsed else None
+        N.check(self._L.crl_car_copy_info(self._h, C.c_void_p(dc.data_ptr()), C.c_void_p(ns.data_ptr()),
+                                          C.c_void_p(el.data_ptr()) if elapsed else None, self._stream()))
+        return (dc, ns, el) if elapsed else (dc, ns)
 
     def step_wait(self):
         self._check_open()
         buf, rew, done = self.step_device(self._actions)
-        self._elapsed += 1
-        dc, ns = self._info_snapshot()
-        infos = CarLazyInfos(self, rew.clone(), ns, done.clone(), dc, self._elapsed.clone())
-        self._elapsed.mul_((~done.bool()).to(torch.int32))
+        dc, ns, el = self._info_snapshot(elapsed=True)
+        infos = CarLazyInfos(self, rew.clone(), ns, done.clone(), dc, el)
         r0 = rew[:, :1].clone()
         d = done.bool()
         d = d[:, None].clone() if self.dones_kind == "dummy" else d.clone()
@@ -193,8 +192,27 @@ class HipCarVecEnv(VecEnv):
         except Exception:
             pass
 
+    # VecEnv.get_attr / set_attr / env_method / render (utils/base_vec_env.py:124-160, 195-217), as on HipPongVecEnv: per-env
+    # handles stand in for DummyVecEnv.envs[i]
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self.envs[i], attr_name) for i in self._get_indices(indices)]
+
+    def set_attr(self, attr_name, value, indices=None):
+        for i in self._get_indices(indices):
+            setattr(self.envs[i], attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return [getattr(self.envs[i], method_name)(*args, **kwargs) for i in self._get_indices(indices)]
+
     def get_images(self, *a, **k):
-        return list(self._obs[self._flip ^ 1][:, 0].cpu().numpy())
+        """Agent 0's newest 96 x 96 frame of every env (what the reference's get_observation(0) returned last)."""
+        return list(self._obs[self._flip ^ 1][:, self.K - 1].cpu().numpy())
+
+    def render(self, mode="rgb_array", *args, **kwargs):
+        imgs = self.get_images()
+        if mode == "rgb_array":
+            return imgs[0] if self.num_envs == 1 else np.stack(imgs)
+        raise NotImplementedError("only mode='rgb_array' is available on the GPU backend")
 
     def terminal_observation(self, env_indices):
         """Observation (P*K, 96, 96) each listed env's episode ended on, at its most recent done step.  ``env_indices``

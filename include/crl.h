@@ -47,8 +47,8 @@ enum { CRL_OK = 0, CRL_EINVAL = -1, CRL_EHIP = -2, CRL_ENOMEM = -3, CRL_ESTATE =
        /* an earlier crl_step was given a Pong action outside {0, 1, 2, 999}: the reference asserts
           action_space.contains(action) (pong/base_pong_env.py:42).  Device-resident actions are
           checked by the step kernel; the flag reaches the host without a sync, so the error is
-          reported by the first crl_step / crl_reset / crl_check that sees it (the offending bat did
-          not move).  crl_check clears it. */
+          reported ONCE, by the first crl_step / crl_reset / crl_check that sees it (that call does no
+          work; the offending bat did not move), and cleared: the next call proceeds. */
        CRL_EACTION = -5 };
 
 enum crl_env_kind {
@@ -231,6 +231,16 @@ int crl_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *bx_host,
 int crl_render_raw(crl_ctx *ctx, const crl_pong_frame *frames_host, int64_t count,
                    uint8_t *out_dev, void *stream);
 
+/* ---- observations by descriptor (BASELINE config #5: every GPU ends up with all N observations)
+ * The reference's "gather" is _flatten_obs over the workers' pixel arrays (utils/subproc_vec_env.py:188-222).  Here a frame
+ * is a pure function of its 8-byte descriptors, so shards exchange those: crl_obs_descriptors copies the descriptors the
+ * current observation was drawn from -- crl_pong_frame [8][N]: stack plane p (0 oldest .. 3 newest), kept frame s (the two
+ * frames MaxAndSkipEnv takes the maximum of) in row 2p + s; raw contexts and frame_stack = 1 use rows 6 and 7 -- and
+ * crl_render_frames_dev draws `count` observations from descriptors in that layout ([8][count], anyone's), out_dev as
+ * crl_step's obs_dev for `count` envs.  64 bytes per env instead of 56 448 (fused 4-stack) or 201 600 (raw). */
+int crl_obs_descriptors(crl_ctx *ctx, crl_pong_frame *desc_out_dev, void *stream);
+int crl_render_frames_dev(crl_ctx *ctx, const crl_pong_frame *desc_dev, int64_t count, uint8_t *out_dev, void *stream);
+
 /* Re-draws the CURRENT state into obs_dev without stepping (after crl_set_state /
  * crl_car_set_state, or for VecEnv.render): same layout as crl_step's obs_dev. */
 int crl_render(crl_ctx *ctx, uint8_t *obs_dev, void *stream);
@@ -306,8 +316,10 @@ int crl_car_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *swap_h
  * num_steps i32 (N) = info[k]["num_steps"] = CarRacing.step_count after the step (:616-620),
  * captured before the auto-reset. */
 int crl_car_info(crl_ctx *ctx, const uint8_t **done_car_dev, const int32_t **num_steps_dev);
-/* Same data copied (device to device, on `stream`) into caller-owned arrays; either may be NULL. */
-int crl_car_copy_info(crl_ctx *ctx, uint8_t *done_car_out_dev, int32_t *num_steps_out_dev, void *stream);
+/* Same data copied (device to device, on `stream`) into caller-owned arrays, plus elapsed i32 (N) = gym TimeLimit's
+ * _elapsed_steps after the step, before the auto-reset (info["TimeLimit.truncated"] is set on the step where it reaches
+ * max_episode_steps = 1000, car_racing/register.py:15-26); any destination may be NULL. */
+int crl_car_copy_info(crl_ctx *ctx, uint8_t *done_car_out_dev, int32_t *num_steps_out_dev, int32_t *elapsed_out_dev, void *stream);
 
 /* ---- FrameStackTensor.update on device (utils/utils.py:158-170) -----------------
  * stack f32 (N, C*k, H, W), in place:  stack *= mask[n];  planes shift down by C (roll -C on dim 1);
@@ -345,7 +357,9 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
 int crl_policy_get_stack(crl_policy *p, uint8_t *stack_out_dev, void *stream);
 int crl_policy_set_stack(crl_policy *p, const uint8_t *stack_in_dev, void *stream);
 
+/* Text of the most recent failing call: of the calling thread (any call, crl_create included), or of one context. */
 const char *crl_last_error(void);
+const char *crl_ctx_last_error(const crl_ctx *ctx);
 const char *crl_version(void);
 
 #ifdef __cplusplus

@@ -275,8 +275,30 @@ def test_car_api_surface_and_time_limit():
     assert (st["elapsed"] == 1).all() and (st["episode"] == 2).all()
     with pytest.raises(AssertionError):
         envs.step(np.zeros((6, 2), np.float32))
+    # VecEnv surface (utils/base_vec_env.py:124-160, 195-217), as on the Pong env
+    assert len(envs.envs) == 6 and envs.get_attr("action_space", [0, 2])[0] is envs.action_space
+    envs.set_attr("note", 7, indices=1)
+    assert envs.env_method("seed", 3, indices=[1]) == [None]
+    img = envs.render("rgb_array")
+    assert img.shape == (6, 96, 96) and img.dtype == np.uint8 and np.array_equal(img[2], envs.envs[2].render())
+    with pytest.raises(NotImplementedError):
+        envs.render("human")
     envs.close()
     envs.close()
+    one = crl.make_envs("cCarRacing-v0", num_envs=2, frame_stack=4, log_dir=None)
+    o = one.reset()
+    assert tuple(o.shape) == (2, 4, 96, 96) and len(one.get_attr("observation_space")) == 2
+    assert one.render().shape == (2, 96, 96) and np.array_equal(one.render()[0], o[0, 3].cpu().numpy())
+    # TimeLimit.truncated follows the device's counter when step_device and step() are mixed, and across set_state
+    st = one.get_state()
+    st["elapsed"][:] = 997
+    one.set_state(st)
+    a = torch.zeros((2, 1, 2), device="cuda")
+    one.step_device(a)
+    one.step_device(a)
+    _, _, d, info = one.step(np.zeros((2, 2), np.float32))
+    assert bool(d.all()) and "TimeLimit.truncated" in info[0]
+    one.close()
 
 
 def test_multiple_frame_stack_semantics():

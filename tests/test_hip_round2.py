@@ -42,8 +42,13 @@ def test_action_containment_host_and_device():
     env.check()                                       # cleared
     env.step_device(bad)
     torch.cuda.synchronize()
+    serial = env._serial
     with pytest.raises(CrlActionError):
-        env.step_device(ok)                           # the next step reports the earlier one
+        env.step_device(ok)                           # the next step reports the earlier one ...
+    assert env._serial == serial                      # ... did no work, left the host mirror alone ...
+    env.step_device(ok)                               # ... and the report was made once: this call proceeds
+    env.step(np.ones((n, 2), np.int64))
+    env.reset()
     env.close()
 
 
@@ -222,7 +227,7 @@ def test_full_size_car_properties():
     env.close()
 
 
-def _two_gpu_worker(rank, world, port, out_dir, backend="nccl"):
+def _two_gpu_worker(rank, world, port, out_dir, backend="nccl", mode="obs"):
     import os
     import sys
 
@@ -246,16 +251,36 @@ def _two_gpu_worker(rank, world, port, out_dir, backend="nccl"):
     env = crl.HipPongVecEnv(sh.count, seed=21, mode="wrapped", resized_dim=42, frame_stack=1, env_id_base=sh.base, device=f"cuda:{dev}")
     env.reset()
     acts = torch.as_tensor(np.random.RandomState(5).randint(0, 3, (steps, total, 2)).astype(np.int32)).cuda()
-    g = crl.StepGather(overlap=True)
     got = []
-    for t in range(steps):
-        out = env.step_device(acts[t, sh.base:sh.base + sh.count].contiguous())
-        if backend != "nccl":
-            out = tuple(x.cpu() for x in out)
-        g.launch(out)                       # ONE packed all-gather (on a side stream when it runs on the GPU) ...
-        if t + 1 < steps:
-            pass                            # ... while the next step could already be simulated
-        got.append([x.cpu().numpy().copy() for x in g.wait()])
+    if mode == "descriptors":
+        # every rank ships 64 bytes per env and re-draws the GLOBAL batch locally (crl_obs_descriptors / crl_render_frames_dev)
+        if backend == "nccl":
+            g = crl.StepGather(overlap=True, mode="descriptors")
+            for t in range(steps):
+                _, rew, done = env.step_device(acts[t, sh.base:sh.base + sh.count].contiguous())
+                g.launch((rew, done), env=env)
+                rew.fill_(-7.0)          # (a later step rewriting the single reward buffer must not reach the message)
+                got.append([x.cpu().numpy().copy() for x in g.wait()])
+        else:  # gloo cannot move device memory: stage the descriptors through the host, re-draw on the GPU
+            for t in range(steps):
+                _, rew, done = env.step_device(acts[t, sh.base:sh.base + sh.count].contiguous())
+                desc = env.obs_descriptors().cpu()
+                parts = [torch.empty_like(desc) for _ in range(world)]
+                dist.all_gather(parts, desc)
+                r_all, d_all = crl.all_gather_step((rew.cpu(), done.cpu()))
+                obs = torch.cat([env.render_descriptors(p.cuda()) for p in parts])
+                got.append([obs.cpu().numpy(), r_all.numpy(), d_all.numpy()])
+    else:
+        g = crl.StepGather(overlap=True)
+        for t in range(steps):
+            a = acts[t, sh.base:sh.base + sh.count].contiguous()
+            if backend == "nccl":
+                slot = g.obs_slot(env._obs[0].shape, env._obs[0].dtype, env.device)   # the env draws into the send buffer
+                out = env.step_device(a, obs_out=slot)
+            else:
+                out = tuple(x.cpu() for x in env.step_device(a))
+            g.launch(out)                       # ONE packed all-gather (on a side stream when it runs on the GPU) ...
+            got.append([x.cpu().numpy().copy() for x in g.wait()])
     if rank == 0:
         np.savez(os.path.join(out_dir, "g.npz"), obs=np.stack([o[0] for o in got]), rew=np.stack([o[1] for o in got]),
                  done=np.stack([o[2] for o in got]))
@@ -299,6 +324,41 @@ def test_two_hip_shards_on_one_gpu_plus_packed_gather_equal_one_batch(tmp_path):
     _check_against_one_batch(tmp_path)
 
 
+def test_two_hip_shards_exchanging_descriptors_equal_one_batch(tmp_path):
+    """Config #5 without moving pixels: each shard ships its frame descriptors (64 bytes per env), every rank re-draws both
+    shards' observations from them (crl_render_frames_dev) == one unsharded HIP batch.  Two processes on GPU 0 over gloo."""
+    _need_gpu()
+    import torch.multiprocessing as mp
+
+    mp.start_processes(_two_gpu_worker, args=(2, _free_port(), str(tmp_path), "gloo", "descriptors"), nprocs=2, join=True, start_method="spawn")
+    _check_against_one_batch(tmp_path)
+
+
+def test_descriptors_redraw_the_observation_exactly():
+    """crl_obs_descriptors + crl_render_frames_dev on one context: raw RGB, fused 84 x 84 4-stack (uint8 and float32), and
+    draw-into-the-caller's-buffer (obs_out)."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 200
+    rs = np.random.RandomState(3)
+    for kw in (dict(mode="raw"), dict(mode="wrapped", resized_dim=84, frame_stack=4), dict(mode="wrapped", resized_dim=42, frame_stack=1),
+               dict(mode="wrapped", resized_dim=84, frame_stack=4, obs_dtype="float32")):
+        env = crl.HipPongVecEnv(n, seed=2, **kw)
+        env.reset()
+        mine = torch.empty_like(env._obs[0])
+        for t in range(40):
+            a = torch.as_tensor(rs.randint(0, 3, (n, 2)).astype(np.int32)).cuda()
+            if t % 2:
+                buf, _, _ = env.step_device(a, obs_out=mine)
+                assert buf.data_ptr() == mine.data_ptr()
+            else:
+                buf, _, _ = env.step_device(a)
+            again = env.render_descriptors(env.obs_descriptors())
+            assert torch.equal(again, buf), (kw, t)
+        env.close()
+
+
 def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
     """BASELINE config #5 in small: two HIP shards on two GPUs + the single packed RCCL all-gather == one unsharded HIP batch.
     Needs two visible GPUs (the driver's multi-GPU node); skipped on a one-GPU box."""
@@ -307,8 +367,9 @@ def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
         pytest.skip("needs 2 GPUs")
     import torch.multiprocessing as mp
 
-    mp.start_processes(_two_gpu_worker, args=(2, _free_port(), str(tmp_path), "nccl"), nprocs=2, join=True, start_method="spawn")
-    _check_against_one_batch(tmp_path)
+    for mode in ("obs", "descriptors"):
+        mp.start_processes(_two_gpu_worker, args=(2, _free_port(), str(tmp_path), "nccl", mode), nprocs=2, join=True, start_method="spawn")
+        _check_against_one_batch(tmp_path)
 
 
 def test_address_linear_gray_writer_is_bit_exact_too():

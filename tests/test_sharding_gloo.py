@@ -47,6 +47,43 @@ def _worker(rank, world, port, total, steps, out_dir):
     dist.destroy_process_group()
 
 
+def _race_worker(rank, world, port, out_dir):
+    """rewards / dones of step t must be what the gather of step t returns even when the caller rewrites its
+    (single) reward and done buffers right after launch()."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from competitive_rl_amd.sharding import StepGather
+
+    g = StepGather(overlap=True)
+    n = 64
+    rew, done = torch.zeros((n, 2)), torch.zeros((n,), dtype=torch.uint8)
+    obs = torch.zeros((n, 2, 1, 8, 8), dtype=torch.uint8)
+    ok = True
+    for t in range(50):
+        slot = g.obs_slot(obs.shape, obs.dtype, "cpu")          # the "env" draws straight into the send buffer
+        slot.fill_((t + rank) % 251)
+        rew.fill_(float(t + 10 * rank))
+        done.fill_((t + rank) % 2)
+        g.launch((slot, rew, done))
+        rew.fill_(-1.0)                                          # the next step rewrites the single reward / done buffers at once
+        done.fill_(9)
+        o, r, d = g.wait()
+        for k in range(world):
+            ok &= bool((o[k * n:(k + 1) * n] == (t + k) % 251).all()) and bool((r[k * n:(k + 1) * n] == t + 10 * k).all())
+            ok &= bool((d[k * n:(k + 1) * n] == (t + k) % 2).all())
+    with open(os.path.join(out_dir, f"race{rank}.txt"), "w") as f:
+        f.write("ok" if ok else "bad")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_is_unaffected_by_buffers_rewritten_after_launch(tmp_path):
+    world = 2
+    mp.start_processes(_race_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    assert all(open(tmp_path / f"race{r}.txt").read() == "ok" for r in range(world))
+
+
 def test_shard_of_partitions_exactly():
     from competitive_rl_amd.sharding import shard_of
 
