@@ -379,6 +379,7 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
             o[13] = c.nimp[0], o[14] = c.nimp[1], o[15] = c.timp[0], o[16] = c.timp[1];
         }
         if (lane == 0) {
+            if ((int)__popcll(m) > kMaxContacts) atomicAdd(s.cap_hits + 1, 1);
             s.nc_new[env] = nc;
             // [1] near-only; touching by manifold count: [2] one, [3] two, [4] three or more
             const int cls = nc == 0 ? 0 : nc >= 3 ? 3 : nc;

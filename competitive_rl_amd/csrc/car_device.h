@@ -118,6 +118,8 @@ struct CarSoA {
     int32_t *near_list, *touch_list;  // [n], [3][n]
     int32_t *touch_all;     // [n] every touching env (any manifold count), [5] of coupled_count: their frames
     int32_t *coupled_to_host;  // host-mapped word: the step's coupled-env count, read by the host one step late (sizes the list launches)
+    int32_t *cap_hits;      // [4] times a fixed capacity was hit since create: [0] a wheel touching more than kWheelSlots tiles (the
+                            //     extra tile is not recorded), [1] more than kMaxContacts manifolds between two cars (the rest are dropped)
     int32_t *zero_next;     // [16] the OTHER step parity's counter block (coupled_count[8] + class counts): car_step_kernel clears it for the next step
     int32_t *nc_new;        // [n] this step's manifold count (car_narrow_kernel)
     float *contact_new;     // [n][kMaxContacts][kContactWords] this step's manifolds with the carried-over impulses

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "car_solver.h"
+#include "crl_internal.h"
 
 namespace crl {
 
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(64) void car_sensor_serial_kernel(CarSoA s, CarCons
                 bool placed = false;
                 for (int k = 0; k < kWheelSlots; k++)
                     if (!placed && wt[w][k] < 0) wt[w][k] = (int16_t)t, placed = true;
+                if (!placed) atomicAdd(s.cap_hits, 1);
                 tile_begin(s, M, ci, ntiles, t, b);
             } else if (!now && was) {
                 for (int k = 0; k < kWheelSlots; k++)
@@ -403,7 +405,8 @@ __global__ __launch_bounds__(64) void car_sensor_serial_kernel(CarSoA s, CarCons
 }
 
 // (one wavefront per workgroup and at most 128 registers: the kernel has to fit on SIMDs next to the register-heavy solve)
-__global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K, int force_serial) {
+__global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K, int force_serial_arg) {
+    const int force_serial = (force_serial_arg & 1) | CRL_ABL(force_serial_arg & 14);  // bit 0: every car through the serial kernel (same results)
     __shared__ int16_t sub[kSubCap][4][64];  // [entry][quarter of the track][owner lane]
     __shared__ uint8_t subcnt[4][64];
     __shared__ int16_t beg[kBeginCap][64];   // an owner's BeginContacts of this step, ascending
@@ -488,6 +491,7 @@ __global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K
 #pragma unroll
             for (int k = 0; k < kWheelSlots; k++)
                 if (!placed && wt[k] < 0) wt[k] = t, slot_near[k] = true, placed = true;
+            if (!placed) atomicAdd(s.cap_hits, 1);  // (never on a real track: a 0.6 x 1.1 wheel overlaps two or three 3.5-long tiles)
             if (nb < kBeginCap) beg[nb][tid] = (int16_t)t;
             else ovf = true;
             nb++;

@@ -854,6 +854,11 @@ int crl_car_set_track(crl_ctx *c, int64_t env, int32_t n, const double *tile_pol
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_set_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
 }
+int crl_car_cap_hits(crl_ctx *c, int32_t *out4_host, void *stream) {
+    CRL_ENTER(c);
+    if (!c || !c->car || !out4_host) return fail(CRL_EINVAL, "not a CarRacing context / null argument");
+    return crl_car_cap_hits_impl(c->car, out4_host, (hipStream_t)stream);
+}
 int crl_car_get_map(crl_ctx *c, int64_t env, uint8_t *palette_host, int32_t *overflow, void *stream) {
     CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");

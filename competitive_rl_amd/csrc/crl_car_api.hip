@@ -170,7 +170,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(cap_hits, 4); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
     A(obs_map, (size_t)kMapBytes * n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
@@ -696,6 +696,12 @@ int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const double
     hipStreamSynchronize(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return crl_fail(CRL_EHIP, "set_track: %s", hipGetErrorString(e));
+    return CRL_OK;
+}
+
+int crl_car_cap_hits_impl(crl_car_ctx *c, int32_t *out4, hipStream_t st) {
+    hipMemcpyAsync(out4, c->s.cap_hits, 16, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return crl_fail(CRL_EHIP, "cap_hits: copy failed");
     return CRL_OK;
 }
 

@@ -9,6 +9,14 @@
 
 int crl_fail(int code, const char *fmt, ...);
 
+// Timing ablations that give WRONG results (skip a phase to size it) exist only in a profiling build (-DCRL_ABLATION):
+// in the shipped library their switches read as zero and the compiler drops the branches.
+#ifdef CRL_ABLATION
+#define CRL_ABL(x) (x)
+#else
+#define CRL_ABL(x) 0
+#endif
+
 struct crl_event_pair {
     hipEvent_t a, b;
 };
@@ -44,6 +52,7 @@ int crl_car_get_track_impl(crl_car_ctx *c, int64_t env, int32_t *n_out, float *t
                            float *start_pose, hipStream_t st);
 int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const double *tile_poly, const double *border_poly,
                            const uint8_t *border, const float *start_pose, hipStream_t st);
+int crl_car_cap_hits_impl(crl_car_ctx *c, int32_t *out4, hipStream_t st);
 int crl_car_get_map_impl(crl_car_ctx *c, int64_t env, uint8_t *palette_host, int32_t *overflow, hipStream_t st);
 int crl_car_set_replay_impl(crl_car_ctx *c, const double *u, const uint8_t *swap, int64_t attempts);
 

@@ -451,7 +451,8 @@ template <bool BF>
 __global__ __launch_bounds__(kMThreads, 1) void pong_policy_mfma_kernel(PolicyWeightsM W, uint8_t *__restrict__ ring, int head,
                                                                   const uint8_t *__restrict__ frame, int64_t frame_stride,
                                                                   int32_t *__restrict__ actions, int64_t action_stride,
-                                                                  float *__restrict__ logits_out, int64_t n, unsigned *__restrict__ ticket, int dbg) {
+                                                                  float *__restrict__ logits_out, int64_t n, unsigned *__restrict__ ticket, int dbg_arg) {
+    const int dbg = CRL_ABL(dbg_arg);  // timing ablations / phase stamps: profiling build only
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *sh_buf = smem;                                             // [2][kME][4][kPlanePad]
     float *sh_wa = reinterpret_cast<float *>(smem + 2 * kMBuf);         // [3][1600]
@@ -847,7 +848,7 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     if (!p || !frame_dev || !actions_dev) return crl_fail(CRL_EINVAL, "crl_policy_act: null argument");
     if (frame_stride < kPlane || (frame_stride & 3) || ((uintptr_t)frame_dev & 3) || action_stride < 1)
         return crl_fail(CRL_EINVAL, "crl_policy_act: frame_stride must be a multiple of 4 and >= 1764, frames 4-byte aligned");
-    static const int dbg = getenv("CRL_POLICY_DEBUG") ? atoi(getenv("CRL_POLICY_DEBUG")) : 0;  // profiling only (wrong outputs)
+    static const int dbg = CRL_ABL(getenv("CRL_POLICY_DEBUG") ? atoi(getenv("CRL_POLICY_DEBUG")) : 0);  // profiling build only (wrong outputs)
     static const int phase = getenv("CRL_POLICY_PHASE") ? atoi(getenv("CRL_POLICY_PHASE")) : 0;  // x 8 128 cycles
     const int64_t groups = (p->n + kEnvsPerWg - 1) / kEnvsPerWg;
     static const int per_cu = getenv("CRL_POLICY_WGS") ? atoi(getenv("CRL_POLICY_WGS")) : 2;  // tuning experiments only
@@ -857,7 +858,7 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     // conv1 on the fp32 matrix instruction; 0 = the packed-FMA kernel of round 1.  Measured at 65 536 envs:
     // 430 us, 757 us, 725-805 us.
     static const int use_mfma = getenv("CRL_POLICY_MFMA") ? atoi(getenv("CRL_POLICY_MFMA")) : 3;
-    static const int mdbg = getenv("CRL_POLICY_MFMA_DEBUG") ? atoi(getenv("CRL_POLICY_MFMA_DEBUG")) : 0;  // profiling only (wrong outputs)
+    static const int mdbg = CRL_ABL(getenv("CRL_POLICY_MFMA_DEBUG") ? atoi(getenv("CRL_POLICY_MFMA_DEBUG")) : 0);  // profiling build only (wrong outputs)
     hipStream_t main_st = (hipStream_t)stream;
     if ((use_mfma == 1 || use_mfma == 3) && !dbg) {
         const int64_t mgroups = (p->n + kME - 1) / kME;

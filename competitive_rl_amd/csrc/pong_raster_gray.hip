@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "pong_device.h"
+#include "crl_internal.h"
 
 namespace crl {
 
@@ -908,7 +909,8 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         const int nb = wblocks < 8192 ? 1 : nb_env;
         const int stride = (int)(((wblocks + nb - 1) / nb + 3) / 4 * 4);  // blocks per round, a multiple of the 4 waves of a workgroup
         const dim3 grid((unsigned)(stride / 4));
-        static const int sweep_mode = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
+        static const int sweep_mode_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
+        const int sweep_mode = sweep_mode_env >= 2 ? CRL_ABL(sweep_mode_env) : sweep_mode_env;  // 2, 3: skeleton timing (wrong pixels), profiling build only
         if ((sweep_mode == 2 || sweep_mode == 3) && p.R == 84) {
             const int dense = sweep_mode == 3;
             if (nb == 1) hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<1>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);

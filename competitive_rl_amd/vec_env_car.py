@@ -279,6 +279,13 @@ class HipCarVecEnv(VecEnv):
         N.check(self._L.crl_car_get_map(self._h, int(env), m.ctypes.data_as(C.c_void_p), C.byref(ov), self._stream()))
         return m, ov.value
 
+    def cap_hits(self):
+        """(wheel-tile slot overflows, car-car manifold overflows, 0, 0) since the env was created: all zero unless a fixed capacity
+        of the device state was hit (which would be a deviation from the reference's unbounded sets / lists)."""
+        out = np.zeros(4, np.int32)
+        N.check(self._L.crl_car_cap_hits(self._h, out.ctypes.data_as(C.c_void_p), self._stream()))
+        return tuple(int(x) for x in out)
+
     def set_replay(self, u, swap):
         """u: [N, attempts, 24] uniforms of _create_track attempts; swap: [N, attempts] birth-place bits."""
         if u is None:

@@ -307,6 +307,11 @@ int crl_car_set_track(crl_ctx *ctx, int64_t env, int32_t n, const double *tile_p
  * 102 / 104 / 107, 5 white, 6 red): palette_host u8 [CRL_CAR_MAP_W][CRL_CAR_MAP_W]; *overflow (optional) = polygon
  * vertices that fell outside the window at the env's last reset (0 for every track). */
 int crl_car_get_map(crl_ctx *ctx, int64_t env, uint8_t *palette_host, int32_t *overflow, void *stream);
+/* How often a fixed capacity of the device state was hit since crl_create (synchronises `stream`): out4_host[0] = a wheel
+ * touching more than 6 track tiles at once (w.tiles is a set in the reference, car_racing_multi_players.py:111-153; the extra
+ * tile is not recorded), [1] = more than CRL_CAR_MAX_CONTACTS manifolds between the two cars of an env (the rest are dropped),
+ * [2], [3] reserved.  Zero on every track of the tests and of a 10^7 env-step soak: a non-zero count means a deviation. */
+int crl_car_cap_hits(crl_ctx *ctx, int32_t *out4_host, void *stream);
 /* Replay mode for CarRacing.reset's randomness: per env `attempts` rows of 24 uniforms (the
  * np_random.uniform draws of one _create_track attempt) and one birth-place swap bit each. */
 int crl_car_set_replay(crl_ctx *ctx, const double *u_host, const uint8_t *swap_host, int64_t attempts);

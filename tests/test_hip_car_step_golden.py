@@ -29,8 +29,9 @@ def test_hip_step_bookkeeping_matches_reference():
         hip = crl.HipCarVecEnv(n, players=players, action_repeat=rep, car_contacts=False)
         hip.reset()
         push_tracks(hip, envs)
-        for e in envs:  # the HIP state keeps at most 6 touched tiles per wheel (a wheel cannot overlap more); the scripted
-            wt = e.e["wheel_tiles"]  # engine of the fixture piled up dozens on one wheel -- friction only, not bookkeeping
+        for e in envs:  # the HIP state keeps at most 6 touched tiles per wheel (a 0.6 x 1.1 wheel overlaps two or three tiles; the library
+            wt = e.e["wheel_tiles"]  # COUNTS any overflow, crl_car_cap_hits, and the full-size tests assert zero); the scripted engine of
+            # the fixture piled up dozens on one wheel -- that only feeds the friction limit, not the bookkeeping under test
             for c in range(2):
                 for w in range(4):
                     bits = np.flatnonzero(np.unpackbits(wt[c, w].view(np.uint8), bitorder="little"))

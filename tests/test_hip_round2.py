@@ -198,6 +198,7 @@ def test_full_size_car_properties():
         torch.cuda.synchronize()
         ck = int(buf.reshape(-1).view(torch.int32).sum(dtype=torch.int64))
         st = env.get_state()
+        assert env.cap_hits() == (0, 0, 0, 0)   # no wheel touched more than 6 tiles, no pair of cars more than 8 manifolds
         env.close()
         return first.clone(), buf.clone(), ck, st, tot_done, rsum
 
@@ -224,6 +225,13 @@ def test_full_size_car_properties():
     assert bool(done.all())
     s = env.get_state()
     assert (s["elapsed"] == 0).all() and (s["episode"] == 2).all()
+    # a longer drive at full size: cars spread over their tracks, hit each other, leave the playfield, get reset
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for t in range(600):
+        env.step_device(torch.rand((n, 2, 2), generator=g, device="cuda") * 2 - 1)
+    assert env.cap_hits() == (0, 0, 0, 0)
+    _, overflow = env.get_map(123)
+    assert overflow == 0
     env.close()
 
 
