@@ -423,8 +423,14 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
                 const int sx = dx >> 16, sy = dy >> 16;
                 uint32_t p;
                 if (!CHECK) {
-                    const uint32_t b = map[((sy >> 4) * kMapBlocks + (sx >> 4)) * 128 + (sy & 15) * 8 + ((sx & 15) >> 1)];
-                    p = (b >> ((sx & 1) * 4)) & 15u;
+                    // straight from the 16.16 coordinates (all non-negative here): block row dy >> 20, block column dx >> 20, row in
+                    // block bits 16-19 of dy, byte in row bits 17-19 of dx, nibble bit 16 of dx; a 32-bit unsigned offset from
+                    // the env's map base (uniform), so the load takes base + offset without 64-bit address arithmetic per pixel
+                    const uint32_t udx = (uint32_t)dx, udy = (uint32_t)dy;
+                    const uint32_t blk = (udy >> 20) * (uint32_t)kMapBlocks + (udx >> 20);
+                    const uint32_t off = (blk << 7) | ((udy >> 13) & 0x78u) | __builtin_amdgcn_ubfe(udx, 17, 3);
+                    const uint32_t b = map[off];
+                    p = __builtin_amdgcn_ubfe(b, (udx >> 14) & 4u, 4);
                 } else {
                     const int ux = dx - rx * 65536, uy = dy - ry * 65536;  // position inside the 192 x 192 crop
                     const bool in_crop = !(ux < 0 || uy < 0 || ux > (192 << 16) - 1 || uy > (192 << 16) - 1);

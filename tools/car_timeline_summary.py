@@ -1,3 +1,4 @@
+"""Per-kernel count / median / max duration (us) of the newest tools/car_timeline.sh trace."""
 import csv, glob, os, collections, sys
 f = sorted(glob.glob("gpurun_out/car_timeline/t/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]
 rows = [r for r in csv.DictReader(open(f)) if "crl::" in r["Kernel_Name"]]

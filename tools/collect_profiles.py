@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = {"raw": "pong_raster_raw_sweep_kernel", "fused84": "pong_raster_gray", "fused84_newest": "pong_raster_gray", "fused84_f32": "pong_raster_gray",
-            "car": "car_raster_kernel", "tournament": "pong_policy_mfma_kernel"}
+            "car": "car_obs_kernel", "tournament": "pong_policy_mfma_kernel"}
 
 
 def main():
@@ -26,8 +26,10 @@ def main():
             continue
         shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, f"{rnd}_{wl}_summary.txt"))
         shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, f"{rnd}_{wl}_pmc_summary.json"))
-        for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
-            shutil.copy(f, os.path.join(dst, f"{rnd}_{wl}_kernel_stats.csv"))
+        # the NEWEST trace only (tools/profile_gpu.sh wipes its output directory first; an older run's csv must never win)
+        stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+        if stats:
+            shutil.copy(stats[-1], os.path.join(dst, f"{rnd}_{wl}_kernel_stats.csv"))
         shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, f"{rnd}_{wl}_bench_under_rocprof.json"))
         pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
         fl = pmc.pop("__flops__", None)

@@ -5,9 +5,10 @@
 # rocprofv3 is given the program itself (python3 bench.py ...), never a shell wrapper; --pmc passes are separate
 # from the kernel-trace/stats pass and use --kernel-trace only.
 set -u
-WL=${1:-raw}; TAG=${2:-r02_$WL}
+WL=${1:-raw}; TAG=${2:-r03_$WL}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT  # one run, one set of files: nothing of an earlier run may be picked up
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --workload $WL --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.err

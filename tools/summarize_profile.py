@@ -17,7 +17,7 @@ def find(root, pat):
 
 def main(out):
     print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
-    for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
+    for f in sorted(find(os.path.join(out, "trace"), "*kernel_stats.csv"), key=os.path.getmtime)[-1:]:
         rows = list(csv.DictReader(open(f)))
         for r in rows[:12]:
             print({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
