@@ -1545,6 +1545,14 @@ void car_oracle_render_analytic(const car_env *e, int viewer, uint8_t *out) {
 
 /* the double-precision functions this build uses, for tests/test_f64_math.py */
 void car_oracle_f64(int fn, const double *a, const double *b, double *out, long n) {
+    if (fn == 6 || fn == 7) { /* b2Rot's float32 sine / cosine (argument and result held in doubles) */
+        for (long i = 0; i < n; i++) {
+            float sn, cs;
+            rot_sincosf((float)a[i], &sn, &cs);
+            out[i] = fn == 6 ? sn : cs;
+        }
+        return;
+    }
     for (long i = 0; i < n; i++)
         out[i] = fn == 0 ? m_sin(a[i]) : fn == 1 ? m_cos(a[i]) : fn == 2 ? m_atan2(a[i], b[i]) : fn == 3 ? t_sin(a[i]) : fn == 4 ? t_cos(a[i]) : t_atan2(a[i], b[i]);
 }

@@ -27,12 +27,27 @@ assert STATE_DT.itemsize == 120 and FRAME_DT.itemsize == 8
 
 
 def build(force=False):
+    """(Re)builds liboracle.so / liboracle_libm.so when the sources changed.  Staleness is decided by a content hash kept
+    beside each library (file times do not survive a copy of the tree), and the whole check runs under a file lock: the
+    subprocess CPU baseline starts one worker per host thread, and all of them come through here at once."""
+    import fcntl
+    import hashlib
     inc = os.path.join(os.path.dirname(HERE), "include")
     srcs = [os.path.join(HERE, f) for f in ("pong_oracle.c", "car_oracle.c", "car_oracle.h", "Makefile")]
     srcs += [os.path.join(inc, f) for f in ("crl.h", "crl_rot.h", "crl_f64.h")]
-    for lib_ in (LIB, LIB_LIBM):
-        if force or not os.path.exists(lib_) or any(os.path.getmtime(lib_) < os.path.getmtime(f) for f in srcs):
-            subprocess.check_call(["make", "-C", HERE, "-B", os.path.basename(lib_)], stdout=subprocess.DEVNULL)
+    h = hashlib.sha256()
+    for f in srcs:
+        h.update(open(f, "rb").read())
+    want = h.hexdigest()
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        for lib_ in (LIB, LIB_LIBM):
+            stamp = lib_ + ".stamp"
+            have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+            if force or not os.path.exists(lib_) or have != want:
+                subprocess.check_call(["make", "-C", HERE, "-B", os.path.basename(lib_)], stdout=subprocess.DEVNULL)
+                with open(stamp, "w") as f:
+                    f.write(want)
     return LIB
 
 

@@ -114,6 +114,8 @@ def _worker(remote, parent_remote, kind, rank):
 
 def time_subproc(kind, num_envs, budget_s, start_method="forkserver"):
     """env-steps/s of `num_envs` one-env worker processes stepped in lock-step through pipes (SubprocVecEnv.step)."""
+    from oracle import pong_oracle as _po
+    _po.build()  # once, here: the workers only load the libraries
     ctx = mp.get_context(start_method)
     remotes, work_remotes = zip(*[ctx.Pipe(duplex=True) for _ in range(num_envs)])
     procs = []

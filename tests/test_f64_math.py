@@ -26,6 +26,30 @@ def test_crl_f64_is_correctly_rounded_on_a_sample():
         assert float(mp.atan2(mp.mpf(float(y[i])), mp.mpf(float(z[i])))) == a[i], (y[i], z[i], a[i])
 
 
+def test_crl_sincosf_is_correctly_rounded_on_a_sample():
+    """include/crl_rot.h: b2Rot's float32 sine / cosine, against mpmath rounded once to float32; and how often glibc's
+    sinf / cosf return the neighbouring float instead"""
+    mp.mp.prec = 120
+    rs = np.random.RandomState(5)
+    x = np.concatenate([rs.uniform(-4, 4, 8000), rs.uniform(-80, 80, 8000), rs.uniform(-1e-3, 1e-3, 2000),
+                        rs.uniform(-2000, 2000, 2000)]).astype(np.float32).astype(np.float64)
+    s, c = co.f64(6, x), co.f64(7, x)
+    sl, cl = co.f64(6, x, libm=True), co.f64(7, x, libm=True)
+
+    def f32(v):  # mpmath -> nearest float32 (round half even): through a 24-bit mpf
+        with mp.workprec(24):
+            return float(+v)
+
+    for i in range(len(x)):
+        xs = mp.mpf(float(x[i]))
+        assert f32(mp.sin(xs)) == s[i], (x[i], s[i])
+        assert f32(mp.cos(xs)) == c[i], (x[i], c[i])
+    miss = float(((sl != s) | (cl != c)).mean())
+    print("fraction of arguments where glibc sinf / cosf is not the correctly rounded float:", miss)
+    assert miss < 0.05
+    assert (np.abs(sl - s) <= np.spacing(np.abs(s).astype(np.float32)).astype(np.float64)).all()
+
+
 def test_fast_variants_stay_within_three_ulp():
     """crl_*_fast (the track walk): plain-double evaluations, compared with the correctly rounded ones"""
     x, y, z = _args(400000, 3)
