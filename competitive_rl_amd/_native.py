@@ -6,7 +6,9 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libcrl_hip.so")
+# CRL_LIB_VARIANT=<tag>: a profiling build made by `python -m competitive_rl_amd.build --variant <tag> <flags>` (e.g. -DCRL_ABLATION:
+# phase cycle stamps, timing ablations); unset = the shipped library
+LIB_PATH = os.path.join(PKG, "libcrl_hip_%s.so" % os.environ["CRL_LIB_VARIANT"] if os.environ.get("CRL_LIB_VARIANT") else "libcrl_hip.so")
 
 CRL_ENV_PONG_DOUBLE, CRL_ENV_CAR_DOUBLE, CRL_ENV_PONG_SINGLE, CRL_ENV_CAR_SINGLE = 1, 2, 3, 4
 CRL_FLAG_STACK_REPLICATE = 1

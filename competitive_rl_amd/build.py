@@ -48,6 +48,23 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(tag, flags, verbose=False):
+    """A profiling build beside the shipped one: every source compiled with `flags` added, objects csrc/<tag>_*.o, library
+    libcrl_hip_<tag>.so (loaded when CRL_LIB_VARIANT=<tag>)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, tag + "_" + s.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, *flags, "-I", os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    out = os.path.join(PKG, "libcrl_hip_%s.so" % tag)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
+    return out
+
+
 def build_c_demo(verbose=False):
     """examples/c_abi_demo: a caller of include/crl.h without Python or torch (links libcrl_hip.so)."""
     build()
@@ -65,5 +82,9 @@ def build_c_demo(verbose=False):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:  # python -m competitive_rl_amd.build --variant abl -DCRL_ABLATION
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_c_demo(verbose=True))

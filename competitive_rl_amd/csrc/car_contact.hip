@@ -291,6 +291,10 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
     // scratch, and reading them from device memory makes every vertex a dependent ~200-cycle load: stage them in LDS)
     __shared__ CarConsts Ks;
     const int lane = threadIdx.x;
+#ifdef CRL_ABLATION
+    const unsigned long long sn0 = __builtin_readcyclecounter();
+    unsigned long long acc1 = 0, acc2 = 0, acc3 = 0, nslot = 0;
+#endif
     __builtin_amdgcn_s_setprio(3);  // on the step's critical path (narrow phase -> touching solve -> their frames), beside bulk kernels
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(s.consts_dev);
@@ -312,7 +316,14 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
     const int count = *s.coupled_count;
     const int64_t M = 2 * s.n;
     if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host) *s.coupled_to_host = count;
+#ifdef CRL_ABLATION
+    const unsigned long long sn1 = __builtin_readcyclecounter();
+#endif
     for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+#ifdef CRL_ABLATION
+        const unsigned long long sa = __builtin_readcyclecounter();
+        unsigned long long sb = sa;
+#endif
         const int64_t env = s.coupled_list[slot];
         const int fa = lane >> 3, fb = lane & 7;
         const bool active = !(fa >= 4 && fb >= 4);
@@ -344,6 +355,9 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
                 ccx[k] = wc.x, ccy[k] = wc.y, crad[k] = sqrtf(r2) + 0.03f;
             }
             const float dx = ccx[0] - ccx[1], dy = ccy[0] - ccy[1], rr = crad[0] + crad[1];
+#ifdef CRL_ABLATION
+            sb = __builtin_readcyclecounter();
+#endif
             if (!(dx * dx + dy * dy > rr * rr)) {
 #pragma unroll
                 for (int k = 0; k < 2; k++) {  // both fixtures into world space once: vertices, and normals as rotv(q, local normal)
@@ -356,6 +370,9 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
                 collide_polygons_w(c, shape_of(K, fa), xf[0], wp[lane][0], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[lane][1], nl[fb < 4 ? fb : 4]);
             }
         }
+#ifdef CRL_ABLATION
+        const unsigned long long sc = __builtin_readcyclecounter();
+#endif
         const bool hit = active && c.count > 0;
         const unsigned long long m = __ballot(hit);
         const int rank = (int)__popcll(m & ((1ull << lane) - 1ull));
@@ -387,7 +404,17 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
             lst[atomicAdd(s.coupled_count + 1 + cls, 1)] = (int32_t)env;
             if (nc) s.touch_all[atomicAdd(s.coupled_count + 5, 1)] = (int32_t)env;
         }
+#ifdef CRL_ABLATION
+        const unsigned long long sd = __builtin_readcyclecounter();
+        acc1 += sb - sa, acc2 += sc - sb, acc3 += sd - sc, nslot++;
+#endif
     }
+#ifdef CRL_ABLATION
+    if (lane == 0 && s.stamps && nslot) {
+        unsigned long long *q = s.stamps + 32;
+        atomicAdd(q + 0, sn1 - sn0), atomicAdd(q + 1, acc1), atomicAdd(q + 2, acc2), atomicAdd(q + 3, acc3), atomicAdd(q + 7, nslot);
+    }
+#endif
 }
 
 // ---- (2) envs whose boxes overlap but where nothing touches: two islands of their own, exactly the per-car kernel,
@@ -621,15 +648,23 @@ __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const int m
 }
 
 // NK = contacts kept in registers (the list this wavefront serves holds envs with nc == NK, or nc >= 3 for NK == 3)
-template <int NK>
-__device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K, const int32_t *list, const int list_count,
+// EPW = envs per wavefront: 32 (one per lane pair) down to 1 -- every lane pair works on the SAME env and pair 0 stores it.  One env
+// per wavefront wastes lanes, not time: the chip has a thousand SIMDs for a few hundred touching envs, every wave-uniform
+// shortcut (which constraint kinds occur, how many manifolds, position iterations until THIS island has converged) becomes
+// exact, and the kernel -- which ends with its slowest wavefront -- no longer pays for the union of its envs' worst cases.
+template <int NK, int EPW>
+__device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K, const int32_t *list, const int list_count, const int slot_base,
                                             CarRegs (*sh_car)[2], Contact (*sh_ct)[kMaxContacts], TouchC (*sh_tc)[kMaxContacts]) {
-    const int pair = threadIdx.x >> 1, me = threadIdx.x & 1;
-    const int slot = blockIdx.x * 32 + pair;
-    const bool live = slot < list_count;
+    const int me = threadIdx.x & 1;
+    const int pair = (threadIdx.x >> 1) % EPW;  // (lane pairs past EPW repeat the first ones' envs and store nothing)
+    const int slot = slot_base + pair;
+    const bool live = slot < list_count && (threadIdx.x >> 1) < EPW;
+#ifdef CRL_ABLATION
+    const unsigned long long st0 = __builtin_readcyclecounter();
+#endif
     // (lanes past the end of the list ride along on the last env's data and store nothing: the DPP swaps and the uniform
     // loop bounds below want every lane of the wavefront in step)
-    const int64_t env = list[live ? slot : list_count - 1];
+    const int64_t env = list[slot < list_count ? slot : list_count - 1];
     const int64_t M = 2 * s.n;
     CarRegs(&car)[2] = sh_car[pair];
     {
@@ -749,9 +784,13 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     }
     bool tail1 = false, tail2 = false;  // contacts past NK (NK == 3 only)
     for (int k = NK; k < nc_wave; k++) tail1 = tail1 || __any(k < nc && tc[k < nc ? k : 0].count == 1), tail2 = tail2 || __any(k < nc && tc[k < nc ? k : 0].count == 2);
+#ifdef CRL_ABLATION
+    const unsigned long long st1 = __builtin_readcyclecounter();
+#endif
+    const int jmode = isl_joint_mode(r);
 #pragma unroll 1
     for (int it = 0; it < 180; it++) {
-        isl_joints_vel(r, jt, K, h);
+        isl_joints_vel_mode(jmode, r, jt, K, h);
 #pragma unroll
         for (int k = 0; k < NK; k++) contact_vel(r, kc[k], me, friction, any1, any2);
         if (NK == 3) {
@@ -772,12 +811,19 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         for (int k = NK; k < nc; k++) ct[k].nimp[0] = tc[k].nimp0, ct[k].nimp[1] = tc[k].nimp1, ct[k].timp[0] = tc[k].timp0, ct[k].timp[1] = tc[k].timp1;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef CRL_ABLATION
+    const unsigned long long st2 = __builtin_readcyclecounter();
+    int pos_iters = 0;
+#endif
     isl_integrate_pos(r, h);
     bool solved = false;
     const V2 hlc = mk(K.hull_lc[0], K.hull_lc[1]);
 #pragma unroll 1
     for (int it = 0; it < 60; it++) {
         float minSep = 0.0f;
+#ifdef CRL_ABLATION
+        pos_iters = it + 1;
+#endif
 #pragma unroll
         for (int k = 0; k < NK; k++) contact_pos(r, kc[k], me, hlc, minSep);
         if (NK == 3) {
@@ -798,6 +844,11 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
             break;
         }
     }
+#ifdef CRL_ABLATION
+    const unsigned long long st3 = __builtin_readcyclecounter();
+    int pi_wave = pos_iters;
+    for (int d = 1; d < 64; d <<= 1) pi_wave = max(pi_wave, __shfl_xor(pi_wave, d));
+#endif
     // one island: it sleeps only when all ten bodies have been still long enough
     const float mm = isl_sleep_scan(r, slp, h);
     const float mo = __shfl_xor(mm, 1);
@@ -820,38 +871,58 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         o[11] = __uint_as_float(c.id[0]), o[12] = __uint_as_float(c.id[1]);
         o[13] = c.nimp[0], o[14] = c.nimp[1], o[15] = c.timp[0], o[16] = c.timp[1];
     }
+#ifdef CRL_ABLATION
+    if (threadIdx.x == 0 && s.stamps) {
+        const unsigned long long st4 = __builtin_readcyclecounter();
+        unsigned long long *q = s.stamps + 8 * (NK - 1);
+        atomicAdd(q + 0, st1 - st0), atomicAdd(q + 1, st2 - st1), atomicAdd(q + 2, st3 - st2), atomicAdd(q + 3, st4 - st3);
+        atomicAdd(q + 4, (unsigned long long)pi_wave), atomicMax(q + 5, st4 - st0), atomicAdd(q + 7, 1ull);
+    }
+#endif
 }
 #undef CRL_SEL
 #undef CRL_PUT
 
-// one instance per manifold-count class; blockIdx.y = class (0: nc == 1, 1: nc == 2, 2: nc >= 3)
+// one launch, blockIdx.y = manifold-count class (0: nc == 1, 1: nc == 2, 2: nc >= 3); the workgroups loop over the class's list.
+// EPW1 = envs per wavefront of class 0 (94 % of the touching envs); two manifolds or more (the slowest islands): one env per wavefront.
+// (LDS rows for 32 envs whatever the class uses: two workgroups per CU, 512 on the chip, is more than a step has)
+template <int EPW1>
 __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K) {
     const int cls = blockIdx.y;
     const int count = s.coupled_count[2 + cls];
-    if ((int)blockIdx.x * 32 >= count) return;
+    const int epw = cls == 0 ? EPW1 : 1;
+    if ((int)blockIdx.x * epw >= count) return;
     __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) CarRegs sh_car[32][2];
     __shared__ __attribute__((aligned(16))) Contact sh_ct[32][kMaxContacts];
     __shared__ __attribute__((aligned(16))) TouchC sh_tc[32][kMaxContacts];
     const int32_t *list = s.touch_list + (int64_t)cls * s.n;
-    if (cls == 0) touch_solve<1>(s, K, list, count, sh_car, sh_ct, sh_tc);
-    else if (cls == 1) touch_solve<2>(s, K, list, count, sh_car, sh_ct, sh_tc);
-    else touch_solve<3>(s, K, list, count, sh_car, sh_ct, sh_tc);
+    for (int base = blockIdx.x * epw; base < count; base += gridDim.x * epw) {
+        if (cls == 0) touch_solve<1, EPW1>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        else if (cls == 1) touch_solve<2, 1>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        else touch_solve<3, 1>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
 }
 
 // world.Step of the coupled envs.  `near_st` (may equal `st`): where the near-only envs are solved, beside the touching ones.
-void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st, hipEvent_t ev_narrow, hipEvent_t ev_near) {
+void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st, hipEvent_t ev_narrow, hipEvent_t ev_near,
+                        bool narrow_elsewhere, hipStream_t narrow_st) {
     if (s.players != 2 || !s.contacts_enabled) return;
     if (!near_st) near_st = st;
+    if (!narrow_elsewhere) narrow_st = st;  // (a stream handle may be null -- the default stream -- so the choice is a flag of its own)
     const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
-    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k);
-    if (near_st != st) {
-        hipEventRecord(ev_narrow, st);
-        hipStreamWaitEvent(near_st, ev_narrow, 0);
-    }
+    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, narrow_st, s, k);
+    if (near_st != st || narrow_st != st) hipEventRecord(ev_narrow, narrow_st);
+    if (near_st != narrow_st) hipStreamWaitEvent(near_st, ev_narrow, 0);
+    if (st != narrow_st) hipStreamWaitEvent(st, ev_narrow, 0);
     hipLaunchKernelGGL(car_near_kernel, dim3((unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512)), dim3(64), 0, near_st, s, k);
     if (near_st != st) hipEventRecord(ev_near, near_st);
-    hipLaunchKernelGGL(car_touch_kernel, dim3((unsigned)((s.n + 31) / 32), 3), dim3(64), 0, st, s, k);
+    static const int epw1 = getenv("CRL_CAR_TOUCH_EPW1") ? atoi(getenv("CRL_CAR_TOUCH_EPW1")) : 8;  // (A/B: 32 | 8 | 4; measured 1.19 / 1.17 / 1.17 ms per step)
+    const unsigned g = (unsigned)((s.n + 31) / 32 < 256 ? (s.n + 31) / 32 : 256);
+    if (epw1 == 4) hipLaunchKernelGGL(car_touch_kernel<4>, dim3(g, 3), dim3(64), 0, st, s, k);
+    else if (epw1 == 8) hipLaunchKernelGGL(car_touch_kernel<8>, dim3(g, 3), dim3(64), 0, st, s, k);
+    else hipLaunchKernelGGL(car_touch_kernel<32>, dim3(g, 3), dim3(64), 0, st, s, k);
     if (near_st != st) hipStreamWaitEvent(st, ev_near, 0);
 }
 

@@ -120,13 +120,17 @@ struct CarSoA {
     int32_t *coupled_to_host;  // host-mapped word: the step's coupled-env count, read by the host one step late (sizes the list launches)
     int32_t *cap_hits;      // [4] times a fixed capacity was hit since create: [0] a wheel touching more than kWheelSlots tiles (the
                             //     extra tile is not recorded), [1] more than kMaxContacts manifolds between two cars (the rest are dropped)
+    unsigned long long *stamps;  // [64] phase cycle counters of the coupled kernels (profiling build, -DCRL_ABLATION, only)
     int32_t *zero_next;     // [16] the OTHER step parity's counter block (coupled_count[8] + class counts): car_step_kernel clears it for the next step
     int32_t *nc_new;        // [n] this step's manifold count (car_narrow_kernel)
     float *contact_new;     // [n][kMaxContacts][kContactWords] this step's manifolds with the carried-over impulses
     int32_t *n_contact;     // [n] touching car-car contacts carried to the next step (warm start)
     float *contact;         // [n][16][kContactWords] persisted manifolds + impulses
     // ---- observations as the reference computes them (car_obs.hip)
-    uint8_t *obs_map;       // [n][kMapBytes] pre-rastered palette map of the env's track (built at reset)
+    uint8_t *obs_map;       // [n][2][kMapBytes] pre-rastered palette map of the env's track (built at reset), two slots per env: the map of
+                            //     a finished env's NEXT episode is built into the other slot while the terminal frame still needs this one
+    uint8_t *map_par;       // [n] which slot is current
+    int map_alt;            // 1 = this view of the state addresses the OTHER slot (the staged reset of the step pipeline)
     uint32_t *map_vtx;      // [n][512][9] map-space vertices (x | y << 16, int16 each, window coordinates) of tile i (5) and its border (4)
     uint32_t *map_yr;       // [n][512] first | last << 16 map row (int16 each) that tile i or its border touches
     int32_t *map_overflow;  // [n] polygon vertices that fell outside the window at the last reset (0 for every track)
@@ -135,6 +139,10 @@ struct CarSoA {
     uint8_t *view_cnt;      // [tiles][16] spans per car polygon
     uint32_t *view_rec;     // [tiles][16][kSpanSlots] spans: y | xl << 8 | xr << 16
 };
+
+__device__ __forceinline__ uint8_t *env_map(const CarSoA &s, int64_t env) {
+    return s.obs_map + (env * 2 + (int64_t)((s.map_par[env] ^ s.map_alt) & 1)) * kMapBytes;
+}
 
 struct ViewParams {  // one (env, viewer) tile: where its 96 x 96 pixels come from, and what is drawn over them
     // source of screen pixel (X, Y) in 16.16 fixed point, in WINDOW coordinates of the map (the crop rectangle folded in):
@@ -196,6 +204,8 @@ struct CarTrackSrc {  // where reset draws come from
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
                       hipStream_t st);
+// live <- stage for the car state of the listed envs, and the envs' map slots flipped (the staged reset of the step pipeline)
+void launch_car_commit_list(const CarSoA &live, const CarSoA &stage, const int32_t *list, const int32_t *list_count, int64_t expected, hipStream_t st);
 void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, const int32_t *list, const int32_t *list_count,
                            int64_t expected, hipStream_t st);
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st);
@@ -204,7 +214,7 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st = nullptr, hipEvent_t ev_narrow = nullptr,
-                        hipEvent_t ev_near = nullptr);  // near_st == nullptr: everything on st
+                        hipEvent_t ev_near = nullptr, bool narrow_elsewhere = false, hipStream_t narrow_st = nullptr);  // near_st == nullptr: everything on st
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
                      int32_t *info_elapsed, int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 

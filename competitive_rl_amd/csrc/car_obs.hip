@@ -111,7 +111,7 @@ __device__ void car_map_band(const CarSoA &s, int64_t env, int band, uint32_t (*
     }
     __syncthreads();
     // compose: 16-byte pieces = rows 2 pr, 2 pr + 1 of block bx; the band's 76 blocks are contiguous in the map
-    uint4 *out = reinterpret_cast<uint4 *>(s.obs_map + env * kMapBytes + (int64_t)band * kMapBlocks * 128);
+    uint4 *out = reinterpret_cast<uint4 *>(env_map(s, env) + (int64_t)band * kMapBlocks * 128);
     for (int q = tid; q < kMapBlocks * 8; q += 256) {
         const int bx = q >> 3, pr = q & 7;
         const uint32_t lx = (s.map_lightx[(bx * 16) >> 5] >> ((bx * 16) & 31)) & 0xFFFFu;
@@ -458,7 +458,7 @@ __device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restric
     const int lane = threadIdx.x;
     const int64_t t = env * s.players + viewer;
     const int dx00 = vp[0], dy00 = vp[1], isin = vp[2], icos = vp[3], rx = vp[4], ry = vp[5], flags = vp[6], text_idx = vp[7];
-    const uint8_t *map = s.obs_map + env * kMapBytes;
+    const uint8_t *map = env_map(s, env);
     uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile);
     // ---- background
     if (flags == 3) {

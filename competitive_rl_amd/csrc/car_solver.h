@@ -182,6 +182,101 @@ __device__ inline void isl_joints_vel(CarRegs &c, const JointTmp &j, const CarCo
     }
 }
 
+// Two more forms of the same iteration -- same operations on the same values per lane, different control flow (a dependent
+// chain of ~200 instructions issued by one wavefront: what counts is how many instructions the wavefront walks through, and
+// every divergent branch is walked by all lanes).  tools/solve_chain_probe.hip: cycles per iteration of a lone wavefront
+//   isl_joints_vel (branches per joint)   1 169 no limit active | 1 811 some lanes at a steering limit
+//   isl_joints_vel_in  (no limit code)      932
+//   isl_joints_vel_sel (selects)          1 377                 | 1 377
+// _in: valid while NO joint of the lane's car is at a limit.  _sel: valid while the REAR joints (2, 3: no steering, they never
+// reach their limits) are not at a limit; the two steered joints compute the 3x3 and the 2x2 answer and select.
+// isl_joint_mode() picks per wavefront.
+__device__ __forceinline__ void isl_joints_vel_in(CarRegs &c, const JointTmp &j, const CarConsts &K, float h) {
+    ISL_CONSTS;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = 3 - q;
+        const V2 r = j.rA[w], rB = mk(0.f, 0.f);
+        {
+            const float Cdot = c.W[w].w - c.H.w - c.motor_speed[w];
+            float impulse = -j.motorMass * Cdot;
+            const float old = c.motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
+            float ni = old + impulse;
+            ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
+            c.motor_imp[w] = ni;
+            impulse = ni - old;
+            c.H.w -= iA * impulse, c.W[w].w += iB * impulse;
+        }
+        const V2 vA = mk(c.H.vx, c.H.vy), vB = mk(c.W[w].vx, c.W[w].vy);
+        const V2 Cdot = ((vB + scross(c.W[w].w, rB)) - vA) - scross(c.H.w, r);
+        const V2 im = solve22_pre(j.mass[w], j.det22[w], -1.0f * Cdot);
+        c.imp[w][0] += im.x, c.imp[w][1] += im.y;
+        c.H.vx -= mA * im.x, c.H.vy -= mA * im.y, c.H.w -= iA * cross(r, im);
+        c.W[w].vx += mB * im.x, c.W[w].vy += mB * im.y, c.W[w].w += iB * cross(rB, im);
+    }
+}
+
+__device__ __forceinline__ void isl_joints_vel_sel(CarRegs &c, const JointTmp &j, const CarConsts &K, float h) {
+    ISL_CONSTS;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int w = 3 - q;
+        const V2 r = j.rA[w], rB = mk(0.f, 0.f);
+        {
+            const float Cdot = c.W[w].w - c.H.w - c.motor_speed[w];
+            float impulse = -j.motorMass * Cdot;
+            const float old = c.motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
+            float ni = old + impulse;
+            ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
+            c.motor_imp[w] = ni;
+            impulse = ni - old;
+            c.H.w -= iA * impulse, c.W[w].w += iB * impulse;
+        }
+        const V2 vA = mk(c.H.vx, c.H.vy), vB = mk(c.W[w].vx, c.W[w].vy);
+        const V2 Cdot1 = ((vB + scross(c.W[w].w, rB)) - vA) - scross(c.H.w, r);
+        const V2 im2 = solve22_pre(j.mass[w], j.det22[w], -1.0f * Cdot1);  // the answer while the limit is inactive
+        float ix = im2.x, iy = im2.y, iz = 0.0f;
+        float n0 = c.imp[w][0] + im2.x, n1 = c.imp[w][1] + im2.y, n2 = c.imp[w][2];
+        bool act = false;
+        if (w < 2) {
+            act = c.lim[w] != LIM_INACTIVE;
+            const float Cdot2 = c.W[w].w - c.H.w;
+            const float b[3] = {Cdot1.x, Cdot1.y, Cdot2};
+            float im[3];
+            solve33_pre(j.mass[w], j.cyz[w], j.det33[w], b, im);
+            im[0] = -im[0], im[1] = -im[1], im[2] = -im[2];
+            const float newI = c.imp[w][2] + im[2];
+            const bool lower = c.lim[w] == LIM_LOWER;
+            const bool clampz = lower ? newI < 0.0f : newI > 0.0f;
+            const V2 rhs = (-1.0f * Cdot1) + c.imp[w][2] * mk(j.mass[w].ez[0], j.mass[w].ez[1]);
+            const V2 red = solve22_pre(j.mass[w], j.det22[w], rhs);
+            const float ax = clampz ? red.x : im[0], ay = clampz ? red.y : im[1], az = clampz ? -c.imp[w][2] : im[2];
+            const float a0 = c.imp[w][0] + ax, a1 = c.imp[w][1] + ay, a2 = clampz ? 0.0f : c.imp[w][2] + im[2];
+            ix = act ? ax : ix, iy = act ? ay : iy, iz = act ? az : iz;
+            n0 = act ? a0 : n0, n1 = act ? a1 : n1, n2 = act ? a2 : n2;
+        }
+        c.imp[w][0] = n0, c.imp[w][1] = n1, c.imp[w][2] = n2;
+        const V2 P = mk(ix, iy);
+        // (the two paths apply the impulse with the same operations except for the + im[2] of the 3x3 one)
+        const float hw_act = c.H.w - iA * (cross(r, P) + iz), hw_in = c.H.w - iA * cross(r, P);
+        const float ww_act = c.W[w].w + iB * (cross(rB, P) + iz), ww_in = c.W[w].w + iB * cross(rB, P);
+        c.H.vx -= mA * P.x, c.H.vy -= mA * P.y;
+        c.W[w].vx += mB * P.x, c.W[w].vy += mB * P.y;
+        c.H.w = act ? hw_act : hw_in, c.W[w].w = act ? ww_act : ww_in;
+    }
+}
+
+// 0: general form, 1: no limit active anywhere in the wavefront, 2: only steered joints at a limit (wave-uniform)
+__device__ __forceinline__ int isl_joint_mode(const CarRegs &c) {
+    const bool rear = c.lim[2] != LIM_INACTIVE || c.lim[3] != LIM_INACTIVE, front = c.lim[0] != LIM_INACTIVE || c.lim[1] != LIM_INACTIVE;
+    return __any(rear) ? 0 : __any(front) ? 2 : 1;
+}
+__device__ __forceinline__ void isl_joints_vel_mode(int mode, CarRegs &c, const JointTmp &j, const CarConsts &K, float h) {
+    if (mode == 1) isl_joints_vel_in(c, j, K, h);
+    else if (mode == 2) isl_joints_vel_sel(c, j, K, h);
+    else isl_joints_vel(c, j, K, h);
+}
+
 __device__ inline void integrate_body(Body &b, float h) {
     const V2 tr = mk(h * b.vx, h * b.vy);
     if (dot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) {
@@ -278,8 +373,17 @@ __device__ inline void island_solve(CarRegs &c, const CarConsts &K, float h, flo
     JointTmp j;
     isl_integrate_vel(c, K, h);
     isl_joints_init(c, j, K, dt_ratio);
+    const int mode = isl_joint_mode(c);  // (the limit states are fixed by isl_joints_init for the whole step)
+    if (mode == 1) {
 #pragma unroll 1
-    for (int it = 0; it < 180; it++) isl_joints_vel(c, j, K, h);
+        for (int it = 0; it < 180; it++) isl_joints_vel_in(c, j, K, h);
+    } else if (mode == 2) {
+#pragma unroll 1
+        for (int it = 0; it < 180; it++) isl_joints_vel_sel(c, j, K, h);
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < 180; it++) isl_joints_vel(c, j, K, h);
+    }
     isl_integrate_pos(c, h);
     bool solved = false;
 #pragma unroll 1

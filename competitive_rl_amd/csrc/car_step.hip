@@ -572,13 +572,13 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
     if (class_list) {
         const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int k = 2; k <= 3; k++) {  // (class 1, the coupled envs, is listed by the narrow phase: near-only and touching)
-            const unsigned long long m = __ballot(cls == k);
+        for (int k = 2; k <= 4; k++) {  // (class 1, the coupled envs, is listed by the narrow phase: near-only and touching); "4" = every finished env
+            const unsigned long long m = __ballot(k == 4 ? cls >= 2 : cls == k);
             if (!m) continue;
             int base = 0;
             if (lane == 0) base = atomicAdd(&class_count[k - 1], (int)__popcll(m));
             base = __shfl(base, 0);
-            if (cls == k) class_list[(int64_t)(k - 1) * s.n + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
+            if (k == 4 ? cls >= 2 : cls == k) class_list[(int64_t)(k - 1) * s.n + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
         }
     }
 }

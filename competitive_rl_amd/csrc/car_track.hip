@@ -380,6 +380,38 @@ void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSr
     hipLaunchKernelGGL(car_reset_list_kernel, dim3((unsigned)want), dim3(64), 0, st, s, k, src, list, list_count);
 }
 
+// The step pipeline resets a finished env EARLY, beside the solves: track arrays in place (nothing reads them once the step's
+// sensor contacts are in), the new map into the env's other slot, the cars' state into a staged copy of the per-car arrays
+// (finish_reset called on a CarSoA whose car-state pointers address the staging arrays) -- the env's terminal frame still
+// needs the old map and the solved bodies.  Once that frame is drawn this kernel makes the new episode current.
+__global__ __launch_bounds__(64) void car_commit_list_kernel(CarSoA live, CarSoA stg, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count) {
+    const int count = *list_count, lane = threadIdx.x;
+    const int64_t n = live.n, M = (int64_t)live.players * n;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int64_t env = list[i];
+        for (int car = 0; car < live.players; car++) {
+            const int64_t ci = car * n + env;
+#define CRL_CP(f, rows) \
+    for (int r = lane; r < (rows); r += 64) live.f[(int64_t)r * M + ci] = stg.f[(int64_t)r * M + ci];
+            CRL_CP(body, 30) CRL_CP(jmotor, 4) CRL_CP(jspeed, 4) CRL_CP(jlimit, 4) CRL_CP(jimp, 12) CRL_CP(wgas, 4) CRL_CP(womega, 4) CRL_CP(wphase, 4)
+            CRL_CP(wtiles, 4 * kWheelSlots) CRL_CP(visited, 16) CRL_CP(reward, 1) CRL_CP(prev_reward, 1) CRL_CP(visited_count, 1) CRL_CP(last_block, 1)
+            CRL_CP(done, 1) CRL_CP(step_count, 1) CRL_CP(first_step, 1) CRL_CP(sleep, 5)
+#undef CRL_CP
+        }
+        if (lane == 0) {
+            live.elapsed[env] = stg.elapsed[env];
+            if (live.n_contact) live.n_contact[env] = stg.n_contact[env], live.coupled[env] = stg.coupled[env];
+            live.map_par[env] ^= 1;
+        }
+    }
+}
+
+void launch_car_commit_list(const CarSoA &live, const CarSoA &stage, const int32_t *list, const int32_t *list_count, int64_t expected, hipStream_t st) {
+    int64_t want = expected + expected / 4 + 32;
+    want = want > live.n ? live.n : want;
+    hipLaunchKernelGGL(car_commit_list_kernel, dim3((unsigned)want), dim3(64), 0, st, live, stage, list, list_count);
+}
+
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st) {
     hipMemsetAsync(s.walk_count, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(car_walk_mark_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, s.walk_list, s.walk_count);

@@ -14,6 +14,8 @@ struct crl_car_ctx {
     crl_opts o;
     int64_t n;
     CarSoA s{};
+    CarSoA stage{};  // only the per-car arrays a reset writes: their staged copies (car_commit_list_kernel)
+    hipEvent_t ev_early3 = nullptr;
     CarConsts K_{};
     CarTrackSrc src{};
     std::vector<void *> allocs;
@@ -28,11 +30,11 @@ struct crl_car_ctx {
     // latency-bound part of a step (coupled solve, track generation for finished envs) runs on a
     // side stream next to the raster; slow_env = pipeline class per env (car_post_kernel)
     uint8_t *slow_env = nullptr;
-    int32_t *class_list = nullptr;   // [3][n] envs of class 1 (coupled), 2 (finished, cars on their own) and 3 (finished and coupled) of the current step, compacted
+    int32_t *class_list = nullptr;   // [4][n] envs of class 1 (coupled), 2 (finished, cars on their own), 3 (finished and coupled) and "4" = 2 and 3 together, of the current step, compacted
     int32_t *class_count = nullptr;  // [3] their lengths (inside `counters`)
     int32_t *counters = nullptr;     // [2][16] per step parity: coupled_count[8], class_count[2]; a step's first kernel clears the other block
     int parity = 0;
-    hipEvent_t ev_nearfr = nullptr;
+    hipEvent_t ev_nearfr = nullptr, ev_post = nullptr;
     hipEvent_t ev_fin3 = nullptr;
     hipEvent_t ev_fin = nullptr;
     int32_t *class_count_host = nullptr, *class_count_hdev = nullptr;  // host-mapped copy (one step late): sizes the next step's launches
@@ -170,17 +172,25 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(cap_hits, 4); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
-    A(obs_map, (size_t)kMapBytes * n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
+    A(obs_map, (size_t)kMapBytes * 2 * n); A(map_par, n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
     A(map_lightx, kMapW / 32); A(map_lighty, kMapW / 32);
     A(view, (size_t)kViewWords * M); A(view_cnt, (size_t)16 * M); A(view_rec, (size_t)kViewRecWords * M);
 #undef A
+    {  // staged copies of the per-car arrays a reset writes
+        CarSoA &g = c->stage;
+#define B(f, cnt) if (!rc) rc = calloc_dev(c, &g.f, (size_t)(cnt))
+        B(body, 30 * M); B(jimp, 12 * M); B(jmotor, 4 * M); B(jspeed, 4 * M); B(jlimit, 4 * M); B(wgas, 4 * M); B(womega, 4 * M); B(wphase, 4 * M);
+        B(wtiles, 4 * kWheelSlots * M); B(visited, 16 * M); B(reward, M); B(prev_reward, M); B(visited_count, M); B(last_block, M); B(done, M);
+        B(step_count, M); B(first_step, M); B(sleep, 5 * M); B(elapsed, n); B(n_contact, n); B(coupled, n);
+#undef B
+    }
     if (!rc) rc = calloc_dev(c, &c->done_car, M);
     if (!rc) rc = calloc_dev(c, &c->done_env, n);
     if (!rc) rc = calloc_dev(c, &c->slow_env, n);
-    if (!rc) rc = calloc_dev(c, &c->class_list, 3 * n);
+    if (!rc) rc = calloc_dev(c, &c->class_list, 4 * n);
     if (!rc) rc = calloc_dev(c, &c->counters, 2 * 16);
     if (!rc) rc = calloc_dev(c, &c->rew_tmp, M);
     if (!rc) rc = calloc_dev(c, &c->info_steps, n);
@@ -232,6 +242,8 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_narrow, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_near, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nearfr, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_early3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
@@ -268,6 +280,22 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
 }
 
 void crl_car_destroy(crl_car_ctx *c) {
+#ifdef CRL_ABLATION
+    if (c && c->s.stamps && getenv("CRL_CAR_STAMPS")) {  // profiling build: mean cycles per wavefront and phase of car_touch_kernel / car_narrow_kernel
+        unsigned long long h[64];
+        hipDeviceSynchronize();
+        hipMemcpy(h, c->s.stamps, sizeof(h), hipMemcpyDeviceToHost);
+        for (int cls = 0; cls < 3; cls++) {
+            const unsigned long long *q = h + 8 * cls;
+            const double w = q[7] ? (double)q[7] : 1.0;
+            fprintf(stderr, "touch class %d: %llu waves; mean cycles setup %.0f | velocity %.0f | position %.0f (%.1f iterations) | store %.0f | max total %llu\n", cls + 1,
+                    q[7], q[0] / w, q[1] / w, q[2] / w, q[4] / w, q[3] / w, q[5]);
+        }
+        const unsigned long long *q = h + 32;
+        const double w = q[7] ? (double)q[7] : 1.0;
+        fprintf(stderr, "narrow: %llu wave-slots; mean cycles prologue %.0f | load+sincos+circle %.0f | collide %.0f | compaction+store %.0f\n", q[7], q[0] / w, q[1] / w, q[2] / w, q[3] / w);
+    }
+#endif
     if (!c) return;
     hipDeviceSynchronize();
     if (getenv("CRL_CAR_DEBUG") && (atoi(getenv("CRL_CAR_DEBUG")) & 64)) crl::car_raster_print_ticks();
@@ -276,6 +304,8 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_narrow) hipEventDestroy(c->ev_narrow);
     if (c->ev_near) hipEventDestroy(c->ev_near);
     if (c->ev_nearfr) hipEventDestroy(c->ev_nearfr);
+    if (c->ev_post) hipEventDestroy(c->ev_post);
+    if (c->ev_early3) hipEventDestroy(c->ev_early3);
     if (c->ev_fin3) hipEventDestroy(c->ev_fin3);
     if (c->ev_fin) hipEventDestroy(c->ev_fin);
     if (c->sens) hipStreamDestroy(c->sens);
@@ -323,6 +353,19 @@ void crl_car_seed(crl_car_ctx *c, uint64_t seed) {
 }
 int64_t crl_car_obs_bytes(const crl_car_ctx *c) { return (int64_t)c->s.players * c->K * CRL_CAR_OBS * CRL_CAR_OBS; }
 
+// The state as the staged reset of the step pipeline sees it: per-car arrays -> their staged copies, the env's OTHER map slot
+static CarSoA stage_view(const crl_car_ctx *c) {
+    CarSoA v = c->s;
+    const CarSoA &g = c->stage;
+    v.body = g.body, v.jimp = g.jimp, v.jmotor = g.jmotor, v.jspeed = g.jspeed, v.jlimit = g.jlimit, v.wgas = g.wgas, v.womega = g.womega, v.wphase = g.wphase;
+    v.wtiles = g.wtiles, v.visited = g.visited, v.reward = g.reward, v.prev_reward = g.prev_reward, v.visited_count = g.visited_count;
+    v.last_block = g.last_block, v.done = g.done, v.step_count = g.step_count, v.first_step = g.first_step, v.sleep = g.sleep;
+    v.elapsed = g.elapsed;
+    if (v.n_contact) v.n_contact = g.n_contact, v.coupled = g.coupled;
+    v.map_alt = 1;
+    return v;
+}
+
 // frames of every env, or of the envs with only_env[e] == want
 // tm (optional): timer 1 brackets the frame kernel alone (car_obs_kernel / car_raster_kernel), for bench.py's roofline
 static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1, crl_timer *tm = nullptr) {
@@ -338,10 +381,10 @@ static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *
     crl_timer_end(tm, 1, st);
 }
 // frames of the envs of a compacted list
-static void frames_list(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const int32_t *list, const int32_t *list_count, int32_t *count_to_host,
-                        int64_t expected) {
-    if (c->analytic) launch_car_raster_list(c->s, c->K_, dst, st, list, list_count, count_to_host, expected);
-    else launch_car_obs_list(c->s, c->K_, dst, st, list, list_count, count_to_host, expected);
+static void frames_list(crl_car_ctx *c, const CarSoA &s, uint8_t *dst, hipStream_t st, const int32_t *list, const int32_t *list_count,
+                        int32_t *count_to_host, int64_t expected) {
+    if (c->analytic) launch_car_raster_list(s, c->K_, dst, st, list, list_count, count_to_host, expected);
+    else launch_car_obs_list(s, c->K_, dst, st, list, list_count, count_to_host, expected);
 }
 
 // newest frames -> obs_dev, through the frame stack when K > 1
@@ -407,7 +450,25 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, st);
         launch_car_coupled(c->s, c->K_, st);
     }
-    launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, st, c->class_list, c->class_count);
+    if (fork) {
+        // The narrow phase (head of the step's critical path: narrow -> touching solve -> their frames), the wheel sensors and the
+        // env-level bookkeeping only need car_step_kernel's output: all three start here, and the per-car solve on `st` waits for none.
+        static const bool sens_after_narrow = getenv("CRL_CAR_SENS_WITH_NARROW") == nullptr;  // (A/B switch: the sensor kernel beside the narrow phase doubles both)
+        hipEventRecord(c->ev_fork, st);
+        hipStreamWaitEvent(c->side, c->ev_fork, 0);
+        hipStreamWaitEvent(c->side2, c->ev_fork, 0);
+        hipStreamWaitEvent(c->sens, c->ev_fork, 0);
+        launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, c->side2, c->class_list,
+                        c->class_count);
+        hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
+        static const bool narrow_on_main = getenv("CRL_CAR_NARROW_ON_MAIN") != nullptr;  // (A/B: the narrow phase directly behind car_step_kernel on the caller's stream saves a cross-stream hop, but then the per-car solve starts together with the touching solve: 1.20 against 1.17 ms per step)
+        launch_car_coupled(c->s, c->K_, c->side, c->side2, c->ev_narrow, c->ev_near, narrow_on_main, st);  // (side ends up behind side2's solve too)
+        if (sens_after_narrow && c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
+        launch_car_sensors(c->s, c->K_, c->sens);
+        hipEventRecord(c->ev_sens, c->sens);
+    } else {
+        launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, st, c->class_list, c->class_count);
+    }
     if (!fork) {
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
         if (obs_dev) frames(c, c->term, st, c->done_env);
@@ -433,14 +494,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         // that share one wait for each other's kernels; the milliseconds-long walk-ahead has a priority class of its own)
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
-        hipEventRecord(c->ev_fork, st);
-        hipStreamWaitEvent(c->side, c->ev_fork, 0);
-        hipStreamWaitEvent(c->sens, c->ev_fork, 0);
-        launch_car_sensors(c->s, c->K_, c->sens);
-        hipEventRecord(c->ev_sens, c->sens);
-        launch_car_coupled(c->s, c->K_, c->side, c->side2, c->ev_narrow, c->ev_near);  // (side ends up behind side2's solve too)
         if (c->s.players == 2 && c->s.contacts_enabled) {
             hipStreamWaitEvent(c->side2, c->ev_sens, 0);
+            hipStreamWaitEvent(c->side2, c->ev_post, 0);
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
             hipEventRecord(c->ev_nearfr, c->side2);
@@ -450,36 +506,65 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, st);
         hipEventRecord(c->ev_term, st);  // (bodies of the non-coupled cars are final)
         hipStreamWaitEvent(st, c->ev_sens, 0);
+        hipStreamWaitEvent(st, c->ev_post, 0);
         crl_timer_end(tm, 0, st);
         frames(c, target, st, c->slow_env, 0, tm);
         // side again: frames of the touching envs (the finished-and-coupled envs' chain runs beside them, on side2)
         hipStreamWaitEvent(c->side, c->ev_sens, 0);
+        hipStreamWaitEvent(c->side, c->ev_post, 0);
         if (c->s.players == 2 && c->s.contacts_enabled) {
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
         }
-        // the finished envs, end to end: terminal frame (info["terminal_observation"]), reset, map, first frame of the new episode.
-        // Class 2 (cars on their own: nearly all of them) on `sens`, as soon as the per-car solve and the sensors are in -- beside the
-        // big frame launch; class 3 (finished AND coupled: their terminal frame shows the coupled solve's result) on `side2`, last.
-        auto finish_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {
-            const int32_t *list = c->class_list + (int64_t)(cls - 1) * c->n, *cnt = c->class_count + (cls - 1);
-            frames_list(c, c->term, q, list, cnt, count_to_host, expected);
-            launch_car_reset_list(c->s, c->K_, c->src, list, cnt, expected, q);
-            launch_car_map_build_list(c->s, q, list, cnt, expected);
-            frames_list(c, target, q, list, cnt, nullptr, expected);
+        // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
+        // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared on
+        // `sens` beside the solves.  What has to wait for the solve is small: the terminal frame (info["terminal_observation"],
+        // drawn from the solved bodies over the OLD map) and the commit that makes the staged episode current.
+        // Class 2 (cars on their own: nearly all of them) waits for the per-car solve; class 3 (finished AND coupled) for the
+        // touching solve, on `side2` -- two small kernels behind the step's longest chain instead of four.
+        const CarSoA sv = stage_view(c);
+        auto list_of = [&](int cls) { return c->class_list + (int64_t)(cls - 1) * c->n; };
+        auto count_of = [&](int cls) { return c->class_count + (cls - 1); };
+        auto early_chain = [&](hipStream_t q, int cls, int64_t expected) {
+            launch_car_reset_list(sv, c->K_, c->src, list_of(cls), count_of(cls), expected, q);
+            launch_car_map_build_list(sv, q, list_of(cls), count_of(cls), expected);
+            frames_list(c, sv, target, q, list_of(cls), count_of(cls), nullptr, expected);
         };
-        hipStreamWaitEvent(c->sens, c->ev_term, 0);
-        finish_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
+        auto late_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {
+            frames_list(c, c->s, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
+            launch_car_commit_list(c->s, sv, list_of(cls), count_of(cls), expected, q);
+        };
+        auto finish_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {  // everything in place, in order
+            frames_list(c, c->s, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
+            launch_car_reset_list(c->s, c->K_, c->src, list_of(cls), count_of(cls), expected, q);
+            launch_car_map_build_list(c->s, q, list_of(cls), count_of(cls), expected);
+            frames_list(c, c->s, target, q, list_of(cls), count_of(cls), nullptr, expected);
+        };
+        const bool staged = !c->analytic;  // (the analytic raster reads the track arrays themselves: it needs them until the terminal frame is drawn)
+        hipStreamWaitEvent(c->sens, c->ev_post, 0);
+        if (staged) {
+            early_chain(c->sens, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
+            hipEventRecord(c->ev_early3, c->sens);
+            hipStreamWaitEvent(c->sens, c->ev_term, 0);
+            late_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
+        } else {
+            hipStreamWaitEvent(c->sens, c->ev_term, 0);
+            finish_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
+        }
         hipEventRecord(c->ev_fin, c->sens);
+        hipStreamWaitEvent(c->side2, c->ev_fin, 0);  // (long complete by then: the caller's stream then only joins side and side2)
         hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // (recorded on side behind the touching AND the near-only solve)
         hipStreamWaitEvent(c->side2, c->ev_sens, 0);
-        finish_chain(c->side2, 3, 8, nullptr);
+        if (staged) {
+            hipStreamWaitEvent(c->side2, c->ev_early3, 0);
+            late_chain(c->side2, 3, 8, nullptr);
+        } else {
+            finish_chain(c->side2, 3, 8, nullptr);
+        }
         hipEventRecord(c->ev_fin3, c->side2);
         hipEventRecord(c->ev_join, c->side);
         queue_walk_ahead(c, c->sens);
-        if (c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(st, c->ev_nearfr, 0);
-        hipStreamWaitEvent(st, c->ev_fin, 0);
-        hipStreamWaitEvent(st, c->ev_fin3, 0);
+        hipStreamWaitEvent(st, c->ev_fin3, 0);  // side2: behind the near-only frames and (through ev_fin) everything on sens
         hipStreamWaitEvent(st, c->ev_join, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
     }
@@ -710,7 +795,10 @@ int crl_car_cap_hits_impl(crl_car_ctx *c, int32_t *out4, hipStream_t st) {
 int crl_car_get_map_impl(crl_car_ctx *c, int64_t env, uint8_t *palette_host, int32_t *overflow, hipStream_t st) {
     if (env < 0 || env >= c->n || !palette_host) return crl_fail(CRL_EINVAL, "bad argument");
     std::vector<uint8_t> raw((size_t)kMapBytes);
-    hipMemcpyAsync(raw.data(), c->s.obs_map + env * kMapBytes, (size_t)kMapBytes, hipMemcpyDeviceToHost, st);
+    uint8_t par = 0;
+    hipMemcpyAsync(&par, c->s.map_par + env, 1, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return crl_fail(CRL_EHIP, "get_map: copy failed");
+    hipMemcpyAsync(raw.data(), c->s.obs_map + (env * 2 + (par & 1)) * kMapBytes, (size_t)kMapBytes, hipMemcpyDeviceToHost, st);
     int32_t ov = 0;
     hipMemcpyAsync(&ov, c->s.map_overflow + env, 4, hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) return crl_fail(CRL_EHIP, "get_map: copy failed");

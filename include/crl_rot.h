@@ -5,8 +5,8 @@
  * results depend on libm's last bit -- which differs between glibc versions (the reference's hosts),
  * other C libraries and the GPU's device library.  Both the HIP kernels (competitive_rl_amd/csrc/car_*.hip)
  * and the CPU oracle (oracle/car_oracle.c, default build) therefore evaluate THIS function: the
- * CORRECTLY ROUNDED float32 sine and cosine -- argument reduction and a Taylor polynomial in float64
- * (relative error < 2^-52), rounded to float32 once, which is the correctly rounded result except when
+ * CORRECTLY ROUNDED float32 sine and cosine -- argument reduction and a Taylor polynomial in float64, every step an
+ * explicit fused multiply-add (relative error < 2^-52), rounded to float32 once, which is the correctly rounded result except when
  * the exact value lies within ~2^-28 ulp of a float32 rounding boundary.  Both sides are compiled with
  * -ffp-contract=off, so every operation rounds once and the float32 state of a car is reproducible
  * bit for bit across CPU and GPU.
@@ -33,19 +33,18 @@ CRL_ROT_FN void crl_sincosf(float x, float *sn, float *cs) {
     }
     const double xd = (double)x;
     const double kf = __builtin_floor(xd * 0x1.45f306dc9c883p-1 + 0.5); /* nearest multiple of pi/2 */
-    /* pi/2 = HI (33 bits: kf * HI is exact) + LO */
-    const double r = (xd - kf * 0x1.921fb54400000p+0) - kf * 0x1.0b4611a626331p-34;
+    /* pi/2 = HI (33 bits: kf * HI is exact) + LO; fused multiply-adds (one rounding each, the same on every machine) */
+    const double r = __builtin_fma(-kf, 0x1.0b4611a626331p-34, __builtin_fma(-kf, 0x1.921fb54400000p+0, xd));
     const double z = r * r;
-    const double ps = -0x1.5555555555555p-3 +
-                      z * (0x1.1111111111111p-7 +
-                           z * (-0x1.a01a01a01a01ap-13 +
-                                z * (0x1.71de3a556c734p-19 + z * (-0x1.ae64567f544e4p-26 + z * (0x1.6124613a86d09p-33 + z * -0x1.ae7f3e733b81fp-41)))));
-    const double pc = -0x1.0000000000000p-1 +
-                      z * (0x1.5555555555555p-5 +
-                           z * (-0x1.6c16c16c16c17p-10 +
-                                z * (0x1.a01a01a01a01ap-16 +
-                                     z * (-0x1.27e4fb7789f5cp-22 + z * (0x1.1eed8eff8d898p-29 + z * (-0x1.93974a8c07c9dp-37 + z * 0x1.ae7f3e733b81fp-45))))));
-    const double s = r + r * (z * ps), c = 1.0 + z * pc;
+    double ps = -0x1.ae7f3e733b81fp-41, pc = 0x1.ae7f3e733b81fp-45;
+    ps = __builtin_fma(z, ps, 0x1.6124613a86d09p-33), pc = __builtin_fma(z, pc, -0x1.93974a8c07c9dp-37);
+    ps = __builtin_fma(z, ps, -0x1.ae64567f544e4p-26), pc = __builtin_fma(z, pc, 0x1.1eed8eff8d898p-29);
+    ps = __builtin_fma(z, ps, 0x1.71de3a556c734p-19), pc = __builtin_fma(z, pc, -0x1.27e4fb7789f5cp-22);
+    ps = __builtin_fma(z, ps, -0x1.a01a01a01a01ap-13), pc = __builtin_fma(z, pc, 0x1.a01a01a01a01ap-16);
+    ps = __builtin_fma(z, ps, 0x1.1111111111111p-7), pc = __builtin_fma(z, pc, -0x1.6c16c16c16c17p-10);
+    ps = __builtin_fma(z, ps, -0x1.5555555555555p-3), pc = __builtin_fma(z, pc, 0x1.5555555555555p-5);
+    pc = __builtin_fma(z, pc, -0x1.0000000000000p-1);
+    const double s = __builtin_fma(r, z * ps, r), c = __builtin_fma(z, pc, 1.0);
     const int q = (int)((long long)kf & 3);
     const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
     *sn = (float)((q == 2 || q == 3) ? -so : so);

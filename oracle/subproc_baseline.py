@@ -54,18 +54,15 @@ class _CarEnv:
 
         from oracle import car_oracle as co
 
-        self.co, self.C = co, C
-        self.L = co.lib()
-        self.L.car_oracle_render.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.co = co
         self.rs = np.random.RandomState(1000 + rank)
         self.e = co.CarEnv()
         self.reset()
 
     def _obs(self):
-        out = np.zeros((2, 96, 96), np.uint8)
-        for v in range(2):
-            self.L.car_oracle_render(self.e.buf.ctypes.data, v, out[v].ctypes.data)
-        return out
+        # get_observation per viewer: the nearest-neighbour rotated crop of the episode's pre-rastered map (built once per
+        # reset, as _render_road does) plus the overlays
+        return np.stack([self.e.render(v) for v in range(2)])
 
     def reset(self):
         while self.e.reset(self.rs.random_sample(24 * 8), int(self.rs.randint(2))) < 0:
