@@ -68,18 +68,22 @@ __device__ inline int fillpoly_row(const int *vx, const int *vy, int nv, int min
     return k;
 }
 
-// One band of 16 map rows of one env.  rank[16][kMapW]: (draw order << 3 | palette) of the last polygon drawn over each pixel.
-__device__ void car_map_band(const CarSoA &s, int64_t env, int band, uint32_t (*rank)[kMapW]) {
+// R map rows (16 = a whole block row, or a quarter of one: rows 4 sub .. 4 sub + 3 of block row `band`) of one env.
+// rank[R][kMapW]: (draw order << 3 | palette) of the last polygon drawn over each pixel.
+// (The quarter-band form is what the step pipeline uses for the few envs it resets per step: a 78 KB workgroup only fits on a CU
+// that the frame kernel's 10 KB wavefronts have left half empty, and waited for one -- 300 us for a dozen maps.)
+template <int R>
+__device__ void car_map_band(const CarSoA &s, int64_t env, int band, int sub, uint32_t (*rank)[kMapW]) {
     const int tid = threadIdx.x;
-    const int Y0 = band * 16;
+    const int Y0 = band * 16 + sub * R;
     uint4 *z = reinterpret_cast<uint4 *>(&rank[0][0]);
-    for (int i = tid; i < 16 * kMapW / 4; i += 256) z[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < R * kMapW / 4; i += 256) z[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int nt = s.ntiles[env];
     for (int i = tid; i < nt; i += 256) {
         const uint32_t yr = s.map_yr[env * kCarMaxTiles + i];
         const int ylo = (int)(int16_t)(yr & 0xFFFFu), yhi = (int)(int16_t)(yr >> 16);
-        if (yhi < Y0 || ylo >= Y0 + 16) continue;
+        if (yhi < Y0 || ylo >= Y0 + R) continue;
         const uint32_t *v = s.map_vtx + (env * kCarMaxTiles + i) * 9;
         const int border = s.border_em[env * kCarMaxTiles + i];
         for (int poly = 0; poly < 2; poly++) {  // the tile, then its border (drawn right after it)
@@ -101,7 +105,7 @@ __device__ void car_map_band(const CarSoA &s, int64_t env, int band, uint32_t (*
             const uint32_t order = (uint32_t)(2 * (nt - 1 - i) + 1 + poly);
             const uint32_t pal = poly ? (border == 1 ? kPalWhite : kPalRed) : (uint32_t)(kPalRoad0 + i % 3);
             const uint32_t key = (order << 3) | pal;
-            for (int y = max(miny, Y0); y <= min(maxy, Y0 + 15); y++) {
+            for (int y = max(miny, Y0); y <= min(maxy, Y0 + R - 1); y++) {
                 int xs[4];
                 const int k = fillpoly_row(vx, vy, nv, miny, maxy, minx, maxx, y, xs);
                 for (int q = 0; q < k; q += 2)
@@ -112,8 +116,9 @@ __device__ void car_map_band(const CarSoA &s, int64_t env, int band, uint32_t (*
     __syncthreads();
     // compose: 16-byte pieces = rows 2 pr, 2 pr + 1 of block bx; the band's 76 blocks are contiguous in the map
     uint4 *out = reinterpret_cast<uint4 *>(env_map(s, env) + (int64_t)band * kMapBlocks * 128);
-    for (int q = tid; q < kMapBlocks * 8; q += 256) {
-        const int bx = q >> 3, pr = q & 7;
+    for (int q0 = tid; q0 < kMapBlocks * (R / 2); q0 += 256) {
+        const int bx = q0 / (R / 2), pr = q0 % (R / 2);  // pr: row pair inside this band
+        const int q = bx * 8 + sub * (R / 2) + pr;       // ... and inside the block
         const uint32_t lx = (s.map_lightx[(bx * 16) >> 5] >> ((bx * 16) & 31)) & 0xFFFFu;
         uint32_t w[4];
 #pragma unroll
@@ -144,14 +149,14 @@ __global__ __launch_bounds__(256) void car_map_build_kernel(CarSoA s, const uint
     __shared__ __attribute__((aligned(16))) uint32_t rank[16][kMapW];
     const int64_t env = env0 + blockIdx.y;
     if (only_env && !only_env[env]) return;
-    car_map_band(s, env, (int)blockIdx.x, rank);
+    car_map_band<16>(s, env, (int)blockIdx.x, 0, rank);
 }
 
 __global__ __launch_bounds__(256) void car_map_build_list_kernel(CarSoA s, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count) {
-    __shared__ __attribute__((aligned(16))) uint32_t rank[16][kMapW];
+    __shared__ __attribute__((aligned(16))) uint32_t rank[4][kMapW];
     const int count = *list_count;
     for (int i = blockIdx.y; i < count; i += gridDim.y) {
-        car_map_band(s, (int64_t)list[i], (int)blockIdx.x, rank);
+        car_map_band<4>(s, (int64_t)list[i], (int)blockIdx.x >> 2, (int)blockIdx.x & 3, rank);
         __syncthreads();
     }
 }
@@ -168,7 +173,7 @@ void launch_car_map_build_list(const CarSoA &s, hipStream_t st, const int32_t *l
     int64_t want = expected + expected / 4 + 8;
     want = want > s.n ? s.n : want;
     want = want > 4096 ? 4096 : want;
-    hipLaunchKernelGGL(car_map_build_list_kernel, dim3(kMapBlocks, (unsigned)want), dim3(256), 0, st, s, list, list_count);
+    hipLaunchKernelGGL(car_map_build_list_kernel, dim3(kMapBlocks * 4, (unsigned)want), dim3(256), 0, st, s, list, list_count);
 }
 
 int car_map_coord(double v) { return (int)(CRL_CAR_OBS_SCALE * -v + kMapSurface / 2.0); }

@@ -130,6 +130,10 @@ static int dev_upload(crl_ctx *c, T **p, const std::vector<T> &v, size_t pad_to 
     return CRL_OK;
 }
 
+// timing events: no system-scope fence when they complete (hip_runtime_api.h: "for events that are only being used to measure
+// timing"): they bracket kernels on the launch stream and must not flush the caches in front of them
+static const unsigned kTimerEvFlags = hipEventDefault | (getenv("CRL_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+
 void crl_timer_begin(crl_timer *t, int which, hipStream_t st) {
     if (!t || !t->on) return;
     crl_event_pair p;
@@ -137,7 +141,7 @@ void crl_timer_begin(crl_timer *t, int which, hipStream_t st) {
         p = t->pool.back();
         t->pool.pop_back();
     } else {
-        hipEventCreate(&p.a), hipEventCreate(&p.b);
+        hipEventCreateWithFlags(&p.a, kTimerEvFlags), hipEventCreateWithFlags(&p.b, kTimerEvFlags);
     }
     hipEventRecord(p.a, st);
     t->ev[which].push_back(p);
@@ -801,8 +805,8 @@ int crl_kernel_timing(crl_ctx *c, int enable) {
     if (c->tm.on && c->tm.pool.empty() && c->tm.ev[0].empty() && c->tm.ev[1].empty()) {
         for (int i = 0; i < 512; i++) {
             crl_event_pair p;
-            if (hipEventCreate(&p.a) != hipSuccess) break;
-            if (hipEventCreate(&p.b) != hipSuccess) {
+            if (hipEventCreateWithFlags(&p.a, kTimerEvFlags) != hipSuccess) break;
+            if (hipEventCreateWithFlags(&p.b, kTimerEvFlags) != hipSuccess) {
                 hipEventDestroy(p.a);
                 break;
             }

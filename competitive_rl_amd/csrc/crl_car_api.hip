@@ -154,6 +154,11 @@ static int calloc_dev(crl_car_ctx *c, T **p, size_t count) {
     return CRL_OK;
 }
 
+// The context's events only order its own streams on one device: no system-scope fence (an L2 writeback + invalidate per record --
+// with 300 MB of fresh frames in flight that is tens of microseconds in front of whatever waits, a dozen times per step).
+// CRL_EVENT_SYSTEM_FENCE=1 restores the default (A/B).
+static const unsigned kEvFlags = hipEventDisableTiming | (getenv("CRL_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+
 int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car_ctx **out) {
     crl_car_ctx *c = new crl_car_ctx();
     c->o = *opts;
@@ -237,27 +242,28 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     }
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (numerically lower = higher priority)
-    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||  // the touching envs: the step's critical path
+    // `side`: the bulk of a step (default priority) -- or, with CRL_CAR_CRIT_ON_SIDE=1, its critical chain (then at high priority)
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, getenv("CRL_CAR_CRIT_ON_SIDE") ? prio_hi : 0) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_narrow, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_near, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_nearfr, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_post, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_early3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fin3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_narrow, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_near, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_nearfr, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_post, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_early3, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fin3, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fin, kEvFlags) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_sens, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_c1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_sens, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_c1, kEvFlags) != hipSuccess ||
         hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own
 
-        hipEventCreateWithFlags(&c->ev_reset, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_walk, kEvFlags) != hipSuccess ||
         hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t)) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_coupled, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_term, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_fork, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_coupled, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_term, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, kEvFlags) != hipSuccess) {
         crl_car_destroy(c);
         return crl_fail(CRL_EHIP, "car create: side stream");
     }
@@ -435,6 +441,12 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     // Rewards and done flags are final after car_step_kernel (the reference evaluates them before
     // world.Step, crmp:576-603), so the env-level bookkeeping does not wait for the coupled solve.
     const bool fork = c->overlap && obs_dev != nullptr;
+    // The step's longest chain (narrow phase -> touching solve -> those envs' frames) runs on the CALLER's stream, directly behind
+    // car_step_kernel and directly in front of the next step's: every cross-stream hop costs tens of microseconds of command-processor
+    // latency, and this chain has none left.  The bulk (per-car solve -> camera -> frames of the envs on their own) forks to `side`
+    // and has the slack to absorb its two hops.  CRL_CAR_CRIT_ON_SIDE=1: the other way round (A/B).
+    static const bool crit_on_main = getenv("CRL_CAR_CRIT_ON_SIDE") == nullptr;
+    const hipStream_t crit = crit_on_main ? st : c->side, bulk = crit_on_main ? c->side : st;
     crl_timer_begin(tm, 0, st);
     auto next_counters = [&]() {  // this sub-step's counter block; car_step_kernel clears the other one for the next
         c->parity ^= 1;
@@ -455,14 +467,14 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         // env-level bookkeeping only need car_step_kernel's output: all three start here, and the per-car solve on `st` waits for none.
         static const bool sens_after_narrow = getenv("CRL_CAR_SENS_WITH_NARROW") == nullptr;  // (A/B switch: the sensor kernel beside the narrow phase doubles both)
         hipEventRecord(c->ev_fork, st);
-        hipStreamWaitEvent(c->side, c->ev_fork, 0);
+        hipStreamWaitEvent(c->side, c->ev_fork, 0);  // (whichever of crit / bulk is not the caller's stream)
         hipStreamWaitEvent(c->side2, c->ev_fork, 0);
         hipStreamWaitEvent(c->sens, c->ev_fork, 0);
         launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, c->side2, c->class_list,
                         c->class_count);
         hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
         static const bool narrow_on_main = getenv("CRL_CAR_NARROW_ON_MAIN") != nullptr;  // (A/B: the narrow phase directly behind car_step_kernel on the caller's stream saves a cross-stream hop, but then the per-car solve starts together with the touching solve: 1.20 against 1.17 ms per step)
-        launch_car_coupled(c->s, c->K_, c->side, c->side2, c->ev_narrow, c->ev_near, narrow_on_main, st);  // (side ends up behind side2's solve too)
+        launch_car_coupled(c->s, c->K_, crit, c->side2, c->ev_narrow, c->ev_near, narrow_on_main && crit != st, st);  // (crit ends up behind side2's solve too)
         if (sens_after_narrow && c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
         launch_car_sensors(c->s, c->K_, c->sens);
         hipEventRecord(c->ev_sens, c->sens);
@@ -501,20 +513,20 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
             hipEventRecord(c->ev_nearfr, c->side2);
         }
-        hipEventRecord(c->ev_coupled, c->side);
-        // main: the per-car solve, then the frames of every env that is neither coupled nor finished
-        launch_car_solve(c->s, c->K_, st);
-        hipEventRecord(c->ev_term, st);  // (bodies of the non-coupled cars are final)
-        hipStreamWaitEvent(st, c->ev_sens, 0);
-        hipStreamWaitEvent(st, c->ev_post, 0);
-        crl_timer_end(tm, 0, st);
-        frames(c, target, st, c->slow_env, 0, tm);
-        // side again: frames of the touching envs (the finished-and-coupled envs' chain runs beside them, on side2)
-        hipStreamWaitEvent(c->side, c->ev_sens, 0);
-        hipStreamWaitEvent(c->side, c->ev_post, 0);
+        hipEventRecord(c->ev_coupled, crit);
+        // bulk: the per-car solve, then the frames of every env that is neither coupled nor finished
+        launch_car_solve(c->s, c->K_, bulk);
+        hipEventRecord(c->ev_term, bulk);  // (bodies of the non-coupled cars are final)
+        hipStreamWaitEvent(bulk, c->ev_sens, 0);
+        hipStreamWaitEvent(bulk, c->ev_post, 0);
+        crl_timer_end(tm, 0, bulk);
+        frames(c, target, bulk, c->slow_env, 0, tm);
+        // crit again: frames of the touching envs (the finished-and-coupled envs' chain runs beside them, on side2)
+        hipStreamWaitEvent(crit, c->ev_sens, 0);
+        hipStreamWaitEvent(crit, c->ev_post, 0);
         if (c->s.players == 2 && c->s.contacts_enabled) {
-            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
-            else launch_car_obs_list(c->s, c->K_, target, c->side, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
+            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
+            else launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
         }
         // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
         // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared on
@@ -552,7 +564,6 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             finish_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
         }
         hipEventRecord(c->ev_fin, c->sens);
-        hipStreamWaitEvent(c->side2, c->ev_fin, 0);  // (long complete by then: the caller's stream then only joins side and side2)
         hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // (recorded on side behind the touching AND the near-only solve)
         hipStreamWaitEvent(c->side2, c->ev_sens, 0);
         if (staged) {
@@ -564,7 +575,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipEventRecord(c->ev_fin3, c->side2);
         hipEventRecord(c->ev_join, c->side);
         queue_walk_ahead(c, c->sens);
-        hipStreamWaitEvent(st, c->ev_fin3, 0);  // side2: behind the near-only frames and (through ev_fin) everything on sens
+        hipStreamWaitEvent(st, c->ev_fin, 0);   // sens: the finished envs on their own
+        hipStreamWaitEvent(st, c->ev_fin3, 0);  // side2: behind the near-only frames
         hipStreamWaitEvent(st, c->ev_join, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
     }
