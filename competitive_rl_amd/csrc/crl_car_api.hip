@@ -572,12 +572,14 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         } else {
             finish_chain(c->side2, 3, 8, nullptr);
         }
-        hipEventRecord(c->ev_fin3, c->side2);
+        // join: side2 collects sens and side behind its own last kernel, so that the caller's stream -- whose last kernel is usually
+        // the last of the step -- passes ONE barrier that is already open instead of three
         hipEventRecord(c->ev_join, c->side);
+        hipStreamWaitEvent(c->side2, c->ev_fin, 0);
+        hipStreamWaitEvent(c->side2, c->ev_join, 0);
+        hipEventRecord(c->ev_fin3, c->side2);
         queue_walk_ahead(c, c->sens);
-        hipStreamWaitEvent(st, c->ev_fin, 0);   // sens: the finished envs on their own
-        hipStreamWaitEvent(st, c->ev_fin3, 0);  // side2: behind the near-only frames
-        hipStreamWaitEvent(st, c->ev_join, 0);
+        hipStreamWaitEvent(st, c->ev_fin3, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
     }
     hipError_t e = hipGetLastError();
