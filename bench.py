@@ -371,7 +371,11 @@ def main():
         G["gather"] = crl.StepGather(overlap=True, mode="descriptors" if args.gather == "descriptors" else "obs")
     results = {}
     for nm in names:
-        results[nm] = run_workload(nm, args, G)
+        if os.environ.get("CRL_BENCH_STREAM"):  # (A/B: the loop on a created stream instead of the legacy default stream)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                results[nm] = run_workload(nm, args, G)
+        else:
+            results[nm] = run_workload(nm, args, G)
         torch.cuda.empty_cache()
     if rank == 0:
         head = results[names[0]]

@@ -522,8 +522,11 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         crl_timer_end(tm, 0, bulk);
         frames(c, target, bulk, c->slow_env, 0, tm);
         // crit again: frames of the touching envs (the finished-and-coupled envs' chain runs beside them, on side2)
-        hipStreamWaitEvent(crit, c->ev_sens, 0);
-        hipStreamWaitEvent(crit, c->ev_post, 0);
+        static const bool abl_skip_waits = CRL_ABL(getenv("CRL_CAR_ABL_SKIP_WAITS") != nullptr);  // profiling build: what the two (long open) barriers cost
+        if (!abl_skip_waits) {
+            hipStreamWaitEvent(crit, c->ev_sens, 0);
+            hipStreamWaitEvent(crit, c->ev_post, 0);
+        }
         if (c->s.players == 2 && c->s.contacts_enabled) {
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
