@@ -281,7 +281,8 @@ def run_workload(name, args, G):
         dt = float(t.item())
     dyn_ms, dyn_n = inner.kernel_time_ms(0)
     ras_ms, ras_n = inner.kernel_time_ms(1)
-    resets = int(env.get_state()["episode"].astype("int64").sum() - episodes_before) if episodes_before is not None else None
+    final_state = env.get_state() if episodes_before is not None else None
+    resets = int(final_state["episode"].astype("int64").sum() - episodes_before) if episodes_before is not None else None
     env.close()
     res = {"value": world * n * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3, "dtype": dtype,
            "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",
@@ -321,10 +322,15 @@ def run_workload(name, args, G):
         return res
     ras_s = ras_ms / max(ras_n, 1) * 1e-3
     bytes_per_env = {"raw": RAW_BYTES, "fused84": FUSED_BYTES, "fused84_f32": FUSED_F32_BYTES, "fused84_newest": NEWEST_BYTES, "car": CAR_BYTES}[name]
-    ach = bytes_per_env * n / ras_s if ras_s > 0 else 0.0
+    drawn = 1.0
+    if name == "car":
+        # the timed launch draws the envs that are neither coupled nor finished (the others' wavefronts exit at once; their frames come
+        # from the list-driven launches): count only what it draws.  coupled: the last step's flags; finished: resets per step.
+        drawn = 1.0 - float((final_state["coupled"] != 0).mean()) - resets / max(args.steps, 1) / n
+    ach = bytes_per_env * n * drawn / ras_s if ras_s > 0 else 0.0
     traffic, tsrc = traffic_of(name)
     res["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                       "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": bytes_per_env * n, "avg_kernel_us": ras_s * 1e6,
+                       "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": bytes_per_env * n * drawn, "avg_kernel_us": ras_s * 1e6,
                        "launches_timed": ras_n, "dynamics_kernel_avg_us": dyn_ms / max(dyn_n, 1) * 1e3}
     if name == "car":
         flop, fsrc = CAR_FLOP_MODEL, "bench.py CAR_FLOP_MODEL (counted from the code paths, DESIGN.md 4b)"
@@ -333,13 +339,16 @@ def run_workload(name, args, G):
             d = json.load(open(ff))
             flop, fsrc = d["f32_flop_per_env_step"], "profiles/flops_car.json: " + d.get("source", "")
         fl = flop * res["value"] / world
-        res["roofline"]["note"] = ("car_obs_kernel = the per-pixel gather of the class-0 envs (every env that is neither coupled nor finished: ~90 % of "
-                                   "the batch; bytes_per_launch counts the whole batch); the step itself is bound by dependent instruction chains "
-                                   "(island solves), see roofline_valu and DESIGN.md")
+        res["roofline"]["envs_drawn_by_timed_launch"] = drawn
+        res["roofline"]["note"] = ("car_obs_kernel = the per-pixel gather from the pre-rastered map for the envs that are neither coupled nor finished "
+                                   "(envs_drawn_by_timed_launch of the batch: bytes_per_launch counts those; `traffic` is the PMC figure of a launch "
+                                   "that draws every env); vector-issue bound (250 instructions per 16 pixels of a lane), not bandwidth bound; the step "
+                                   "itself ends with the touching cars' island solve, see roofline_valu and DESIGN.md 4.4")
         res["roofline_valu"] = {"bound": "valu_fp32", "achieved": fl / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / FP32_PEAK,
                                 "flop_per_env_step": flop, "flop_source": fsrc,
-                                "limiter": "neither roof: the island solves are 180 x 4 dependent Gauss-Seidel joint updates per car (one lane each: "
-                                           "~8.5 cycles per dependent instruction), and a touching pair of cars adds its contacts to that chain; see DESIGN.md"}
+                                "limiter": "neither roof: the island solves are 180 x 4 Gauss-Seidel joint updates per car on one lane each (a lone "
+                                           "wavefront issues one instruction per ~5.3 cycles: 900-1 800 cycles per iteration), a touching pair of cars adds "
+                                           "~1 350 cycles per contact and iteration, and the step ends with the slowest such island; see DESIGN.md 4.2 / 4.4"}
     return res
 
 

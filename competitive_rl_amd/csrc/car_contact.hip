@@ -609,6 +609,7 @@ __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const int m
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const bool ok = q.ok && j < q.ccount;
+        if (!__any(ok)) continue;  // (no island of this wavefront has this point: with one env per wavefront, exactly this island)
         // this lane's body (centre, angle) -> its transform; the partner's through DPP
         const float ocx = CRL_SEL(cx, bi), ocy = CRL_SEL(cy, bi), oa = CRL_SEL(a, bi);
         XF ox;

@@ -476,6 +476,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         static const bool narrow_on_main = getenv("CRL_CAR_NARROW_ON_MAIN") != nullptr;  // (A/B: the narrow phase directly behind car_step_kernel on the caller's stream saves a cross-stream hop, but then the per-car solve starts together with the touching solve: 1.20 against 1.17 ms per step)
         launch_car_coupled(c->s, c->K_, crit, c->side2, c->ev_narrow, c->ev_near, narrow_on_main && crit != st, st);  // (crit ends up behind side2's solve too)
         if (sens_after_narrow && c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
+        hipStreamWaitEvent(c->sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the
+                                                     // frame launches pass ONE barrier each -- on the legacy default stream they cost 30-40 us apiece)
         launch_car_sensors(c->s, c->K_, c->sens);
         hipEventRecord(c->ev_sens, c->sens);
     } else {
@@ -508,7 +510,6 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
         if (c->s.players == 2 && c->s.contacts_enabled) {
             hipStreamWaitEvent(c->side2, c->ev_sens, 0);
-            hipStreamWaitEvent(c->side2, c->ev_post, 0);
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
             hipEventRecord(c->ev_nearfr, c->side2);
@@ -518,14 +519,12 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, bulk);
         hipEventRecord(c->ev_term, bulk);  // (bodies of the non-coupled cars are final)
         hipStreamWaitEvent(bulk, c->ev_sens, 0);
-        hipStreamWaitEvent(bulk, c->ev_post, 0);
         crl_timer_end(tm, 0, bulk);
         frames(c, target, bulk, c->slow_env, 0, tm);
         // crit again: frames of the touching envs (the finished-and-coupled envs' chain runs beside them, on side2)
         static const bool abl_skip_waits = CRL_ABL(getenv("CRL_CAR_ABL_SKIP_WAITS") != nullptr);  // profiling build: what the two (long open) barriers cost
         if (!abl_skip_waits) {
             hipStreamWaitEvent(crit, c->ev_sens, 0);
-            hipStreamWaitEvent(crit, c->ev_post, 0);
         }
         if (c->s.players == 2 && c->s.contacts_enabled) {
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
@@ -556,7 +555,6 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             frames_list(c, c->s, target, q, list_of(cls), count_of(cls), nullptr, expected);
         };
         const bool staged = !c->analytic;  // (the analytic raster reads the track arrays themselves: it needs them until the terminal frame is drawn)
-        hipStreamWaitEvent(c->sens, c->ev_post, 0);
         if (staged) {
             early_chain(c->sens, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
             hipEventRecord(c->ev_early3, c->sens);

@@ -622,3 +622,77 @@ def test_make_competitive_car_racing_matches_double_env():
         assert ia[0] == {"num_steps": ir[0][0]["num_steps"]}
     for e in (a, b, ref):
         e.close()
+
+
+def test_staged_reset_pipeline_equals_the_sequential_step():
+    """The pipelined step prepares a finished env's next episode EARLY on a staged copy (second map slot, staged car arrays) and
+    commits it behind the terminal frame; CRL_CAR_NO_OVERLAP=1 selects the plain sequence on one stream with everything in
+    place.  Same library, same states, same actions: every output of a step and the whole state afterwards must be identical --
+    in particular for envs that finish WHILE their cars touch (terminal frame from the touching solve, then the commit), and
+    when most of the batch finishes in one step."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 96
+    a = crl.HipCarVecEnv(n, seed=21)
+    os.environ["CRL_CAR_NO_OVERLAP"] = "1"
+    try:
+        b = crl.HipCarVecEnv(n, seed=21)  # (the switch is read when the context is created)
+    finally:
+        del os.environ["CRL_CAR_NO_OVERLAP"]
+    a.reset(), b.reset()
+    assert torch.equal(a.render_current(), b.render_current())
+    g = torch.Generator(device="cuda").manual_seed(5)
+
+    def both(act):
+        oa, ra, da = a.step_device(act)
+        ob, rb, db = b.step_device(act)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+        idx = torch.nonzero(da).reshape(-1)
+        if len(idx):
+            assert torch.equal(torch.stack(a.terminal_observation(idx)), torch.stack(b.terminal_observation(idx)))
+        return da
+
+    for t in range(30):
+        act = torch.rand((n, 2, 2), generator=g, device="cuda") * 2 - 1
+        act[:, :, 1] = act[:, :, 1].abs()
+        both(act)
+    # car 1 beside car 0, wheels overlapping (the narrow phase finds manifolds at once); a third of those envs two steps from
+    # the TimeLimit, and in a later step most of the batch at once
+    st = a.get_state()
+    touch = np.arange(n) % 3 == 0
+    c0, c1 = st["car"][:, 0], st["car"][:, 1]
+    ang = c0["hull"]["a"].astype(np.float64)
+    lat = np.stack([np.cos(ang), np.sin(ang)], 1) * 2.6
+    for body in ("hull", "wheel"):
+        src0, dst = c0[body], c1[body]
+        for f in ("a", "vx", "vy", "w"):
+            dst[f][touch] = src0[f][touch]
+        if body == "hull":
+            dst["cx"][touch] = src0["cx"][touch] + lat[touch, 0]
+            dst["cy"][touch] = src0["cy"][touch] + lat[touch, 1]
+        else:
+            dst["cx"][touch] = src0["cx"][touch] + lat[touch, 0][:, None]
+            dst["cy"][touch] = src0["cy"][touch] + lat[touch, 1][:, None]
+    st["elapsed"][touch & (np.arange(n) % 2 == 0)] = 997
+    st["elapsed"][np.arange(n) % 7 == 3] = 995
+    a.set_state(st), b.set_state(st)
+    seen = {"finished_while_coupled": 0, "finished": 0}
+    for t in range(8):
+        act = torch.rand((n, 2, 2), generator=g, device="cuda") * 2 - 1
+        coupled_before = a.get_state()["coupled"] != 0
+        if t == 6:
+            s2 = a.get_state()
+            s2["elapsed"][np.arange(n) % 4 != 0] = 999  # three quarters of the batch finish in this step
+            a.set_state(s2), b.set_state(s2)
+        d = both(act).cpu().numpy().astype(bool)
+        sa, sb = a.get_state(), b.get_state()
+        assert sa.tobytes() == sb.tobytes(), t
+        seen["finished"] += int(d.sum())
+        seen["finished_while_coupled"] += int((d & coupled_before).sum())
+        for e in np.nonzero(d)[0][:3]:
+            ma, oa_ = a.get_map(int(e))
+            mb, ob_ = b.get_map(int(e))
+            assert np.array_equal(ma, mb) and oa_ == ob_ == 0
+    assert seen["finished"] > n // 2 and seen["finished_while_coupled"] > 0, seen
+    a.close(), b.close()
