@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
             int32_t *lst = nc ? s.touch_list + (int64_t)(cls - 1) * s.n : s.near_list;
             lst[atomicAdd(s.coupled_count + 1 + cls, 1)] = (int32_t)env;
             if (nc) s.touch_all[atomicAdd(s.coupled_count + 5, 1)] = (int32_t)env;
+            if (nc >= 2) s.touch_multi[atomicAdd(s.coupled_count + 6, 1)] = (int32_t)env;
         }
 #ifdef CRL_ABLATION
         const unsigned long long sd = __builtin_readcyclecounter();
@@ -888,8 +889,8 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 // EPW1 = envs per wavefront of class 0 (94 % of the touching envs); two manifolds or more (the slowest islands): one env per wavefront.
 // (LDS rows for 32 envs whatever the class uses: two workgroups per CU, 512 on the chip, is more than a step has)
 template <int EPW1>
-__global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K) {
-    const int cls = blockIdx.y;
+__global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, int cls0) {
+    const int cls = cls0 + blockIdx.y;
     const int count = s.coupled_count[2 + cls];
     const int epw = cls == 0 ? EPW1 : 1;
     if ((int)blockIdx.x * epw >= count) return;
@@ -908,21 +909,32 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K) {
 
 // world.Step of the coupled envs.  `near_st` (may equal `st`): where the near-only envs are solved, beside the touching ones.
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st, hipEvent_t ev_narrow, hipEvent_t ev_near,
-                        bool narrow_elsewhere, hipStream_t narrow_st) {
+                        bool narrow_elsewhere, hipStream_t narrow_st, bool split, hipStream_t one_st) {
     if (s.players != 2 || !s.contacts_enabled) return;
     if (!near_st) near_st = st;
     if (!narrow_elsewhere) narrow_st = st;  // (a stream handle may be null -- the default stream -- so the choice is a flag of its own)
     const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
     hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, narrow_st, s, k);
-    if (near_st != st || narrow_st != st) hipEventRecord(ev_narrow, narrow_st);
+    if (near_st != st || narrow_st != st || split) hipEventRecord(ev_narrow, narrow_st);
     if (near_st != narrow_st) hipStreamWaitEvent(near_st, ev_narrow, 0);
     if (st != narrow_st) hipStreamWaitEvent(st, ev_narrow, 0);
     hipLaunchKernelGGL(car_near_kernel, dim3((unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512)), dim3(64), 0, near_st, s, k);
     static const int epw1 = getenv("CRL_CAR_TOUCH_EPW1") ? atoi(getenv("CRL_CAR_TOUCH_EPW1")) : 8;  // (A/B: 32 | 8 | 4; measured 1.19 / 1.17 / 1.17 ms per step)
     const unsigned g = (unsigned)((s.n + 31) / 32 < 256 ? (s.n + 31) / 32 : 256);
-    if (epw1 == 4) hipLaunchKernelGGL(car_touch_kernel<4>, dim3(g, 3), dim3(64), 0, st, s, k);
-    else if (epw1 == 8) hipLaunchKernelGGL(car_touch_kernel<8>, dim3(g, 3), dim3(64), 0, st, s, k);
-    else hipLaunchKernelGGL(car_touch_kernel<32>, dim3(g, 3), dim3(64), 0, st, s, k);
+    // split: the one-manifold envs (94 % of the touching ones, never the slowest) on a stream of their own -- `st` then only carries
+    // the islands with two manifolds or more, and behind them only THEIR frames
+    auto touch = [&](hipStream_t q, unsigned classes, int cls0) {
+        if (epw1 == 4) hipLaunchKernelGGL(car_touch_kernel<4>, dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+        else if (epw1 == 32) hipLaunchKernelGGL(car_touch_kernel<32>, dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+        else hipLaunchKernelGGL(car_touch_kernel<8>, dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+    };
+    if (split) {
+        hipStreamWaitEvent(one_st, ev_narrow, 0);
+        touch(one_st, 1, 0);
+        touch(st, 2, 1);
+    } else {
+        touch(st, 3, 0);
+    }
     (void)ev_near;  // (near_st's own later work is ordered behind the near-only solve by the stream; nobody else reads those envs before the step's join)
 }
 

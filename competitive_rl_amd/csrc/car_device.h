@@ -117,6 +117,7 @@ struct CarSoA {
                             //     with one / two / three-or-more manifolds
     int32_t *near_list, *touch_list;  // [n], [3][n]
     int32_t *touch_all;     // [n] every touching env (any manifold count), [5] of coupled_count: their frames
+    int32_t *touch_multi;   // [n] the touching envs with two manifolds or more, [6] of coupled_count: their frames when the one-manifold envs have a stream of their own
     int32_t *coupled_to_host;  // host-mapped word: the step's coupled-env count, read by the host one step late (sizes the list launches)
     int32_t *cap_hits;      // [4] times a fixed capacity was hit since create: [0] a wheel touching more than kWheelSlots tiles (the
                             //     extra tile is not recorded), [1] more than kMaxContacts manifolds between two cars (the rest are dropped)
@@ -214,7 +215,8 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st = nullptr, hipEvent_t ev_narrow = nullptr,
-                        hipEvent_t ev_near = nullptr, bool narrow_elsewhere = false, hipStream_t narrow_st = nullptr);  // near_st == nullptr: everything on st
+                        hipEvent_t ev_near = nullptr, bool narrow_elsewhere = false, hipStream_t narrow_st = nullptr, bool split = false,
+                        hipStream_t one_st = nullptr);  // near_st == nullptr: everything on st
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
                      int32_t *info_elapsed, int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 

@@ -15,7 +15,8 @@ struct crl_car_ctx {
     int64_t n;
     CarSoA s{};
     CarSoA stage{};  // only the per-car arrays a reset writes: their staged copies (car_commit_list_kernel)
-    hipEvent_t ev_early3 = nullptr;
+    hipEvent_t ev_early3 = nullptr, ev_one = nullptr, ev_onefr = nullptr;
+    hipStream_t one = nullptr;  // the touching envs with ONE manifold: solve and frames (high priority: a queue class of its own)
     CarConsts K_{};
     CarTrackSrc src{};
     std::vector<void *> allocs;
@@ -177,7 +178,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(touch_multi, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
     A(obs_map, (size_t)kMapBytes * 2 * n); A(map_par, n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
@@ -250,6 +251,8 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_nearfr, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_post, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_early3, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_one, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_onefr, kEvFlags) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->one, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin3, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin, kEvFlags) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
@@ -312,6 +315,9 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_nearfr) hipEventDestroy(c->ev_nearfr);
     if (c->ev_post) hipEventDestroy(c->ev_post);
     if (c->ev_early3) hipEventDestroy(c->ev_early3);
+    if (c->ev_one) hipEventDestroy(c->ev_one);
+    if (c->ev_onefr) hipEventDestroy(c->ev_onefr);
+    if (c->one) hipStreamDestroy(c->one);
     if (c->ev_fin3) hipEventDestroy(c->ev_fin3);
     if (c->ev_fin) hipEventDestroy(c->ev_fin);
     if (c->sens) hipStreamDestroy(c->sens);
@@ -447,6 +453,10 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     // and has the slack to absorb its two hops.  CRL_CAR_CRIT_ON_SIDE=1: the other way round (A/B).
     static const bool crit_on_main = getenv("CRL_CAR_CRIT_ON_SIDE") == nullptr;
     const hipStream_t crit = crit_on_main ? st : c->side, bulk = crit_on_main ? c->side : st;
+    // the touching envs with ONE manifold (94 % of them, never the slowest) are solved and drawn on a stream of their own; `crit` then
+    // carries the islands with two manifolds or more and, behind them, only THEIR frames.  Off by default; CRL_CAR_TOUCH_SPLIT=1 (A/B)
+    static const bool touch_split_env = getenv("CRL_CAR_TOUCH_SPLIT") != nullptr;  // (measured: no gain -- the frame launch behind the solve takes 80 us for 70 envs as for 1 100)
+    const bool touch_split = touch_split_env && !c->analytic && c->s.players == 2 && c->s.contacts_enabled;
     crl_timer_begin(tm, 0, st);
     auto next_counters = [&]() {  // this sub-step's counter block; car_step_kernel clears the other one for the next
         c->parity ^= 1;
@@ -474,7 +484,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
                         c->class_count);
         hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
         static const bool narrow_on_main = getenv("CRL_CAR_NARROW_ON_MAIN") != nullptr;  // (A/B: the narrow phase directly behind car_step_kernel on the caller's stream saves a cross-stream hop, but then the per-car solve starts together with the touching solve: 1.20 against 1.17 ms per step)
-        launch_car_coupled(c->s, c->K_, crit, c->side2, c->ev_narrow, c->ev_near, narrow_on_main && crit != st, st);  // (crit ends up behind side2's solve too)
+        const bool split = touch_split;
+        launch_car_coupled(c->s, c->K_, crit, c->side2, c->ev_narrow, c->ev_near, narrow_on_main && crit != st, st, split, c->one);
+        if (split) hipEventRecord(c->ev_one, c->one);  // the one-manifold islands are solved
         if (sens_after_narrow && c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
         hipStreamWaitEvent(c->sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the
                                                      // frame launches pass ONE barrier each -- on the legacy default stream they cost 30-40 us apiece)
@@ -527,8 +539,16 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             hipStreamWaitEvent(crit, c->ev_sens, 0);
         }
         if (c->s.players == 2 && c->s.contacts_enabled) {
-            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
-            else launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
+            if (c->analytic) {
+                launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
+            } else if (!touch_split) {
+                launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
+            } else {  // the islands with two manifolds or more here; the one-manifold envs' frames behind their own solve, on their own stream
+                launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_multi, c->s.coupled_count + 6, nullptr, exp_coupled / 8 + 16, c->slow_env, 1);
+                hipStreamWaitEvent(c->one, c->ev_sens, 0);
+                launch_car_obs_list(c->s, c->K_, target, c->one, c->s.touch_list, c->s.coupled_count + 2, nullptr, exp_coupled, c->slow_env, 1);
+                hipEventRecord(c->ev_onefr, c->one);
+            }
         }
         // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
         // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared on
@@ -556,16 +576,23 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         };
         const bool staged = !c->analytic;  // (the analytic raster reads the track arrays themselves: it needs them until the terminal frame is drawn)
         if (staged) {
-            early_chain(c->sens, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
-            hipEventRecord(c->ev_early3, c->sens);
+            // (on the high-priority stream when it is free: the map build's small workgroups then get CU slots ahead of the frame
+            // kernel's 32 768 wavefronts instead of behind them -- 320 us for a dozen maps otherwise.  CRL_CAR_EARLY_ON_SENS=1: A/B)
+            static const bool early_hi_env = getenv("CRL_CAR_EARLY_ON_SENS") == nullptr;
+            const hipStream_t eq = (early_hi_env && !touch_split) ? c->one : c->sens;
+            if (eq != c->sens) hipStreamWaitEvent(eq, c->ev_sens, 0);
+            early_chain(eq, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
+            hipEventRecord(c->ev_early3, eq);
             hipStreamWaitEvent(c->sens, c->ev_term, 0);
+            if (eq != c->sens) hipStreamWaitEvent(c->sens, c->ev_early3, 0);
             late_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
         } else {
             hipStreamWaitEvent(c->sens, c->ev_term, 0);
             finish_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
         }
         hipEventRecord(c->ev_fin, c->sens);
-        hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // (recorded on side behind the touching AND the near-only solve)
+        hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve (two manifolds or more -- or all of them)
+        if (touch_split) hipStreamWaitEvent(c->side2, c->ev_one, 0);
         hipStreamWaitEvent(c->side2, c->ev_sens, 0);
         if (staged) {
             hipStreamWaitEvent(c->side2, c->ev_early3, 0);
@@ -578,6 +605,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipEventRecord(c->ev_join, c->side);
         hipStreamWaitEvent(c->side2, c->ev_fin, 0);
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
+        if (touch_split) hipStreamWaitEvent(c->side2, c->ev_onefr, 0);
         hipEventRecord(c->ev_fin3, c->side2);
         queue_walk_ahead(c, c->sens);
         hipStreamWaitEvent(st, c->ev_fin3, 0);
