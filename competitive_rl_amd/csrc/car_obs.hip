@@ -403,9 +403,11 @@ __global__ __launch_bounds__(64) void car_poly_kernel(CarSoA s, CarConsts K, con
 static constexpr int kPitch = 28;  // dwords per tile row in LDS (96 B of pixels + 16 B: the 4-row patch stores spread over the banks)
 
 // CHECK = false: every source pixel is inside the window and inside the crop (ViewParams.flags == 3)
+// it0, it_step: which of the nine 32 x 32-pixel regions this wavefront draws (0, 1: all of them; w, W: every W-th from w on)
 template <bool CHECK>
 __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, const int dx00, const int dy00, const int isin, const int icos,
-                                               const int rx, const int ry, uint32_t *__restrict__ tile, const int lane) {
+                                               const int rx, const int ry, uint32_t *__restrict__ tile, const int lane, const int it0 = 0,
+                                               const int it_step = 1) {
     uint32_t bgpal = 0;
     if (CHECK) {  // rotate()'s background colour = the crop's first pixel
         if (rx >= 0 && ry >= 0 && rx < kMapW && ry < kMapW) {
@@ -414,7 +416,7 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
         }
     }
 #pragma unroll 1
-    for (int it = 0; it < 9; it++) {
+    for (int it = it0; it < 9; it += it_step) {
         // a wavefront iteration covers a 32 x 32-pixel region: lane = a 4 x 4 patch, so one load instruction reads 64 pixels
         // of ONE region (a handful of 128-byte blocks) and a lane's 16 loads stay within one or two blocks
         const int X0 = 32 * (it % 3) + 4 * (lane & 7), Y0 = 32 * (it / 3) + 4 * (lane >> 3);
@@ -458,21 +460,27 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
 }
 
 // vp: ViewParams words; rec / cnt: the car polygons' spans (global memory from the camera / polygon kernels, or LDS in the fused kernel)
+// WAVES wavefronts per tile: 1 (the big launch: throughput), or 4 (the list launches at the end of a step's chains: latency -- the
+// nine background regions are shared out, the overlays stay with wavefront 0 -- LDS operations of ONE wavefront execute in
+// program order, which is what makes a later layer overwrite an earlier one --, the stream-out is shared again)
+template <int WAVES = 1>
 __device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restrict__ obs, const int64_t env, const int viewer, uint32_t *tile,
                                              const int32_t *vp, const uint32_t *rec, const uint8_t *cnt) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = env * s.players + viewer;
     const int dx00 = vp[0], dy00 = vp[1], isin = vp[2], icos = vp[3], rx = vp[4], ry = vp[5], flags = vp[6], text_idx = vp[7];
     const uint8_t *map = env_map(s, env);
     uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile);
     // ---- background
     if (flags == 3) {
-        obs_background<false>(map, dx00, dy00, isin, icos, rx, ry, tile, lane);
+        obs_background<false>(map, dx00, dy00, isin, icos, rx, ry, tile, lane, wave, WAVES);
     } else if (flags & 4) {
-        for (int i = lane; i < 96 * kPitch; i += 64) tile[i] = G_GRASS * 0x01010101u;
+        for (int i = threadIdx.x; i < 96 * kPitch; i += 64 * WAVES) tile[i] = G_GRASS * 0x01010101u;
     } else {
-        obs_background<true>(map, dx00, dy00, isin, icos, rx, ry, tile, lane);
+        obs_background<true>(map, dx00, dy00, isin, icos, rx, ry, tile, lane, wave, WAVES);
     }
+    if (WAVES > 1) __syncthreads();
+    if (wave == 0) {
     // ---- cars.  Draw order: car 0 wheels (black), car 0 hull, car 1 wheels, car 1 hull; within a layer every span has the
     // same colour, and LDS operations of ONE wavefront execute in program order, so a later layer simply overwrites
     const uint32_t *cnt32 = reinterpret_cast<const uint32_t *>(cnt);  // one byte per polygon, one word per layer
@@ -511,12 +519,14 @@ __device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restric
         for (int row = 0; row < 5; row++)
             if ((rows[row] >> lane) & 1u) tile8[(91 + row) * (kPitch * 4) + lane] = 255;
     }
+    }  // wave 0: overlays
+    if (WAVES > 1) __syncthreads();
     // ---- stream the tile out: 16 B per lane, 1 KiB contiguous per wave store
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + t * (96 * 96));
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const int c = i * 64 + lane, row = c / 6, col = c - row * 6;
-        out[c] = *reinterpret_cast<const uint4 *>(&tile[row * kPitch + col * 4]);
+    for (int i = 0; i < (9 + WAVES - 1) / WAVES; i++) {
+        const int c = (i * WAVES + wave) * 64 + lane, row = c / 6, col = c - row * 6;
+        if (WAVES == 1 || c < 576) out[c] = *reinterpret_cast<const uint4 *>(&tile[row * kPitch + col * 4]);
     }
 }
 
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(64) void car_obs_list_kernel(CarSoA s, CarConsts K,
             }
             if (lane < 16) cnt_s[lane] = (uint8_t)poly_compute(s, K, env, viewer, lane, cam, reinterpret_cast<uint32_t *>(vp_s) + 8, rec_s + lane * kSpanSlots);
             __syncthreads();
-            car_obs_tile(s, obs, env, viewer, tile, vp_s, rec_s, cnt_s);
+            car_obs_tile(s, obs, env, viewer, tile, vp_s, rec_s, cnt_s);  // (<4>, 256 threads: 135 us instead of 70 for a thousand tiles -- four times the camera work, and four wavefronts to place per tile)
         }
         __syncthreads();  // the next tile reuses the LDS
     }

@@ -2,8 +2,7 @@ python -m pytest tests/test_hip_car_parity.py tests/test_hip_round2.py tests/tes
 B="python bench.py --workload car --steps 400 --warmup 5 --no-cpu-baseline"
 P='import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["config"].get("resets_in_timed_region"), d["roofline"]["avg_kernel_us"])'
 for k in 1 2 3; do
-echo "== early on hi"; $B 2>/dev/null | tail -1 | python -c "$P"
-echo "== early on sens"; CRL_CAR_EARLY_ON_SENS=1 $B 2>/dev/null | tail -1 | python -c "$P"
+echo "== default"; $B 2>/dev/null | tail -1 | python -c "$P"
 done
 echo "== from reset"; CRL_BENCH_CAR_PREROLL=0 $B 2>/dev/null | tail -1 | python -c "$P"
-CAR_STEPS=100 bash tools/car_timeline.sh > gpurun_out/tl_x1.txt 2>&1; python tools/car_timeline_summary.py > gpurun_out/tl_x1_summ.txt
+CAR_STEPS=100 bash tools/car_timeline.sh > gpurun_out/tl_y1.txt 2>&1; python tools/car_timeline_summary.py > gpurun_out/tl_y1_summ.txt
