@@ -164,20 +164,23 @@ struct WPoly {
     V2 w[8], n[8];  // world vertices, world edge normals
     int cnt;
 };
+// MAXV: the largest vertex count among the polygons the wavefront collides this time (4: boxes and the hull's quadrilaterals -- a
+// quarter of the 8 x 8 table)
+template <int MAXV>
 __device__ inline float max_separation_w(int &edge, const WPoly &p1, const WPoly &p2) {
-    // both polygons' data comes in with back-to-back LDS reads and is indexed statically (8 x 8, entries past a polygon's
+    // both polygons' data comes in with back-to-back LDS reads and is indexed statically (MAXV x MAXV, entries past a polygon's
     // count switched off): a rolled double loop is a chain of ~100-cycle LDS round trips
-    V2 n1[8], v1[8], w2[8];
+    V2 n1[MAXV], v1[MAXV], w2[MAXV];
 #pragma unroll
-    for (int i = 0; i < 8; i++) n1[i] = p1.n[i], v1[i] = p1.w[i], w2[i] = p2.w[i];
+    for (int i = 0; i < MAXV; i++) n1[i] = p1.n[i], v1[i] = p1.w[i], w2[i] = p2.w[i];
     const int c1 = p1.cnt, c2 = p2.cnt;
     float best = -3.4e38f;
     int bi = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < MAXV; i++) {
         float si = 3.4e38f;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < MAXV; j++) {
             const float sij = dot(n1[i], w2[j] - v1[i]);
             if (j < c2 && sij < si) si = sij;
         }
@@ -187,14 +190,15 @@ __device__ inline float max_separation_w(int &edge, const WPoly &p1, const WPoly
     return best;
 }
 // nl: local edge normals of every fixture shape (table in LDS, [fixture][edge]), as shape_normal computes them
+template <int MAXV>
 __device__ void collide_polygons_w(Contact &c, const Shape &pa, const XF &xa, const WPoly &wa, const V2 *nla, const Shape &pb, const XF &xb,
                                    const WPoly &wb, const V2 *nlb) {
     c.count = 0;
     const float totalRadius = 0.02f;
     int edgeA, edgeB;
-    const float sepA = max_separation_w(edgeA, wa, wb);
+    const float sepA = max_separation_w<MAXV>(edgeA, wa, wb);
     if (sepA > totalRadius) return;
-    const float sepB = max_separation_w(edgeB, wb, wa);
+    const float sepB = max_separation_w<MAXV>(edgeB, wb, wa);
     if (sepB > totalRadius) return;
     const bool flip = sepB > 0.98f * sepA + 0.001f;
     const Shape &p1 = flip ? pb : pa, &p2 = flip ? pa : pb;
@@ -297,6 +301,11 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
 #endif
     __builtin_amdgcn_s_setprio(3);  // on the step's critical path (narrow phase -> touching solve -> their frames), beside bulk kernels
     {
+        const int count0 = *s.coupled_count;
+        if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host) *s.coupled_to_host = count0;
+        if ((int)blockIdx.x >= count0) return;  // (before the tables are staged: most of the grid has nothing to do)
+    }
+    {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(s.consts_dev);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&Ks);
         for (int i = lane; i < (int)(sizeof(CarConsts) / 4); i += 64) dst[i] = src[i];
@@ -306,16 +315,24 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
     (void)Kv;
     // local edge normals of the five distinct shapes (hull polygons 0-3, wheel box): one lane per edge, once per workgroup
     __shared__ V2 nl[8][8];
+    __shared__ float circ[5][3];  // bounding circle of each shape (local centre, radius + margin): rejects most pairs cheaply
     if (lane < 40) {
         const int f = lane >> 3, e = lane & 7;  // f = 4: every wheel
         const Shape sh = shape_of(K, f);
         if (e < sh.n) nl[f][e] = shape_normal(sh, e);
+        if (e == 0) {
+            V2 ctr = mk(0.f, 0.f);
+            for (int i = 0; i < sh.n; i++) ctr = ctr + shape_vertex(sh, i);
+            ctr = (1.0f / sh.n) * ctr;
+            float r2 = 0.f;
+            for (int i = 0; i < sh.n; i++) r2 = fmaxf(r2, dot(shape_vertex(sh, i) - ctr, shape_vertex(sh, i) - ctr));
+            circ[f][0] = ctr.x, circ[f][1] = ctr.y, circ[f][2] = sqrtf(r2) + 0.03f;
+        }
     }
     __syncthreads();
     __shared__ WPoly wp[64][2];
     const int count = *s.coupled_count;
     const int64_t M = 2 * s.n;
-    if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host) *s.coupled_to_host = count;
 #ifdef CRL_ABLATION
     const unsigned long long sn1 = __builtin_readcyclecounter();
 #endif
@@ -344,21 +361,19 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
                 const V2 lc = f < 4 ? mk(K.hull_lc[0], K.hull_lc[1]) : mk(0.f, 0.f);
                 xf[k].p = mk(bx, by) - rotv(xf[k].s, xf[k].c, lc);
                 // bounding circle of the fixture (world centre, radius): circles that do not overlap cannot be within the
-                // 0.02 contact margin -- rejects most pairs cheaply
-                const Shape sh = shape_of(K, f);
-                V2 ctr = mk(0.f, 0.f);
-                for (int i = 0; i < sh.n; i++) ctr = ctr + shape_vertex(sh, i);
-                ctr = (1.0f / sh.n) * ctr;
-                float r2 = 0.f;
-                for (int i = 0; i < sh.n; i++) r2 = fmaxf(r2, dot(shape_vertex(sh, i) - ctr, shape_vertex(sh, i) - ctr));
-                const V2 wc = xmul(xf[k], ctr);
-                ccx[k] = wc.x, ccy[k] = wc.y, crad[k] = sqrtf(r2) + 0.03f;
+                // 0.02 contact margin
+                const float *cq = circ[f < 4 ? f : 4];
+                const V2 wc = xmul(xf[k], mk(cq[0], cq[1]));
+                ccx[k] = wc.x, ccy[k] = wc.y, crad[k] = cq[2];
             }
             const float dx = ccx[0] - ccx[1], dy = ccy[0] - ccy[1], rr = crad[0] + crad[1];
 #ifdef CRL_ABLATION
             sb = __builtin_readcyclecounter();
 #endif
-            if (!(dx * dx + dy * dy > rr * rr)) {
+            const bool cand = !(dx * dx + dy * dy > rr * rr);
+            // (wave-uniform: does any candidate pair of this env involve the hull's octagon?)
+            const bool big = __any(cand && (shape_of(K, fa).n > 4 || shape_of(K, fb).n > 4));
+            if (cand) {
 #pragma unroll
                 for (int k = 0; k < 2; k++) {  // both fixtures into world space once: vertices, and normals as rotv(q, local normal)
                     const int f = k ? fb : fa;
@@ -367,7 +382,8 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
                     w.cnt = sh.n;
                     for (int i = 0; i < sh.n; i++) w.w[i] = xmul(xf[k], shape_vertex(sh, i)), w.n[i] = rotv(xf[k].s, xf[k].c, nl[f < 4 ? f : 4][i]);
                 }
-                collide_polygons_w(c, shape_of(K, fa), xf[0], wp[lane][0], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[lane][1], nl[fb < 4 ? fb : 4]);
+                if (big) collide_polygons_w<8>(c, shape_of(K, fa), xf[0], wp[lane][0], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[lane][1], nl[fb < 4 ? fb : 4]);
+                else collide_polygons_w<4>(c, shape_of(K, fa), xf[0], wp[lane][0], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[lane][1], nl[fb < 4 ? fb : 4]);
             }
         }
 #ifdef CRL_ABLATION
