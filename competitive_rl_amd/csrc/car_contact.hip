@@ -670,7 +670,10 @@ __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const int m
 // per wavefront wastes lanes, not time: the chip has a thousand SIMDs for a few hundred touching envs, every wave-uniform
 // shortcut (which constraint kinds occur, how many manifolds, position iterations until THIS island has converged) becomes
 // exact, and the kernel -- which ends with its slowest wavefront -- no longer pays for the union of its envs' worst cases.
-template <int NK, int EPW>
+// TAIL: the env may have more manifolds than the NK kept in registers; those go through their LDS rows every iteration
+// (44 LDS reads per row and iteration -- still far cheaper than what the register allocator does when three rows, five bodies and
+// four joints do not fit 512 registers: NK = 3 spilled 167 of them, 66 scratch accesses inside the velocity loop)
+template <int NK, int EPW, bool TAIL>
 __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K, const int32_t *list, const int list_count, const int slot_base,
                                             CarRegs (*sh_car)[2], Contact (*sh_ct)[kMaxContacts], TouchC (*sh_tc)[kMaxContacts]) {
     const int me = threadIdx.x & 1;
@@ -800,7 +803,7 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         kc[k] = kc_load(tc[ok ? k : 0], ct[ok ? k : 0], me, ok, K);
         any1 = any1 || __any(kc[k].count == 1), any2 = any2 || __any(kc[k].count == 2);
     }
-    bool tail1 = false, tail2 = false;  // contacts past NK (NK == 3 only)
+    bool tail1 = false, tail2 = false;  // contacts past NK (TAIL only)
     for (int k = NK; k < nc_wave; k++) tail1 = tail1 || __any(k < nc && tc[k < nc ? k : 0].count == 1), tail2 = tail2 || __any(k < nc && tc[k < nc ? k : 0].count == 2);
 #ifdef CRL_ABLATION
     const unsigned long long st1 = __builtin_readcyclecounter();
@@ -811,7 +814,7 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         isl_joints_vel_mode(jmode, r, jt, K, h);
 #pragma unroll
         for (int k = 0; k < NK; k++) contact_vel(r, kc[k], me, friction, any1, any2);
-        if (NK == 3) {
+        if (TAIL) {
 #pragma unroll 1
             for (int k = NK; k < nc_wave; k++) {
                 const bool ok = k < nc;
@@ -844,7 +847,7 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 #endif
 #pragma unroll
         for (int k = 0; k < NK; k++) contact_pos(r, kc[k], me, hlc, minSep);
-        if (NK == 3) {
+        if (TAIL) {
 #pragma unroll 1
             for (int k = NK; k < nc_wave; k++) {
                 const bool ok = k < nc;
@@ -903,8 +906,9 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 
 // one launch, blockIdx.y = manifold-count class (0: nc == 1, 1: nc == 2, 2: nc >= 3); the workgroups loop over the class's list.
 // EPW1 = envs per wavefront of class 0 (94 % of the touching envs); two manifolds or more (the slowest islands): one env per wavefront.
+// NK2 / NK3: manifolds kept in registers for classes 1 and 2 (the rest through LDS).
 // (LDS rows for 32 envs whatever the class uses: two workgroups per CU, 512 on the chip, is more than a step has)
-template <int EPW1>
+template <int EPW1, int NK2, int NK3>
 __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, int cls0) {
     const int cls = cls0 + blockIdx.y;
     const int count = s.coupled_count[2 + cls];
@@ -916,9 +920,9 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
     __shared__ __attribute__((aligned(16))) TouchC sh_tc[32][kMaxContacts];
     const int32_t *list = s.touch_list + (int64_t)cls * s.n;
     for (int base = blockIdx.x * epw; base < count; base += gridDim.x * epw) {
-        if (cls == 0) touch_solve<1, EPW1>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
-        else if (cls == 1) touch_solve<2, 1>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
-        else touch_solve<3, 1>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        if (cls == 0) touch_solve<1, EPW1, false>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        else if (cls == 1) touch_solve<NK2, 1, (NK2 < 2)>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        else touch_solve<NK3, 1, true>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
 }
@@ -935,14 +939,18 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hip
     if (near_st != narrow_st) hipStreamWaitEvent(near_st, ev_narrow, 0);
     if (st != narrow_st) hipStreamWaitEvent(st, ev_narrow, 0);
     hipLaunchKernelGGL(car_near_kernel, dim3((unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512)), dim3(64), 0, near_st, s, k);
-    static const int epw1 = getenv("CRL_CAR_TOUCH_EPW1") ? atoi(getenv("CRL_CAR_TOUCH_EPW1")) : 8;  // (A/B: 32 | 8 | 4; measured 1.19 / 1.17 / 1.17 ms per step)
+    static const int epw1 = getenv("CRL_CAR_TOUCH_EPW1") ? atoi(getenv("CRL_CAR_TOUCH_EPW1")) : 8;  // (A/B: 32 | 8; measured 1.19 / 1.17 ms per step)
     const unsigned g = (unsigned)((s.n + 31) / 32 < 256 ? (s.n + 31) / 32 : 256);
     // split: the one-manifold envs (94 % of the touching ones, never the slowest) on a stream of their own -- `st` then only carries
     // the islands with two manifolds or more, and behind them only THEIR frames
+    // registers for (two-manifold class, three-or-more class): 23 = two and three rows (A/B: 11 | 12 | 22 | 23)
+    static const int nkreg = getenv("CRL_CAR_TOUCH_NKREG") ? atoi(getenv("CRL_CAR_TOUCH_NKREG")) : 23;
     auto touch = [&](hipStream_t q, unsigned classes, int cls0) {
-        if (epw1 == 4) hipLaunchKernelGGL(car_touch_kernel<4>, dim3(g, classes), dim3(64), 0, q, s, k, cls0);
-        else if (epw1 == 32) hipLaunchKernelGGL(car_touch_kernel<32>, dim3(g, classes), dim3(64), 0, q, s, k, cls0);
-        else hipLaunchKernelGGL(car_touch_kernel<8>, dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+        if (epw1 == 32) hipLaunchKernelGGL((car_touch_kernel<32, 2, 3>), dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+        else if (nkreg == 11) hipLaunchKernelGGL((car_touch_kernel<8, 1, 1>), dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+        else if (nkreg == 12) hipLaunchKernelGGL((car_touch_kernel<8, 1, 2>), dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+        else if (nkreg == 22) hipLaunchKernelGGL((car_touch_kernel<8, 2, 2>), dim3(g, classes), dim3(64), 0, q, s, k, cls0);
+        else hipLaunchKernelGGL((car_touch_kernel<8, 2, 3>), dim3(g, classes), dim3(64), 0, q, s, k, cls0);
     };
     if (split) {
         hipStreamWaitEvent(one_st, ev_narrow, 0);
