@@ -87,6 +87,7 @@ struct CarSoA {
     uint32_t *episode;  // resets so far (RNG counter)
     int32_t *ntiles;
     float4 *tile_aabb;  // [512][n]
+    float4 *tile_blk;   // [64][n] union of the boxes of tiles 8 b .. 8 b + 7: what the wheel sensors' broadphase looks at first
     float *tile_poly;   // [512][10][n]  CCW float32 (b2PolygonShape)
     float *border_poly; // [512][8][n]
     uint8_t *border;    // [512][n]  0 none, 1 white, 2 red

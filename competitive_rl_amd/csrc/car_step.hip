@@ -443,15 +443,37 @@ __global__ __launch_bounds__(64, 4) void car_sensor_kernel(CarSoA s, CarConsts K
     const int per = (ntiles + 3) >> 2, tbeg = w * per, tend = min(tbeg + per, ntiles);
     int c4[4] = {0, 0, 0, 0};
     bool ovf = (force_serial & 1) != 0;  // bits 2, 4, 8: timing ablations (wrong results): no polygon distance / no polygon loads / no scan
+    // two passes: which 8-tile blocks of the quarter come near any of the car's wheel boxes (one united box per block: 16 bytes
+    // instead of 128), then only those blocks' tiles, in ascending order as before.  (A wavefront holds 16 cars at 16 different
+    // places: testing every tile box cost 4.8 KB per car and step and was the largest fetch of the whole step.)
+    uint32_t hit = 0;
+    const int b0 = tbeg >> 3, nblk = tend > tbeg ? ((tend - 1) >> 3) - b0 + 1 : 0;  // <= 17 for 512 tiles
+    if (!(force_serial & 8)) {
 #pragma unroll 1
-    for (int t0 = tbeg; t0 < tend && !(force_serial & 8); t0 += 8) {
+        for (int k0 = 0; k0 < nblk; k0 += 6) {
+            float4 B[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) B[j] = s.tile_blk[(int64_t)(b0 + min(k0 + j, nblk - 1)) * s.n + env];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const bool any = box_near(qb[0], B[j]) || box_near(qb[1], B[j]) || box_near(qb[2], B[j]) || box_near(qb[3], B[j]);
+                if (any && k0 + j < nblk) hit |= 1u << (k0 + j);
+            }
+        }
+    }
+#pragma unroll 1
+    while (__any(hit != 0u)) {
+        const bool on = hit != 0u;
+        const int kb = on ? __builtin_ctz(hit) : 0;
+        hit &= hit - 1u;
+        const int base = (b0 + kb) * 8;
         float4 bbs[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) bbs[j] = s.tile_aabb[(int64_t)min(t0 + j, tend - 1) * s.n + env];
+        for (int j = 0; j < 8; j++) bbs[j] = s.tile_aabb[(int64_t)min(max(base + j, tbeg), max(tend - 1, 0)) * s.n + env];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const int t = t0 + j;
-            if (t >= tend) continue;
+            const int t = base + j;
+            if (!on || t < tbeg || t >= tend) continue;
 #pragma unroll
             for (int o = 0; o < 4; o++) {
                 if (box_near(qb[o], bbs[j])) {

@@ -219,6 +219,17 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
         s.map_yr[env * kCarMaxTiles + i] = (uint32_t)(uint16_t)(int16_t)ylo | ((uint32_t)(uint16_t)(int16_t)yhi << 16);
     }
     if (overflow) atomicAdd(&s.map_overflow[env], overflow);
+    // the boxes of 8 consecutive tiles, united: the sensors' broadphase tests these first (the tile boxes above were stored by
+    // other lanes of this wavefront: agent-scope fence before they are read back)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    for (int b = lane; 8 * b < len; b += 64) {
+        float4 u = s.tile_aabb_em[env * kCarMaxTiles + 8 * b];
+        for (int t = 8 * b + 1; t < min(8 * b + 8, len); t++) {
+            const float4 q = s.tile_aabb_em[env * kCarMaxTiles + t];
+            u = make_float4(fminf(u.x, q.x), fminf(u.y, q.y), fmaxf(u.z, q.z), fmaxf(u.w, q.w));
+        }
+        s.tile_blk[(int64_t)b * n + env] = u;
+    }
     const double ia = T(0, 1), ix = T(0, 2), iy = T(0, 3);
     if (lane == 0) s.start_pose[0 * n + env] = (float)ia, s.start_pose[1 * n + env] = (float)ix, s.start_pose[2 * n + env] = (float)iy;
     if (lane < s.players) {

@@ -173,7 +173,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(body, 30 * M); A(jimp, 12 * M); A(jmotor, 4 * M); A(jspeed, 4 * M); A(jlimit, 4 * M);
     A(wgas, 4 * M); A(womega, 4 * M); A(wphase, 4 * M); A(wtiles, 4 * kWheelSlots * M); A(visited, 16 * M);
     A(reward, M); A(prev_reward, M); A(step_acc, M); A(visited_count, M); A(last_block, M); A(done, M); A(step_count, M); A(first_step, M);
-    A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
+    A(elapsed, n); A(episode, n); A(ntiles, n); A(tile_aabb, (size_t)kCarMaxTiles * n); A(tile_blk, (size_t)(kCarMaxTiles / 8) * n); A(tile_poly, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
@@ -809,6 +809,14 @@ int crl_car_set_track_impl(crl_car_ctx *c, int64_t env, int32_t nt, const double
     hipMemcpyAsync(c->s.ntiles + env, &nt, 4, hipMemcpyHostToDevice, st);
     hipMemcpy2DAsync(c->s.tile_poly + env, n * 4, tp.data(), 4, 4, (size_t)nt * 10, hipMemcpyHostToDevice, st);
     hipMemcpy2DAsync(c->s.tile_aabb + env, n * 16, aabb.data(), 16, 16, (size_t)nt, hipMemcpyHostToDevice, st);
+    std::vector<float4> blk((size_t)(nt + 7) / 8);
+    for (int b = 0; b < (int)blk.size(); b++) {
+        float4 u = aabb[8 * b];
+        for (int t = 8 * b + 1; t < std::min(8 * b + 8, (int)nt); t++)
+            u = make_float4(std::min(u.x, aabb[t].x), std::min(u.y, aabb[t].y), std::max(u.z, aabb[t].z), std::max(u.w, aabb[t].w));
+        blk[b] = u;
+    }
+    hipMemcpy2DAsync(c->s.tile_blk + env, n * 16, blk.data(), 16, 16, blk.size(), hipMemcpyHostToDevice, st);
     hipMemcpy2DAsync(c->s.border_poly + env, n * 4, bp.data(), 4, 4, (size_t)nt * 8, hipMemcpyHostToDevice, st);
     hipMemcpy2DAsync(c->s.border + env, n, bflag.data(), 1, 1, (size_t)nt, hipMemcpyHostToDevice, st);
     if (start_pose) hipMemcpy2DAsync(c->s.start_pose + env, n * 4, start_pose, 4, 4, 3, hipMemcpyHostToDevice, st);
