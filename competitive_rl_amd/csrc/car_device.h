@@ -97,7 +97,7 @@ struct CarSoA {
     float *tile_poly_em;   // [n][512][10]
     float *border_poly_em; // [n][512][8]
     uint8_t *border_em;    // [n][512]
-    double *track_scratch;  // [2500][4][n] points (alpha, beta, x, y; f64) of the walk generated AHEAD for the env's next episode
+    double *track_scratch;  // [n][2500][4] points (alpha, beta, x, y; f64) of the walk generated AHEAD for the env's next episode
     double *track_scratch_b;  // same shape: where a reset walks inline when no finished walk-ahead is there
     uint32_t *walk_tag;     // [n] episode index the stored walk belongs to (0xFFFFFFFF = none); written last, device-scope release
     int32_t *walk_list, *walk_count;  // [n], [1]: the envs the current walk-ahead launch has to walk, compacted

@@ -71,7 +71,8 @@ __device__ inline void walk_init(Walk &w) {
     w.x = 1.5 * CAR_TRACK_RAD, w.y = 0, w.beta = 0, w.dest_i = 0, w.laps = 0, w.visited_other_side = 0;
 }
 
-// Walks one track attempt, keeping EVERY point in `pts` (global scratch [kWalkMax][4] per env, stride n:
+// Walks one track attempt, keeping EVERY point in `pts` (global scratch [kWalkMax][4] per env, env-major -- with the points strided by
+// the env count every store of the milliseconds-long walk-ahead opened another page, and the TLB misses slowed whatever ran beside it:
 // 80 KB per env buys not having to repeat the ~2 500-step f64 walk once the lap's end points are known).
 // On success returns the lap length and, in *first, the index of its first point; 0 otherwise.
 static constexpr int kWalkMax = 2500;
@@ -140,7 +141,7 @@ __device__ inline void store_poly_ccw(const double (*v)[2], int nv, float *dst, 
 __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const double *trk, int len, int swap, uint8_t *flag /* LDS [512] */) {
     const int64_t n = s.n, M = (int64_t)s.players * n;
     const int lane = threadIdx.x & 63;
-    auto T = [&](int i, int q) { return trk[((int64_t)i * 4 + q) * n]; };
+    auto T = [&](int i, int q) { return trk[(int64_t)i * 4 + q]; };  // (env-major scratch: a walk's points are contiguous)
     if (lane == 0) s.ntiles[env] = len, s.map_overflow[env] = 0;
     // one vertex of a polygon of render_road_for_observation_map (crmp:745-753): (obs_scale * -v + world_size / 2), truncated
     // by pygame; kept in window coordinates as int16 (the window holds every track: map_overflow counts what does not fit)
@@ -292,7 +293,7 @@ __device__ void gen_walk(const CarSoA &s, const CarTrackSrc &src, int64_t env, u
                 }
             }
         }
-        len = create_track(u, pts, s.n, &first);
+        len = create_track(u, pts, 1, &first);
     }
     *len_out = len, *first_out = first, *swap_out = swap;
 }
@@ -329,14 +330,14 @@ __device__ inline void reset_one_env(CarSoA &s, const CarConsts &K, const CarTra
     const double *pts;
     if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == episode) {
         len = s.walk_len[env], first = s.walk_first[env], swap = s.walk_swap[env];
-        pts = s.track_scratch + env;
+        pts = s.track_scratch + env * (int64_t)(kWalkMax * 4);
     } else {
-        if (lane == 0) gen_walk(s, src, env, episode, s.track_scratch_b + env, &len, &first, &swap);
+        if (lane == 0) gen_walk(s, src, env, episode, s.track_scratch_b + env * (int64_t)(kWalkMax * 4), &len, &first, &swap);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // lane 0's points are read by the whole wave below
         len = __shfl(len, 0), first = __shfl(first, 0), swap = __shfl(swap, 0);
-        pts = s.track_scratch_b + env;
+        pts = s.track_scratch_b + env * (int64_t)(kWalkMax * 4);
     }
-    finish_reset(s, K, env, pts + (int64_t)first * 4 * s.n, len, swap, flag);
+    finish_reset(s, K, env, pts + (int64_t)first * 4, len, swap, flag);
     // The episode index is what the walk-ahead compares its tag with: it is published only now, with a release, after
     // every lane has consumed the stored walk -- a walk-ahead wavefront that starts while this reset is still reading
     // `track_scratch` sees the old index (tag == episode: nothing to do) and cannot overwrite the points under it.
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSr
     const uint32_t episode = __hip_atomic_load(&s.episode[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == episode) return;
     int len, first, swap;
-    gen_walk(s, src, env, episode, s.track_scratch + env, &len, &first, &swap);
+    gen_walk(s, src, env, episode, s.track_scratch + env * (int64_t)(kWalkMax * 4), &len, &first, &swap);
     s.walk_len[env] = len, s.walk_first[env] = first, s.walk_swap[env] = swap;
     __hip_atomic_store(&s.walk_tag[env], episode, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }

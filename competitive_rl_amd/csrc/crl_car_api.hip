@@ -258,7 +258,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_c1, kEvFlags) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own
+        hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, getenv("CRL_CAR_GEN_NORMAL_PRIO") ? 0 : prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own (A/B switch)
 
         hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_walk, kEvFlags) != hipSuccess ||
