@@ -35,7 +35,7 @@ struct crl_car_ctx {
     int32_t *class_count = nullptr;  // [3] their lengths (inside `counters`)
     int32_t *counters = nullptr;     // [2][16] per step parity: coupled_count[8], class_count[2]; a step's first kernel clears the other block
     int parity = 0;
-    hipEvent_t ev_nearfr = nullptr, ev_post = nullptr;
+    hipEvent_t ev_post = nullptr;
     hipEvent_t ev_fin3 = nullptr;
     hipEvent_t ev_fin = nullptr;
     int32_t *class_count_host = nullptr, *class_count_hdev = nullptr;  // host-mapped copy (one step late): sizes the next step's launches
@@ -43,7 +43,7 @@ struct crl_car_ctx {
     hipStream_t side2 = nullptr;  // the near-only coupled envs (plain island solves), beside the touching ones on `side`
     hipEvent_t ev_narrow = nullptr, ev_near = nullptr;
     hipStream_t sens = nullptr;  // the wheel-sensor contacts of a step, beside its solve
-    hipEvent_t ev_sens = nullptr, ev_c1 = nullptr;
+    hipEvent_t ev_sens = nullptr;
     hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
     hipEvent_t ev_reset = nullptr;
     hipEvent_t ev_walk = nullptr;  // recorded behind every walk-ahead launch: no new one is queued while it is pending
@@ -248,7 +248,6 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_narrow, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_near, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_nearfr, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_post, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_early3, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_one, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_onefr, kEvFlags) != hipSuccess ||
@@ -257,7 +256,6 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_fin, kEvFlags) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_c1, kEvFlags) != hipSuccess ||
         hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, getenv("CRL_CAR_GEN_NORMAL_PRIO") ? 0 : prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own (A/B switch)
 
         hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess ||
@@ -312,7 +310,6 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->side2) hipStreamDestroy(c->side2);
     if (c->ev_narrow) hipEventDestroy(c->ev_narrow);
     if (c->ev_near) hipEventDestroy(c->ev_near);
-    if (c->ev_nearfr) hipEventDestroy(c->ev_nearfr);
     if (c->ev_post) hipEventDestroy(c->ev_post);
     if (c->ev_early3) hipEventDestroy(c->ev_early3);
     if (c->ev_one) hipEventDestroy(c->ev_one);
@@ -322,7 +319,6 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_fin) hipEventDestroy(c->ev_fin);
     if (c->sens) hipStreamDestroy(c->sens);
     if (c->ev_sens) hipEventDestroy(c->ev_sens);
-    if (c->ev_c1) hipEventDestroy(c->ev_c1);
     if (c->gen) hipStreamDestroy(c->gen);
     if (c->ev_reset) hipEventDestroy(c->ev_reset);
     if (c->ev_walk) hipEventDestroy(c->ev_walk);
@@ -508,23 +504,24 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             crl_timer_end(tm, 1, st);
         }
     } else {
-        // Four streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished, 3 finished and coupled):
-        //   st     per-car solve -> frames of class 0 (the big launch)
+        // Streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished, 3 finished and coupled);
+        // crit / bulk: the caller's stream and `side` (see the top of the function):
+        //   crit   narrow phase of the coupled envs -> the touching ones' island solve -> their frames (the step's longest chain)
+        //   bulk   per-car solve -> camera, polygons -> frames of class 0 (the big launch)
+        //   side2  env bookkeeping; the coupled envs where nothing touches (two islands of their own) -> their frames; behind the
+        //          touching solve the terminal frames + commit of the envs that are finished AND coupled; the step's join
         //   sens   wheel sensors (tile rewards, road_visited: they read the transforms the step started from and feed nothing into
-        //          its solve; every frame shows the reward, so every frame launch waits for them); then the finished envs: terminal
-        //          frame, reset, map, first frame of the new episode
-        //   side   narrow phase of the coupled envs -> the touching ones' island solve -> their frames
-        //   side2  the coupled envs where nothing touches (two islands of their own) -> their frames; then the few envs that are
-        //          finished AND coupled
-        // (no more streams than that: the runtime maps streams of one priority onto four hardware queues, and two streams
-        // that share one wait for each other's kernels; the milliseconds-long walk-ahead has a priority class of its own)
+        //          its solve; every frame shows the reward, so every frame launch waits for them); behind the per-car solve the
+        //          terminal frames + commit of the finished envs on their own
+        //   one    (high priority) the finished envs' NEW episode, prepared early on the staged view: reset, map, first frame
+        // (streams of one priority share four hardware queues, and two streams that share one wait for each other's kernels;
+        // the milliseconds-long walk-ahead has a priority class of its own)
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
         if (c->s.players == 2 && c->s.contacts_enabled) {
             hipStreamWaitEvent(c->side2, c->ev_sens, 0);
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
-            hipEventRecord(c->ev_nearfr, c->side2);
         }
         hipEventRecord(c->ev_coupled, crit);
         // bulk: the per-car solve, then the frames of every env that is neither coupled nor finished

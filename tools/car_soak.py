@@ -1,5 +1,7 @@
-"""Race hunt for the two-stream CarRacing step: two identical runs must produce identical rewards,
-dones and frame checksums at every step (run on the GPU box: PYTHONPATH=. python tools/car_soak.py)."""
+"""Race hunt for the multi-stream CarRacing step: two identical runs must produce identical rewards, dones and frame checksums
+at every step, and so must a third run with CRL_CAR_NO_OVERLAP=1 (one stream, everything in place: the sequential reference of
+the pipeline -- staged resets, walk-ahead timing and all).  Run on the GPU box: PYTHONPATH=. python tools/car_soak.py [envs] [steps]"""
+import os
 import sys
 
 import torch
@@ -29,9 +31,12 @@ def run():
 
 a, sa = run()
 b, sb = run()
-bad = [t for t in range(steps) if a[t] != b[t]]
+os.environ["CRL_CAR_NO_OVERLAP"] = "1"  # (read when the context is created)
+c, sc = run()
+del os.environ["CRL_CAR_NO_OVERLAP"]
+bad = [t for t in range(steps) if a[t] != b[t] or a[t] != c[t]]
 print("steps", steps, "envs", n, "episodes ended", sum(x[2] for x in a), "coupled at end", int(sa["coupled"].sum()),
       "first mismatching step", bad[0] if bad else None)
 assert not bad
-assert (sa.tobytes() == sb.tobytes())
+assert sa.tobytes() == sb.tobytes() and sa.tobytes() == sc.tobytes()
 print("identical")
