@@ -10,8 +10,10 @@
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on
  * success or a negative CRL_E* code (crl_last_error() has the text); all
- * device work is enqueued on the caller's HIP stream (`stream` is a
- * hipStream_t passed as void*); a context is bound to one GPU and is not
+ * device work is ordered on the caller's HIP stream (`stream` is a
+ * hipStream_t passed as void*: whatever the caller enqueues there afterwards
+ * sees the results; a CarRacing step forks to the context's own streams and
+ * joins them back before it returns); a context is bound to one GPU and is not
  * thread-safe; `*_dev` pointers are device memory owned by the caller
  * (e.g. torch tensors), `*_host` pointers are host memory.
  */
