@@ -146,10 +146,10 @@ __device__ void car_map_band(const CarSoA &s, int64_t env, int band, int sub, ui
 }
 
 __global__ __launch_bounds__(256) void car_map_build_kernel(CarSoA s, const uint8_t *__restrict__ only_env, int64_t env0) {
-    __shared__ __attribute__((aligned(16))) uint32_t rank[16][kMapW];
+    __shared__ __attribute__((aligned(16))) uint32_t rank[4][kMapW];  // (quarter bands here too: 8 workgroups per CU instead of 2)
     const int64_t env = env0 + blockIdx.y;
     if (only_env && !only_env[env]) return;
-    car_map_band<16>(s, env, (int)blockIdx.x, 0, rank);
+    car_map_band<4>(s, env, (int)blockIdx.x >> 2, (int)blockIdx.x & 3, rank);
 }
 
 __global__ __launch_bounds__(256) void car_map_build_list_kernel(CarSoA s, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count) {
@@ -165,7 +165,7 @@ void launch_car_map_build(const CarSoA &s, hipStream_t st, const uint8_t *only_e
     if (count < 0) count = s.n - first;
     for (int64_t e0 = first; e0 < first + count; e0 += 32768) {  // gridDim.y <= 65 535
         const int64_t m = first + count - e0 < 32768 ? first + count - e0 : 32768;
-        hipLaunchKernelGGL(car_map_build_kernel, dim3(kMapBlocks, (unsigned)m), dim3(256), 0, st, s, only_env, e0);
+        hipLaunchKernelGGL(car_map_build_kernel, dim3(kMapBlocks * 4, (unsigned)m), dim3(256), 0, st, s, only_env, e0);
     }
 }
 
