@@ -928,16 +928,24 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
 }
 
 // world.Step of the coupled envs.  `near_st` (may equal `st`): where the near-only envs are solved, beside the touching ones.
+void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st) {
+    const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
+    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k);
+}
+
+// skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous step); the caller has ordered `st`,
+// `near_st` and `one_st` behind it
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st, hipEvent_t ev_narrow, hipEvent_t ev_near,
-                        bool narrow_elsewhere, hipStream_t narrow_st, bool split, hipStream_t one_st) {
+                        bool narrow_elsewhere, hipStream_t narrow_st, bool split, hipStream_t one_st, bool skip_narrow) {
     if (s.players != 2 || !s.contacts_enabled) return;
     if (!near_st) near_st = st;
     if (!narrow_elsewhere) narrow_st = st;  // (a stream handle may be null -- the default stream -- so the choice is a flag of its own)
-    const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
-    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, narrow_st, s, k);
-    if (near_st != st || narrow_st != st || split) hipEventRecord(ev_narrow, narrow_st);
-    if (near_st != narrow_st) hipStreamWaitEvent(near_st, ev_narrow, 0);
-    if (st != narrow_st) hipStreamWaitEvent(st, ev_narrow, 0);
+    if (!skip_narrow) {
+        launch_car_narrow(s, k, narrow_st);
+        if (near_st != st || narrow_st != st || split) hipEventRecord(ev_narrow, narrow_st);
+        if (near_st != narrow_st) hipStreamWaitEvent(near_st, ev_narrow, 0);
+        if (st != narrow_st) hipStreamWaitEvent(st, ev_narrow, 0);
+    }
     hipLaunchKernelGGL(car_near_kernel, dim3((unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512)), dim3(64), 0, near_st, s, k);
     static const int epw1 = getenv("CRL_CAR_TOUCH_EPW1") ? atoi(getenv("CRL_CAR_TOUCH_EPW1")) : 8;  // (A/B: 32 | 8; measured 1.19 / 1.17 ms per step)
     const unsigned g = (unsigned)((s.n + 31) / 32 < 256 ? (s.n + 31) / 32 : 256);
@@ -953,7 +961,7 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hip
         else hipLaunchKernelGGL((car_touch_kernel<8, 2, 3>), dim3(g, classes), dim3(64), 0, q, s, k, cls0);
     };
     if (split) {
-        hipStreamWaitEvent(one_st, ev_narrow, 0);
+        if (!skip_narrow) hipStreamWaitEvent(one_st, ev_narrow, 0);
         touch(one_st, 1, 0);
         touch(st, 2, 1);
     } else {

@@ -212,12 +212,14 @@ void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSr
                            int64_t expected, hipStream_t st);
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st);
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
-                     hipStream_t st);
+                     hipStream_t st, bool do_broad = true);
+void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st);
+void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st = nullptr, hipEvent_t ev_narrow = nullptr,
                         hipEvent_t ev_near = nullptr, bool narrow_elsewhere = false, hipStream_t narrow_st = nullptr, bool split = false,
-                        hipStream_t one_st = nullptr);  // near_st == nullptr: everything on st
+                        hipStream_t one_st = nullptr, bool skip_narrow = false);  // near_st == nullptr: everything on st
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
                      int32_t *info_elapsed, int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void car_solve_kernel(CarSoA s, CarConsts K) {
 
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
                                                       float *__restrict__ rew_out, uint8_t *__restrict__ done_car, int sub,
-                                                      int repeat) {
+                                                      int repeat, int do_broad) {
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 16 && s.zero_next) s.zero_next[threadIdx.x] = 0;  // the NEXT step's counters (the other parity's block: nobody reads it now)
@@ -251,16 +251,24 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
     // car_coupled_kernel (cars whose fixtures may touch): this kernel only decides which, and hands
     // over the tyre forces and the joint motor targets.  Bodies and joint impulses are not modified
     // here, so both lanes of an env read the same pre-solve poses of both cars.
+    // do_broad == 0: the decision (and the narrow phase) were made AHEAD, at the end of the previous step, from the same poses
+    // (car_broad_kernel): this kernel then only takes the flag
     bool coupled = false;
     if (s.players == 2 && s.contacts_enabled) {
-        const int64_t c0 = env, c1 = s.n + env;
-        coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
-                            s.body[2 * M + c1]);
-        if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
+        if (do_broad) {
+            const int64_t c0 = env, c1 = s.n + env;
+            coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
+                                s.body[2 * M + c1]);
+            if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
+        } else {
+            coupled = s.coupled[env] != 0;
+        }
     }
 #pragma unroll
     for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
-    if (s.players == 2) {
+    if (s.players == 2 && !do_broad) {
+        if (car == 0 && !coupled) s.n_contact[env] = 0;  // (Box2D destroys the contacts of fixtures whose boxes no longer overlap)
+    } else if (s.players == 2) {
         // one atomic per WAVEFRONT, not per coupled env: a tenth of 16 384 envs on one address took longer than the rest of the kernel
         const bool mine = car == 0 && coupled;
         const unsigned long long m = __ballot(mine);
@@ -294,6 +302,35 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
         rew_out[env * s.players + car] = (float)acc;
     }
     if (done_car) done_car[env * s.players + car] = (uint8_t)done;
+}
+
+// The broadphase of the NEXT step, run at the end of this one (the poses a step's Collide sees are the ones the previous solve
+// left: Car.step moves nothing): one lane per env, the same two tests as in car_step_kernel, the coupled flags and the compacted
+// list into the next step's counter block.  car_narrow_kernel follows on the same stream -- the step's longest chain then starts
+// with the touching solve instead of with two more kernels.
+__global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K) {
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t M = 2 * s.n;
+    bool coupled = false;
+    if (env < s.n) {
+        const int64_t c0 = env, c1 = s.n + env;
+        coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
+                            s.body[2 * M + c1]);
+        if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
+        s.coupled[env] = coupled ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(coupled);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(s.coupled_count, (int)__popcll(m));
+        base = __shfl(base, (int)__ffsll((long long)m) - 1);
+        if (coupled) s.coupled_list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
+    }
+}
+
+void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st) {
+    hipLaunchKernelGGL(car_broad_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k);
 }
 
 // world.Step's Collide for the wheel sensors (FrictionDetector, crmp:111-153): Begin / EndContact of every wheel with the
@@ -606,9 +643,9 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
 }
 
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
-                     hipStream_t st) {
+                     hipStream_t st, bool do_broad) {
     const int64_t M = (int64_t)s.players * s.n;
-    hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car, sub, repeat);
+    hipLaunchKernelGGL(car_step_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k, actions, rew, done_car, sub, repeat, do_broad ? 1 : 0);
 }
 
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st) {

@@ -15,7 +15,10 @@ struct crl_car_ctx {
     int64_t n;
     CarSoA s{};
     CarSoA stage{};  // only the per-car arrays a reset writes: their staged copies (car_commit_list_kernel)
-    hipEvent_t ev_early3 = nullptr, ev_one = nullptr, ev_onefr = nullptr;
+    hipEvent_t ev_early3 = nullptr, ev_one = nullptr, ev_onefr = nullptr, ev_collide = nullptr;
+    bool collide_valid = false;  // the NEXT step's broadphase + narrow phase already ran, at the end of the last step (car_broad_kernel)
+    bool collide_dirty = false;  // ... was enqueued and not consumed yet: its counter block has to be cleared if the results are not used
+    int32_t *coupled2 = nullptr, *lists2 = nullptr;  // [2][n] coupled flags, [2][6][n] near / touch lists: one block per step parity
     hipStream_t one = nullptr;  // the touching envs with ONE manifold: solve and frames (high priority: a queue class of its own)
     CarConsts K_{};
     CarTrackSrc src{};
@@ -155,6 +158,16 @@ static int calloc_dev(crl_car_ctx *c, T **p, size_t count) {
     return CRL_OK;
 }
 
+// coupled flags, near / touch lists and the counter block of step parity `par` (the step pipeline runs the NEXT step's broadphase
+// and narrow phase at the end of a step, into the other block, while this step's frame launches still read this block's lists)
+static void point_parity(const crl_car_ctx *c, CarSoA &v, int par) {
+    const int64_t n = c->n;
+    v.coupled = c->coupled2 + par * n;
+    int32_t *l = c->lists2 + (int64_t)par * 6 * n;
+    v.near_list = l, v.touch_list = l + n, v.touch_all = l + 4 * n, v.touch_multi = l + 5 * n;
+    v.coupled_count = c->counters + 16 * par;
+}
+
 // The context's events only order its own streams on one device: no system-scope fence (an L2 writeback + invalidate per record --
 // with 300 MB of fresh frames in flight that is tens of microseconds in front of whatever waits, a dozen times per step).
 // CRL_EVENT_SYSTEM_FENCE=1 restores the default (A/B).
@@ -178,13 +191,15 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled, n); A(coupled_list, n); A(near_list, n); A(touch_list, 3 * n); A(touch_all, n); A(touch_multi, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled_list, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
     A(obs_map, (size_t)kMapBytes * 2 * n); A(map_par, n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
     A(map_lightx, kMapW / 32); A(map_lighty, kMapW / 32);
     A(view, (size_t)kViewWords * M); A(view_cnt, (size_t)16 * M); A(view_rec, (size_t)kViewRecWords * M);
 #undef A
+    if (!rc) rc = calloc_dev(c, &c->coupled2, 2 * n);
+    if (!rc) rc = calloc_dev(c, &c->lists2, 2 * 6 * n);
     {  // staged copies of the per-car arrays a reset writes
         CarSoA &g = c->stage;
 #define B(f, cnt) if (!rc) rc = calloc_dev(c, &g.f, (size_t)(cnt))
@@ -229,7 +244,8 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     }
     c->class_count_host[0] = c->class_count_host[1] = (int32_t)std::min<int64_t>(n, 64);
     c->s.coupled_to_host = c->class_count_hdev;
-    c->s.coupled_count = c->counters, c->class_count = c->counters + 8, c->s.zero_next = c->counters + 16;
+    point_parity(c, c->s, 0);
+    c->class_count = c->counters + 8, c->s.zero_next = c->counters + 16;
     c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
     c->analytic = getenv("CRL_CAR_OBS_ANALYTIC") && atoi(getenv("CRL_CAR_OBS_ANALYTIC")) != 0;
     {
@@ -249,7 +265,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_narrow, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_near, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_post, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_early3, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_early3, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_collide, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_one, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_onefr, kEvFlags) != hipSuccess ||
         hipStreamCreateWithPriority(&c->one, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin3, kEvFlags) != hipSuccess ||
@@ -312,6 +328,7 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_near) hipEventDestroy(c->ev_near);
     if (c->ev_post) hipEventDestroy(c->ev_post);
     if (c->ev_early3) hipEventDestroy(c->ev_early3);
+    if (c->ev_collide) hipEventDestroy(c->ev_collide);
     if (c->ev_one) hipEventDestroy(c->ev_one);
     if (c->ev_onefr) hipEventDestroy(c->ev_onefr);
     if (c->one) hipStreamDestroy(c->one);
@@ -405,7 +422,14 @@ static void draw(crl_car_ctx *c, uint8_t *obs_dev, bool fill_all, hipStream_t st
     launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, fill_all, c->K, c->n, c->s.players, st);
 }
 
+// Before the state is changed from outside: the collide-ahead of the last step may still be reading it, and its results are void
+static void void_collide_ahead(crl_car_ctx *c, hipStream_t st) {
+    if (c->collide_dirty) hipStreamWaitEvent(st, c->ev_collide, 0);
+    c->collide_valid = false;
+}
+
 int crl_car_reset(crl_car_ctx *c, uint8_t *obs_dev, hipStream_t st) {
+    void_collide_ahead(c, st);
     // Full reset: every env needs a walk now.  The walk kernel does them one per LANE (64 envs per wavefront);
     // the reset kernel, one wavefront per env, then only builds the tiles.  (Any walk-ahead still running on the
     // context's own stream writes the same scratch: wait for it first; a full reset is rare.)
@@ -456,13 +480,26 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     crl_timer_begin(tm, 0, st);
     auto next_counters = [&]() {  // this sub-step's counter block; car_step_kernel clears the other one for the next
         c->parity ^= 1;
-        c->s.coupled_count = c->counters + 16 * c->parity, c->class_count = c->s.coupled_count + 8;
+        point_parity(c, c->s, c->parity);
+        c->class_count = c->s.coupled_count + 8;
         c->s.zero_next = c->counters + 16 * (c->parity ^ 1);
     };
+    // Collide ahead: when the last step ended with the broadphase + narrow phase of THIS one (same poses: Car.step moves nothing),
+    // the step's longest chain starts with the touching solve.  Not with action repeats (every sub-step collides), not after the
+    // state was changed from outside (reset, set_state, set_track), not in the one-stream mode.  CRL_CAR_NO_COLLIDE_AHEAD=1: A/B
+    static const bool ahead_env = getenv("CRL_CAR_NO_COLLIDE_AHEAD") == nullptr;
+    const bool can_ahead = ahead_env && fork && c->repeat == 1 && c->s.players == 2 && c->s.contacts_enabled;
+    const bool ahead = can_ahead && c->collide_valid;
+    c->collide_valid = false;
+    if (!ahead && c->collide_dirty) {  // results of a collide-ahead that will not be used (the state was changed in between): its counters go
+        hipStreamWaitEvent(st, c->ev_collide, 0);
+        hipMemsetAsync(c->counters + 16 * (c->parity ^ 1), 0, 8 * sizeof(int32_t), st);  // (the block this step is about to use)
+    }
+    c->collide_dirty = false;
     for (int sub = 0; sub < c->repeat; sub++) {  // action repetition: Car.step + world.Step per repeat (crmp:576-603)
         next_counters();
         // Car.step, rewards, done flags; decides which cars are solved together
-        launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, sub, c->repeat, st);
+        launch_car_step(c->s, c->K_, actions_dev, rew_dev ? rew_dev : c->rew_tmp, c->done_car, sub, c->repeat, st, !ahead);
         if (fork && sub == c->repeat - 1) break;  // the last world.Step is forked below
         launch_car_sensors(c->s, c->K_, st);  // world.Step: Collide (wheel sensors), then Solve
         launch_car_solve(c->s, c->K_, st);
@@ -481,9 +518,14 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
         static const bool narrow_on_main = getenv("CRL_CAR_NARROW_ON_MAIN") != nullptr;  // (A/B: the narrow phase directly behind car_step_kernel on the caller's stream saves a cross-stream hop, but then the per-car solve starts together with the touching solve: 1.20 against 1.17 ms per step)
         const bool split = touch_split;
-        launch_car_coupled(c->s, c->K_, crit, c->side2, c->ev_narrow, c->ev_near, narrow_on_main && crit != st, st, split, c->one);
+        if (ahead) {  // (side2 ran the narrow phase itself; crit, bulk and `one` wait for it)
+            hipStreamWaitEvent(crit, c->ev_collide, 0);
+            hipStreamWaitEvent(bulk, c->ev_collide, 0);
+            if (split) hipStreamWaitEvent(c->one, c->ev_collide, 0);
+        }
+        launch_car_coupled(c->s, c->K_, crit, c->side2, c->ev_narrow, c->ev_near, narrow_on_main && crit != st, st, split, c->one, ahead);
         if (split) hipEventRecord(c->ev_one, c->one);  // the one-manifold islands are solved
-        if (sens_after_narrow && c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
+        if (!ahead && sens_after_narrow && c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
         hipStreamWaitEvent(c->sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the
                                                      // frame launches pass ONE barrier each -- on the legacy default stream they cost 30-40 us apiece)
         launch_car_sensors(c->s, c->K_, c->sens);
@@ -604,6 +646,17 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
         if (touch_split) hipStreamWaitEvent(c->side2, c->ev_onefr, 0);
         hipEventRecord(c->ev_fin3, c->side2);
+        if (can_ahead) {
+            // every solve of this step is in (side2 is behind the near-only and the touching solve; ev_term: the per-car solve) and
+            // every finished env is committed: the next step's Collide, into the other parity block, beside this step's last frames
+            CarSoA nx = c->s;
+            point_parity(c, nx, c->parity ^ 1);
+            hipStreamWaitEvent(c->side2, c->ev_term, 0);
+            launch_car_broad(nx, c->K_, c->side2);
+            launch_car_narrow(nx, c->K_, c->side2);
+            hipEventRecord(c->ev_collide, c->side2);
+            c->collide_valid = c->collide_dirty = true;
+        }
         queue_walk_ahead(c, c->sens);
         hipStreamWaitEvent(st, c->ev_fin3, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
@@ -693,6 +746,7 @@ int crl_car_get_state_impl(crl_car_ctx *c, crl_car_env_state *out, int64_t first
 }
 
 int crl_car_set_state_impl(crl_car_ctx *c, const crl_car_env_state *in, int64_t first, int64_t count, hipStream_t st) {
+    void_collide_ahead(c, st);
     if (first < 0 || count < 0 || first + count > c->n) return crl_fail(CRL_EINVAL, "bad range");
     HostCopy h;
     pull_all(c, h, st);
