@@ -290,7 +290,7 @@ __device__ inline V2 rel_vel(const BRef &A, const BRef &B, V2 rA, V2 rB) {
 // impulses are carried over from last step's manifolds by contact id (warm starting).  The env goes to one of two lists:
 // `touch` (one island with contacts: car_touch_kernel) or `near` (the boxes overlap but nothing touches: two islands of
 // their own, car_near_kernel = the per-car solve).
-__global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) {
+__global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, int urgent) {
     // (the fixture tables are indexed per lane at run time: a by-value kernel argument would first be copied to every lane's
     // scratch, and reading them from device memory makes every vertex a dependent ~200-cycle load: stage them in LDS)
     __shared__ CarConsts Ks;
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv) 
     const unsigned long long sn0 = __builtin_readcyclecounter();
     unsigned long long acc1 = 0, acc2 = 0, acc3 = 0, nslot = 0;
 #endif
-    __builtin_amdgcn_s_setprio(3);  // on the step's critical path (narrow phase -> touching solve -> their frames), beside bulk kernels
+    if (urgent) __builtin_amdgcn_s_setprio(3);  // in front of the touching solve it heads the step's critical path; run ahead, at the end of the
+                                                // previous step, it must not take issue slots from that step's last frames and the next car_step_kernel
     {
         const int count0 = *s.coupled_count;
         if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host) *s.coupled_to_host = count0;
@@ -928,9 +929,9 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
 }
 
 // world.Step of the coupled envs.  `near_st` (may equal `st`): where the near-only envs are solved, beside the touching ones.
-void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st) {
+void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent) {
     const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
-    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k);
+    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k, urgent ? 1 : 0);
 }
 
 // skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous step); the caller has ordered `st`,
@@ -941,7 +942,7 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hip
     if (!near_st) near_st = st;
     if (!narrow_elsewhere) narrow_st = st;  // (a stream handle may be null -- the default stream -- so the choice is a flag of its own)
     if (!skip_narrow) {
-        launch_car_narrow(s, k, narrow_st);
+        launch_car_narrow(s, k, narrow_st, true);
         if (near_st != st || narrow_st != st || split) hipEventRecord(ev_narrow, narrow_st);
         if (near_st != narrow_st) hipStreamWaitEvent(near_st, ev_narrow, 0);
         if (st != narrow_st) hipStreamWaitEvent(st, ev_narrow, 0);

@@ -214,7 +214,7 @@ void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t 
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st, bool do_broad = true);
 void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st);
-void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st);
+void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st = nullptr, hipEvent_t ev_narrow = nullptr,

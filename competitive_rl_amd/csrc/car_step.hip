@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64) void car_solve_kernel(CarSoA s, CarConsts K) {
 __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, const float *__restrict__ actions,
                                                       float *__restrict__ rew_out, uint8_t *__restrict__ done_car, int sub,
                                                       int repeat, int do_broad) {
+    __builtin_amdgcn_s_setprio(2);  // first kernel of the step's longest chain; the collide-ahead of the step may still be running beside it
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < 16 && s.zero_next) s.zero_next[threadIdx.x] = 0;  // the NEXT step's counters (the other parity's block: nobody reads it now)

@@ -653,7 +653,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             point_parity(c, nx, c->parity ^ 1);
             hipStreamWaitEvent(c->side2, c->ev_term, 0);
             launch_car_broad(nx, c->K_, c->side2);
-            launch_car_narrow(nx, c->K_, c->side2);
+            launch_car_narrow(nx, c->K_, c->side2, false);
             hipEventRecord(c->ev_collide, c->side2);
             c->collide_valid = c->collide_dirty = true;
         }
