@@ -695,4 +695,18 @@ def test_staged_reset_pipeline_equals_the_sequential_step():
             mb, ob_ = b.get_map(int(e))
             assert np.array_equal(ma, mb) and oa_ == ob_ == 0
     assert seen["finished"] > n // 2 and seen["finished_while_coupled"] > 0, seen
+    # the pipelined env runs the NEXT step's broadphase + narrow phase at the end of a step; whatever comes between two steps must
+    # either keep those results valid or void them: steps without observations (one-stream path), a full reset, both in a row
+    for t in range(10):
+        act = torch.rand((n, 2, 2), generator=g, device="cuda") * 2 - 1
+        if t in (2, 3, 6):
+            ra, da = a.step_device(act, render=False)[1:]
+            rb, db = b.step_device(act, render=False)[1:]
+            assert torch.equal(ra, rb) and torch.equal(da, db)
+        else:
+            both(act)
+        if t == 7:
+            a.reset(), b.reset()
+        assert a.get_state().tobytes() == b.get_state().tobytes(), t
+    assert torch.equal(a.render_current(), b.render_current())
     a.close(), b.close()
