@@ -48,9 +48,14 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_variant(tag, flags, verbose=False):
+def build_variant(tag, flags, verbose=False, force=True):
     """A profiling build beside the shipped one: every source compiled with `flags` added, objects csrc/<tag>_*.o, library
     libcrl_hip_<tag>.so (loaded when CRL_LIB_VARIANT=<tag>)."""
+    out = os.path.join(PKG, "libcrl_hip_%s.so" % tag)
+    if not force and os.path.exists(out):
+        t = os.path.getmtime(out)
+        if not any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS):
+            return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for s in SOURCES:
@@ -60,9 +65,15 @@ def build_variant(tag, flags, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
-    out = os.path.join(PKG, "libcrl_hip_%s.so" % tag)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
     return out
+
+
+def build_abl(verbose=False):
+    """The profiling variant (-DCRL_ABLATION): the superseded kernels (round 2's analytic CarRacing raster, the first Pong
+    writers, the packed-FMA opponent network), the timing ablations that give WRONG output and the phase cycle stamps live
+    only here; tests that A/B a superseded kernel against the checker load it with CRL_LIB_VARIANT=abl."""
+    return build_variant("abl", ["-DCRL_ABLATION"], verbose=verbose, force=False)
 
 
 def build_c_demo(verbose=False):

@@ -129,7 +129,7 @@ struct CarSoA {
     int32_t *n_contact;     // [n] touching car-car contacts carried to the next step (warm start)
     float *contact;         // [n][16][kContactWords] persisted manifolds + impulses
     // ---- observations as the reference computes them (car_obs.hip)
-    uint8_t *obs_map;       // [n][2][kMapBytes] pre-rastered palette map of the env's track (built at reset), two slots per env: the map of
+    uint8_t *obs_map;       // [2][n][kMapBytes] (one slot in the one-stream mode) pre-rastered palette map of the env's track (built at reset), two slots per env: the map of
                             //     a finished env's NEXT episode is built into the other slot while the terminal frame still needs this one
     uint8_t *map_par;       // [n] which slot is current
     int map_alt;            // 1 = this view of the state addresses the OTHER slot (the staged reset of the step pipeline)
@@ -143,7 +143,7 @@ struct CarSoA {
 };
 
 __device__ __forceinline__ uint8_t *env_map(const CarSoA &s, int64_t env) {
-    return s.obs_map + (env * 2 + (int64_t)((s.map_par[env] ^ s.map_alt) & 1)) * kMapBytes;
+    return s.obs_map + ((int64_t)((s.map_par[env] ^ s.map_alt) & 1) * s.n + env) * kMapBytes;
 }
 
 struct ViewParams {  // one (env, viewer) tile: where its 96 x 96 pixels come from, and what is drawn over them
@@ -223,11 +223,17 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hip
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
                      int32_t *info_elapsed, int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 
+// car_raster.hip: round 2's analytic raster, profiling build only (CRL_CAR_OBS_ANALYTIC=1)
+#ifdef CRL_ABLATION
 // only_env: draw env e iff only_env[e] == want; nullptr = every env
 void launch_car_raster(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void launch_car_raster_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
                             int32_t *count_to_host, int64_t expected);
 void car_raster_print_ticks();  // CRL_CAR_DEBUG & 64
+#else
+inline void launch_car_raster(const CarSoA &, const CarConsts &, uint8_t *, hipStream_t, const uint8_t * = nullptr, int = 1) {}
+inline void launch_car_raster_list(const CarSoA &, const CarConsts &, uint8_t *, hipStream_t, const int32_t *, const int32_t *, int32_t *, int64_t) {}
+#endif
 // car_obs.hip: the reference's observation pipeline
 void launch_car_map_build(const CarSoA &s, hipStream_t st, const uint8_t *only_env = nullptr, int64_t first = 0, int64_t count = -1);  // envs [first, first + count), all or only_env[e] != 0
 void launch_car_map_build_list(const CarSoA &s, hipStream_t st, const int32_t *list, const int32_t *list_count, int64_t expected);

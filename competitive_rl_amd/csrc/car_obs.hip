@@ -599,4 +599,35 @@ void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipS
     hipLaunchKernelGGL(car_obs_list_kernel, dim3((unsigned)(want * s.players)), dim3(64), 0, st, s, k, obs, list, list_count, count_to_host, filter, want_cls);
 }
 
+// MultipleFrameStack + FlattenMultiAgentObservation + WrapPyTorch (reference
+// utils/atari_wrappers.py:262-334, 12-37): per agent the last K frames, oldest first, agents
+// concatenated on the channel axis -> (N, 2K, 96, 96).  reset() fills all K slots with the first
+// frame (:284-290), which is also what an auto-reset does.  Pure HBM copy: reads K-1 planes,
+// writes K planes into the context's own stack and the caller's obs tensor.
+__global__ __launch_bounds__(256) void car_stack_kernel(const uint4 *__restrict__ frame, uint4 *__restrict__ stack,
+                                                        uint4 *__restrict__ obs, const uint8_t *__restrict__ fill_env,
+                                                        int fill_all, int K, int64_t n, int players) {
+    const int64_t tile = blockIdx.x;  // (env, agent)
+    const int64_t env = tile / players;
+    const bool fill = fill_all || fill_env[env];
+    const int chunks = 96 * 96 / 16;
+    const uint4 *f = frame + tile * chunks;
+    uint4 *st = stack + tile * K * chunks;
+    uint4 *ob = obs + tile * K * chunks;
+    for (int c = threadIdx.x; c < chunks; c += 256) {
+        const uint4 newest = f[c];
+        for (int k = 0; k < K - 1; k++) {
+            const uint4 v = fill ? newest : st[(int64_t)(k + 1) * chunks + c];
+            st[(int64_t)k * chunks + c] = v, ob[(int64_t)k * chunks + c] = v;
+        }
+        st[(int64_t)(K - 1) * chunks + c] = newest, ob[(int64_t)(K - 1) * chunks + c] = newest;
+    }
+}
+
+void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,
+                      int players, hipStream_t st) {
+    hipLaunchKernelGGL(car_stack_kernel, dim3((unsigned)(players * n)), dim3(256), 0, st, reinterpret_cast<const uint4 *>(frame),
+                       reinterpret_cast<uint4 *>(stack), reinterpret_cast<uint4 *>(obs), fill_env, fill_all ? 1 : 0, K, n, players);
+}
+
 }  // namespace crl

@@ -261,15 +261,13 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
             coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
                                 s.body[2 * M + c1]);
             if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
-        } else {
-            coupled = s.coupled[env] != 0;
         }
+        // (do_broad == 0: the flag is NOT read here -- car_broad_kernel wrote it on another stream that this kernel is not
+        // ordered behind; car_post_kernel, which runs behind it, destroys the contacts of the envs that are no longer coupled)
     }
 #pragma unroll
     for (int w = 0; w < 4; w++) s.wforce[(2 * w + 0) * M + ci] = fx[w], s.wforce[(2 * w + 1) * M + ci] = fy[w];
-    if (s.players == 2 && !do_broad) {
-        if (car == 0 && !coupled) s.n_contact[env] = 0;  // (Box2D destroys the contacts of fixtures whose boxes no longer overlap)
-    } else if (s.players == 2) {
+    if (s.players == 2 && do_broad) {
         // one atomic per WAVEFRONT, not per coupled env: a tenth of 16 384 envs on one address took longer than the rest of the kernel
         const bool mine = car == 0 && coupled;
         const unsigned long long m = __ballot(mine);
@@ -624,6 +622,10 @@ __global__ __launch_bounds__(256) void car_post_kernel(CarSoA s, const uint8_t *
         // step-pipeline class: 0 = frame can be drawn now, 1 = after the coupled solve, 2 = finished (terminal frame, reset, first
         // frame), 3 = finished and coupled (the same, after the coupled solve)
         const bool cp = s.coupled && s.coupled[env];
+        // Box2D destroys the contacts of fixtures whose boxes no longer overlap (b2ContactManager::Collide).  Here rather than in
+        // car_step_kernel: with the collide-ahead the flag was written by car_broad_kernel on THIS kernel's stream (side2), which the
+        // caller's stream is not ordered behind; nothing reads n_contact of a non-coupled env before the step's join.
+        if (s.coupled && s.n_contact && !cp) s.n_contact[env] = 0;
         cls = d ? (cp ? 3 : 2) : (cp ? 1 : 0);
         if (slow_env) slow_env[env] = (uint8_t)cls;
     }

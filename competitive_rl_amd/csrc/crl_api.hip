@@ -33,6 +33,10 @@ using namespace crl;
 static thread_local std::string g_err;
 static thread_local std::string *g_ctx_err = nullptr;
 
+// entry points that take no crl_ctx (crl_policy_*, crl_frame_stack_update): their failures are the thread's, not those of
+// whichever context the thread touched last (which another thread may have destroyed since)
+void crl_fail_no_ctx(void) { g_ctx_err = nullptr; }
+
 int crl_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -410,7 +414,9 @@ void crl_destroy(crl_ctx *c) {
     if (!c) return;
     hipSetDevice(c->o.device);
     hipDeviceSynchronize();
+#ifdef CRL_ABLATION
     if (getenv("CRL_GRAY_DEBUG") && (atoi(getenv("CRL_GRAY_DEBUG")) & 128)) crl::pong_gray_print_ticks();
+#endif
     if (c->car) crl_car_destroy(c->car);
     for (void *p : c->allocs) hipFree(p);
     for (int w = 0; w < 2; w++)
@@ -847,13 +853,11 @@ int crl_car_set_state(crl_ctx *c, const crl_car_env_state *in, int64_t first, in
 int crl_car_get_track(crl_ctx *c, int64_t env, int32_t *n, float *tile_poly, float *border_poly, uint8_t *border,
                       float *start_pose, void *stream) {
     CRL_ENTER(c);
-    CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_get_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);
 }
 int crl_car_set_track(crl_ctx *c, int64_t env, int32_t n, const double *tile_poly, const double *border_poly, const uint8_t *border,
                       const float *start_pose, void *stream) {
-    CRL_ENTER(c);
     CRL_ENTER(c);
     if (!c || !c->car) return fail(CRL_EINVAL, "not a CarRacing context");
     return crl_car_set_track_impl(c->car, env, n, tile_poly, border_poly, border, start_pose, (hipStream_t)stream);

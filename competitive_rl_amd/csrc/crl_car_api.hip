@@ -56,6 +56,7 @@ struct crl_car_ctx {
     bool car0_only = false;         // crl_opts.done_policy == CRL_CAR_DONE_CAR0
     hipEvent_t ev_fork = nullptr, ev_coupled = nullptr, ev_term = nullptr, ev_join = nullptr;
     bool overlap = true;
+    bool collide_ahead = true;  // CRL_CAR_NO_COLLIDE_AHEAD=1 (read when the context is created): every step runs its own Collide (A/B, twin tests)
     bool analytic = false;  // CRL_CAR_OBS_ANALYTIC=1: rounds 1-2' analytic raster (car_raster.hip) instead of map + gather, for A/B
 };
 
@@ -182,6 +183,18 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     s.n = n, s.players = players;
     s.contacts_enabled = (players == 2 && !(opts->flags & CRL_FLAG_CAR_NO_CONTACTS)) ? 1 : 0;
     int rc = 0;
+    c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
+    c->collide_ahead = !getenv("CRL_CAR_NO_COLLIDE_AHEAD");
+    c->analytic = CRL_ABL(getenv("CRL_CAR_OBS_ANALYTIC") && atoi(getenv("CRL_CAR_OBS_ANALYTIC")) != 0);
+    {   // the pre-rastered maps, [slot][env]: 739 328 bytes per env and slot -- by far the largest part of the context.  The second
+        // slot exists only for the step pipeline's staged reset (a finished env's next map is built while its terminal frame still
+        // reads the current one); the one-stream mode builds in place
+        const size_t slots = c->overlap && !c->analytic ? 2 : 1;
+        rc = calloc_dev(c, &s.obs_map, (size_t)kMapBytes * slots * n);
+        if (rc == CRL_ENOMEM)
+            rc = crl_fail(CRL_ENOMEM, "car create: %zu map slot(s) of %d bytes for each of %lld envs (%.1f GB) do not fit; fewer envs per context, or CRL_CAR_NO_OVERLAP=1 (one slot)",
+                          slots, (int)kMapBytes, (long long)n, (double)kMapBytes * slots * n / 1e9);
+    }
 #define A(f, cnt) if (!rc) rc = calloc_dev(c, &s.f, (size_t)(cnt))
     A(body, 30 * M); A(jimp, 12 * M); A(jmotor, 4 * M); A(jspeed, 4 * M); A(jlimit, 4 * M);
     A(wgas, 4 * M); A(womega, 4 * M); A(wphase, 4 * M); A(wtiles, 4 * kWheelSlots * M); A(visited, 16 * M);
@@ -194,7 +207,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled_list, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
-    A(obs_map, (size_t)kMapBytes * 2 * n); A(map_par, n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
+    A(map_par, n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
     A(map_lightx, kMapW / 32); A(map_lighty, kMapW / 32);
     A(view, (size_t)kViewWords * M); A(view_cnt, (size_t)16 * M); A(view_rec, (size_t)kViewRecWords * M);
 #undef A
@@ -246,8 +259,6 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     c->s.coupled_to_host = c->class_count_hdev;
     point_parity(c, c->s, 0);
     c->class_count = c->counters + 8, c->s.zero_next = c->counters + 16;
-    c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
-    c->analytic = getenv("CRL_CAR_OBS_ANALYTIC") && atoi(getenv("CRL_CAR_OBS_ANALYTIC")) != 0;
     {
         uint32_t lx[kMapW / 32], ly[kMapW / 32];
         car_map_light_masks(lx, ly);
@@ -321,7 +332,9 @@ void crl_car_destroy(crl_car_ctx *c) {
 #endif
     if (!c) return;
     hipDeviceSynchronize();
+#ifdef CRL_ABLATION
     if (getenv("CRL_CAR_DEBUG") && (atoi(getenv("CRL_CAR_DEBUG")) & 64)) crl::car_raster_print_ticks();
+#endif
     if (c->side) hipStreamDestroy(c->side);
     if (c->side2) hipStreamDestroy(c->side2);
     if (c->ev_narrow) hipEventDestroy(c->ev_narrow);
@@ -487,8 +500,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     // Collide ahead: when the last step ended with the broadphase + narrow phase of THIS one (same poses: Car.step moves nothing),
     // the step's longest chain starts with the touching solve.  Not with action repeats (every sub-step collides), not after the
     // state was changed from outside (reset, set_state, set_track), not in the one-stream mode.  CRL_CAR_NO_COLLIDE_AHEAD=1: A/B
-    static const bool ahead_env = getenv("CRL_CAR_NO_COLLIDE_AHEAD") == nullptr;
-    const bool can_ahead = ahead_env && fork && c->repeat == 1 && c->s.players == 2 && c->s.contacts_enabled;
+    const bool can_ahead = c->collide_ahead && fork && c->repeat == 1 && c->s.players == 2 && c->s.contacts_enabled;
     const bool ahead = can_ahead && c->collide_valid;
     c->collide_valid = false;
     if (!ahead && c->collide_dirty) {  // results of a collide-ahead that will not be used (the state was changed in between): its counters go
@@ -900,7 +912,7 @@ int crl_car_get_map_impl(crl_car_ctx *c, int64_t env, uint8_t *palette_host, int
     uint8_t par = 0;
     hipMemcpyAsync(&par, c->s.map_par + env, 1, hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) return crl_fail(CRL_EHIP, "get_map: copy failed");
-    hipMemcpyAsync(raw.data(), c->s.obs_map + (env * 2 + (par & 1)) * kMapBytes, (size_t)kMapBytes, hipMemcpyDeviceToHost, st);
+    hipMemcpyAsync(raw.data(), c->s.obs_map + ((int64_t)(par & 1) * c->n + env) * kMapBytes, (size_t)kMapBytes, hipMemcpyDeviceToHost, st);
     int32_t ov = 0;
     hipMemcpyAsync(&ov, c->s.map_overflow + env, 4, hipMemcpyDeviceToHost, st);
     if (hipStreamSynchronize(st) != hipSuccess) return crl_fail(CRL_EHIP, "get_map: copy failed");

@@ -8,6 +8,7 @@
 #include "../../include/crl.h"
 
 int crl_fail(int code, const char *fmt, ...);
+void crl_fail_no_ctx(void);  // first line of every entry point without a crl_ctx argument
 
 // Timing ablations that give WRONG results (skip a phase to size it) exist only in a profiling build (-DCRL_ABLATION):
 // in the shipped library their switches read as zero and the compiler drops the branches.

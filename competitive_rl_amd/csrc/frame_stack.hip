@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void frame_stack_update_kernel(float *__restri
 
 extern "C" int crl_frame_stack_update(float *stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
                                       const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream) {
+    crl_fail_no_ctx();
     if (!stack_dev || !obs_dev) return crl_fail(CRL_EINVAL, "frame_stack_update: null tensor");
     if (n <= 0 || c <= 0 || k <= 0 || hw <= 0) return crl_fail(CRL_EINVAL, "frame_stack_update: bad shape n=%lld c=%d k=%d hw=%lld", (long long)n, c, k, (long long)hw);
     if (obs_dtype != CRL_OBS_U8 && obs_dtype != CRL_OBS_F32) return crl_fail(CRL_EINVAL, "frame_stack_update: obs_dtype %d", obs_dtype);

@@ -777,6 +777,7 @@ extern "C" {
 
 int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, const float *conv1_b, const float *conv2_w,
                       const float *conv2_b, const float *actor_w, const float *actor_b, crl_policy **out) {
+    crl_fail_no_ctx();
     if (!out || num_envs <= 0 || !conv1_w || !conv1_b || !conv2_w || !conv2_b || !actor_w || !actor_b)
         return crl_fail(CRL_EINVAL, "crl_policy_create: bad arguments");
     HIP_TRY(hipSetDevice(device));
@@ -837,6 +838,7 @@ void crl_policy_destroy(crl_policy *p) {
 }
 
 int crl_policy_reset(crl_policy *p, void *stream) {
+    crl_fail_no_ctx();
     if (!p) return crl_fail(CRL_EINVAL, "crl_policy_reset: null policy");
     HIP_TRY(hipMemsetAsync(p->ring, 0, (size_t)p->n * kRingBytes, (hipStream_t)stream));
     p->head = 0;
@@ -845,34 +847,38 @@ int crl_policy_reset(crl_policy *p, void *stream) {
 
 int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride, int32_t *actions_dev, int64_t action_stride,
                    float *logits_dev, void *stream) {
+    crl_fail_no_ctx();
     if (!p || !frame_dev || !actions_dev) return crl_fail(CRL_EINVAL, "crl_policy_act: null argument");
     if (frame_stride < kPlane || (frame_stride & 3) || ((uintptr_t)frame_dev & 3) || action_stride < 1)
         return crl_fail(CRL_EINVAL, "crl_policy_act: frame_stride must be a multiple of 4 and >= 1764, frames 4-byte aligned");
-    static const int dbg = CRL_ABL(getenv("CRL_POLICY_DEBUG") ? atoi(getenv("CRL_POLICY_DEBUG")) : 0);  // profiling build only (wrong outputs)
-    static const int phase = getenv("CRL_POLICY_PHASE") ? atoi(getenv("CRL_POLICY_PHASE")) : 0;  // x 8 128 cycles
-    const int64_t groups = (p->n + kEnvsPerWg - 1) / kEnvsPerWg;
-    static const int per_cu = getenv("CRL_POLICY_WGS") ? atoi(getenv("CRL_POLICY_WGS")) : 2;  // tuning experiments only
-    const unsigned grid = (unsigned)(groups < per_cu * p->cus ? groups : per_cu * p->cus);  // persistent: two workgroups per CU
     HIP_TRY(hipMemsetAsync(p->ticket, 0, sizeof(unsigned), (hipStream_t)stream));
-    // CRL_POLICY_MFMA: 3 (default) = matrix-pipe kernel, conv1 as three exact bf16 products per tap; 1 = the same kernel with
-    // conv1 on the fp32 matrix instruction; 0 = the packed-FMA kernel of round 1.  Measured at 65 536 envs:
-    // 430 us, 757 us, 725-805 us.
-    static const int use_mfma = getenv("CRL_POLICY_MFMA") ? atoi(getenv("CRL_POLICY_MFMA")) : 3;
-    static const int mdbg = CRL_ABL(getenv("CRL_POLICY_MFMA_DEBUG") ? atoi(getenv("CRL_POLICY_MFMA_DEBUG")) : 0);  // profiling build only (wrong outputs)
     hipStream_t main_st = (hipStream_t)stream;
+    // The matrix-pipe kernel, conv1 as three exact bf16 products per tap (430 us at 65 536 envs).  Profiling build only
+    // (CRL_POLICY_MFMA): 1 = the same kernel with conv1 on the fp32 matrix instruction (757 us), 0 = the packed-FMA kernel of
+    // round 1 (725-805 us); CRL_POLICY_DEBUG / CRL_POLICY_MFMA_DEBUG skip phases (wrong outputs).
+    static const int use_mfma = CRL_ABL(getenv("CRL_POLICY_MFMA") != nullptr) ? atoi(getenv("CRL_POLICY_MFMA")) : 3;
+    static const int dbg = CRL_ABL(getenv("CRL_POLICY_DEBUG") ? atoi(getenv("CRL_POLICY_DEBUG")) : 0);
+    static const int mdbg = CRL_ABL(getenv("CRL_POLICY_MFMA_DEBUG") ? atoi(getenv("CRL_POLICY_MFMA_DEBUG")) : 0);
     if ((use_mfma == 1 || use_mfma == 3) && !dbg) {
         const int64_t mgroups = (p->n + kME - 1) / kME;
         const unsigned mgrid = (unsigned)(mgroups < p->cus ? mgroups : p->cus);  // persistent: one workgroup per CU
-        if (use_mfma == 3)
-            hipLaunchKernelGGL(pong_policy_mfma_kernel<true>, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
+#ifdef CRL_ABLATION
+        if (use_mfma != 3)
+            hipLaunchKernelGGL(pong_policy_mfma_kernel<false>, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
                                frame_stride, actions_dev, action_stride, logits_dev, p->n, p->ticket, mdbg);
         else
-            hipLaunchKernelGGL(pong_policy_mfma_kernel<false>, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
+#endif
+            hipLaunchKernelGGL(pong_policy_mfma_kernel<true>, dim3(mgrid), dim3(kMThreads), kMLds, main_st, p->WM, p->ring, p->head, frame_dev,
                                frame_stride, actions_dev, action_stride, logits_dev, p->n, p->ticket, mdbg);
         HIP_TRY(hipGetLastError());
         p->head = (p->head + 1) & 3;
         return CRL_OK;
     }
+#ifdef CRL_ABLATION
+    static const int phase = getenv("CRL_POLICY_PHASE") ? atoi(getenv("CRL_POLICY_PHASE")) : 0;  // x 8 128 cycles
+    const int64_t groups = (p->n + kEnvsPerWg - 1) / kEnvsPerWg;
+    static const int per_cu = getenv("CRL_POLICY_WGS") ? atoi(getenv("CRL_POLICY_WGS")) : 2;  // tuning experiments only
+    const unsigned grid = (unsigned)(groups < per_cu * p->cus ? groups : per_cu * p->cus);  // persistent: two workgroups per CU
     if (dbg == 4)
         hipLaunchKernelGGL(pong_policy_light_kernel<2>, dim3(grid), dim3(kPolicyThreads), 0, (hipStream_t)stream, p->W, p->ring, p->head,
                            frame_dev, frame_stride, actions_dev, action_stride, logits_dev, p->n, dbg, phase, p->ticket);
@@ -885,9 +891,13 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     HIP_TRY(hipGetLastError());
     p->head = (p->head + 1) & 3;
     return CRL_OK;
+#else
+    return crl_fail(CRL_ESTATE, "crl_policy_act: no kernel selected");
+#endif
 }
 
 static int copy_stack(crl_policy *p, uint8_t *ext, int to_ring, void *stream) {
+    crl_fail_no_ctx();
     if (!p || !ext) return crl_fail(CRL_EINVAL, "crl_policy stack copy: null argument");
     const int64_t words = p->n * CRL_POLICY_STACK * kPlaneWords;
     hipLaunchKernelGGL(pong_policy_copy_stack_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p->ring, ext,

@@ -120,7 +120,7 @@ __device__ inline Box rect_box(const GrayGeom &q, int c0, int c1, int r0, int r1
     return b;
 }
 
-static constexpr int kTileLds = 7168;  // >= 84*84, multiple of 16
+[[maybe_unused]] static constexpr int kTileLds = 7168;  // >= 84*84, multiple of 16
 static constexpr int kTabLds = 6144;   // dense tap tables + first/last maps (4.6 KB at R = 84)
 static constexpr int kMaxR = 96;       // largest resized_dim the LDS tile holds (84) rounded up
 
@@ -185,6 +185,7 @@ __device__ inline Box rect_box_lds(const uint8_t *__restrict__ tabs, const GrayT
     return b;
 }
 
+#ifdef CRL_ABLATION  // the first tile kernel (four tiles per workgroup, per-pixel evaluator): profiling build only, CRL_GRAY_DEBUG=8
 __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                GrayGeom q, uint8_t *__restrict__ obs) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][kTileLds];
@@ -313,6 +314,8 @@ __global__ __launch_bounds__(256) void pong_raster_gray_kernel(const uint64_t *_
         for (int w = lane; w < (RR >> 2); w += 64) out32[w] = tl32[w];
     }
 }
+
+#endif  // CRL_ABLATION
 
 // ---------------------------------------------------------------------------------------
 // Production kernel: ONE WAVEFRONT PER (env, plane group), looping over the group's planes
@@ -600,6 +603,7 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_ker
     }
 }
 
+#ifdef CRL_ABLATION  // bit-exact and slower than the env kernel (lab notes 4.3a): profiling build only, CRL_GRAY_SWEEP=1
 // ---------------------------------------------------------------------------------------
 // Address-linear writer (round 2; CRL_GRAY_SWEEP=0 falls back to the env kernel above).
 //
@@ -865,6 +869,8 @@ void pong_gray_print_ticks() {
             "row/col words %llu | LDS fill %llu | patch %llu | stream-out %llu\n", t[7], t[0] / t[7], t[1] / t[7], t[2] / t[7], t[3] / t[7], t[4] / t[7], t[5] / t[7]);
 }
 
+#endif  // CRL_ABLATION
+
 void launch_pong_gray_templates(const GrayParams &p, const uint8_t *x_first, const uint8_t *x_last, const uint8_t *y_first,
                                 const uint8_t *y_last, int band_rows, int band_chunks, uint8_t *band, uint8_t *rest,
                                 hipStream_t st) {
@@ -886,17 +892,21 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     q.band = p.band, q.rest = rest, q.zero_row0 = zero_row0, q.zero_row1 = zero_row1;
     q.x_first = x_first, q.x_last = x_last, q.y_first = y_first, q.y_last = y_last;
     q.tab_blob = tab_blob, q.t = tofs;
+    q.debug = 0;
+#ifdef CRL_ABLATION
+    const int64_t tiles = p.n * q.views * p.K;
+    // profiling build only: CRL_GRAY_DEBUG bits skip phases of the env kernel (WRONG pixels) or select the first tile kernel (8);
+    // CRL_GRAY_SWEEP=1 the address-linear writer (bit-exact, slower), 2 | 3 its skeletons (wrong pixels)
     {
         static const int dbg = getenv("CRL_GRAY_DEBUG") ? atoi(getenv("CRL_GRAY_DEBUG")) : 0;
         q.debug = dbg;
     }
-    const int64_t tiles = p.n * q.views * p.K;
     if ((q.debug & 8) && !p.obs_f32) {
         hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
                            p.obs);
         return;
     }
-    // address-linear writer (uint8 output, 16-byte-aligned tiles, three-tap tables: R = 84 and similar sizes).  OFF by default:
+    // address-linear writer (uint8 output, 16-byte-aligned tiles, three-tap tables: R = 84 and similar sizes):
     // bit-exact, but 1.0-2.0 ms against the env kernel's 0.75 ms at 65 536 envs -- every block has to read per-tile metadata
     // first, and a dependent read in a store-saturated memory system takes microseconds.
     static const int sweep_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
@@ -909,8 +919,7 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         const int nb = wblocks < 8192 ? 1 : nb_env;
         const int stride = (int)(((wblocks + nb - 1) / nb + 3) / 4 * 4);  // blocks per round, a multiple of the 4 waves of a workgroup
         const dim3 grid((unsigned)(stride / 4));
-        static const int sweep_mode_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
-        const int sweep_mode = sweep_mode_env >= 2 ? CRL_ABL(sweep_mode_env) : sweep_mode_env;  // 2, 3: skeleton timing (wrong pixels), profiling build only
+        const int sweep_mode = sweep_env;
         if ((sweep_mode == 2 || sweep_mode == 3) && p.R == 84) {
             const int dense = sweep_mode == 3;
             if (nb == 1) hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<1>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);
@@ -931,12 +940,13 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
 #undef CRL_SWEEP
         return;
     }
+#endif  // CRL_ABLATION
     // planes per wave: the whole stack of an env per wave once there are enough envs to fill
     // the chip (256 CUs x 16 waves), one plane per wave below that
-    static const int ppw_env = getenv("CRL_GRAY_PPW") ? atoi(getenv("CRL_GRAY_PPW")) : 0;  // tuning experiments only
+    static const int ppw_env = CRL_ABL(getenv("CRL_GRAY_PPW") ? atoi(getenv("CRL_GRAY_PPW")) : 0);  // tuning experiments (profiling build)
     int ppw = (p.n >= 8192 && !(q.debug & 16)) ? p.K : 1;
     if (ppw_env > 0 && p.K % ppw_env == 0) ppw = ppw_env;
-    static const bool small_off = getenv("CRL_GRAY_SMALL_OFF") != nullptr;  // A/B: the R <= 45 instance off
+    static const bool small_off = CRL_ABL(getenv("CRL_GRAY_SMALL_OFF") != nullptr);  // A/B: the R <= 45 instance off
     const int64_t waves = p.n * (p.K / ppw);
     const dim3 grid((unsigned)((waves + 3) / 4));
     if (p.obs_f32) {
@@ -948,9 +958,13 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
             hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
         return;
     }
-    if (q.debug & ~16)  // any ablation switch: the instrumented instance
+#ifdef CRL_ABLATION
+    if (q.debug & ~16) {  // any ablation switch: the instrumented instance
         hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
-    else if (tofs.max_taps <= 3)
+        return;
+    }
+#endif
+    if (tofs.max_taps <= 3)
         hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
     else if (p.R * p.R <= 2048 && !small_off)
         hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);

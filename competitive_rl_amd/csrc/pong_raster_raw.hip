@@ -18,6 +18,7 @@
 // original one workgroup per env (thread t writes chunks t, t+256, ...; CRL_RAW_SWEEP=0 CRL_RAW_LINEAR=0), kept for A/B.
 #include <stdlib.h>
 
+#include "crl_internal.h"
 #include "pong_device.h"
 
 namespace crl {
@@ -78,6 +79,7 @@ __device__ __forceinline__ Frame pick_frame(const Frame &f0, const Frame &f1, bo
     return f;
 }
 
+#ifdef CRL_ABLATION  // superseded writers (one workgroup per env; workgroup-contiguous): profiling build only, CRL_RAW_SWEEP=0
 __global__ __launch_bounds__(256) void pong_raster_raw_kernel(const uint64_t *__restrict__ frames,
                                                               const uint4 *__restrict__ atlas_rgb, int ink_row0,
                                                               int ink_row1, uint4 *__restrict__ obs, int views, int dbg) {
@@ -122,6 +124,8 @@ __global__ __launch_bounds__(THREADS) void pong_raster_raw_linear_kernel(const u
     }
 }
 
+#endif  // CRL_ABLATION
+
 // Sweep variant of the address-linear kernel: thread t of workgroup b writes chunks b * 256 + t + i * (gridDim.x * 256),
 // i = 0 .. ITERS-1 -- every "round" i of the whole chip is one dense linear sweep over 1/ITERS of the tensor.  Pure-store
 // probes (tools/store_order_probe.hip): a wavefront that walks through a private contiguous span makes the chip write a
@@ -158,10 +162,12 @@ __global__ __launch_bounds__(256) void pong_raster_raw_sweep_kernel(const uint64
 void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *atlas_rgb, int ink_row0, int ink_row1,
                             uint8_t *obs, int views, hipStream_t st) {
     if (n <= 0) return;
-    static const int dbg = getenv("CRL_RAW_DEBUG") ? atoi(getenv("CRL_RAW_DEBUG")) : 0;
-    static const int lin = getenv("CRL_RAW_LINEAR") ? atoi(getenv("CRL_RAW_LINEAR")) : 2;
-    static const int sweep = getenv("CRL_RAW_SWEEP") ? atoi(getenv("CRL_RAW_SWEEP")) : 4;  // 0: the workgroup-contiguous kernels below
-    if (sweep > 0 && (views == 1 || views == 2)) {
+    // (profiling build only: CRL_RAW_DEBUG bit 1 = constant chunks, i.e. WRONG pixels, to size the pixel arithmetic; CRL_RAW_SWEEP /
+    // CRL_RAW_LINEAR select the superseded writers)
+    static const int dbg = CRL_ABL(getenv("CRL_RAW_DEBUG") ? atoi(getenv("CRL_RAW_DEBUG")) : 0);
+    static const int sweep = CRL_ABL(getenv("CRL_RAW_SWEEP") != nullptr) ? atoi(getenv("CRL_RAW_SWEEP")) : 4;
+    if (views != 1 && views != 2) return;  // (crl_create admits nothing else)
+    if (sweep > 0) {
         const int64_t total = n * views * kFrameChunks;
         const uint4 *at = reinterpret_cast<const uint4 *>(atlas_rgb);
         uint4 *ob = reinterpret_cast<uint4 *>(obs);
@@ -169,16 +175,21 @@ void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *at
     hipLaunchKernelGGL((pong_raster_raw_sweep_kernel<I, V>), dim3((unsigned)((total + 256 * I - 1) / (256 * I))), dim3(256), 0, st, frames, \
                        at, ink_row0, ink_row1, ob, n, dbg)
         if (views == 2) {
+#ifdef CRL_ABLATION
             if (sweep <= 2) CRL_LAUNCH_SWEEP(2, 2);
-            else if (sweep <= 4) CRL_LAUNCH_SWEEP(4, 2);
-            else CRL_LAUNCH_SWEEP(8, 2);
+            else if (sweep > 4) CRL_LAUNCH_SWEEP(8, 2);
+            else
+#endif
+                CRL_LAUNCH_SWEEP(4, 2);
         } else {
             CRL_LAUNCH_SWEEP(4, 1);
         }
 #undef CRL_LAUNCH_SWEEP
         return;
     }
-    if (lin > 0 && (views == 1 || views == 2)) {
+#ifdef CRL_ABLATION
+    static const int lin = getenv("CRL_RAW_LINEAR") ? atoi(getenv("CRL_RAW_LINEAR")) : 2;
+    if (lin > 0) {
         const int64_t total = n * views * kFrameChunks;
         const uint4 *at = reinterpret_cast<const uint4 *>(atlas_rgb);
         uint4 *ob = reinterpret_cast<uint4 *>(obs);
@@ -198,6 +209,7 @@ void launch_pong_raster_raw(const uint64_t *frames, int64_t n, const uint8_t *at
     }
     hipLaunchKernelGGL(pong_raster_raw_kernel, dim3((unsigned)n), dim3(256), 0, st, frames,
                        reinterpret_cast<const uint4 *>(atlas_rgb), ink_row0, ink_row1, reinterpret_cast<uint4 *>(obs), views, dbg);
+#endif
 }
 
 }  // namespace crl

@@ -94,7 +94,13 @@ class StepGather:
 
     def launch(self, tensors, env=None):
         """tensors: the step's outputs (observation first in mode="obs"; in mode="descriptors" pass (rewards, done, ...) and
-        the env whose descriptors are to be shipped)."""
+        the env whose descriptors are to be shipped).
+
+        Order: ``launch(t) ... wait(t) ... launch(t+1)``.  A launch that finds the previous collective still pending first
+        orders the caller's stream behind it (its result is dropped: ``recv`` is about to be rewritten) -- the pack below
+        writes the send buffer that collective reads, and ``_buffers`` may replace both buffers on a size change."""
+        if self.work is not None:
+            self.wait(materialize=False)
         if self.mode == "descriptors":
             assert env is not None, 'mode="descriptors" needs the env'
             self.env = env

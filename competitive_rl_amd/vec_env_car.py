@@ -127,9 +127,9 @@ class HipCarVecEnv(VecEnv):
     def reset(self):
         self._check_open()
         buf = self._obs[self._flip]
-        self._flip ^= 1
-        self._serial += 1
         N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
+        self._flip ^= 1  # (only after the call went through: a failed one leaves get_images / lazy infos on the drawn buffer)
+        self._serial += 1
         return self._out(buf)
 
     def step_async(self, actions):
@@ -149,11 +149,13 @@ class HipCarVecEnv(VecEnv):
         if not (actions_f32.is_contiguous() and actions_f32.dtype == torch.float32 and actions_f32.device == self.device):
             raise AssertionError("step_device needs a contiguous float32 tensor on the env's device")
         buf = self._obs[self._flip]
-        self._prev_buf = self._obs[self._flip ^ 1]  # observation before this step (the stack's older planes)
-        self._flip ^= 1
-        self._serial += 1
         N.check(self._L.crl_step(self._h, C.c_void_p(actions_f32.data_ptr()), C.c_void_p(buf.data_ptr()) if render else None,
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+        self._serial += 1
+        if not render:  # nothing was drawn: the buffers stay as they are, and there is no observation to hand out
+            return None, self._rew, self._done
+        self._prev_buf = self._obs[self._flip ^ 1]  # observation before this step (the stack's older planes)
+        self._flip ^= 1
         return buf, self._rew, self._done
 
     def _info_snapshot(self, elapsed=False):

@@ -101,3 +101,28 @@ def test_c_abi_demo_links_against_the_library():
 
     exe = build_c_demo()
     assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+def test_shipped_library_carries_no_debug_switches_or_superseded_kernels():
+    """wrong-output switches (CRL_*_DEBUG, skeleton sweeps, phase skips) and the superseded kernels (round 2's
+    analytic CarRacing raster, the first Pong writers, the packed-FMA opponent network) exist only in the profiling variant
+    (-DCRL_ABLATION -> libcrl_hip_abl.so); the shipped library contains neither their names nor their code objects."""
+    import subprocess
+
+    from competitive_rl_amd import _native as N
+    from competitive_rl_amd.build import PKG, build
+
+    build()
+    lib = os.path.join(PKG, "libcrl_hip.so")
+    out = subprocess.run(["strings", "-n", "6", lib], capture_output=True, text=True, check=True).stdout
+    hdr = open(os.path.join(ROOT, "include", "crl.h")).read()
+    switches = sorted(x for x in set(re.findall(r"\bCRL_[A-Z0-9_]{3,}\b", out)) if x not in hdr)  # (enum names occur in error texts)
+    assert not [s for s in switches if "DEBUG" in s or "_ABL" in s or "STAMPS" in s or "ANALYTIC" in s], switches
+    assert len(switches) <= 12, switches  # alternative CORRECT paths only (DESIGN.md section 11)
+    kernels = set(re.findall(r"_ZN3crl\d+([a-z_0-9]+kernel)", out))
+    dead = {"car_raster_kernel", "car_raster_list_kernel", "pong_raster_raw_kernel", "pong_raster_raw_linear_kernel",
+            "pong_raster_gray_kernel", "pong_raster_gray_sweep_kernel", "pong_gray_sweep_skeleton_kernel", "pong_gray_header_kernel",
+            "pong_policy_light_kernel"}
+    assert kernels and not (kernels & dead), sorted(kernels & dead)
+    assert {"car_obs_kernel", "car_touch_kernel", "pong_raster_raw_sweep_kernel", "pong_raster_gray_env_kernel", "pong_policy_mfma_kernel"} <= kernels
+    assert os.path.basename(N.LIB_PATH) == "libcrl_hip.so" or os.environ.get("CRL_LIB_VARIANT")

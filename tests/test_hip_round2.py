@@ -381,12 +381,17 @@ def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
 
 
 def test_address_linear_gray_writer_is_bit_exact_too():
-    """The optional address-linear fused-84 writer (CRL_GRAY_SWEEP=1: header kernel + aligned 1-KiB-block sweep, DESIGN.md
-    4.3) against the oracle, in a child process because the switch is read once per process."""
+    """The address-linear fused-84 writer (header kernel + aligned 1-KiB-block sweep; bit-exact and slower,
+    so it lives in the profiling variant only: CRL_LIB_VARIANT=abl CRL_GRAY_SWEEP=1) against the oracle, in a child process
+    because library and switch are chosen once per process."""
     _need_gpu()
     import os
     import subprocess
     import sys
+
+    from competitive_rl_amd.build import PKG
+    if not os.path.exists(os.path.join(PKG, "libcrl_hip_abl.so")):
+        pytest.skip("libcrl_hip_abl.so not built (python -m competitive_rl_amd.build --variant abl -DCRL_ABLATION)")
 
     code = r"""
 import numpy as np, torch, sys
@@ -408,7 +413,7 @@ for K, n in ((4, 130), (1, 67)):
     env.close()
 print("sweep ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRL_GRAY_SWEEP="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRL_GRAY_SWEEP="1", CRL_LIB_VARIANT="abl"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sweep ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 

@@ -72,6 +72,18 @@ def _race_worker(rank, world, port, out_dir):
         for k in range(world):
             ok &= bool((o[k * n:(k + 1) * n] == (t + k) % 251).all()) and bool((r[k * n:(k + 1) * n] == t + 10 * k).all())
             ok &= bool((d[k * n:(k + 1) * n] == (t + k) % 2).all())
+    # launch(t+1) before wait(t) -- in the non-aliased modes there is ONE send buffer, and a size change replaces
+    # both buffers: the second launch must first order itself behind the pending collective; its own result is what wait() returns
+    g2 = StepGather(overlap=True)
+    for t in range(20):
+        a = torch.full((n, 3), float(t + rank))
+        g2.launch((a, done))
+        b = torch.full((n + t, 3), float(100 + t + rank))      # (different size: the buffers are reallocated)
+        g2.launch((b,))
+        (rb,) = g2.wait()
+        for k in range(world):
+            ok &= bool((rb[k * (n + t):(k + 1) * (n + t)] == 100 + t + k).all())
+        ok &= g2.wait() is None
     with open(os.path.join(out_dir, f"race{rank}.txt"), "w") as f:
         f.write("ok" if ok else "bad")
     dist.barrier()
