@@ -10,8 +10,10 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "liboracle.so")
-LIB_LIBM = os.path.join(HERE, "liboracle_libm.so")  # same sources with -DCRL_LIBM: the host libm's sin / cos / atan2
+# CRL_ORACLE_SUFFIX=_asan: the sanitizer builds of oracle/Makefile (`make asan`), for tests/test_oracle_sanitizers.py
+_SUFFIX = os.environ.get("CRL_ORACLE_SUFFIX", "")
+LIB = os.path.join(HERE, "liboracle%s.so" % _SUFFIX)
+LIB_LIBM = os.path.join(HERE, "liboracle_libm%s.so" % _SUFFIX)  # same sources with -DCRL_LIBM: the host libm's sin / cos / atan2
 
 RAW, GRAY = 0, 1
 
