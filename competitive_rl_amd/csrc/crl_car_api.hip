@@ -38,6 +38,7 @@ struct crl_car_ctx {
     int32_t *class_count = nullptr;  // [3] their lengths (inside `counters`)
     int32_t *counters = nullptr;     // [2][16] per step parity: coupled_count[8], class_count[2]; a step's first kernel clears the other block
     int parity = 0;
+    int32_t serial = 0;  // steps of the pipelined path so far: what car_epoch_kernel publishes behind a step's wheel sensors
     hipEvent_t ev_post = nullptr;
     hipEvent_t ev_fin3 = nullptr;
     hipEvent_t ev_fin = nullptr;
@@ -204,7 +205,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled_list, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled_list, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(sens_epoch, 4); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
     A(map_par, n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
@@ -270,8 +271,8 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     }
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (numerically lower = higher priority)
-    // `side`: the bulk of a step (default priority) -- or, with CRL_CAR_CRIT_ON_SIDE=1, its critical chain (then at high priority)
-    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, getenv("CRL_CAR_CRIT_ON_SIDE") ? prio_hi : 0) != hipSuccess ||
+    // `side`: the bulk of a step (default priority)
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, 0) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_narrow, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_near, kEvFlags) != hipSuccess ||
@@ -283,8 +284,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_fin, kEvFlags) != hipSuccess ||
         hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, kEvFlags) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, getenv("CRL_CAR_GEN_NORMAL_PRIO") ? 0 : prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own (A/B switch)
-
+        hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own
         hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_walk, kEvFlags) != hipSuccess ||
         hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t)) != hipSuccess ||
@@ -480,16 +480,11 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     // Rewards and done flags are final after car_step_kernel (the reference evaluates them before
     // world.Step, crmp:576-603), so the env-level bookkeeping does not wait for the coupled solve.
     const bool fork = c->overlap && obs_dev != nullptr;
-    // The step's longest chain (narrow phase -> touching solve -> those envs' frames) runs on the CALLER's stream, directly behind
+    const bool contacts = c->s.players == 2 && c->s.contacts_enabled;
+    // The step's longest chain (touching solve, which also draws its envs' frames) runs on the CALLER's stream, directly behind
     // car_step_kernel and directly in front of the next step's: every cross-stream hop costs tens of microseconds of command-processor
-    // latency, and this chain has none left.  The bulk (per-car solve -> camera -> frames of the envs on their own) forks to `side`
-    // and has the slack to absorb its two hops.  CRL_CAR_CRIT_ON_SIDE=1: the other way round (A/B).
-    static const bool crit_on_main = getenv("CRL_CAR_CRIT_ON_SIDE") == nullptr;
-    const hipStream_t crit = crit_on_main ? st : c->side, bulk = crit_on_main ? c->side : st;
-    // the touching envs with ONE manifold (94 % of them, never the slowest) are solved and drawn on a stream of their own; `crit` then
-    // carries the islands with two manifolds or more and, behind them, only THEIR frames.  Off by default; CRL_CAR_TOUCH_SPLIT=1 (A/B)
-    static const bool touch_split_env = getenv("CRL_CAR_TOUCH_SPLIT") != nullptr;  // (measured: no gain -- the frame launch behind the solve takes 80 us for 70 envs as for 1 100)
-    const bool touch_split = touch_split_env && !c->analytic && c->s.players == 2 && c->s.contacts_enabled;
+    // latency.  The bulk (per-car solve -> camera -> frames of the envs on their own) forks to `side` and has the slack for its hops.
+    const hipStream_t crit = st, bulk = c->side;
     crl_timer_begin(tm, 0, st);
     auto next_counters = [&]() {  // this sub-step's counter block; car_step_kernel clears the other one for the next
         c->parity ^= 1;
@@ -499,8 +494,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     };
     // Collide ahead: when the last step ended with the broadphase + narrow phase of THIS one (same poses: Car.step moves nothing),
     // the step's longest chain starts with the touching solve.  Not with action repeats (every sub-step collides), not after the
-    // state was changed from outside (reset, set_state, set_track), not in the one-stream mode.  CRL_CAR_NO_COLLIDE_AHEAD=1: A/B
-    const bool can_ahead = c->collide_ahead && fork && c->repeat == 1 && c->s.players == 2 && c->s.contacts_enabled;
+    // state was changed from outside (reset, set_state), not in the one-stream mode.  CRL_CAR_NO_COLLIDE_AHEAD=1: A/B, twin tests
+    const bool can_ahead = c->collide_ahead && fork && c->repeat == 1 && contacts;
     const bool ahead = can_ahead && c->collide_valid;
     c->collide_valid = false;
     if (!ahead && c->collide_dirty) {  // results of a collide-ahead that will not be used (the state was changed in between): its counters go
@@ -517,35 +512,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_solve(c->s, c->K_, st);
         launch_car_coupled(c->s, c->K_, st);
     }
-    if (fork) {
-        // The narrow phase (head of the step's critical path: narrow -> touching solve -> their frames), the wheel sensors and the
-        // env-level bookkeeping only need car_step_kernel's output: all three start here, and the per-car solve on `st` waits for none.
-        static const bool sens_after_narrow = getenv("CRL_CAR_SENS_WITH_NARROW") == nullptr;  // (A/B switch: the sensor kernel beside the narrow phase doubles both)
-        hipEventRecord(c->ev_fork, st);
-        hipStreamWaitEvent(c->side, c->ev_fork, 0);  // (whichever of crit / bulk is not the caller's stream)
-        hipStreamWaitEvent(c->side2, c->ev_fork, 0);
-        hipStreamWaitEvent(c->sens, c->ev_fork, 0);
-        launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, c->side2, c->class_list,
-                        c->class_count);
-        hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
-        static const bool narrow_on_main = getenv("CRL_CAR_NARROW_ON_MAIN") != nullptr;  // (A/B: the narrow phase directly behind car_step_kernel on the caller's stream saves a cross-stream hop, but then the per-car solve starts together with the touching solve: 1.20 against 1.17 ms per step)
-        const bool split = touch_split;
-        if (ahead) {  // (side2 ran the narrow phase itself; crit, bulk and `one` wait for it)
-            hipStreamWaitEvent(crit, c->ev_collide, 0);
-            hipStreamWaitEvent(bulk, c->ev_collide, 0);
-            if (split) hipStreamWaitEvent(c->one, c->ev_collide, 0);
-        }
-        launch_car_coupled(c->s, c->K_, crit, c->side2, c->ev_narrow, c->ev_near, narrow_on_main && crit != st, st, split, c->one, ahead);
-        if (split) hipEventRecord(c->ev_one, c->one);  // the one-manifold islands are solved
-        if (!ahead && sens_after_narrow && c->s.players == 2 && c->s.contacts_enabled) hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
-        hipStreamWaitEvent(c->sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the
-                                                     // frame launches pass ONE barrier each -- on the legacy default stream they cost 30-40 us apiece)
-        launch_car_sensors(c->s, c->K_, c->sens);
-        hipEventRecord(c->ev_sens, c->sens);
-    } else {
-        launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, st, c->class_list, c->class_count);
-    }
     if (!fork) {
+        launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, st, c->class_list, c->class_count);
         // info["terminal_observation"] (dummy_vec_env.py:55-57): draw finished envs before they are reset
         if (obs_dev) frames(c, c->term, st, c->done_env);
         launch_car_reset(c->s, c->K_, c->src, true, c->done_env, st);
@@ -558,55 +526,71 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             crl_timer_end(tm, 1, st);
         }
     } else {
-        // Streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished, 3 finished and coupled);
-        // crit / bulk: the caller's stream and `side` (see the top of the function):
-        //   crit   narrow phase of the coupled envs -> the touching ones' island solve -> their frames (the step's longest chain)
+        // Streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished, 3 finished and coupled):
+        //   crit   (the caller's) [narrow phase of the coupled envs ->] the touching ones' island solve + THEIR FRAMES, drawn by the
+        //          wavefront that solved the island (car_touch_kernel's epilogue): the step's longest chain is two kernels
         //   bulk   per-car solve -> camera, polygons -> frames of class 0 (the big launch)
         //   side2  env bookkeeping; the coupled envs where nothing touches (two islands of their own) -> their frames; behind the
-        //          touching solve the terminal frames + commit of the envs that are finished AND coupled; the step's join
+        //          touching solve the commit of the envs that are finished AND coupled; the step's join; the NEXT step's Collide
         //   sens   wheel sensors (tile rewards, road_visited: they read the transforms the step started from and feed nothing into
-        //          its solve; every frame shows the reward, so every frame launch waits for them); behind the per-car solve the
-        //          terminal frames + commit of the finished envs on their own
+        //          its solve; every frame shows the reward, so every frame launch waits for them -- the touching solve's epilogue
+        //          through the epoch word car_epoch_kernel publishes behind them); behind the per-car solve the terminal frames +
+        //          commit of the finished envs on their own
         //   one    (high priority) the finished envs' NEW episode, prepared early on the staged view: reset, map, first frame
         // (streams of one priority share four hardware queues, and two streams that share one wait for each other's kernels;
         // the milliseconds-long walk-ahead has a priority class of its own)
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
+        const int32_t serial = ++c->serial;
+        hipEventRecord(c->ev_fork, st);
+        hipStreamWaitEvent(c->side, c->ev_fork, 0);
+        hipStreamWaitEvent(c->side2, c->ev_fork, 0);
+        hipStreamWaitEvent(c->sens, c->ev_fork, 0);
+        launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, c->side2, c->class_list,
+                        c->class_count);
+        hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
+        if (ahead) {  // (side2 ran the narrow phase itself, at the end of the last step; crit and bulk wait for it)
+            hipStreamWaitEvent(crit, c->ev_collide, 0);
+            hipStreamWaitEvent(bulk, c->ev_collide, 0);
+        }
+        // the wheel sensors are ENQUEUED before the touching solve whose epilogue waits for their epoch word: whatever hardware queue
+        // the two streams land in, the producer is ahead of the consumer
+        const bool touch_draws = contacts && !c->analytic;
+        const CarTouchDraw td = {serial, target, c->term, c->slow_env};
+        if (contacts && !ahead) {  // narrow phase at the head of crit; the sensor kernel beside it doubles both: sensors behind it
+            launch_car_narrow(c->s, c->K_, crit, true);
+            hipEventRecord(c->ev_narrow, crit);
+            hipStreamWaitEvent(c->side2, c->ev_narrow, 0);
+            hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
+        }
+        hipStreamWaitEvent(c->sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens / the epoch word then stand for the bookkeeping as well)
+        launch_car_sensors(c->s, c->K_, c->sens);
+        launch_car_epoch(c->s, serial, c->sens);
+        hipEventRecord(c->ev_sens, c->sens);
+        launch_car_coupled(c->s, c->K_, crit, c->side2, nullptr, true, touch_draws ? &td : nullptr);  // near-only solve on side2, touching solve (+ frames) on crit
+        hipEventRecord(c->ev_coupled, crit);
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
-        if (c->s.players == 2 && c->s.contacts_enabled) {
+        if (contacts) {  // frames of the near-only envs
             hipStreamWaitEvent(c->side2, c->ev_sens, 0);
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
         }
-        hipEventRecord(c->ev_coupled, crit);
         // bulk: the per-car solve, then the frames of every env that is neither coupled nor finished
         launch_car_solve(c->s, c->K_, bulk);
         hipEventRecord(c->ev_term, bulk);  // (bodies of the non-coupled cars are final)
         hipStreamWaitEvent(bulk, c->ev_sens, 0);
         crl_timer_end(tm, 0, bulk);
         frames(c, target, bulk, c->slow_env, 0, tm);
-        // crit again: frames of the touching envs (the finished-and-coupled envs' chain runs beside them, on side2)
-        static const bool abl_skip_waits = CRL_ABL(getenv("CRL_CAR_ABL_SKIP_WAITS") != nullptr);  // profiling build: what the two (long open) barriers cost
-        if (!abl_skip_waits) {
+        if (contacts && !touch_draws) {  // (profiling build, analytic raster: the touching envs' frames as a launch behind their solve)
             hipStreamWaitEvent(crit, c->ev_sens, 0);
-        }
-        if (c->s.players == 2 && c->s.contacts_enabled) {
-            if (c->analytic) {
-                launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
-            } else if (!touch_split) {
-                launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1);
-            } else {  // the islands with two manifolds or more here; the one-manifold envs' frames behind their own solve, on their own stream
-                launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_multi, c->s.coupled_count + 6, nullptr, exp_coupled / 8 + 16, c->slow_env, 1);
-                hipStreamWaitEvent(c->one, c->ev_sens, 0);
-                launch_car_obs_list(c->s, c->K_, target, c->one, c->s.touch_list, c->s.coupled_count + 2, nullptr, exp_coupled, c->slow_env, 1);
-                hipEventRecord(c->ev_onefr, c->one);
-            }
+            launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
         }
         // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
-        // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared on
-        // `sens` beside the solves.  What has to wait for the solve is small: the terminal frame (info["terminal_observation"],
+        // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared
+        // beside the solves.  What has to wait for the solve is small: the terminal frame (info["terminal_observation"],
         // drawn from the solved bodies over the OLD map) and the commit that makes the staged episode current.
         // Class 2 (cars on their own: nearly all of them) waits for the per-car solve; class 3 (finished AND coupled) for the
-        // touching solve, on `side2` -- two small kernels behind the step's longest chain instead of four.
+        // touching solve, on `side2`: the touching ones' terminal frames come from the solve's epilogue (class 5 then), the rest
+        // (coupled, nothing touching: rare) from a list launch, then the commit.
         const CarSoA sv = stage_view(c);
         auto list_of = [&](int cls) { return c->class_list + (int64_t)(cls - 1) * c->n; };
         auto count_of = [&](int cls) { return c->class_count + (cls - 1); };
@@ -616,7 +600,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             frames_list(c, sv, target, q, list_of(cls), count_of(cls), nullptr, expected);
         };
         auto late_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {
-            frames_list(c, c->s, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
+            if (c->analytic) launch_car_raster_list(c->s, c->K_, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
+            else launch_car_obs_list(c->s, c->K_, c->term, q, list_of(cls), count_of(cls), count_to_host, expected, c->slow_env, cls);
             launch_car_commit_list(c->s, sv, list_of(cls), count_of(cls), expected, q);
         };
         auto finish_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {  // everything in place, in order
@@ -627,23 +612,20 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         };
         const bool staged = !c->analytic;  // (the analytic raster reads the track arrays themselves: it needs them until the terminal frame is drawn)
         if (staged) {
-            // (on the high-priority stream when it is free: the map build's small workgroups then get CU slots ahead of the frame
-            // kernel's 32 768 wavefronts instead of behind them -- 320 us for a dozen maps otherwise.  CRL_CAR_EARLY_ON_SENS=1: A/B)
-            static const bool early_hi_env = getenv("CRL_CAR_EARLY_ON_SENS") == nullptr;
-            const hipStream_t eq = (early_hi_env && !touch_split) ? c->one : c->sens;
-            if (eq != c->sens) hipStreamWaitEvent(eq, c->ev_sens, 0);
-            early_chain(eq, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
-            hipEventRecord(c->ev_early3, eq);
+            // on the high-priority stream: the map build's small workgroups then get CU slots ahead of the frame kernel's 32 768
+            // wavefronts instead of behind them (320 us for a dozen maps otherwise)
+            hipStreamWaitEvent(c->one, c->ev_sens, 0);
+            early_chain(c->one, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
+            hipEventRecord(c->ev_early3, c->one);
             hipStreamWaitEvent(c->sens, c->ev_term, 0);
-            if (eq != c->sens) hipStreamWaitEvent(c->sens, c->ev_early3, 0);
+            hipStreamWaitEvent(c->sens, c->ev_early3, 0);
             late_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
         } else {
             hipStreamWaitEvent(c->sens, c->ev_term, 0);
             finish_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
         }
         hipEventRecord(c->ev_fin, c->sens);
-        hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve (two manifolds or more -- or all of them)
-        if (touch_split) hipStreamWaitEvent(c->side2, c->ev_one, 0);
+        hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve
         hipStreamWaitEvent(c->side2, c->ev_sens, 0);
         if (staged) {
             hipStreamWaitEvent(c->side2, c->ev_early3, 0);
@@ -656,7 +638,6 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipEventRecord(c->ev_join, c->side);
         hipStreamWaitEvent(c->side2, c->ev_fin, 0);
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
-        if (touch_split) hipStreamWaitEvent(c->side2, c->ev_onefr, 0);
         hipEventRecord(c->ev_fin3, c->side2);
         if (can_ahead) {
             // every solve of this step is in (side2 is behind the near-only and the touching solve; ev_term: the per-car solve) and

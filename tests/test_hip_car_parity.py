@@ -710,3 +710,68 @@ def test_staged_reset_pipeline_equals_the_sequential_step():
         assert a.get_state().tobytes() == b.get_state().tobytes(), t
     assert torch.equal(a.render_current(), b.render_current())
     a.close(), b.close()
+
+
+def _park_cars_side_by_side(st, touch):
+    """car 1 beside car 0, wheels overlapping (the narrow phase finds manifolds at once), for the envs of `touch`"""
+    c0, c1 = st["car"][:, 0], st["car"][:, 1]
+    ang = c0["hull"]["a"].astype(np.float64)
+    lat = np.stack([np.cos(ang), np.sin(ang)], 1) * 2.6
+    for body in ("hull", "wheel"):
+        src0, dst = c0[body], c1[body]
+        for f in ("a", "vx", "vy", "w"):
+            dst[f][touch] = src0[f][touch]
+        if body == "hull":
+            dst["cx"][touch] = src0["cx"][touch] + lat[touch, 0]
+            dst["cy"][touch] = src0["cy"][touch] + lat[touch, 1]
+        else:
+            dst["cx"][touch] = src0["cx"][touch] + lat[touch, 0][:, None]
+            dst["cy"][touch] = src0["cy"][touch] + lat[touch, 1][:, None]
+
+
+def test_collide_ahead_back_to_back_steps_without_host_syncs():
+    """with the collide-ahead, step t+1's first kernel is enqueued while step t's broadphase for it may still
+    be running on another stream.  Hundreds of step_device calls in a row with NO host synchronisation in between (the twin
+    test's get_state calls would hide a cross-stream race), half the envs touching, against a context created with
+    CRL_CAR_NO_COLLIDE_AHEAD=1 (every step runs its own Collide on the caller's stream): every reward, done flag and frame of
+    every step, and the final state incl. manifolds and impulses, must be identical."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps = 512, 300
+    a = crl.HipCarVecEnv(n, seed=33)
+    os.environ["CRL_CAR_NO_COLLIDE_AHEAD"] = "1"
+    try:
+        b = crl.HipCarVecEnv(n, seed=33)  # (read when the context is created)
+    finally:
+        del os.environ["CRL_CAR_NO_COLLIDE_AHEAD"]
+    a.reset(), b.reset()
+    st = a.get_state()
+    touch = np.arange(n) % 2 == 0
+    _park_cars_side_by_side(st, touch)
+    st["elapsed"] = (np.arange(n) * 7) % 1000  # episodes end (TimeLimit) all along the run
+    a.set_state(st), b.set_state(st)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    acts = torch.rand((steps, n, 2, 2), generator=g, device="cuda") * 2 - 1
+    acts[:, :, 1, 0] = -acts[:, :, 0, 0]  # the cars steer towards each other again and again
+    log = {k: [torch.zeros((steps, n, 2), device="cuda"), torch.zeros((steps, n), dtype=torch.uint8, device="cuda"),
+               torch.zeros((steps, n), dtype=torch.int64, device="cuda")] for k in "ab"}
+    w = torch.arange(1, 2 * 96 * 96 + 1, device="cuda", dtype=torch.int64)
+    for rep in range(2):  # (b after a, then interleaved call by call: different overlap of the two contexts' streams)
+        for t in range(steps // 2 * rep, steps // 2 * (rep + 1)):
+            for k, e in (("a", a), ("b", b)) if rep else (("a", a),):
+                o, r, d = e.step_device(acts[t])
+                log[k][0][t].copy_(r), log[k][1][t].copy_(d), log[k][2][t].copy_((o.view(n, -1).to(torch.int64) * w).sum(1))
+        if not rep:
+            for t in range(0, steps // 2):
+                o, r, d = b.step_device(acts[t])
+                log["b"][0][t].copy_(r), log["b"][1][t].copy_(d), log["b"][2][t].copy_((o.view(n, -1).to(torch.int64) * w).sum(1))
+    torch.cuda.synchronize()
+    for i, what in enumerate(("rewards", "dones", "frame checksums")):
+        same = (log["a"][i] == log["b"][i]).reshape(steps, -1).all(1)
+        assert bool(same.all()), (what, "first differing step", int(torch.nonzero(~same)[0]))
+    sa, sb = a.get_state(), b.get_state()
+    assert sa.tobytes() == sb.tobytes()
+    assert int((sa["n_contact"] > 0).sum()) > 0 and int(log["a"][1].sum()) > n // 4, "the run must contain touching cars and episode ends"
+    assert a.cap_hits() == b.cap_hits() == (0, 0, 0, 0)
+    a.close(), b.close()
