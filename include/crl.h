@@ -369,6 +369,15 @@ const char *crl_last_error(void);
 const char *crl_ctx_last_error(const crl_ctx *ctx);
 const char *crl_version(void);
 
+/* Device self-test of include/crl_rot.h (no context needed): evaluates crl_sincosf on the float32 bit patterns
+ * [first_bits, first_bits + count) that lie in its domain and compares each result with the double-double evaluation of
+ * include/crl_f64.h rounded once to float32.  out5_host: [0] arguments tested, [1] sine results that are not the correctly
+ * rounded float32, [2] cosine likewise, [3] results too close to a rounding boundary for the double-double bound to decide,
+ * [4] first mismatching bit pattern + 1 (0 = none).  The whole space (first_bits 0, count 2^32) takes a few seconds.
+ * Replaces nothing in the reference: Box2D calls the host libm's sinf / cosf (b2Math.h b2Rot::Set, via box2d-py,
+ * car_racing/car_racing_multi_players.py:600); this pins the one evaluation both sides of the parity tests share. */
+int crl_selftest_sincosf(int32_t device, uint64_t first_bits, uint64_t count, uint64_t *out5_host);
+
 #ifdef __cplusplus
 }
 #endif

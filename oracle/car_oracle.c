@@ -659,7 +659,7 @@ static inline v2 xmul(xform t, v2 v) { return vadd(rot(t.s, t.c, v), t.p); }
 static inline v2 qmulT(xform t, v2 v) { return V(t.c * v.x + t.s * v.y, -t.s * v.x + t.c * v.y); }
 static inline v2 xmulT(xform t, v2 v) { return qmulT(t, vsub(v, t.p)); }
 
-typedef struct { const float (*v)[2]; int n; v2 nrm[8]; } shape;
+typedef struct { const float (*v)[2]; int n; v2 nrm[8]; v2 centroid; } shape;
 static shape SH[8]; /* 0-3 hull polygons, 4-7 the wheel box */
 static int SH_ready = 0;
 static void shapes_init(void) {
@@ -673,6 +673,17 @@ static void shapes_init(void) {
             v2 n = V(e.y, -e.x); /* b2Cross(edge, 1) */
             float len = sqrtf(vdot(n, n));
             SH[f].nrm[i] = vmul(1.0f / len, n);
+        }
+        { /* b2PolygonShape::Set -> ComputeCentroid (b2PolygonShape.cpp): area-weighted, reference point = origin */
+            v2 c = V(0, 0);
+            float area = 0;
+            for (int i = 0; i < SH[f].n; i++) {
+                v2 p2 = V(SH[f].v[i][0], SH[f].v[i][1]), p3 = i + 1 < SH[f].n ? V(SH[f].v[i + 1][0], SH[f].v[i + 1][1]) : V(SH[f].v[0][0], SH[f].v[0][1]);
+                float D = vcross(p2, p3), ta = 0.5f * D;
+                area += ta;
+                c = vadd(c, vmul(ta * (1.0f / 3.0f), vadd(p2, p3)));
+            }
+            SH[f].centroid = vmul(1.0f / area, c);
         }
     }
     SH_ready = 1;
@@ -692,7 +703,81 @@ static xform xf_of(const bref *r) {
     return t;
 }
 
-/* b2FindMaxSeparation (exhaustive form): best edge of poly1 against poly2's vertices */
+/* b2FindMaxSeparation: which published form?  box2d-py ~=2.3.5 is not in the reference tree, and Box2D changed this function
+ * between 2.3.0 and 2.3.1; DESIGN.md section 9 tabulates what is assumed per function.  CRL_B2_COLLIDE selects (compile time):
+ *   0 (default, = the HIP kernels): exhaustive search over poly1's edges, dot products in the WORLD frame, flip rule 0.98 / 0.001
+ *   1  Box2D 2.3.1+ as published: exhaustive search in poly2's frame (b2MulT(xf2, xf1)), flip rule separationB > separationA + 0.1 linearSlop
+ *   2  Box2D 2.3.0 as published: hill climb from the edge facing the other centroid (b2EdgeSeparation), flip rule 0.98 / 0.001
+ * The three agree on every manifold except where two edges' separations tie to the last bit or the flip rule is at its threshold;
+ * tests/test_oracle_car_physics.py counts the differences over a contact-rich soak (CPU only; builds: make -C oracle variants). */
+#ifndef CRL_B2_COLLIDE
+#define CRL_B2_COLLIDE 0
+#endif
+#if CRL_B2_COLLIDE == 1
+static float max_separation(int *edge, const shape *p1, xform x1, const shape *p2, xform x2) {
+    xform xf; /* b2MulT(xf2, xf1) */
+    xf.s = x2.c * x1.s - x2.s * x1.c, xf.c = x2.c * x1.c + x2.s * x1.s;
+    xf.p = qmulT(x2, vsub(x1.p, x2.p));
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int i = 0; i < p1->n; i++) {
+        v2 n = rot(xf.s, xf.c, p1->nrm[i]), v1 = xmul(xf, V(p1->v[i][0], p1->v[i][1]));
+        float si = 3.4e38f;
+        for (int j = 0; j < p2->n; j++) {
+            float sij = vdot(n, vsub(V(p2->v[j][0], p2->v[j][1]), v1));
+            if (sij < si) si = sij;
+        }
+        if (si > best) best = si, bi = i;
+    }
+    *edge = bi;
+    return best;
+}
+#elif CRL_B2_COLLIDE == 2
+static float edge_separation(const shape *p1, xform x1, int edge1, const shape *p2, xform x2) { /* b2EdgeSeparation */
+    v2 normal1World = rot(x1.s, x1.c, p1->nrm[edge1]), normal1 = qmulT(x2, normal1World);
+    int index = 0;
+    float minDot = 3.4e38f;
+    for (int i = 0; i < p2->n; i++) {
+        float d = vdot(V(p2->v[i][0], p2->v[i][1]), normal1);
+        if (d < minDot) minDot = d, index = i;
+    }
+    v2 v1 = xmul(x1, V(p1->v[edge1][0], p1->v[edge1][1])), v2_ = xmul(x2, V(p2->v[index][0], p2->v[index][1]));
+    return vdot(vsub(v2_, v1), normal1World);
+}
+static float max_separation(int *edgeIndex, const shape *p1, xform x1, const shape *p2, xform x2) {
+    const int count1 = p1->n;
+    v2 d = vsub(xmul(x2, p2->centroid), xmul(x1, p1->centroid)), dLocal1 = qmulT(x1, d);
+    int edge = 0;
+    float maxDot = -3.4e38f;
+    for (int i = 0; i < count1; i++) {
+        float dt = vdot(p1->nrm[i], dLocal1);
+        if (dt > maxDot) maxDot = dt, edge = i;
+    }
+    float s = edge_separation(p1, x1, edge, p2, x2);
+    int prevEdge = edge - 1 >= 0 ? edge - 1 : count1 - 1;
+    float sPrev = edge_separation(p1, x1, prevEdge, p2, x2);
+    int nextEdge = edge + 1 < count1 ? edge + 1 : 0;
+    float sNext = edge_separation(p1, x1, nextEdge, p2, x2);
+    int bestEdge, increment;
+    float bestSeparation;
+    if (sPrev > s && sPrev > sNext) increment = -1, bestEdge = prevEdge, bestSeparation = sPrev;
+    else if (sNext > s) increment = 1, bestEdge = nextEdge, bestSeparation = sNext;
+    else {
+        *edgeIndex = edge;
+        return s;
+    }
+    for (;;) {
+        if (increment == -1) edge = bestEdge - 1 >= 0 ? bestEdge - 1 : count1 - 1;
+        else edge = bestEdge + 1 < count1 ? bestEdge + 1 : 0;
+        s = edge_separation(p1, x1, edge, p2, x2);
+        if (s > bestSeparation) bestEdge = edge, bestSeparation = s;
+        else break;
+    }
+    *edgeIndex = bestEdge;
+    return bestSeparation;
+}
+#else
+/* exhaustive form, world frame: best edge of poly1 against poly2's vertices */
 static float max_separation(int *edge, const shape *p1, xform x1, const shape *p2, xform x2) {
     float best = -3.4e38f;
     int bi = 0;
@@ -708,6 +793,7 @@ static float max_separation(int *edge, const shape *p1, xform x1, const shape *p
     *edge = bi;
     return best;
 }
+#endif
 
 typedef struct { v2 v; uint32_t id; } clipv;
 #define MKID(ia, ib, ta, tb) ((uint32_t)(ia) | ((uint32_t)(ib) << 8) | ((uint32_t)(ta) << 16) | ((uint32_t)(tb) << 24))
@@ -737,7 +823,12 @@ static void collide_polygons(car_contact *c, const shape *pa, xform xa, const sh
     const shape *p1, *p2;
     xform x1, x2;
     int edge1, flip;
-    if (sepB > 0.98f * sepA + 0.001f) p1 = pb, p2 = pa, x1 = xb, x2 = xa, edge1 = edgeB, c->type = 1, flip = 1;
+#if CRL_B2_COLLIDE == 1
+    const int flip_rule = sepB > sepA + 0.1f * 0.005f; /* k_tol = 0.1f * b2_linearSlop */
+#else
+    const int flip_rule = sepB > 0.98f * sepA + 0.001f; /* k_relativeTol, k_absoluteTol */
+#endif
+    if (flip_rule) p1 = pb, p2 = pa, x1 = xb, x2 = xa, edge1 = edgeB, c->type = 1, flip = 1;
     else p1 = pa, p2 = pb, x1 = xa, x2 = xb, edge1 = edgeA, c->type = 0, flip = 0;
     /* b2FindIncidentEdge */
     clipv inc[2];
@@ -1170,6 +1261,44 @@ void car_oracle_step_repeat(car_env *e, const double (*actions)[2], int repeat, 
 void car_oracle_step(car_env *e, const double (*actions)[2], double step_reward[2], int done[2]) {
     car_oracle_step_repeat(e, actions, 1, step_reward, done);
 }
+
+/* n envs stepped at once over the host's cores (the long parity soaks of tests/: thousands of envs per step) */
+void car_oracle_step_batch(car_env *e, long n, const double *actions /*[n][2][2]*/, double *step_reward /*[n][2]*/, int32_t *done /*[n][2]*/) {
+    car_oracle_consts();
+    shapes_init();
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long i = 0; i < n; i++) {
+        int d[2];
+        car_oracle_step(&e[i], actions ? (const double(*)[2])(actions + 4 * i) : 0, step_reward + 2 * i, d);
+        done[2 * i] = d[0], done[2 * i + 1] = d[1];
+    }
+}
+
+/* world.Step alone: Collide of the two cars + the island solve(s), WITHOUT Car.step (the forces the bodies carry are applied as
+ * they are, the joint motor targets stay): the physics property tests of tests/test_oracle_car_physics.py (momentum through a
+ * collision with the tyre forces off) */
+void car_oracle_world_step(car_env *e) {
+    car_oracle_consts();
+    shapes_init();
+    const float h = (float)(1.0 / FPS), dt_ratio = e->inv_dt0 * h;
+    if (e->contacts_enabled) collide_cars(e);
+    if (e->contacts_enabled && e->n_contact > 0) {
+        island_solve_coupled(e, h, dt_ratio, 180, 60);
+    } else {
+        island_solve(&e->car[1], h, dt_ratio, 180, 60);
+        island_solve(&e->car[0], h, dt_ratio, 180, 60);
+    }
+    e->inv_dt0 = 1.0f / h;
+}
+
+/* b2ContactManager::Collide for the two cars of each env, from the poses it holds: the manifolds (without stepping) */
+void car_oracle_collide_batch(car_env *e, long n) {
+    car_oracle_consts();
+    shapes_init();
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < n; i++) collide_cars(&e[i]);
+}
+int car_oracle_collide_variant(void) { return CRL_B2_COLLIDE; }
 
 void car_oracle_hull_position(const car_env *e, int c, float out[3]) {
     float s, co;

@@ -45,6 +45,9 @@ def _configure(L):
     L.car_oracle_reset.restype = i32
     L.car_oracle_step.argtypes = [vp, vp, vp, vp]
     L.car_oracle_step_repeat.argtypes = [vp, vp, i32, vp, vp]
+    L.car_oracle_step_batch.argtypes = [vp, C.c_long, vp, vp, vp]
+    L.car_oracle_collide_batch.argtypes = [vp, C.c_long]
+    L.car_oracle_world_step.argtypes = [vp]
     L.car_oracle_contact_event.argtypes = [vp, i32, i32, i32, i32]
     L.car_oracle_hull_position.argtypes = [vp, i32, vp]
     L.car_oracle_wheel_on_road.argtypes = [vp, i32, i32]
@@ -145,6 +148,10 @@ class CarEnv:
             self.L.car_oracle_step(_p(self.buf), _p(a), _p(rew), _p(done))
         return rew, done
 
+    def world_step(self):
+        """world.Step alone (Collide of the cars + island solve), no Car.step"""
+        self.L.car_oracle_world_step(_p(self.buf))
+
     def step_repeat(self, actions, repeat):
         rew, done = np.zeros(2), np.zeros(2, np.int32)
         a = np.ascontiguousarray(actions, np.float64).reshape(2, 2)
@@ -202,3 +209,46 @@ class CarEnv:
         out = np.zeros(3, np.float32)
         self.L.car_oracle_hull_position(_p(self.buf), c, _p(out))
         return out
+
+
+class CarBatch:
+    """n oracle envs in ONE structured array, stepped together over the host's cores (car_oracle_step_batch): the long parity
+    soaks.  ``self.E[i]`` is env i's car_env; ``view(i)`` a CarEnv over the same memory (render, reset, map)."""
+
+    def __init__(self, n, libm=False):
+        self.n = int(n)
+        self.E = np.zeros(self.n, ENV_DT)
+        self.L = lib(libm)
+        self.libm = libm
+        self._views = {}
+
+    def view(self, i):
+        v = self._views.get(i)
+        if v is None:
+            v = CarEnv.__new__(CarEnv)
+            v.buf, v.L, v._map, v._map_key = self.E[i:i + 1], self.L, None, None
+            v.e = v.buf[0]
+            self._views[i] = v
+        return v
+
+    def step(self, actions):
+        """actions (n, 2, 2) or None (the action-less step a reset ends with) -> step rewards (n, 2) f64, per-car done (n, 2) i32"""
+        rew, done = np.zeros((self.n, 2)), np.zeros((self.n, 2), np.int32)
+        a = None if actions is None else np.ascontiguousarray(actions, np.float64).reshape(self.n, 2, 2)
+        self.L.car_oracle_step_batch(_p(self.E), self.n, None if a is None else _p(a), _p(rew), _p(done))
+        return rew, done
+
+
+def collide_variant(which):
+    """liboracle_b2v<which>.so: the oracle with another published form of b2CollidePolygons' edge search (car_oracle.c
+    CRL_B2_COLLIDE = 1: Box2D 2.3.1+, 2: Box2D 2.3.0); built on demand (make -C oracle variants).  Only for counting disagreements."""
+    import os
+    import subprocess
+
+    key = ("b2v", int(which))
+    if key not in _libs:
+        subprocess.check_call(["make", "-C", _po.HERE, "variants"], stdout=subprocess.DEVNULL)
+        L = _configure(C.CDLL(os.path.join(_po.HERE, "liboracle_b2v%d.so" % int(which))))
+        assert L.car_oracle_collide_variant() == int(which)
+        _libs[key] = L
+    return _libs[key]

@@ -86,3 +86,32 @@ def test_distance_to_the_host_libm():
         out[name] = float(diff.mean())
     print("fraction of calls where the host libm differs from the correctly rounded value:", out)
     assert all(v < 5e-3 for v in out.values())
+
+
+@pytest.mark.gpu
+def test_crl_sincosf_is_correctly_rounded_for_every_float32_argument():
+    """the sample above is 20 000 arguments; the space is small enough to sweep.  crl_selftest_sincosf (include/crl.h)
+    evaluates crl_sincosf on EVERY float32 bit pattern of its domain (|x| < 2^20 * pi/2: 2.5e9 arguments) on the GPU and
+    compares with the double-double evaluation of include/crl_f64.h (~2^-95) rounded once to float32: 0 mismatches, and no
+    argument so close to a rounding boundary that the double-double bound could not decide."""
+    import ctypes as C
+
+    import torch
+
+    from competitive_rl_amd import _native as N
+
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+    L = N.load()
+    tot = np.zeros(5, np.uint64)
+    for first in range(0, 1 << 32, 1 << 30):  # four launches of 2^30 bit patterns
+        out = np.zeros(5, np.uint64)
+        N.check(L.crl_selftest_sincosf(0, first, 1 << 30, out.ctypes.data_as(C.c_void_p)))
+        tot[:4] += out[:4]
+        tot[4] = tot[4] or out[4]
+    tested, bad_s, bad_c, undecided, first_bad = (int(v) for v in tot)
+    print("crl_sincosf sweep: tested", tested, "sin mismatches", bad_s, "cos mismatches", bad_c, "undecided", undecided)
+    # 2 x (bit patterns below 0x49C90FDB = 1647099.0f's neighbourhood) incl. both zeros
+    assert tested > 2_400_000_000, tested
+    assert bad_s == 0 and bad_c == 0, (bad_s, bad_c, hex(first_bad - 1))
+    assert undecided == 0, undecided

@@ -222,3 +222,185 @@ def test_island_sleep_zeroes_sub_tolerance_velocities_after_half_a_second():
         e.step([[0.0, 1.0], [0.0, 0.0]])
     assert np.all(e.e["car"][0]["sleep_time"] == 0.0)
     assert e.e["car"][0]["hull"]["vx"] ** 2 + e.e["car"][0]["hull"]["vy"] ** 2 > 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# properties that need no Box2D binary, and a count of how often the published forms of b2CollidePolygons'
+# edge search disagree (DESIGN.md section 9 tabulates which Box2D revision each restated function follows)
+
+def _momenta(e):
+    """total linear momentum and angular momentum about the origin of the ten bodies, in float64"""
+    k = co.consts()
+    P, Lz = np.zeros(2), 0.0
+    for c in range(2):
+        car = e.e["car"][c]
+        bodies = [(car["hull"], float(k["hull_mass"]), float(k["hull_I"]))] + [(car["wheel"][w], float(k["wheel_mass"]), float(k["wheel_I"])) for w in range(4)]
+        for b, m, inertia in bodies:
+            v = np.array([b["vx"], b["vy"]], np.float64)
+            r = np.array([b["cx"], b["cy"]], np.float64)
+            P += m * v
+            Lz += inertia * float(b["w"]) + m * (r[0] * v[1] - r[1] * v[0])
+    return P, Lz
+
+
+def test_momentum_is_conserved_through_a_collision_without_tyre_forces():
+    """Two cars, no tyre forces (world.Step alone: car_oracle_world_step), one driven into the other at an angle: every impulse the
+    solver applies -- joint point / limit / motor constraints, contact normal and friction, the 2-point block solver -- acts
+    equal and opposite on two bodies at one point, so the total linear momentum and the angular momentum about the origin of
+    the ten bodies must survive the crash up to float32 rounding (the position pass moves bodies by at most a few slops per
+    step without touching velocities: the bound on the angular part allows for that)."""
+    e = fresh_env()
+    e.e["contacts_enabled"] = 1
+    hd = _park_car1_ahead(e, 7.0)
+    for _ in range(20):
+        e.step([[0.0, 0.0], [0.0, 0.0]])  # settle
+    lat = np.array([hd[1], -hd[0]])
+    for c, v in ((0, 9.0 * hd + 1.5 * lat), (1, -2.0 * hd)):  # car 0 into car 1, slightly across; car 1 rolls towards it
+        car = e.e["car"][c]
+        car["hull"]["vx"], car["hull"]["vy"] = v
+        car["wheel"]["vx"], car["wheel"]["vy"] = v[0], v[1]
+        car["hull"]["w"] = 0.3 if c == 0 else 0.0
+        car["motor_speed"][:] = 0.0
+    for c in range(2):
+        for b in [e.e["car"][c]["hull"]] + [e.e["car"][c]["wheel"][w] for w in range(4)]:
+            b["fx"] = b["fy"] = 0.0
+    P0, L0 = _momenta(e)
+    touched, worstP, worstL = 0, 0.0, 0.0
+    scaleP, scaleL = np.abs(P0).max(), max(abs(L0), 1.0)
+    for t in range(60):
+        e.world_step()
+        touched += int(e.e["n_contact"]) > 0
+        P, L = _momenta(e)
+        worstP, worstL = max(worstP, np.abs(P - P0).max() / scaleP), max(worstL, abs(L - L0) / scaleL)
+    assert touched >= 5, touched
+    assert worstP < 2e-5, worstP
+    assert worstL < 2e-3, worstL
+    # and the crash did exchange momentum: car 1 now moves along +hd
+    assert float(np.dot([e.e["car"][1]["hull"]["vx"], e.e["car"][1]["hull"]["vy"]], hd)) > 1.0
+
+
+def test_joint_anchors_are_within_linear_slop_after_every_converged_position_solve():
+    """b2RevoluteJoint::SolvePositionConstraints returns `positionError <= b2_linearSlop` measured BEFORE its last correction;
+    the island stops iterating when every joint says so.  While driving (no contacts) every step converges, so after the
+    step each wheel's anchor is within linearSlop of the hull's anchor -- checked in float64 from the stored poses."""
+    e = fresh_env()
+    rs = np.random.RandomState(3)
+    worst = 0.0
+    for t in range(200):
+        a = rs.uniform(-1, 1, (2, 2))
+        a[:, 1] = abs(a[:, 1]) if t < 120 else -abs(a[:, 1])
+        e.step(a)
+        for c in range(2):
+            worst = max(worst, float(anchor_errors(e, c).max()))
+    assert worst <= 0.005 * (1 + 1e-3), worst
+
+
+def test_warm_started_steady_contact_reproduces_its_impulses():
+    """A pushing contact that persists: the next step's Collide finds the same manifolds with the same contact ids and hands
+    the solver EXACTLY the accumulated normal / tangent impulses the previous solve ended with (b2Contact::Update copies them by
+    id; b2ContactSolver::WarmStart applies them), and with that start the solve lands close to where it started: the
+    impulses change by a few per cent per step instead of being rebuilt from zero."""
+    e = fresh_env()
+    e.e["contacts_enabled"] = 1
+    _park_car1_ahead(e, 8.0)
+    L = co.lib()
+    carried = steady = 0
+    for t in range(170):
+        before = {int(e.e["contact"][k]["pair"]): e.e["contact"][k].copy() for k in range(int(e.e["n_contact"]))}
+        probe = e.buf.copy()
+        L.car_oracle_collide_batch(co._p(probe), 1)  # what this step's Collide will hand to the solver
+        for k in range(int(probe[0]["n_contact"])):
+            c = probe[0]["contact"][k]
+            old = before.get(int(c["pair"]))
+            if old is None:
+                continue
+            for i_ in range(int(c["count"])):
+                match = [j_ for j_ in range(int(old["count"])) if int(old["id"][j_]) == int(c["id"][i_])]
+                if match:
+                    assert c["nimp"][i_] == old["nimp"][match[0]] and c["timp"][i_] == old["timp"][match[0]], (t, k, i_)
+                    carried += 1
+                else:
+                    assert c["nimp"][i_] == 0.0 and c["timp"][i_] == 0.0, (t, k, i_)
+        e.step([[0.0, 1.0], [0.0, 0.0]])
+        if t >= 130 and before:
+            after = {int(e.e["contact"][k]["pair"]): e.e["contact"][k] for k in range(int(e.e["n_contact"]))}
+            assert set(after) == set(before), (t, sorted(before), sorted(after))
+            tot_b = sum(float(c["nimp"][:int(c["count"])].sum()) for c in before.values())
+            tot_a = sum(float(c["nimp"][:int(c["count"])].sum()) for c in after.values())
+            assert tot_b > 1.0 and abs(tot_a - tot_b) / tot_b < 0.3, (t, tot_b, tot_a)
+            steady += 1
+    assert carried > 100 and steady >= 35, (carried, steady)
+
+
+def test_count_where_the_published_forms_of_the_polygon_edge_search_disagree():
+    """Box2D changed b2FindMaxSeparation between 2.3.0 (hill climb from the edge facing the other centroid; flip rule
+    0.98 / 0.001) and 2.3.1 (exhaustive search in polygon 2's frame; flip rule + 0.1 linearSlop); the oracle and the HIP kernels
+    search exhaustively with world-frame dot products and the 2.3.0 flip rule.  box2d-py ~=2.3.5 cannot
+    be installed here to say which one the reference runs, so this test MEASURES the disagreement instead: a contact-rich soak
+    is stepped with the default build, and at every step the three forms compute the manifolds from the same poses."""
+    from tests.car_scenarios import make_oracle_envs
+
+    n, steps, base = 192, 120, 16
+    seeds = make_oracle_envs(base, seed0=40)
+    B = co.CarBatch(n)
+    rs = np.random.RandomState(8)
+    for i in range(n):
+        B.E[i] = seeds[i % base].e
+    # car 1 next to car 0 at a random relative pose (some overlapping, some a little apart)
+    c0, c1 = B.E["car"][:, 0], B.E["car"][:, 1]
+    ang = c0["hull"]["a"].astype(np.float64) + rs.uniform(0, 2 * np.pi, n)
+    dist = rs.uniform(1.8, 5.5, n)
+    dx, dy = (np.cos(ang) * dist).astype(np.float32), (np.sin(ang) * dist).astype(np.float32)
+    turn = rs.uniform(-np.pi, np.pi, n).astype(np.float32)
+    for i in range(n):  # rotate car 1 about its hull centre by `turn`, then move it
+        cs, sn = np.cos(turn[i]), np.sin(turn[i])
+        hx, hy = float(c1["hull"]["cx"][i]), float(c1["hull"]["cy"][i])
+        for w in range(4):
+            rx, ry = float(c1["wheel"]["cx"][i, w]) - hx, float(c1["wheel"]["cy"][i, w]) - hy
+            c1["wheel"]["cx"][i, w], c1["wheel"]["cy"][i, w] = hx + cs * rx - sn * ry, hy + sn * rx + cs * ry
+            c1["wheel"]["a"][i, w] += turn[i]
+        c1["hull"]["a"][i] += turn[i]
+        ox, oy = float(c0["hull"]["cx"][i]) + dx[i] - hx, float(c0["hull"]["cy"][i]) + dy[i] - hy
+        c1["hull"]["cx"][i] += ox
+        c1["hull"]["cy"][i] += oy
+        c1["wheel"]["cx"][i] += ox
+        c1["wheel"]["cy"][i] += oy
+    libs = {0: co.lib(), 1: co.collide_variant(1), 2: co.collide_variant(2)}
+    tot = {k: dict(manifolds=0, missing=0, extra=0, flip=0, face=0, ids=0, points=0) for k in (1, 2)}
+    ref_manifolds = 0
+    for t in range(steps):
+        found = {}
+        for k, L in libs.items():
+            Ev = B.E.copy()
+            L.car_oracle_collide_batch(co._p(Ev), n)
+            found[k] = Ev
+        R = found[0]
+        for i in range(n):
+            ref = {int(R["contact"][i, j]["pair"]): R["contact"][i, j] for j in range(int(R["n_contact"][i]))}
+            ref_manifolds += len(ref)
+            for k in (1, 2):
+                alt = {int(found[k]["contact"][i, j]["pair"]): found[k]["contact"][i, j] for j in range(int(found[k]["n_contact"][i]))}
+                d = tot[k]
+                d["manifolds"] += len(alt)
+                d["missing"] += len(set(ref) - set(alt))
+                d["extra"] += len(set(alt) - set(ref))
+                for pair in set(ref) & set(alt):
+                    a, b = ref[pair], alt[pair]
+                    if int(a["type"]) != int(b["type"]):
+                        d["flip"] += 1
+                    elif tuple(a["ln"]) != tuple(b["ln"]):
+                        d["face"] += 1
+                    elif int(a["count"]) != int(b["count"]):
+                        d["points"] += 1
+                    elif not np.array_equal(a["id"][:int(a["count"])], b["id"][:int(b["count"])]):
+                        d["ids"] += 1
+        acts = rs.uniform(-1, 1, (n, 2, 2))
+        acts[:, 1] = -acts[:, 0] if t % 20 < 10 else acts[:, 1]
+        B.step(acts)
+    print("manifolds (default form):", ref_manifolds, "| Box2D 2.3.1 form:", tot[1], "| Box2D 2.3.0 form:", tot[2])
+    assert ref_manifolds > 3000
+    for k in (1, 2):
+        d = tot[k]
+        differing = d["missing"] + d["extra"] + d["flip"] + d["face"] + d["ids"] + d["points"]
+        # recorded in DESIGN.md section 9; the bound only keeps the statement honest if the scenario or the code changes
+        assert differing <= 0.05 * ref_manifolds, (k, d, ref_manifolds)
