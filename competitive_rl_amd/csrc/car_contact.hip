@@ -11,9 +11,7 @@
 // not collide with wheels).  friction = sqrt(0.2*0.2), restitution = 0, polygonRadius = 0.01.
 #include <stdlib.h>
 
-#include "car_obs_tile.h"
 #include "car_solver.h"
-#include "crl_internal.h"
 
 namespace crl {
 
@@ -910,20 +908,12 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 // one launch, blockIdx.y = manifold-count class (0: nc == 1, 1: nc == 2, 2: nc >= 3); the workgroups loop over the class's list.
 // EPW1 = envs per wavefront of class 0 (94 % of the touching envs); two manifolds or more (the slowest islands): one env per wavefront.
 // NK2 / NK3: manifolds kept in registers for classes 1 and 2 (the rest through LDS).
-//
-// Epilogue (draw.on): the wavefront that solved an island also DRAWS that env's two frames (camera, car polygons, tile: the code of
-// car_obs_list_kernel) -- the step's longest chain then ends with this kernel instead of with a barrier and a frame launch behind it.
-// The frames show the reward, which the wheel sensors of the step add to on another stream: the epilogue first waits (acquire) for
-// the epoch word that car_epoch_kernel publishes behind them (they finish some 400 us earlier; the wait is bounded and a give-up is
-// counted in cap_hits[2]).  An env that finished its episode in this step gets its frame into `term` (info["terminal_observation"];
-// the new episode's first frame comes from the staged reset) and is marked class 5 so that the finished envs' chain does not redraw it.
-struct TouchDraw {
-    int on;
-    int32_t serial;
-    uint8_t *target, *term, *slow_env;
-};
+// (Round 4 tried an epilogue in which the wavefront that solved an island also draws that env's two frames, behind an epoch word
+// published by the wheel sensors' stream: one tile takes a lone wavefront ~75 us, so two or eight tiles in a row behind a solve are
+// slower than the list launch that draws them side by side -- and a kernel that spins on another kernel's output deadlocks as soon
+// as both are only partly dispatched.  docs/LAB_NOTES_r04.md.)
 template <int EPW1, int NK2, int NK3>
-__global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, int cls0, TouchDraw draw) {
+__global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, int cls0) {
     const int cls = cls0 + blockIdx.y;
     const int count = s.coupled_count[2 + cls];
     const int epw = cls == 0 ? EPW1 : 1;
@@ -932,32 +922,12 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
     __shared__ __attribute__((aligned(16))) CarRegs sh_car[EPW1][2];
     __shared__ __attribute__((aligned(16))) Contact sh_ct[EPW1][kMaxContacts];
     __shared__ __attribute__((aligned(16))) TouchC sh_tc[EPW1][kMaxContacts];
-    __shared__ __attribute__((aligned(16))) CarObsLds sh_obs;
     const int32_t *list = s.touch_list + (int64_t)cls * s.n;
     for (int base = blockIdx.x * epw; base < count; base += gridDim.x * epw) {
         if (cls == 0) touch_solve<1, EPW1, false>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         else if (cls == 1) touch_solve<NK2, 1, (NK2 < 2)>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         else touch_solve<NK3, 1, true>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (!draw.on) continue;
-        {   // the step's wheel sensors and env bookkeeping (reward read-out, class of the env)
-            int spins = 0;
-            while (__hip_atomic_load(s.sens_epoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != draw.serial) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 22)) {
-                    if (threadIdx.x == 0) atomicAdd(s.cap_hits + 2, 1);
-                    break;
-                }
-            }
-        }
-        __threadfence();  // the bodies this wavefront has just stored, and the other kernels' rewards / classes: through L2, no stale L1 line
-        for (int e = 0; e < epw && base + e < count; e++) {
-            const int64_t env = list[base + e];
-            const int ecls = draw.slow_env[env];
-            uint8_t *dst = ecls >= 2 ? draw.term : draw.target;
-            for (int v = 0; v < 2; v++) car_obs_draw_tile(s, K, dst, env, v, sh_obs);
-            if (ecls >= 2 && threadIdx.x == 0) draw.slow_env[env] = 5;
-        }
     }
 }
 
@@ -969,8 +939,7 @@ void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool
 
 // skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous step); the caller has ordered `st`,
 // `near_st` and `one_st` behind it
-void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st, hipEvent_t ev_narrow, bool skip_narrow,
-                        const CarTouchDraw *draw) {
+void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st, hipEvent_t ev_narrow, bool skip_narrow) {
     if (s.players != 2 || !s.contacts_enabled) return;
     if (!near_st) near_st = st;
     if (!skip_narrow) {
@@ -981,16 +950,8 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hip
         }
     }
     hipLaunchKernelGGL(car_near_kernel, dim3((unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512)), dim3(64), 0, near_st, s, k);
-    [[maybe_unused]] static const int epw1 = CRL_ABL(getenv("CRL_CAR_TOUCH_EPW1") != nullptr) ? atoi(getenv("CRL_CAR_TOUCH_EPW1")) : 4;  // (profiling build: 2 | 4 | 8)
-    const unsigned g = (unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512);
-    TouchDraw d = {0, 0, nullptr, nullptr, nullptr};
-    if (draw) d.on = 1, d.serial = draw->serial, d.target = draw->target, d.term = draw->term, d.slow_env = draw->slow_env;
-#ifdef CRL_ABLATION
-    if (epw1 == 8) hipLaunchKernelGGL((car_touch_kernel<8, 2, 3>), dim3(g, 3), dim3(64), 0, st, s, k, 0, d);
-    else if (epw1 == 2) hipLaunchKernelGGL((car_touch_kernel<2, 2, 3>), dim3(g, 3), dim3(64), 0, st, s, k, 0, d);
-    else
-#endif
-        hipLaunchKernelGGL((car_touch_kernel<4, 2, 3>), dim3(g, 3), dim3(64), 0, st, s, k, 0, d);
+    const unsigned g = (unsigned)((s.n + 31) / 32 < 256 ? (s.n + 31) / 32 : 256);
+    hipLaunchKernelGGL((car_touch_kernel<8, 2, 3>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
 }
 
 }  // namespace crl

@@ -125,8 +125,6 @@ struct CarSoA {
     unsigned long long *stamps;  // [64] phase cycle counters of the coupled kernels (profiling build, -DCRL_ABLATION, only)
     int32_t *zero_next;     // [16] the OTHER step parity's counter block (coupled_count[8] + class counts): car_step_kernel clears it for the next step
     int32_t *nc_new;        // [n] this step's manifold count (car_narrow_kernel)
-    int32_t *sens_epoch;    // [1] serial of the last step whose wheel-sensor kernels (and env bookkeeping) have completed: set by
-                            //     car_epoch_kernel behind them, awaited by the touching solve's frame epilogue (device-scope release / acquire)
     float *contact_new;     // [n][kMaxContacts][kContactWords] this step's manifolds with the carried-over impulses
     int32_t *n_contact;     // [n] touching car-car contacts carried to the next step (warm start)
     float *contact;         // [n][16][kContactWords] persisted manifolds + impulses
@@ -219,15 +217,10 @@ void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
-// draw (optional): the touching solve draws its envs' frames itself (car_touch_kernel's epilogue)
-struct CarTouchDraw {
-    int32_t serial;                      // what car_epoch_kernel publishes behind this step's wheel sensors
-    uint8_t *target, *term, *slow_env;   // the caller's frames, the terminal frames, the env classes of car_post_kernel
-};
 // near_st == nullptr: everything on st.  skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous
 // step); the caller has ordered `st` and `near_st` behind it
 void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hipStream_t near_st = nullptr, hipEvent_t ev_narrow = nullptr,
-                        bool skip_narrow = false, const CarTouchDraw *draw = nullptr);
+                        bool skip_narrow = false);
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,
                      int32_t *info_elapsed, int max_episode_steps, bool car0_only, hipStream_t st, int32_t *class_list = nullptr, int32_t *class_count = nullptr);
 
@@ -247,18 +240,8 @@ void launch_car_map_build(const CarSoA &s, hipStream_t st, const uint8_t *only_e
 void launch_car_map_build_list(const CarSoA &s, hipStream_t st, const int32_t *list, const int32_t *list_count, int64_t expected);
 void launch_car_view(const CarSoA &s, const CarConsts &k, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
-// one (env, viewer) frame by the calling wavefront: camera, car polygons, tile -- what car_obs_list_kernel runs per tile, callable from
-// other kernels (the touching solve draws its own envs' frames); tile / vp_s / rec_s / cnt_s: LDS of the caller (car_obs_lds_bytes)
-struct CarObsLds {
-    uint32_t tile[96 * 28];
-    int32_t vp_s[16];
-    uint32_t rec_s[kViewRecWords];
-    uint8_t cnt_s[16];
-};
-// (car_obs_tile.h: car_obs_draw_tile(s, K, obs, env, viewer, lds))
-void launch_car_epoch(const CarSoA &s, int32_t serial, hipStream_t st);
 void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
-                         int32_t *count_to_host, int64_t expected, const uint8_t *filter = nullptr, int want_cls = 0);
+                         int32_t *count_to_host, int64_t expected, const uint8_t *filter = nullptr, int want_cls = 0, bool urgent = false);
 void car_map_light_masks(uint32_t *lightx, uint32_t *lighty);  // host: the squares' columns / rows (kMapW / 32 words each)
 int car_map_coord(double v);                                     // host: (int)(obs_scale * -v + 5000), as the map polygons' vertices
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,

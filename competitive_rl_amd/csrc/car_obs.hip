@@ -234,7 +234,8 @@ __global__ __launch_bounds__(64) void car_obs_kernel(CarSoA s, uint8_t *__restri
 // dependent launches of a few hundred wavefronts each cost three launch latencies at the end of a step.
 __global__ __launch_bounds__(64) void car_obs_list_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
                                                           const int32_t *__restrict__ list_count, int32_t *__restrict__ count_to_host,
-                                                          const uint8_t *__restrict__ filter, int want) {
+                                                          const uint8_t *__restrict__ filter, int want, int urgent) {
+    if (urgent) __builtin_amdgcn_s_setprio(3);  // the launch at the end of the step's longest chain, beside the big frame launch's 32 768 wavefronts
     __shared__ __attribute__((aligned(16))) uint32_t tile[96 * kPitch];
     __shared__ __attribute__((aligned(16))) int32_t vp_s[16];
     __shared__ __attribute__((aligned(16))) uint32_t rec_s[kViewRecWords];
@@ -262,12 +263,6 @@ __global__ __launch_bounds__(64) void car_obs_list_kernel(CarSoA s, CarConsts K,
     }
 }
 
-// behind the wheel-sensor kernels of a step: publishes that they (and what their stream waited for: the env bookkeeping) are complete
-__global__ void car_epoch_kernel(int32_t *epoch, int32_t serial) {
-    if (threadIdx.x == 0) __hip_atomic_store(epoch, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-void launch_car_epoch(const CarSoA &s, int32_t serial, hipStream_t st) { hipLaunchKernelGGL(car_epoch_kernel, dim3(1), dim3(64), 0, st, s.sens_epoch, serial); }
-
 // camera + car polygons of every env (or of the envs with only_env[e] == want): what launch_car_obs reads
 void launch_car_view(const CarSoA &s, const CarConsts &k, hipStream_t st, const uint8_t *only_env, int want) {
     const int64_t tiles = s.n * s.players;
@@ -282,10 +277,10 @@ void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream
 // the envs of a compacted list (its length in device memory; `expected` = the caller's guess of it, only for the grid size),
 // optionally only those with filter[env] == want
 void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
-                         int32_t *count_to_host, int64_t expected, const uint8_t *filter, int want_cls) {
+                         int32_t *count_to_host, int64_t expected, const uint8_t *filter, int want_cls, bool urgent) {
     int64_t want = expected + expected / 4 + 32;  // slack: a launch that falls short loops, it does not miss tiles
     want = want > s.n ? s.n : want;
-    hipLaunchKernelGGL(car_obs_list_kernel, dim3((unsigned)(want * s.players)), dim3(64), 0, st, s, k, obs, list, list_count, count_to_host, filter, want_cls);
+    hipLaunchKernelGGL(car_obs_list_kernel, dim3((unsigned)(want * s.players)), dim3(64), 0, st, s, k, obs, list, list_count, count_to_host, filter, want_cls, urgent ? 1 : 0);
 }
 
 // MultipleFrameStack + FlattenMultiAgentObservation + WrapPyTorch (reference

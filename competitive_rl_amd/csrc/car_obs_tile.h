@@ -1,6 +1,5 @@
-// car_obs_tile.h -- the per-frame device code of the CarRacing observation (camera, car polygons, 96 x 96 tile), shared by
-// car_obs.hip (frame kernels) and car_contact.hip (the touching solve draws its own envs' frames in its epilogue).  The library is
-// built without relocatable device code, so device functions called from two translation units live in a header.
+// car_obs_tile.h -- the per-frame device code of the CarRacing observation (camera, car polygons, 96 x 96 tile) of car_obs.hip's
+// frame kernels, in a header so that another kernel can draw a frame itself (the library is built without relocatable device code).
 // What is restated, and from where: see the head of car_obs.hip.
 #pragma once
 #include "car_device.h"
@@ -90,14 +89,7 @@ __device__ __forceinline__ void camera_compute(const CarSoA &s, const CarConsts 
     }
     if (far) flags = 4;
     vp.dx00 = dx00 + rx * 65536, vp.dy00 = dy00 + ry * 65536, vp.isin = isin, vp.icos = icos, vp.rx = rx, vp.ry = ry, vp.flags = flags;
-    vp.text_idx = -1;
-    if (s.text_bits) {
-        const double r = s.reward[me];
-        const double rr = rint(r);  // "%.0f" rounds half to even
-        int idx = (int)rr - CRL_CAR_TEXT_RMIN;
-        if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
-        vp.text_idx = min(max(idx, 0), CRL_CAR_TEXT_STRINGS - 1);
-    }
+    vp.text_idx = -1;  // (the reward read-out is looked up by the tile itself: the camera does not depend on the step's wheel sensors)
     cam = make_float4(sn, cs, off.x, off.y);  // the float32 camera for the car polygons (Car.draw_for_pygame's tmp transform and offset)
 }
 // 16 lanes per tile: lane q = car polygon q of the draw order -> its scanline spans; lanes 0-7 also one indicator rectangle each.
@@ -263,7 +255,15 @@ __device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restric
                                              const int32_t *vp, const uint32_t *rec, const uint8_t *cnt) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = env * s.players + viewer;
-    const int dx00 = vp[0], dy00 = vp[1], isin = vp[2], icos = vp[3], rx = vp[4], ry = vp[5], flags = vp[6], text_idx = vp[7];
+    const int dx00 = vp[0], dy00 = vp[1], isin = vp[2], icos = vp[3], rx = vp[4], ry = vp[5], flags = vp[6];
+    int text_idx = -1;  // which of the pre-rendered "%05.0f" strings shows the viewer's reward (crmp:666-670)
+    if (s.text_bits) {
+        const double r = s.reward[(int64_t)viewer * s.n + env];
+        const double rr = rint(r);  // "%.0f" rounds half to even
+        int idx = (int)rr - CRL_CAR_TEXT_RMIN;
+        if (rr == 0.0 && (r < 0.0 || (r == 0.0 && signbit(r)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
+        text_idx = min(max(idx, 0), CRL_CAR_TEXT_STRINGS - 1);
+    }
     const uint8_t *map = env_map(s, env);
     uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile);
     // ---- background
@@ -323,24 +323,6 @@ __device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restric
         const int c = (i * WAVES + wave) * 64 + lane, row = c / 6, col = c - row * 6;
         if (WAVES == 1 || c < 576) out[c] = *reinterpret_cast<const uint4 *>(&tile[row * kPitch + col * 4]);
     }
-}
-
-// One frame by the calling wavefront (64 lanes, all active), LDS from the caller: the body of car_obs_list_kernel's loop for kernels
-// that draw their own envs (car_touch_kernel's epilogue).  The caller makes the bodies / rewards it reads visible first.
-static_assert(kPitch == 28, "CarObsLds::tile");
-__device__ inline void car_obs_draw_tile(const CarSoA &s, const CarConsts &K, uint8_t *obs, int64_t env, int viewer, CarObsLds &lds) {
-    const int lane = threadIdx.x & 63;
-    ViewParams vp;
-    float4 cam;
-    camera_compute(s, K, env, viewer, vp, cam);
-    if (lane == 0) {
-        const int32_t *src = reinterpret_cast<const int32_t *>(&vp);
-        for (int i = 0; i < 8; i++) lds.vp_s[i] = src[i];
-    }
-    if (lane < 16) lds.cnt_s[lane] = (uint8_t)poly_compute(s, K, env, viewer, lane, cam, reinterpret_cast<uint32_t *>(lds.vp_s) + 8, lds.rec_s + lane * kSpanSlots);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (one wavefront: LDS operations execute in program order; this keeps the compiler from moving them)
-    car_obs_tile(s, obs, env, viewer, lds.tile, lds.vp_s, lds.rec_s, lds.cnt_s);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile reuses the LDS
 }
 
 }  // namespace crl

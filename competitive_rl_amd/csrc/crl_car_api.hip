@@ -18,6 +18,7 @@ struct crl_car_ctx {
     hipEvent_t ev_early3 = nullptr, ev_one = nullptr, ev_onefr = nullptr, ev_collide = nullptr;
     bool collide_valid = false;  // the NEXT step's broadphase + narrow phase already ran, at the end of the last step (car_broad_kernel)
     bool collide_dirty = false;  // ... was enqueued and not consumed yet: its counter block has to be cleared if the results are not used
+    bool collide_joined = false; // ... and the step's join already waited for it
     int32_t *coupled2 = nullptr, *lists2 = nullptr;  // [2][n] coupled flags, [2][6][n] near / touch lists: one block per step parity
     hipStream_t one = nullptr;  // the touching envs with ONE manifold: solve and frames (high priority: a queue class of its own)
     CarConsts K_{};
@@ -38,7 +39,6 @@ struct crl_car_ctx {
     int32_t *class_count = nullptr;  // [3] their lengths (inside `counters`)
     int32_t *counters = nullptr;     // [2][16] per step parity: coupled_count[8], class_count[2]; a step's first kernel clears the other block
     int parity = 0;
-    int32_t serial = 0;  // steps of the pipelined path so far: what car_epoch_kernel publishes behind a step's wheel sensors
     hipEvent_t ev_post = nullptr;
     hipEvent_t ev_fin3 = nullptr;
     hipEvent_t ev_fin = nullptr;
@@ -205,7 +205,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
     A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
-    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled_list, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(sens_epoch, 4); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
+    A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled_list, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
     A(map_par, n); A(map_vtx, (size_t)kCarMaxTiles * 9 * n); A(map_yr, (size_t)kCarMaxTiles * n); A(map_overflow, n);
@@ -406,14 +406,19 @@ static CarSoA stage_view(const crl_car_ctx *c) {
 
 // frames of every env, or of the envs with only_env[e] == want
 // tm (optional): timer 1 brackets the frame kernel alone (car_obs_kernel / car_raster_kernel), for bench.py's roofline
-static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1, crl_timer *tm = nullptr) {
+// before_tiles (optional): an event the tiles -- not the camera / polygon kernels in front of them -- have to wait for (the wheel
+// sensors of the step: the tiles show the reward)
+static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1, crl_timer *tm = nullptr,
+                   hipEvent_t before_tiles = nullptr) {
     if (c->analytic) {
+        if (before_tiles) hipStreamWaitEvent(st, before_tiles, 0);
         crl_timer_begin(tm, 1, st);
         launch_car_raster(c->s, c->K_, dst, st, only_env, want);
         crl_timer_end(tm, 1, st);
         return;
     }
     launch_car_view(c->s, c->K_, st, only_env, want);
+    if (before_tiles) hipStreamWaitEvent(st, before_tiles, 0);
     crl_timer_begin(tm, 1, st);
     launch_car_obs(c->s, c->K_, dst, st, only_env, want);
     crl_timer_end(tm, 1, st);
@@ -481,7 +486,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     // world.Step, crmp:576-603), so the env-level bookkeeping does not wait for the coupled solve.
     const bool fork = c->overlap && obs_dev != nullptr;
     const bool contacts = c->s.players == 2 && c->s.contacts_enabled;
-    // The step's longest chain (touching solve, which also draws its envs' frames) runs on the CALLER's stream, directly behind
+    // The step's longest chain (touching solve -> those envs' frames) runs on the CALLER's stream, directly behind
     // car_step_kernel and directly in front of the next step's: every cross-stream hop costs tens of microseconds of command-processor
     // latency.  The bulk (per-car solve -> camera -> frames of the envs on their own) forks to `side` and has the slack for its hops.
     const hipStream_t crit = st, bulk = c->side;
@@ -527,46 +532,40 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         }
     } else {
         // Streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished, 3 finished and coupled):
-        //   crit   (the caller's) [narrow phase of the coupled envs ->] the touching ones' island solve + THEIR FRAMES, drawn by the
-        //          wavefront that solved the island (car_touch_kernel's epilogue): the step's longest chain is two kernels
+        //   crit   (the caller's) [narrow phase of the coupled envs ->] the touching ones' island solve -> their frames (the step's longest chain)
         //   bulk   per-car solve -> camera, polygons -> frames of class 0 (the big launch)
         //   side2  env bookkeeping; the coupled envs where nothing touches (two islands of their own) -> their frames; behind the
         //          touching solve the commit of the envs that are finished AND coupled; the step's join; the NEXT step's Collide
         //   sens   wheel sensors (tile rewards, road_visited: they read the transforms the step started from and feed nothing into
-        //          its solve; every frame shows the reward, so every frame launch waits for them -- the touching solve's epilogue
-        //          through the epoch word car_epoch_kernel publishes behind them); behind the per-car solve the terminal frames +
+        //          its solve; every frame shows the reward, so every frame launch waits for them); behind the per-car solve the terminal frames +
         //          commit of the finished envs on their own
         //   one    (high priority) the finished envs' NEW episode, prepared early on the staged view: reset, map, first frame
         // (streams of one priority share four hardware queues, and two streams that share one wait for each other's kernels;
         // the milliseconds-long walk-ahead has a priority class of its own)
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
-        const int32_t serial = ++c->serial;
+        static const int x_mode = getenv("CRL_CAR_X") ? atoi(getenv("CRL_CAR_X")) : 35;  // experiments: 1 urgent touch frames, 2 late chain reordered, 4 join by two barriers, 8 touch frames on side2, 16 collide-ahead early on `one`, inside the join
         hipEventRecord(c->ev_fork, st);
         hipStreamWaitEvent(c->side, c->ev_fork, 0);
         hipStreamWaitEvent(c->side2, c->ev_fork, 0);
-        hipStreamWaitEvent(c->sens, c->ev_fork, 0);
+        const hipStream_t sens = (x_mode & 32) ? c->one : c->sens;  // (32: the wheel sensors on the high-priority stream, in front of the finished envs' early chain -- one normal-priority stream less)
+        hipStreamWaitEvent(sens, c->ev_fork, 0);
         launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, c->side2, c->class_list,
                         c->class_count);
         hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
-        if (ahead) {  // (side2 ran the narrow phase itself, at the end of the last step; crit and bulk wait for it)
+        if (ahead && !c->collide_joined) {  // (side2 ran the narrow phase itself, at the end of the last step; crit and bulk wait for it)
             hipStreamWaitEvent(crit, c->ev_collide, 0);
             hipStreamWaitEvent(bulk, c->ev_collide, 0);
         }
-        // the wheel sensors are ENQUEUED before the touching solve whose epilogue waits for their epoch word: whatever hardware queue
-        // the two streams land in, the producer is ahead of the consumer
-        const bool touch_draws = contacts && !c->analytic;
-        const CarTouchDraw td = {serial, target, c->term, c->slow_env};
         if (contacts && !ahead) {  // narrow phase at the head of crit; the sensor kernel beside it doubles both: sensors behind it
             launch_car_narrow(c->s, c->K_, crit, true);
             hipEventRecord(c->ev_narrow, crit);
             hipStreamWaitEvent(c->side2, c->ev_narrow, 0);
-            hipStreamWaitEvent(c->sens, c->ev_narrow, 0);
+            hipStreamWaitEvent(sens, c->ev_narrow, 0);
         }
-        hipStreamWaitEvent(c->sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens / the epoch word then stand for the bookkeeping as well)
-        launch_car_sensors(c->s, c->K_, c->sens);
-        launch_car_epoch(c->s, serial, c->sens);
-        hipEventRecord(c->ev_sens, c->sens);
-        launch_car_coupled(c->s, c->K_, crit, c->side2, nullptr, true, touch_draws ? &td : nullptr);  // near-only solve on side2, touching solve (+ frames) on crit
+        hipStreamWaitEvent(sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the frame launches pass ONE barrier each)
+        launch_car_sensors(c->s, c->K_, sens);
+        hipEventRecord(c->ev_sens, sens);
+        launch_car_coupled(c->s, c->K_, crit, c->side2, nullptr, true);  // near-only solve on side2, touching solve on crit
         hipEventRecord(c->ev_coupled, crit);
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
         if (contacts) {  // frames of the near-only envs
@@ -577,20 +576,25 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         // bulk: the per-car solve, then the frames of every env that is neither coupled nor finished
         launch_car_solve(c->s, c->K_, bulk);
         hipEventRecord(c->ev_term, bulk);  // (bodies of the non-coupled cars are final)
-        hipStreamWaitEvent(bulk, c->ev_sens, 0);
         crl_timer_end(tm, 0, bulk);
-        frames(c, target, bulk, c->slow_env, 0, tm);
-        if (contacts && !touch_draws) {  // (profiling build, analytic raster: the touching envs' frames as a launch behind their solve)
+        if (x_mode & 64) {  // camera and polygons directly behind the solve; only the tiles (they show the reward) wait for the sensors
+            hipStreamWaitEvent(bulk, c->ev_post, 0);  // (the env classes the three kernels filter by)
+            frames(c, target, bulk, c->slow_env, 0, tm, c->ev_sens);
+        } else {
+            hipStreamWaitEvent(bulk, c->ev_sens, 0);
+            frames(c, target, bulk, c->slow_env, 0, tm);
+        }
+        if (contacts && !(x_mode & 8)) {  // crit again: the touching envs' frames, behind their solve
             hipStreamWaitEvent(crit, c->ev_sens, 0);
-            launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
+            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
+            else launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, (x_mode & 1) != 0);
         }
         // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
         // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared
         // beside the solves.  What has to wait for the solve is small: the terminal frame (info["terminal_observation"],
         // drawn from the solved bodies over the OLD map) and the commit that makes the staged episode current.
         // Class 2 (cars on their own: nearly all of them) waits for the per-car solve; class 3 (finished AND coupled) for the
-        // touching solve, on `side2`: the touching ones' terminal frames come from the solve's epilogue (class 5 then), the rest
-        // (coupled, nothing touching: rare) from a list launch, then the commit.
+        // touching solve, on `side2` -- two small kernels behind the step's longest chain instead of four.
         const CarSoA sv = stage_view(c);
         auto list_of = [&](int cls) { return c->class_list + (int64_t)(cls - 1) * c->n; };
         auto count_of = [&](int cls) { return c->class_count + (cls - 1); };
@@ -617,16 +621,30 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             hipStreamWaitEvent(c->one, c->ev_sens, 0);
             early_chain(c->one, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
             hipEventRecord(c->ev_early3, c->one);
-            hipStreamWaitEvent(c->sens, c->ev_term, 0);
-            hipStreamWaitEvent(c->sens, c->ev_early3, 0);
-            late_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
+            const hipStream_t late = (x_mode & 32) ? c->side2 : sens;  // (32: behind the near-only envs' frames, side2 idles until the touching solve is in)
+            hipStreamWaitEvent(late, c->ev_term, 0);
+            if (x_mode & 2) {  // terminal frames as soon as the per-car solve is in; only the commit waits for the new episode
+                launch_car_obs_list(c->s, c->K_, c->term, late, list_of(2), count_of(2), c->class_count_hdev + 1, exp_done, c->slow_env, 2);
+                hipStreamWaitEvent(late, c->ev_early3, 0);
+                launch_car_commit_list(c->s, sv, list_of(2), count_of(2), exp_done, late);
+            } else {
+                hipStreamWaitEvent(late, c->ev_early3, 0);
+                late_chain(late, 2, exp_done, c->class_count_hdev + 1);
+            }
+            hipEventRecord(c->ev_fin, late);
         } else {
-            hipStreamWaitEvent(c->sens, c->ev_term, 0);
-            finish_chain(c->sens, 2, exp_done, c->class_count_hdev + 1);
+            hipStreamWaitEvent(sens, c->ev_term, 0);
+            finish_chain(sens, 2, exp_done, c->class_count_hdev + 1);
+            hipEventRecord(c->ev_fin, sens);
         }
-        hipEventRecord(c->ev_fin, c->sens);
         hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve
         hipStreamWaitEvent(c->side2, c->ev_sens, 0);
+        if (contacts && (x_mode & 8)) {
+            // the touching envs' frames HERE rather than behind their solve on the caller's stream: a barrier packet on a created stream
+            // costs 5-12 us, on the legacy default stream 30-55 us even when it is long open
+            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
+            else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, (x_mode & 1) != 0);
+        }
         if (staged) {
             hipStreamWaitEvent(c->side2, c->ev_early3, 0);
             late_chain(c->side2, 3, 8, nullptr);
@@ -636,10 +654,27 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         // join: side2 collects sens and side behind its own last kernel, so that the caller's stream -- whose last kernel is usually
         // the last of the step -- passes ONE barrier that is already open instead of three
         hipEventRecord(c->ev_join, c->side);
-        hipStreamWaitEvent(c->side2, c->ev_fin, 0);
+        c->collide_joined = false;
+        if (can_ahead && (x_mode & 16)) {
+            // The next step's Collide as soon as every solve of this step is in and every finished env is committed (it does not
+            // need the frames): on `one`, beside this step's last frames, and INSIDE the join -- the next step then starts without a
+            // barrier between car_step_kernel and the touching solve
+            CarSoA nx = c->s;
+            point_parity(c, nx, c->parity ^ 1);
+            hipEventRecord(c->ev_near, c->side2);  // (behind the near-only solve, the touching solve and the commit of class 3)
+            hipStreamWaitEvent(c->one, c->ev_near, 0);
+            hipStreamWaitEvent(c->one, c->ev_fin, 0);   // commit of class 2
+            hipStreamWaitEvent(c->one, c->ev_term, 0);  // the per-car solve
+            launch_car_broad(nx, c->K_, c->one);
+            launch_car_narrow(nx, c->K_, c->one, false);
+            hipEventRecord(c->ev_collide, c->one);
+            hipStreamWaitEvent(c->side2, c->ev_collide, 0);
+            c->collide_valid = c->collide_dirty = c->collide_joined = true;
+        }
+        if (!(x_mode & 4)) hipStreamWaitEvent(c->side2, c->ev_fin, 0);
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
         hipEventRecord(c->ev_fin3, c->side2);
-        if (can_ahead) {
+        if (can_ahead && !(x_mode & 16)) {
             // every solve of this step is in (side2 is behind the near-only and the touching solve; ev_term: the per-car solve) and
             // every finished env is committed: the next step's Collide, into the other parity block, beside this step's last frames
             CarSoA nx = c->s;
@@ -650,8 +685,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             hipEventRecord(c->ev_collide, c->side2);
             c->collide_valid = c->collide_dirty = true;
         }
-        queue_walk_ahead(c, c->sens);
+        queue_walk_ahead(c, (x_mode & 32) ? c->side2 : sens);
         hipStreamWaitEvent(st, c->ev_fin3, 0);
+        if (x_mode & 4) hipStreamWaitEvent(st, c->ev_fin, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
     }
     hipError_t e = hipGetLastError();

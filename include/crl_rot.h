@@ -6,8 +6,11 @@
  * other C libraries and the GPU's device library.  Both the HIP kernels (competitive_rl_amd/csrc/car_*.hip)
  * and the CPU oracle (oracle/car_oracle.c, default build) therefore evaluate THIS function: the
  * CORRECTLY ROUNDED float32 sine and cosine -- argument reduction and a Taylor polynomial in float64, every step an
- * explicit fused multiply-add (relative error < 2^-52), rounded to float32 once, which is the correctly rounded result except when
- * the exact value lies within ~2^-28 ulp of a float32 rounding boundary.  Both sides are compiled with
+ * explicit fused multiply-add (relative error < 2^-52), rounded to float32 once; when that float64 value lies within 2^-50 of a
+ * float32 rounding boundary (one argument in ~2^25) the rounding is decided in double-double instead (Ziv's strategy).  Proven,
+ * not sampled: crl_selftest_sincosf (csrc/crl_selftest.hip, tests/test_f64_math.py) sweeps EVERY float32 argument of the domain
+ * against a double-double evaluation on the GPU, tools/sincosf_sweep_cpu.c does the same on the host: 0 misses, 0 undecided
+ * (before the slow path existed: one argument pair, +-0x1.33333p+13).  Both sides are compiled with
  * -ffp-contract=off, so every operation rounds once and the float32 state of a car is reproducible
  * bit for bit across CPU and GPU.
  *
@@ -19,11 +22,54 @@
 #ifndef CRL_ROT_H_
 #define CRL_ROT_H_
 
+#include "crl_f64.h"
+
 #if defined(__HIPCC__)
 #define CRL_ROT_FN __host__ __device__ static inline
+#define CRL_ROT_SLOW __host__ __device__ static __attribute__((noinline))
 #else
 #define CRL_ROT_FN static inline
+#define CRL_ROT_SLOW static __attribute__((noinline))
 #endif
+
+/* Correct rounding of a double-double v (relative error ~2^-95, |v| in float32's normal range) to float32: the float nearest
+ * to the leading double, moved to its neighbour when the low word carries v across the midpoint in between. */
+CRL_ROT_FN float crl_dd_to_f32(crl_dd v) {
+    float f = (float)v.h;
+    const double d = (v.h - (double)f) + v.l; /* v - f: the first difference is exact */
+    if (d == 0.0) return f;
+    union { float f; unsigned u; } q;
+    q.f = f;
+    /* neighbour of f in the direction of v (f != 0 here: the callers handle zero): one step in the integer representation */
+    const int away = (d > 0.0) == (f > 0.0f); /* towards larger magnitude? */
+    q.u = away ? q.u + 1u : q.u - 1u;
+    const double mid = 0.5 * ((double)f + (double)q.f); /* exact: 25 significant bits */
+    const double e = (v.h - mid) + v.l;                  /* v - mid */
+    if ((d > 0.0 && e > 0.0) || (d < 0.0 && e < 0.0)) f = q.f;
+    return f;
+}
+
+/* The rare slow path of crl_sincosf: the float64 result sits within ~2^-50 (relative) of a float32 rounding boundary, where
+ * its own error (~2^-52) could tip the rounding: decide in double-double (include/crl_f64.h).  Taken for ~1 argument in 2^25;
+ * the exhaustive sweeps (crl_selftest_sincosf on the GPU, tools/sincosf_sweep_cpu.c) found exactly one float32 argument pair,
+ * +-0x1.33333p+13, whose sine needs it: sin = 0x1.63f4bbp-2 - 2^-56, 2^-30 ulp below a midpoint. */
+CRL_ROT_SLOW void crl_sincosf_slow(float x, float *sn, float *cs) {
+    crl_dd s, c;
+    if (!crl_sincos_dd((double)x, &s, &c)) {
+        *sn = *cs = __builtin_nanf("");
+        return;
+    }
+    *sn = crl_dd_to_f32(s), *cs = crl_dd_to_f32(c);
+}
+
+/* does the double v lie within 8 of its own ulps (2^-50 relative) of the midpoint between two float32 values?  (the 29
+ * mantissa bits below float32's: 0x10000000 is the midpoint) */
+CRL_ROT_FN int crl_near_f32_midpoint(double v) {
+    union { double d; unsigned long long u; } q;
+    q.d = v;
+    const unsigned low = (unsigned)(q.u & 0x1FFFFFFFull);
+    return (low - 0x10000000u + 8u) <= 16u;
+}
 
 /* |x| < 2^20 * pi/2 (angles of a car: a few hundred radians at most) */
 CRL_ROT_FN void crl_sincosf(float x, float *sn, float *cs) {
@@ -45,6 +91,10 @@ CRL_ROT_FN void crl_sincosf(float x, float *sn, float *cs) {
     ps = __builtin_fma(z, ps, -0x1.5555555555555p-3), pc = __builtin_fma(z, pc, 0x1.5555555555555p-5);
     pc = __builtin_fma(z, pc, -0x1.0000000000000p-1);
     const double s = __builtin_fma(r, z * ps, r), c = __builtin_fma(z, pc, 1.0);
+    if (crl_near_f32_midpoint(s) | crl_near_f32_midpoint(c)) { /* Ziv's test: too close to a rounding boundary for 2^-52 to decide */
+        crl_sincosf_slow(x, sn, cs);
+        return;
+    }
     const int q = (int)((long long)kf & 3);
     const double so = (q & 1) ? c : s, co = (q & 1) ? s : c;
     *sn = (float)((q == 2 || q == 3) ? -so : so);

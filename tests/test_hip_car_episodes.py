@@ -22,7 +22,7 @@ def _need_gpu():
         pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
 
 
-def batch_to_hip_state(E, elapsed=None):
+def batch_to_hip_state(E, elapsed=None, episode=None):
     """oracle car_env array (oracle.car_oracle.ENV_DT) -> crl_car_env_state array, vectorised over the envs"""
     from competitive_rl_amd import _native as N
 
@@ -39,6 +39,8 @@ def batch_to_hip_state(E, elapsed=None):
         q["step_count"], q["first_step"] = E["step_count"], (E["inv_dt0"] == 0).astype(np.int32)
         q["wheel_tiles"], q["visited"] = E["wheel_tiles"][:, c], E["visited"][:, c]
     st["elapsed"] = E["step_count"] if elapsed is None else elapsed
+    if episode is not None:
+        st["episode"] = episode  # resets so far: indexes the replayed / Philox draws of the env's NEXT track
     st["n_contact"] = E["n_contact"]
     for f in ("pair", "count", "type", "ln", "lp", "pt", "id", "nimp", "timp"):
         st["contact"][f] = E["contact"][f]
@@ -126,7 +128,7 @@ def test_pipelined_step_equals_the_oracle_through_episode_ends():
         touch = np.nonzero(np.arange(n) % 3 == ph % 3)[0]
         _park_beside(B.E, touch)
         elapsed[:] = 1000 - 4 - (np.arange(n) * 11 + 5 * ph) % (steps - 8)
-        hip.set_state(batch_to_hip_state(B.E, elapsed))
+        hip.set_state(batch_to_hip_state(B.E, elapsed, episode))
         for t in range(steps):
             acts = rs.uniform(-1, 1, (n, 2, 2)).astype(np.float32)
             acts[:, 1, 0] = -acts[:, 0, 0] * (t % 7 < 4)  # the parked cars keep bumping into each other

@@ -1,0 +1,34 @@
+"""Quick CarRacing step timing at full size, for A/B runs under a short `timeout` (no pre-roll, prints as it goes).
+PYTHONPATH=. python tools/car_quick.py [envs] [steps]"""
+import sys
+import time
+
+import torch
+
+import os
+
+import competitive_rl_amd as crl
+
+n, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, int(sys.argv[2]) if len(sys.argv) > 2 else 300
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 50  # steps between host synchronisations
+env = crl.HipCarVecEnv(n, seed=1)
+st = None
+env.reset()
+g = torch.Generator(device="cuda").manual_seed(3)
+acts = torch.rand((64, n, 2, 2), generator=g, device="cuda") * 2 - 1
+# steady-state mix: stagger the TimeLimit
+s0 = env.get_state()
+s0["elapsed"] = (torch.arange(n).numpy() * 7) % 1000
+env.set_state(s0)
+torch.cuda.synchronize()
+user_stream = torch.cuda.Stream() if os.environ.get("QUICK_STREAM") else None  # the caller works on a created stream instead of the legacy default stream
+if user_stream is not None:
+    torch.cuda.set_stream(user_stream)
+for blk in range(steps // K):
+    t0 = time.time()
+    for t in range(K):
+        env.step_device(acts[(blk * K + t) % 64])
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / K * 1e3
+    print(f"steps {blk * K:5d}-{blk * K + K - 1:5d}: {dt:8.3f} ms/step  cap_hits {env.cap_hits()}", flush=True)
+env.close()

@@ -33,6 +33,7 @@ int main(int argc, char **argv) {
         crl_dd ds, dc; crl_sincos_dd((double)x, &ds, &dc);
         int rs = check_cr32(s, ds), rc = check_cr32(c, dc);
         tested++; bs += rs == 1; bc += rc == 1; und += (rs == 2) + (rc == 2);
+        if (rs == 1 || rc == 1) printf("MISS bits 0x%08x x=%a sin=%a cos=%a dd_s=(%a,%a) dd_c=(%a,%a)\n", (unsigned)i, x, s, c, ds.h, ds.l, dc.h, dc.l);
         gl += check_cr32(sinf(x), ds) == 1;
     }
     printf("tested %llu bad_s %llu bad_c %llu undecided %llu glibc_sinf_miss %llu\n", tested, bs, bc, und, gl);
