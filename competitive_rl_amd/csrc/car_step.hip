@@ -67,7 +67,7 @@ __device__ inline float poly_dist2(const V2 (&A)[4], const V2 (&B)[5]) {
 // polygons, 4 wheels; wheels do not collide with wheels), grown by more than the polygon radii.
 // No overlapping pair => b2CollidePolygons would find no manifold point for this env.
 // (a routing decision like cars_near: hardware sine / cosine, and a margin of 0.04 where the contact margin is 0.02)
-__device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_t M, int64_t c0, int64_t c1) {
+__device__ inline bool fixtures_near(const float *__restrict__ body, const CarConsts &K, int64_t M, int64_t c0, int64_t c1) {
     // (fully unrolled: the 16 boxes stay in registers)
     float bb[2][8][4];
 #pragma unroll
@@ -76,7 +76,7 @@ __device__ inline bool fixtures_near(const CarSoA &s, const CarConsts &K, int64_
 #pragma unroll
         for (int f = 0; f < 8; f++) {
             const int o = f < 4 ? 0 : 6 + 6 * (f - 4);
-            const float cx = s.body[(o + 0) * M + ci], cy = s.body[(o + 1) * M + ci], a = s.body[(o + 2) * M + ci];
+            const float cx = body[(o + 0) * M + ci], cy = body[(o + 1) * M + ci], a = body[(o + 2) * M + ci];
             float sn, cs;
             fast_sincosf(a, &sn, &cs);
             const V2 lc = f < 4 ? mk(K.hull_lc[0], K.hull_lc[1]) : mk(0.f, 0.f);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
             const int64_t c0 = env, c1 = s.n + env;
             coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
                                 s.body[2 * M + c1]);
-            if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
+            if (coupled) coupled = fixtures_near(s.body, K, M, c0, c1);
         }
         // (do_broad == 0: the flag is NOT read here -- car_broad_kernel wrote it on another stream that this kernel is not
         // ordered behind; car_post_kernel, which runs behind it, destroys the contacts of the envs that are no longer coupled)
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K) {
         const int64_t c0 = env, c1 = s.n + env;
         coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
                             s.body[2 * M + c1]);
-        if (coupled) coupled = fixtures_near(s, K, M, c0, c1);
+        if (coupled) coupled = fixtures_near(s.body, K, M, c0, c1);
         s.coupled[env] = coupled ? 1 : 0;
     }
     const unsigned long long m = __ballot(coupled);

@@ -15,12 +15,11 @@ struct crl_car_ctx {
     int64_t n;
     CarSoA s{};
     CarSoA stage{};  // only the per-car arrays a reset writes: their staged copies (car_commit_list_kernel)
-    hipEvent_t ev_early3 = nullptr, ev_one = nullptr, ev_onefr = nullptr, ev_collide = nullptr;
+    hipEvent_t ev_early3 = nullptr, ev_collide = nullptr;
     bool collide_valid = false;  // the NEXT step's broadphase + narrow phase already ran, at the end of the last step (car_broad_kernel)
     bool collide_dirty = false;  // ... was enqueued and not consumed yet: its counter block has to be cleared if the results are not used
-    bool collide_joined = false; // ... and the step's join already waited for it
     int32_t *coupled2 = nullptr, *lists2 = nullptr;  // [2][n] coupled flags, [2][6][n] near / touch lists: one block per step parity
-    hipStream_t one = nullptr;  // the touching envs with ONE manifold: solve and frames (high priority: a queue class of its own)
+    hipStream_t one = nullptr;  // HIGH priority (a queue class of its own): the wheel sensors, then the finished envs' early chain
     CarConsts K_{};
     CarTrackSrc src{};
     std::vector<void *> allocs;
@@ -41,14 +40,13 @@ struct crl_car_ctx {
     int parity = 0;
     hipEvent_t ev_post = nullptr;
     hipEvent_t ev_fin3 = nullptr;
-    hipEvent_t ev_fin = nullptr;
     int32_t *class_count_host = nullptr, *class_count_hdev = nullptr;  // host-mapped copy (one step late): sizes the next step's launches
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;  // the near-only coupled envs (plain island solves), beside the touching ones on `side`
-    hipEvent_t ev_narrow = nullptr, ev_near = nullptr;
-    hipStream_t sens = nullptr;  // the wheel-sensor contacts of a step, beside its solve
+    hipEvent_t ev_narrow = nullptr;
     hipEvent_t ev_sens = nullptr;
     hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
+    std::vector<hipStream_t> pads;  // idle streams that only occupy hardware-queue slots (crl_car_create)
     hipEvent_t ev_reset = nullptr;
     hipEvent_t ev_walk = nullptr;  // recorded behind every walk-ahead launch: no new one is queued while it is pending
     bool walk_pending = false;
@@ -271,20 +269,44 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     }
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (numerically lower = higher priority)
-    // `side`: the bulk of a step (default priority)
-    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, 0) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_narrow, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_near, kEvFlags) != hipSuccess ||
+    {
+        // WHICH stream shares a hardware pipe with which is decided by the order in which their hardware queues are created: the
+        // runtime gives every priority class up to four queues and the driver deals new queues round the chip's four pipes (one
+        // micro-engine each, which serves its queues' barrier and dispatch packets one after the other).  Measured (round 4,
+        // 16 384 envs, steady state, tools/car_quick.py; docs/LAB_NOTES_r04.md): with the walk-ahead's queue (one 15 ms kernel
+        // after the other) or the high-priority queue on the pipe of the CALLER's stream -- which carries the step's longest chain --
+        // a step takes 1.03-1.08 ms instead of 0.92; the walk-ahead beside `side2` (join, next step's Collide) 1.04; beside `side`
+        // (the bulk, which has slack) 0.92.  In a process whose first streams are these (the legacy default stream's queue came
+        // first: pipe 0) the order below puts side, side2 and `one` on pipes 1-3, an idle low-priority queue on the caller's pipe
+        // and the walk-ahead beside `side`.  CRL_CAR_STREAM_ORDER (letters s 2 o g, d / D / H = an idle normal / low / high
+        // priority stream) re-deals them for a process that created streams before this context.
+        const char *order = getenv("CRL_CAR_STREAM_ORDER") ? getenv("CRL_CAR_STREAM_ORDER") : "s2oDg";
+        bool ok = true;
+        for (const char *q = order; *q && ok; q++) {
+            hipStream_t pad = nullptr;
+            if (*q == 's' && !c->side) ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, 0) == hipSuccess;  // the bulk of a step
+            else if (*q == '2' && !c->side2) ok = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) == hipSuccess;
+            else if (*q == 'o' && !c->one) ok = hipStreamCreateWithPriority(&c->one, hipStreamNonBlocking, prio_hi) == hipSuccess;
+            else if (*q == 'g' && !c->gen) ok = hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) == hipSuccess;  // milliseconds-long walks: a priority class of its own
+            else if (*q == 'd') ok = hipStreamCreateWithFlags(&pad, hipStreamNonBlocking) == hipSuccess;
+            else if (*q == 'D') ok = hipStreamCreateWithPriority(&pad, hipStreamNonBlocking, prio_lo) == hipSuccess;
+            else if (*q == 'H') ok = hipStreamCreateWithPriority(&pad, hipStreamNonBlocking, prio_hi) == hipSuccess;
+            if (pad) c->pads.push_back(pad);
+        }
+        if (ok && !c->side) ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, 0) == hipSuccess;  // (a letter the order string left out)
+        if (ok && !c->side2) ok = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) == hipSuccess;
+        if (ok && !c->one) ok = hipStreamCreateWithPriority(&c->one, hipStreamNonBlocking, prio_hi) == hipSuccess;
+        if (ok && !c->gen) ok = hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) == hipSuccess;
+        if (!ok) {
+            crl_car_destroy(c);
+            return crl_fail(CRL_EHIP, "car create: streams");
+        }
+    }
+    if (hipEventCreateWithFlags(&c->ev_narrow, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_post, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_early3, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_collide, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_one, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_onefr, kEvFlags) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->one, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin3, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fin, kEvFlags) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->sens, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, kEvFlags) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) != hipSuccess ||  // milliseconds-long walks: a queue class of its own
         hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_walk, kEvFlags) != hipSuccess ||
         hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t)) != hipSuccess ||
@@ -338,18 +360,14 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->side) hipStreamDestroy(c->side);
     if (c->side2) hipStreamDestroy(c->side2);
     if (c->ev_narrow) hipEventDestroy(c->ev_narrow);
-    if (c->ev_near) hipEventDestroy(c->ev_near);
     if (c->ev_post) hipEventDestroy(c->ev_post);
     if (c->ev_early3) hipEventDestroy(c->ev_early3);
     if (c->ev_collide) hipEventDestroy(c->ev_collide);
-    if (c->ev_one) hipEventDestroy(c->ev_one);
-    if (c->ev_onefr) hipEventDestroy(c->ev_onefr);
     if (c->one) hipStreamDestroy(c->one);
     if (c->ev_fin3) hipEventDestroy(c->ev_fin3);
-    if (c->ev_fin) hipEventDestroy(c->ev_fin);
-    if (c->sens) hipStreamDestroy(c->sens);
     if (c->ev_sens) hipEventDestroy(c->ev_sens);
     if (c->gen) hipStreamDestroy(c->gen);
+    for (hipStream_t p : c->pads) hipStreamDestroy(p);
     if (c->ev_reset) hipEventDestroy(c->ev_reset);
     if (c->ev_walk) hipEventDestroy(c->ev_walk);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -406,19 +424,14 @@ static CarSoA stage_view(const crl_car_ctx *c) {
 
 // frames of every env, or of the envs with only_env[e] == want
 // tm (optional): timer 1 brackets the frame kernel alone (car_obs_kernel / car_raster_kernel), for bench.py's roofline
-// before_tiles (optional): an event the tiles -- not the camera / polygon kernels in front of them -- have to wait for (the wheel
-// sensors of the step: the tiles show the reward)
-static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1, crl_timer *tm = nullptr,
-                   hipEvent_t before_tiles = nullptr) {
+static void frames(crl_car_ctx *c, uint8_t *dst, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1, crl_timer *tm = nullptr) {
     if (c->analytic) {
-        if (before_tiles) hipStreamWaitEvent(st, before_tiles, 0);
         crl_timer_begin(tm, 1, st);
         launch_car_raster(c->s, c->K_, dst, st, only_env, want);
         crl_timer_end(tm, 1, st);
         return;
     }
     launch_car_view(c->s, c->K_, st, only_env, want);
-    if (before_tiles) hipStreamWaitEvent(st, before_tiles, 0);
     crl_timer_begin(tm, 1, st);
     launch_car_obs(c->s, c->K_, dst, st, only_env, want);
     crl_timer_end(tm, 1, st);
@@ -534,25 +547,26 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         // Streams over disjoint classes of envs (car_post_kernel's slow_env: 0 on its own, 1 coupled, 2 finished, 3 finished and coupled):
         //   crit   (the caller's) [narrow phase of the coupled envs ->] the touching ones' island solve -> their frames (the step's longest chain)
         //   bulk   per-car solve -> camera, polygons -> frames of class 0 (the big launch)
-        //   side2  env bookkeeping; the coupled envs where nothing touches (two islands of their own) -> their frames; behind the
-        //          touching solve the commit of the envs that are finished AND coupled; the step's join; the NEXT step's Collide
-        //   sens   wheel sensors (tile rewards, road_visited: they read the transforms the step started from and feed nothing into
-        //          its solve; every frame shows the reward, so every frame launch waits for them); behind the per-car solve the terminal frames +
-        //          commit of the finished envs on their own
-        //   one    (high priority) the finished envs' NEW episode, prepared early on the staged view: reset, map, first frame
+        //   side2  env bookkeeping; the coupled envs where nothing touches (two islands of their own) -> their frames; the terminal
+        //          frames of the finished envs on their own as soon as the per-car solve is in, their commit once the new episode is
+        //          staged; behind the touching solve the terminal frames + commit of the envs that are finished AND coupled; the
+        //          step's join; the NEXT step's Collide
+        //   one    (HIGH priority) the wheel sensors (tile rewards, road_visited: they read the transforms the step started from and
+        //          feed nothing into its solve; every frame shows the reward, so every frame launch waits for them), then the finished
+        //          envs' NEW episode, prepared early on the staged view: reset, map, first frame.  Round 4: the sensors used to have a
+        //          normal-priority stream of their own and finished at ~350 us; here they are done at ~135-250 us, everything that
+        //          waits for them starts earlier, and the context needs one stream less (1.03 -> 0.93 ms per step, same box)
         // (streams of one priority share four hardware queues, and two streams that share one wait for each other's kernels;
         // the milliseconds-long walk-ahead has a priority class of its own)
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
-        static const int x_mode = getenv("CRL_CAR_X") ? atoi(getenv("CRL_CAR_X")) : 35;  // experiments: 1 urgent touch frames, 2 late chain reordered, 4 join by two barriers, 8 touch frames on side2, 16 collide-ahead early on `one`, inside the join
         hipEventRecord(c->ev_fork, st);
         hipStreamWaitEvent(c->side, c->ev_fork, 0);
         hipStreamWaitEvent(c->side2, c->ev_fork, 0);
-        const hipStream_t sens = (x_mode & 32) ? c->one : c->sens;  // (32: the wheel sensors on the high-priority stream, in front of the finished envs' early chain -- one normal-priority stream less)
-        hipStreamWaitEvent(sens, c->ev_fork, 0);
+        hipStreamWaitEvent(c->one, c->ev_fork, 0);
         launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, c->side2, c->class_list,
                         c->class_count);
         hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
-        if (ahead && !c->collide_joined) {  // (side2 ran the narrow phase itself, at the end of the last step; crit and bulk wait for it)
+        if (ahead) {  // (side2 ran the narrow phase itself, at the end of the last step; crit and bulk wait for it)
             hipStreamWaitEvent(crit, c->ev_collide, 0);
             hipStreamWaitEvent(bulk, c->ev_collide, 0);
         }
@@ -560,53 +574,42 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             launch_car_narrow(c->s, c->K_, crit, true);
             hipEventRecord(c->ev_narrow, crit);
             hipStreamWaitEvent(c->side2, c->ev_narrow, 0);
-            hipStreamWaitEvent(sens, c->ev_narrow, 0);
+            hipStreamWaitEvent(c->one, c->ev_narrow, 0);
         }
-        hipStreamWaitEvent(sens, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the frame launches pass ONE barrier each)
-        launch_car_sensors(c->s, c->K_, sens);
-        hipEventRecord(c->ev_sens, sens);
+        hipStreamWaitEvent(c->one, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the frame launches pass ONE barrier each)
+        launch_car_sensors(c->s, c->K_, c->one);
+        hipEventRecord(c->ev_sens, c->one);
         launch_car_coupled(c->s, c->K_, crit, c->side2, nullptr, true);  // near-only solve on side2, touching solve on crit
         hipEventRecord(c->ev_coupled, crit);
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
+        hipStreamWaitEvent(c->side2, c->ev_sens, 0);  // (every frame shows the reward)
         if (contacts) {  // frames of the near-only envs
-            hipStreamWaitEvent(c->side2, c->ev_sens, 0);
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled);
             else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
         }
         // bulk: the per-car solve, then the frames of every env that is neither coupled nor finished
         launch_car_solve(c->s, c->K_, bulk);
         hipEventRecord(c->ev_term, bulk);  // (bodies of the non-coupled cars are final)
+        hipStreamWaitEvent(bulk, c->ev_sens, 0);
         crl_timer_end(tm, 0, bulk);
-        if (x_mode & 64) {  // camera and polygons directly behind the solve; only the tiles (they show the reward) wait for the sensors
-            hipStreamWaitEvent(bulk, c->ev_post, 0);  // (the env classes the three kernels filter by)
-            frames(c, target, bulk, c->slow_env, 0, tm, c->ev_sens);
-        } else {
-            hipStreamWaitEvent(bulk, c->ev_sens, 0);
-            frames(c, target, bulk, c->slow_env, 0, tm);
-        }
-        if (contacts && !(x_mode & 8)) {  // crit again: the touching envs' frames, behind their solve
+        frames(c, target, bulk, c->slow_env, 0, tm);
+        if (contacts) {  // crit again: the touching envs' frames, behind their solve (wave priority 3: beside the big launch's 32 768 wavefronts)
             hipStreamWaitEvent(crit, c->ev_sens, 0);
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
-            else launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, (x_mode & 1) != 0);
+            else launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, true);
         }
         // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
         // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared
-        // beside the solves.  What has to wait for the solve is small: the terminal frame (info["terminal_observation"],
-        // drawn from the solved bodies over the OLD map) and the commit that makes the staged episode current.
-        // Class 2 (cars on their own: nearly all of them) waits for the per-car solve; class 3 (finished AND coupled) for the
-        // touching solve, on `side2` -- two small kernels behind the step's longest chain instead of four.
+        // beside the solves, on the sensors' stream.  What has to wait for a solve is small: the terminal frame
+        // (info["terminal_observation"], drawn from the solved bodies over the OLD map) and -- behind the new episode's staging --
+        // the commit that makes it current.  Class 2 (cars on their own: nearly all of them) waits for the per-car solve; class 3
+        // (finished AND coupled) for the touching solve: two small kernels behind the step's longest chain.
         const CarSoA sv = stage_view(c);
         auto list_of = [&](int cls) { return c->class_list + (int64_t)(cls - 1) * c->n; };
         auto count_of = [&](int cls) { return c->class_count + (cls - 1); };
-        auto early_chain = [&](hipStream_t q, int cls, int64_t expected) {
-            launch_car_reset_list(sv, c->K_, c->src, list_of(cls), count_of(cls), expected, q);
-            launch_car_map_build_list(sv, q, list_of(cls), count_of(cls), expected);
-            frames_list(c, sv, target, q, list_of(cls), count_of(cls), nullptr, expected);
-        };
-        auto late_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {
+        auto terminal_frames = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {
             if (c->analytic) launch_car_raster_list(c->s, c->K_, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
             else launch_car_obs_list(c->s, c->K_, c->term, q, list_of(cls), count_of(cls), count_to_host, expected, c->slow_env, cls);
-            launch_car_commit_list(c->s, sv, list_of(cls), count_of(cls), expected, q);
         };
         auto finish_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {  // everything in place, in order
             frames_list(c, c->s, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
@@ -615,79 +618,46 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             frames_list(c, c->s, target, q, list_of(cls), count_of(cls), nullptr, expected);
         };
         const bool staged = !c->analytic;  // (the analytic raster reads the track arrays themselves: it needs them until the terminal frame is drawn)
+        hipStreamWaitEvent(c->side2, c->ev_term, 0);
         if (staged) {
-            // on the high-priority stream: the map build's small workgroups then get CU slots ahead of the frame kernel's 32 768
-            // wavefronts instead of behind them (320 us for a dozen maps otherwise)
-            hipStreamWaitEvent(c->one, c->ev_sens, 0);
-            early_chain(c->one, 4, exp_done + 8);  // every finished env, class 2 and 3 alike
+            // early chain, every finished env (class 2 and 3 alike), at high priority: the map build's small workgroups get CU slots
+            // ahead of the frame kernel's 32 768 wavefronts instead of behind them (320 us for a dozen maps otherwise)
+            launch_car_reset_list(sv, c->K_, c->src, list_of(4), count_of(4), exp_done + 8, c->one);
+            launch_car_map_build_list(sv, c->one, list_of(4), count_of(4), exp_done + 8);
+            frames_list(c, sv, target, c->one, list_of(4), count_of(4), nullptr, exp_done + 8);
             hipEventRecord(c->ev_early3, c->one);
-            const hipStream_t late = (x_mode & 32) ? c->side2 : sens;  // (32: behind the near-only envs' frames, side2 idles until the touching solve is in)
-            hipStreamWaitEvent(late, c->ev_term, 0);
-            if (x_mode & 2) {  // terminal frames as soon as the per-car solve is in; only the commit waits for the new episode
-                launch_car_obs_list(c->s, c->K_, c->term, late, list_of(2), count_of(2), c->class_count_hdev + 1, exp_done, c->slow_env, 2);
-                hipStreamWaitEvent(late, c->ev_early3, 0);
-                launch_car_commit_list(c->s, sv, list_of(2), count_of(2), exp_done, late);
-            } else {
-                hipStreamWaitEvent(late, c->ev_early3, 0);
-                late_chain(late, 2, exp_done, c->class_count_hdev + 1);
-            }
-            hipEventRecord(c->ev_fin, late);
+            terminal_frames(c->side2, 2, exp_done, c->class_count_hdev + 1);  // (side2 idles between the near-only envs' frames and the touching solve)
+            hipStreamWaitEvent(c->side2, c->ev_early3, 0);
+            launch_car_commit_list(c->s, sv, list_of(2), count_of(2), exp_done, c->side2);
         } else {
-            hipStreamWaitEvent(sens, c->ev_term, 0);
-            finish_chain(sens, 2, exp_done, c->class_count_hdev + 1);
-            hipEventRecord(c->ev_fin, sens);
+            finish_chain(c->side2, 2, exp_done, c->class_count_hdev + 1);
         }
         hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve
-        hipStreamWaitEvent(c->side2, c->ev_sens, 0);
-        if (contacts && (x_mode & 8)) {
-            // the touching envs' frames HERE rather than behind their solve on the caller's stream: a barrier packet on a created stream
-            // costs 5-12 us, on the legacy default stream 30-55 us even when it is long open
-            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
-            else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, (x_mode & 1) != 0);
-        }
         if (staged) {
-            hipStreamWaitEvent(c->side2, c->ev_early3, 0);
-            late_chain(c->side2, 3, 8, nullptr);
+            terminal_frames(c->side2, 3, 8, nullptr);
+            launch_car_commit_list(c->s, sv, list_of(3), count_of(3), 8, c->side2);
         } else {
             finish_chain(c->side2, 3, 8, nullptr);
         }
-        // join: side2 collects sens and side behind its own last kernel, so that the caller's stream -- whose last kernel is usually
-        // the last of the step -- passes ONE barrier that is already open instead of three
+        // join: side2 collects the bulk stream (and, through ev_early3, the high-priority one) behind its own last kernel, so that the
+        // caller's stream -- whose last kernel is usually the last of the step -- passes ONE barrier instead of three
         hipEventRecord(c->ev_join, c->side);
-        c->collide_joined = false;
-        if (can_ahead && (x_mode & 16)) {
-            // The next step's Collide as soon as every solve of this step is in and every finished env is committed (it does not
-            // need the frames): on `one`, beside this step's last frames, and INSIDE the join -- the next step then starts without a
-            // barrier between car_step_kernel and the touching solve
-            CarSoA nx = c->s;
-            point_parity(c, nx, c->parity ^ 1);
-            hipEventRecord(c->ev_near, c->side2);  // (behind the near-only solve, the touching solve and the commit of class 3)
-            hipStreamWaitEvent(c->one, c->ev_near, 0);
-            hipStreamWaitEvent(c->one, c->ev_fin, 0);   // commit of class 2
-            hipStreamWaitEvent(c->one, c->ev_term, 0);  // the per-car solve
-            launch_car_broad(nx, c->K_, c->one);
-            launch_car_narrow(nx, c->K_, c->one, false);
-            hipEventRecord(c->ev_collide, c->one);
-            hipStreamWaitEvent(c->side2, c->ev_collide, 0);
-            c->collide_valid = c->collide_dirty = c->collide_joined = true;
-        }
-        if (!(x_mode & 4)) hipStreamWaitEvent(c->side2, c->ev_fin, 0);
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
         hipEventRecord(c->ev_fin3, c->side2);
-        if (can_ahead && !(x_mode & 16)) {
-            // every solve of this step is in (side2 is behind the near-only and the touching solve; ev_term: the per-car solve) and
+        if (can_ahead) {
+            // every solve of this step is in (side2 is behind the near-only and the touching solve and ev_term: the per-car solve) and
             // every finished env is committed: the next step's Collide, into the other parity block, beside this step's last frames
+            // and the next car_step_kernel.  (Measured, round 4: earlier -- right behind the solves, reading the finished envs' staged
+            // bodies -- or inside the join, so that the next step needs no barrier for it: both slower, docs/LAB_NOTES_r04.md.)
             CarSoA nx = c->s;
             point_parity(c, nx, c->parity ^ 1);
-            hipStreamWaitEvent(c->side2, c->ev_term, 0);
             launch_car_broad(nx, c->K_, c->side2);
             launch_car_narrow(nx, c->K_, c->side2, false);
             hipEventRecord(c->ev_collide, c->side2);
             c->collide_valid = c->collide_dirty = true;
         }
-        queue_walk_ahead(c, (x_mode & 32) ? c->side2 : sens);
+        queue_walk_ahead(c, c->side2);
         hipStreamWaitEvent(st, c->ev_fin3, 0);
-        if (x_mode & 4) hipStreamWaitEvent(st, c->ev_fin, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
     }
     hipError_t e = hipGetLastError();

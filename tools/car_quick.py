@@ -11,14 +11,16 @@ import competitive_rl_amd as crl
 
 n, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, int(sys.argv[2]) if len(sys.argv) > 2 else 300
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 50  # steps between host synchronisations
-env = crl.HipCarVecEnv(n, seed=1)
+env = crl.HipCarVecEnv(n, seed=int(os.environ.get("QUICK_SEED", "0")))
 st = None
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(3)
-acts = torch.rand((64, n, 2, 2), generator=g, device="cuda") * 2 - 1
+NA = int(os.environ.get("QUICK_ACTIONS", "16"))  # distinct action tensors, cycled (bench.py: 16 -- a car then repeats a 0.32 s pattern,
+# drives in circles and meets its partner far more often than under fresh random actions: 7 % touching envs instead of ~3 %)
+acts = torch.rand((NA, n, 2, 2), generator=g, device="cuda") * 2 - 1
 # steady-state mix: stagger the TimeLimit
 s0 = env.get_state()
-s0["elapsed"] = (torch.arange(n).numpy() * 7) % 1000
+s0["elapsed"] = (torch.arange(n, dtype=torch.int64) * 1000 // n).numpy()
 env.set_state(s0)
 torch.cuda.synchronize()
 user_stream = torch.cuda.Stream() if os.environ.get("QUICK_STREAM") else None  # the caller works on a created stream instead of the legacy default stream
@@ -27,7 +29,7 @@ if user_stream is not None:
 for blk in range(steps // K):
     t0 = time.time()
     for t in range(K):
-        env.step_device(acts[(blk * K + t) % 64])
+        env.step_device(acts[(blk * K + t) % NA])
     torch.cuda.synchronize()
     dt = (time.time() - t0) / K * 1e3
     print(f"steps {blk * K:5d}-{blk * K + K - 1:5d}: {dt:8.3f} ms/step  cap_hits {env.cap_hits()}", flush=True)
