@@ -216,8 +216,10 @@ def run_workload(name, args, G):
         desc = {"raw": f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)",
                 "fused84": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack (N,2,4,84,84) u8, 1 step = 4 frames "
                            "(BASELINE config #3)",
-                "fused84_f32": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack, float32 output (N,2,4,84,84) "
-                               "as DummyVecEnv's buffers hold it (SURVEY 8d config-3 variant, 225 792 B/env), 1 step = 4 frames",
+                "fused84_f32": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack, float32 output (N,2,4,84,84): the "
+                               "uint8 values widened to the dtype DummyVecEnv's buffers have (SURVEY 8d config-3 variant, 225 792 B/env; the "
+                               "reference's own UNROUNDED float32 values are obs_dtype='float32_ref', 2 M env-steps/s, not benchmarked here), "
+                               "1 step = 4 frames",
                 "fused84_newest": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA, newest plane only (N,2,1,84,84) u8, "
                                   "1 step = 4 frames (variant of BASELINE config #3)"}[name]
         kernel = "pong_raster_raw_sweep_kernel" if name == "raw" else "pong_raster_gray_env_kernel"
@@ -396,6 +398,15 @@ def main():
                 "data": "synthetic", "config": head["config"], "roofline": head.get("roofline")}
         if "roofline_valu" in head:
             line["roofline_valu"] = head["roofline_valu"]
+        # what ran where: one process per GPU, contiguous env ranges by global id, no data-path collective unless
+        # --gather asks for the config-#5 all-gather; the collective library the ranks would use
+        npg = head["config"]["envs_per_gpu"]
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:  # (a build without the collective library)
+            rccl = f"unavailable ({type(exc).__name__})"
+        line["comm"] = {"backend": "nccl (= RCCL on ROCm)" if world > 1 else "none (one rank)", "rccl_version": rccl, "world": world,
+                        "env_ranges": [[r * npg, (r + 1) * npg] for r in range(world)], "gather": args.gather}
         if world > 1 and args.gather != "none":
             line["config"]["gather"] = args.gather + (" (64 bytes of frame descriptors per env in one packed all_gather_into_tensor per step; every rank re-draws all shards' observations)"
                                                       if args.gather == "descriptors" else

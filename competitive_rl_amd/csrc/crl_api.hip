@@ -340,7 +340,7 @@ int crl_create(const crl_opts *opts, const uint8_t *score_atlas_host, crl_ctx **
     }
     if (opts->action_repeat != 0 || opts->done_policy != 0)
         return fail(CRL_EINVAL, "action_repeat / done_policy are CarRacing options (must be 0 for Pong)");
-    if (opts->obs_dtype != CRL_OBS_U8 && !(opts->obs_dtype == CRL_OBS_F32 && opts->obs_mode == CRL_OBS_GRAY_RESIZED))
+    if (opts->obs_dtype != CRL_OBS_U8 && !((opts->obs_dtype == CRL_OBS_F32 || opts->obs_dtype == CRL_OBS_F32_REF) && opts->obs_mode == CRL_OBS_GRAY_RESIZED))
         return fail(CRL_EINVAL, "obs_dtype %d unsupported for this obs_mode", opts->obs_dtype);
     if (opts->obs_mode == CRL_OBS_GRAY_RESIZED) {
         if (opts->resized_dim < 8 || opts->resized_dim > 84 || (opts->resized_dim * opts->resized_dim) % 4)
@@ -449,7 +449,7 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         p.ring = c->s.ring, p.n = c->n, p.R = c->o.resized_dim, p.K = c->o.frame_stack, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
-        p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32, p.hdr = c->tile_hdr;
+        p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype, p.hdr = c->tile_hdr;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
@@ -552,7 +552,7 @@ int64_t crl_obs_bytes_per_env(const crl_ctx *c) {
     if (!c) return 0;
     if (c->car) return crl_car_obs_bytes(c->car);
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) return pong_views(c) * (int64_t)CRL_PONG_FRAME_BYTES;
-    return pong_views(c) * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim * (c->o.obs_dtype == CRL_OBS_F32 ? 4 : 1);
+    return pong_views(c) * (int64_t)c->o.frame_stack * c->o.resized_dim * c->o.resized_dim * (c->o.obs_dtype != CRL_OBS_U8 ? 4 : 1);
 }
 
 // Draws `m` frame pairs that already sit in device memory as a single-plane ring ([8][m], planes 0..2 unused).
@@ -565,7 +565,7 @@ static int render_ring(crl_ctx *c, const uint64_t *ring_dev, int64_t m, uint8_t 
         p.ring = ring_dev, p.n = m, p.R = c->o.resized_dim, p.K = 1, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
-        p.obs = out_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32;
+        p.obs = out_dev, p.obs_f32 = c->o.obs_dtype;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
@@ -667,7 +667,7 @@ int crl_render_frames_dev(crl_ctx *c, const crl_pong_frame *desc_dev, int64_t co
         p.ring = ring, p.n = count, p.R = c->o.resized_dim, p.K = c->o.frame_stack, p.views = pong_views(c);
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
-        p.obs = out_dev, p.obs_f32 = c->o.obs_dtype == CRL_OBS_F32;
+        p.obs = out_dev, p.obs_f32 = c->o.obs_dtype;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }

@@ -236,7 +236,7 @@ struct GrayParams {
     const int32_t *xsi, *ysi;       // source index per tap
     const float *xalpha, *yalpha;   // weight per tap
     uint8_t *obs;                   // [n][2][K][R][R]
-    bool obs_f32;                   // obs is float32 (CRL_OBS_F32): same values, widened in the store epilogue
+    int obs_f32;                    // crl_obs_dtype of obs: 1 = float32, same values, widened in the store epilogue; 2 = the reference's unrounded float32 path
     void *hdr;                      // scratch for the address-linear writer: 64 B per (env, view, plane) tile, or nullptr
 };
 void launch_pong_raster_gray(const GrayParams &p, hipStream_t st);

@@ -41,9 +41,15 @@ def get_compute_action_function(agent_name, num_envs=1, device=None):
 
 
 class TournamentEnvWrapper:
+    """Same protocol as the reference's wrapper (competitive_pong_env.py:9-53: step / reset / reset_opponent / get_agent_names /
+    seed, a single-agent view of a two-player env); the opponent's action never leaves the device: both columns of one int32
+    (N, 2) action tensor are filled in place and handed to the env's device step."""
+
     def __init__(self, env, num_envs, agent_names=None):
-        self.env = env
+        self.env, self.num_envs = env, num_envs
         device = getattr(env, "device", None)
+        if device is None:
+            raise RuntimeError("TournamentEnvWrapper needs the HIP vector env (there is no CPU fallback)")
         names = get_builtin_agent_names() if agent_names is None else list(agent_names)
         cnn = [n for n in names if n in BUILTIN_CHECKPOINTS]
         if cnn and getattr(env, "R", 42) != 42:
@@ -51,73 +57,58 @@ class TournamentEnvWrapper:
                              "or pass agent_names without them")
         self.agents = {name: get_compute_action_function(name, num_envs, device) for name in names}
         self.agent_names = list(self.agents)
-        self.prev_opponent_obs = None
-        self.current_agent_name = "RULE_BASED" if "RULE_BASED" in self.agents else self.agent_names[0]
-        self.current_agent = self.agents[self.current_agent_name]
-        self.observation_space = env.observation_space[0]
-        self.action_space = env.action_space[0]
-        self.num_envs = num_envs
-        self._act = None if device is None else torch.zeros((num_envs, 2), dtype=torch.int32, device=device)
+        self.observation_space, self.action_space = env.observation_space[0], env.action_space[0]
+        self.prev_opponent_obs = None  # what the opponent acts on: the right-hand view of the previous step / reset
+        self._act = torch.zeros((num_envs, 2), dtype=torch.int32, device=device)
+        self._select("RULE_BASED" if "RULE_BASED" in self.agents else self.agent_names[0])  # the reference starts with RULE_BASED
+
+    # ---- opponent
+    def _select(self, name):
+        self.current_agent_name, self.current_agent = name, self.agents[name]
 
     def get_agent_names(self):
         return self.agent_names
 
     def reset_opponent(self, agent_name=None):
-        if agent_name is None:
-            self.current_agent_name = random.choice(self.agent_names)
-        else:
-            assert agent_name in self.agent_names, self.agent_names
-            self.current_agent_name = agent_name
-        self.current_agent = self.agents[self.current_agent_name]
+        name = random.choice(self.agent_names) if agent_name is None else agent_name
+        assert name in self.agent_names, self.agent_names
+        self._select(name)
 
-    def step(self, action):
-        if self._act is not None:
-            # device path: our column from the caller; the opponent's column is written in place by the
-            # policy kernel (WEAK / MEDIUM) or is the constant 999 (RULE_BASED) -- no host round trip
-            if isinstance(action, torch.Tensor):
-                mine = action.to(self._act.device, torch.int32).reshape(-1)
-            else:
-                mine = torch.as_tensor(np.asarray(action).reshape(-1), dtype=torch.int32).to(self._act.device)
-            self._act[:, 0] = mine
-            if isinstance(self.current_agent, Policy):
-                self.current_agent.act_device(self.prev_opponent_obs, out=self._act[:, 1])
-            elif self.current_agent_name == "RULE_BASED":
-                self._act[:, 1] = CHEAT_CODES
-            else:
-                theirs = np.asarray(self.current_agent(self.prev_opponent_obs)).reshape(-1)
-                self._act[:, 1] = torch.as_tensor(theirs, dtype=torch.int32).to(self._act.device)
-            tuple_action = self._act
+    def _fill_actions(self, mine_i32):
+        """column 0 <- the caller's actions, column 1 <- the current opponent's: written in place by the policy kernel
+        (WEAK / MEDIUM), the constant 999 (RULE_BASED, resolved by the step kernel = auto_action), or a host callable (RANDOM)"""
+        self._act[:, 0] = mine_i32
+        agent = self.current_agent
+        if isinstance(agent, Policy):
+            agent.act_device(self.prev_opponent_obs, out=self._act[:, 1])
+        elif self.current_agent_name == "RULE_BASED":
+            self._act[:, 1] = CHEAT_CODES
         else:
-            if isinstance(action, torch.Tensor):
-                action = action.detach().cpu().numpy()
-            tuple_action = np.stack([np.asarray(action).reshape(-1),
-                                     np.asarray(self.current_agent(self.prev_opponent_obs)).reshape(-1)], axis=1)
-        obs, rew, done, info = self.env.step(tuple_action)
+            theirs = np.asarray(agent(self.prev_opponent_obs)).reshape(-1)
+            self._act[:, 1] = torch.as_tensor(theirs, dtype=torch.int32).to(self._act.device)
+        return self._act
+
+    # ---- VecEnv protocol, agent 0's view
+    def step(self, action):
+        if not isinstance(action, torch.Tensor):
+            action = torch.as_tensor(np.asarray(action).reshape(-1), dtype=torch.int32)
+        obs, rew, done, info = self.env.step(self._fill_actions(action.to(self._act.device, torch.int32).reshape(-1)))
         self.prev_opponent_obs = obs[1]
-        if done.ndim == 2:
-            done = done[:, 0]
+        done = done[:, 0] if done.ndim == 2 else done
         return obs[0], rew[:, 0].reshape(-1, 1), done.reshape(-1, 1), info
 
     def step_device(self, actions_i32):
         """Hot-loop entry (no host work, no clones, no sync): ``actions_i32`` is an int32 (N,) device tensor;
         returns the env's device buffers (obs (N, 2, K, R, R) -- view 0 is the caller's --, rewards (N, 2),
         done (N,)) like HipPongVecEnv.step_device."""
-        self._act[:, 0] = actions_i32
-        if isinstance(self.current_agent, Policy):
-            self.current_agent.act_device(self.prev_opponent_obs, out=self._act[:, 1])
-        elif self.current_agent_name == "RULE_BASED":
-            self._act[:, 1] = CHEAT_CODES
-        else:
-            self._act[:, 1] = torch.as_tensor(np.asarray(self.current_agent(self.prev_opponent_obs)).reshape(-1),
-                                              dtype=torch.int32).to(self._act.device)
-        buf, rew, done = self.env.step_device(self._act)
+        buf, rew, done = self.env.step_device(self._fill_actions(actions_i32))
         self.prev_opponent_obs = buf[:, 1]
         return buf, rew, done
 
     def reset(self, **kwargs):
-        obs = self.env.reset(**kwargs)
-        self.prev_opponent_obs = obs[1]
-        return obs[0]
+        views = self.env.reset(**kwargs)
+        self.prev_opponent_obs = views[1]
+        return views[0]
 
     def seed(self, s):
         self.env.seed(s)

@@ -163,7 +163,9 @@ class HipPongVecEnv(VecEnv):
             raise RuntimeError("HipPongVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
         assert mode in ("wrapped", "raw") and output in ("torch", "numpy") and dones in ("dummy", "subproc")
-        assert obs_dtype in ("uint8", "float32")
+        assert obs_dtype in ("uint8", "float32", "float32_ref")
+        if obs_dtype == "float32_ref" and mode != "wrapped":
+            raise ValueError('obs_dtype="float32_ref" is the wrapped (WarpFrame) observation of the reference\'s float32 step path')
         self._L = N.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.device.index is None:
@@ -178,7 +180,8 @@ class HipPongVecEnv(VecEnv):
                          resized_dim=self.R if mode == "wrapped" else 0, frame_stack=self.K if mode == "wrapped" else 1,
                          num_envs=int(num_envs), env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1),
                          device=self.device.index or 0, flags=N.CRL_FLAG_STACK_REPLICATE if stack_replicate else 0,
-                         obs_dtype=N.CRL_OBS_F32 if (obs_dtype == "float32" and mode == "wrapped") else N.CRL_OBS_U8)
+                         obs_dtype=(N.CRL_OBS_F32_REF if obs_dtype == "float32_ref" else N.CRL_OBS_F32) if (obs_dtype != "uint8" and mode == "wrapped")
+                         else N.CRL_OBS_U8)
         self._atlas = N.load_score_atlas() if score_atlas is None else np.ascontiguousarray(score_atlas, np.uint8)
         assert self._atlas.size == N.ATLAS_BYTES
         h = C.c_void_p()
@@ -199,7 +202,9 @@ class HipPongVecEnv(VecEnv):
         dev = self.device
         # float32 observations (DummyVecEnv's buffer dtype): the wrapped raster stores them directly; the raw RGB frames are
         # uint8 in the library and widened by torch on request (a 53 GB tensor at 65 536 envs -- not a hot path)
-        self._buf_dtype = torch.float32 if (obs_dtype == "float32" and mode == "wrapped") else torch.uint8
+        # "float32_ref": the values the reference's step() itself returns under old gym's float32 Box -- unrounded INTER_AREA averages
+        # of the float gray frame on step(), rounded on reset() (include/crl.h CRL_OBS_F32_REF); "float32": the uint8 values, widened
+        self._buf_dtype = torch.float32 if (obs_dtype != "uint8" and mode == "wrapped") else torch.uint8
         self._obs = [torch.empty(self._obs_shape, dtype=self._buf_dtype, device=dev) for _ in range(2)]
         self._flip = 0
         self._serial = 0  # steps + resets so far: lazy infos check it before drawing terminal observations

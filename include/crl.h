@@ -157,6 +157,13 @@ enum crl_obs_dtype {
     /* DummyVecEnv's observation buffers are float32 holding 0..255 (utils/dummy_vec_env.py:37-44;
        SURVEY 8d config-3 variant, 225 792 B/env): same values, widened in the raster's store */
     CRL_OBS_F32 = 1,
+    /* The reference's own float32 values.  Old gym's Box defaults to float32, so MaxAndSkipEnv's buffers are float32
+       (utils/atari_wrappers.py:104-116) and WarpFrame.parse_single_frame (:215-219) runs cv2.cvtColor / cv2.resize on FLOAT
+       frames during step(): the observation is the UNROUNDED INTER_AREA average of gray = R*0.299f + G*0.587f + B*0.114f
+       (e.g. 254.99998 where the uint8 path says 255); reset() -- and the auto-reset of a finished env -- goes through the
+       uint8 image and yields rounded values.  A plane whose two kept frames are the same frame is such a reset observation.
+       Costs a per-pixel evaluation (32 ms per step at 65 536 envs: 2 M env-steps/s); CRL_OBS_F32 is the fast float32 tensor. */
+    CRL_OBS_F32_REF = 2,
 };
 
 typedef struct crl_ctx crl_ctx;

@@ -52,9 +52,9 @@ def forward(wts, stack_u8):
 class PolicyOracle:
     """Policy(…, use_light_model=True) of utils/policy_serving.py as a callable on (N, 1, 42, 42) frames."""
 
-    def __init__(self, weights, num_envs):
+    def __init__(self, weights, num_envs, dtype=np.uint8):
         self.w = weights
-        self.stack = np.zeros((num_envs, 4, 42, 42), np.uint8)
+        self.stack = np.zeros((num_envs, 4, 42, 42), dtype)  # (float32: the frames of the reference's unrounded float32 step path)
         self.logits = None
 
     def reset(self):

@@ -82,6 +82,8 @@ def lib():
         L.pong_oracle_terminal_observation.argtypes = [vp, i64, vp]
         L.pong_oracle_render_raw.argtypes = [vp, i64, vp, vp]
         L.pong_oracle_render_gray.argtypes = [vp, vp, vp, i32, i32, vp]
+        L.pong_oracle_render_gray_f32.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        L.pong_oracle_set_f32ref.argtypes = [vp, i32]
         L.pong_oracle_area_table.restype = i32
         L.pong_oracle_area_table.argtypes = [i32, i32, vp, vp, vp]
         L.pong_oracle_state_size.restype = i32
@@ -109,6 +111,15 @@ def render_raw(frames, atlas):
     return out
 
 
+def render_gray_f32(fa, fb, atlas, view, R, rounded=False):
+    """the reference's float32 step path for one frame pair (unrounded), or the uint8 path as floats (rounded=True)"""
+    fa = np.ascontiguousarray(fa, dtype=FRAME_DT).reshape(1)
+    fb = np.ascontiguousarray(fb, dtype=FRAME_DT).reshape(1)
+    out = np.empty((R, R), np.float32)
+    lib().pong_oracle_render_gray_f32(_p(fa), _p(fb), _p(atlas), view, R, int(rounded), _p(out))
+    return out
+
+
 def render_gray(fa, fb, atlas, view, R):
     fa = np.ascontiguousarray(fa, dtype=FRAME_DT).reshape(1)
     fb = np.ascontiguousarray(fb, dtype=FRAME_DT).reshape(1)
@@ -121,7 +132,7 @@ class PongOracle:
     """Batch of cPongDouble envs with VecEnv.step/reset semantics (auto-reset)."""
 
     def __init__(self, num_envs, atlas, obs_mode=RAW, resized_dim=84, frame_stack=1, seed=0, env_id_base=0,
-                 single=False, replicate=False):
+                 single=False, replicate=False, obs_dtype="uint8"):
         self.n, self.mode, self.R, self.K = int(num_envs), obs_mode, int(resized_dim), int(frame_stack)
         self.atlas = np.ascontiguousarray(atlas, np.uint8)
         assert self.atlas.size == 22 * 22 * 34 * 160
@@ -130,7 +141,11 @@ class PongOracle:
         self.single, self.V = bool(single), 1 if single else 2
         lib().pong_oracle_set_mode(self.h, int(single), int(replicate))
         shape = (self.n, self.V, 210, 160, 3) if obs_mode == RAW else (self.n, self.V, self.K, self.R, self.R)
-        self.obs = np.zeros(shape, np.uint8)
+        assert obs_dtype in ("uint8", "float32_ref")
+        self.f32ref = obs_dtype == "float32_ref"  # the reference's unrounded float32 step path (pong_oracle_render_gray_f32)
+        assert not (self.f32ref and obs_mode == RAW)
+        lib().pong_oracle_set_f32ref(self.h, int(self.f32ref))
+        self.obs = np.zeros(shape, np.float32 if self.f32ref else np.uint8)
         self.rew = np.zeros((self.n,) if single else (self.n, 2), np.float32)
         self.done = np.zeros((self.n,), np.uint8)
 
@@ -188,6 +203,6 @@ class PongOracle:
 
     def terminal_observation(self, i):
         shape = (self.V, 210, 160, 3) if self.mode == RAW else (self.V, self.R, self.R)
-        out = np.empty(shape, np.uint8)
+        out = np.empty(shape, np.float32 if self.f32ref else np.uint8)
         lib().pong_oracle_terminal_observation(self.h, int(i), _p(out))
         return out

@@ -83,6 +83,41 @@ def test_float32_store_epilogue_equals_uint8(atlas, R, K):
     f.close()
 
 
+@pytest.mark.parametrize("R,K", [(84, 4), (42, 1), (84, 1), (42, 4)])
+def test_float32_ref_equals_the_oracles_unrounded_observation(atlas, R, K):
+    """obs_dtype="float32_ref" (include/crl.h CRL_OBS_F32_REF): the reference's own float32 values -- unrounded INTER_AREA
+    averages of the float gray frame on step() (utils/atari_wrappers.py:104-116, 215-219), rounded on reset() and on the
+    auto-reset of a finished env -- bit for bit against the oracle (same float32 operation order, no contraction), stack
+    planes and terminal observations included."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import pong_oracle as po
+
+    n, steps = 50, 400 if R == 42 else 160
+    rs = np.random.RandomState(R + K)
+    f = crl.HipPongVecEnv(n, seed=6, mode="wrapped", resized_dim=R, frame_stack=K, obs_dtype="float32_ref")
+    ora = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=R, frame_stack=K, seed=6, obs_dtype="float32_ref")
+    of = torch.stack(f.reset(), 1)
+    assert of.dtype == torch.float32
+    assert np.array_equal(of.cpu().numpy(), ora.reset())
+    fractional = seen = 0
+    for t in range(steps):
+        a = rs.randint(0, 3, (n, 2))
+        obs, rew, done, infos = f.step(a)
+        oo, orew, odone = ora.step(a)
+        got = torch.stack(obs, 1).cpu().numpy()
+        assert np.array_equal(got, oo), (t, float(np.abs(got - oo).max()), int((got != oo).sum()))
+        assert np.array_equal(rew.cpu().numpy(), orew)
+        fractional += int((got != np.rint(got)).sum())
+        for i in np.nonzero(odone)[0][:2]:
+            term = torch.stack(infos[int(i)]["terminal_observation"]).cpu().numpy()[:, 0]
+            assert np.array_equal(term, ora.terminal_observation(int(i))), (t, i)
+            assert np.array_equal(got[i, :, -1], np.rint(got[i, :, -1]))  # the auto-reset's observation: rounded again
+            seen += 1
+    assert fractional > 1000 and (seen > 0 or R != 42)
+    f.close()
+
+
 @pytest.mark.parametrize("R", [64, 32, 48])
 def test_other_resized_dims_match_oracle(atlas, R):
     """crl_create accepts any even resized_dim in 8..84; sizes other than the reference's 84 / 42 take the same

@@ -1,0 +1,80 @@
+"""The reference's float32 step path (include/crl.h CRL_OBS_F32_REF), oracle side.  Old gym's Box defaults to
+float32, so MaxAndSkipEnv's buffers are float32 (utils/atari_wrappers.py:104-116) and WarpFrame (:215-219) hands cv2 FLOAT
+frames during step(): unrounded INTER_AREA averages of the float gray image; reset() goes through the uint8 image."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import policy_oracle as P
+from oracle import pong_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("R,K", [(84, 4), (42, 1)])
+def test_float32_ref_is_the_unrounded_twin_of_the_uint8_observation(atlas, R, K):
+    n = 6
+    a = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=R, frame_stack=K, seed=3)
+    b = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=R, frame_stack=K, seed=3, obs_dtype="float32_ref")
+    assert np.array_equal(a.reset().astype(np.float32), b.reset()), "reset(): the uint8 image through WarpFrame -> rounded values"
+    rs = np.random.RandomState(0)
+    frac, dones = [], 0
+    for t in range(900):
+        act = rs.randint(0, 3, (n, 2))
+        oa, ra, da = a.step(act)
+        ob, rb, db = b.step(act)
+        assert np.array_equal(ra, rb) and np.array_equal(da, db)
+        d = np.abs(ob - oa.astype(np.float32))
+        assert d.max() <= 0.5 + 1e-4, (t, float(d.max()))  # the uint8 observation is this one rounded
+        clear = d < 0.499
+        assert np.array_equal(np.rint(ob)[clear], oa.astype(np.float32)[clear]), t
+        frac.append(float((ob != np.rint(ob)).mean()))
+        for i in np.nonzero(da)[0]:
+            dones += 1
+            # the auto-reset's observation is a reset observation again: integer-valued newest plane
+            assert np.array_equal(ob[i, :, -1], np.rint(ob[i, :, -1])), (t, i)
+            ta, tb = a.terminal_observation(i), b.terminal_observation(i)
+            assert np.abs(tb - ta.astype(np.float32)).max() <= 0.5 + 1e-4 and (tb != np.rint(tb)).any(), (t, i)
+    assert dones > 0 and 0.005 < np.mean(frac) < 0.2, (dones, np.mean(frac))
+
+
+def test_float_gray_of_an_achromatic_pixel():
+    """cvtColor RGB2GRAY on float32: v * 0.299f + v * 0.587f + v * 0.114f, one rounding per operation -- within an ulp of v"""
+    v = np.arange(256, dtype=np.float32)
+    g = (v * np.float32(0.299) + v * np.float32(0.587)) + v * np.float32(0.114)
+    assert g.dtype == np.float32 and np.abs(g - v).max() <= 2e-5
+    # a full-white court: every output pixel is that gray value under INTER_AREA weights that sum to 1 within rounding
+    atlas = np.zeros(22 * 22 * 34 * 160, np.uint8)
+    f = np.zeros(1, po.FRAME_DT)
+    f["ball_x"], f["ball_y"], f["bat_l_y"], f["bat_r_y"] = 70, 100, 90, 90
+    out = po.render_gray_f32(f, f, atlas, 0, 84)
+    assert abs(float(out[-1, 5]) - 255.0) < 1e-3  # bottom band: white
+
+
+@pytest.mark.parametrize("name", ["weak", "medium"])
+def test_how_often_the_opponent_network_decides_differently_on_unrounded_frames(atlas, name):
+    """The tournament opponent (utils/policy_serving.py:49-66) sees the float32 frames in the reference; the HIP policy kernel
+    is fed the uint8 frames.  Same games, same frames up to the rounding: how often does the greedy action differ?
+    (Recorded in DESIGN.md section 9; the bound only keeps the statement honest.)"""
+    w = P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_%s.npz" % name))
+    n, steps = 48, 500
+    a = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=11)
+    b = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=11, obs_dtype="float32_ref")
+    pa, pb = P.PolicyOracle(w, n), P.PolicyOracle(w, n, dtype=np.float32)
+    oa, ob = a.reset(), b.reset()
+    rs = np.random.RandomState(4)
+    differ = close_calls = 0
+    worst = 0.0
+    for t in range(steps):
+        xa, xb = pa(oa[:, 1]), pb(ob[:, 1])  # the right-hand view, as TournamentEnvWrapper feeds it
+        differ += int((xa != xb).sum())
+        worst = max(worst, float(np.abs(pa.logits - pb.logits).max()))
+        top2 = np.sort(pa.logits, 1)
+        close_calls += int(((top2[:, -1] - top2[:, -2]) < 1e-3).sum())
+        act = rs.randint(0, 3, (n, 2))
+        oa, _, _ = a.step(act)
+        ob, _, _ = b.step(act)
+    print(f"{name}: greedy action differs on {differ} of {n * steps} decisions; max |logit difference| {worst:.2e}; "
+          f"decisions with the two best logits closer than 1e-3: {close_calls}")
+    assert differ <= 0.005 * n * steps and worst < 0.3
