@@ -58,7 +58,7 @@ def test_how_often_the_opponent_network_decides_differently_on_unrounded_frames(
     is fed the uint8 frames.  Same games, same frames up to the rounding: how often does the greedy action differ?
     (Recorded in DESIGN.md section 9; the bound only keeps the statement honest.)"""
     w = P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_%s.npz" % name))
-    n, steps = 48, 500
+    n, steps = 32, 250
     a = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=11)
     b = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=11, obs_dtype="float32_ref")
     pa, pb = P.PolicyOracle(w, n), P.PolicyOracle(w, n, dtype=np.float32)
@@ -77,4 +77,4 @@ def test_how_often_the_opponent_network_decides_differently_on_unrounded_frames(
         ob, _, _ = b.step(act)
     print(f"{name}: greedy action differs on {differ} of {n * steps} decisions; max |logit difference| {worst:.2e}; "
           f"decisions with the two best logits closer than 1e-3: {close_calls}")
-    assert differ <= 0.005 * n * steps and worst < 0.3
+    assert differ <= 0.005 * n * steps and worst < 0.3  # measured over 24 000 decisions: WEAK 25, MEDIUM 17 (0.1 %)
