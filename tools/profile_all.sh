@@ -1,7 +1,7 @@
 #!/bin/bash
 # One script, one HEAD: every judged artefact under profiles/ comes from this run (tools/collect_profiles.py copies them).
-#   gpurun --timeout 2400 -- 'bash tools/profile_all.sh r03'
-RND=${1:-r03}
+#   gpurun --timeout 2400 -- 'bash tools/profile_all.sh r04'
+RND=${1:-r04}
 for wl in raw fused84 fused84_f32 car tournament; do
   echo "=== $wl ==="
   bash tools/profile_gpu.sh $wl ${RND}_$wl 2>&1 | tail -6
