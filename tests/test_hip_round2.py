@@ -502,3 +502,36 @@ def test_small_class_launches_loop_when_the_class_is_larger_than_expected():
     assert int((term[:, 0, :80] == 161).sum() + (term[:, 0, :80] == 176).sum()) > 0.9 * term[:, 0, :80].numel()
     del before
     env.close()
+
+
+def test_car_stream_order_switch_is_robust():
+    """CRL_CAR_STREAM_ORDER only deals the context's hardware queues differently: any string -- letters left out,
+    repeated, unknown -- must still give a working context with identical results (child process: read at create)."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import competitive_rl_amd as crl
+n = 96
+g = torch.Generator(device="cuda").manual_seed(1)
+acts = torch.rand((40, n, 2, 2), generator=g, device="cuda") * 2 - 1
+env = crl.HipCarVecEnv(n, seed=9)
+env.reset()
+tot = torch.zeros((), dtype=torch.int64, device="cuda")
+for t in range(40):
+    o, r, d = env.step_device(acts[t])
+    tot += o.to(torch.int64).sum() + (r * 1000).to(torch.int64).sum()
+print("checksum", int(tot))
+env.close()
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = set()
+    for order in ("s2oDg", "g", "xyz", "ddddHHs2ogDD", ""):
+        env = dict(os.environ, CRL_CAR_STREAM_ORDER=order) if order is not None else dict(os.environ)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "checksum" in r.stdout, (order, r.stdout[-500:], r.stderr[-1500:])
+        sums.add(r.stdout.strip().splitlines()[-1])
+    assert len(sums) == 1, sums
