@@ -879,7 +879,7 @@ void pong_gray_print_ticks() {
 // kept frames are the same frame is such a reset observation (consecutive frames of a running game differ in the ball's x).
 // One wavefront per (env, view, plane) tile, lanes over the output columns, every tap evaluated from the frame descriptors in
 // OpenCV's accumulation order (eval_pixel's); source rows of the empty court are skipped (wave-uniform).  This is the exact
-// mode, not the fast one: 32 ms per step at 65 536 envs (measured) against 2.7 ms for the widened uint8 values (CRL_OBS_F32).
+// mode, not the fast one (milliseconds per step at 65 536 envs against 2.7 ms for the widened uint8 values, CRL_OBS_F32).
 __device__ inline float gray_of_f32(int v) {
     const float f = (float)v;
     return f * 0.299f + f * 0.587f + f * 0.114f;  // (one rounding per operation: -ffp-contract=off)
@@ -887,6 +887,7 @@ __device__ inline float gray_of_f32(int v) {
 
 __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g, int R, int K, int views,
                                                                float *__restrict__ obs) {
+    constexpr int MAXT = 6;  // taps per output pixel and axis (R >= 8: at most ceil(210 / 8) ... the tables of crl_create never exceed 5; checked below)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int tiles_per_env = views * K;
@@ -900,9 +901,9 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
         for (int i = lane; i < R * R; i += 64) out[i] = 0.0f;
         return;
     }
+    const bool rounded = pa == pb || fa.sl == 255 || fb.sl == 255;  // a reset observation: the uint8 path
     if (fa.sl == 255) fa = fb;
     else if (fb.sl == 255) fb = fa;
-    const bool rounded = pa == pb || unpack_frame(pa).sl == 255 || unpack_frame(pb).sl == 255;  // a reset observation: the uint8 path
     // court rows that hold a ball or a bat of either frame (view coordinates do not change rows)
     auto row_live = [&](int r) {
         if (r < CRL_PONG_TOP || r >= CRL_PONG_BOTTOM) return true;
@@ -911,20 +912,30 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
                (unsigned)(r - fa.br) < (unsigned)CRL_PONG_BAT_H || (unsigned)(r - fb.br) < (unsigned)CRL_PONG_BAT_H;
     };
 #pragma unroll 1
-    for (int dy = 0; dy < R; dy++) {
-        const int j0 = g.yofs[dy], j1 = g.yofs[dy + 1];
+    for (int dx = lane; dx < R; dx += 64) {  // this lane's column: its taps stay in registers for the whole tile
+        const int k0 = g.xofs[dx], nk = g.xofs[dx + 1] - k0;
+        int cs[MAXT];
+        float al[MAXT];
+#pragma unroll
+        for (int k = 0; k < MAXT; k++) cs[k] = k < nk ? g.xsi[k0 + k] : 0, al[k] = k < nk ? g.xalpha[k0 + k] : 0.f;
 #pragma unroll 1
-        for (int dx = lane; dx < R; dx += 64) {
-            const int k0 = g.xofs[dx], k1 = g.xofs[dx + 1];
+        for (int dy = 0; dy < R; dy++) {
+            const int j0 = g.yofs[dy], j1 = g.yofs[dy + 1];
             float sum = 0.f;
             for (int j = j0; j < j1; j++) {
-                const int r = g.ysi[j];
+                const int r = g.ysi[j];  // (wave-uniform, like the row tests)
                 float buf = 0.f;
                 if (row_live(r)) {
-                    for (int k = k0; k < k1; k++) {
-                        const int c = g.xsi[k];
-                        const int sv = max(px_view(fa, g.atlas_gray, view, r, c), px_view(fb, g.atlas_gray, view, r, c));
-                        buf = buf + (rounded ? (float)sv : gray_of_f32(sv)) * g.xalpha[k];
+#pragma unroll
+                    for (int k = 0; k < MAXT; k++) {
+                        if (k < nk) {
+                            const int sv = max(px_view(fa, g.atlas_gray, view, r, cs[k]), px_view(fb, g.atlas_gray, view, r, cs[k]));
+                            buf = buf + (rounded ? (float)sv : gray_of_f32(sv)) * al[k];
+                        }
+                    }
+                    for (int k = MAXT; k < nk; k++) {  // (never with crl_create's sizes; kept exact for any table)
+                        const int sv = max(px_view(fa, g.atlas_gray, view, r, g.xsi[k0 + k]), px_view(fb, g.atlas_gray, view, r, g.xsi[k0 + k]));
+                        buf = buf + (rounded ? (float)sv : gray_of_f32(sv)) * g.xalpha[k0 + k];
                     }
                 }
                 const float tj = g.yalpha[j] * buf;

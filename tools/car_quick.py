@@ -20,7 +20,9 @@ NA = int(os.environ.get("QUICK_ACTIONS", "16"))  # distinct action tensors, cycl
 acts = torch.rand((NA, n, 2, 2), generator=g, device="cuda") * 2 - 1
 # steady-state mix: stagger the TimeLimit
 s0 = env.get_state()
-s0["elapsed"] = (torch.arange(n, dtype=torch.int64) * 1000 // n).numpy()
+PERIOD = int(os.environ.get("QUICK_EPISODE", "1000"))  # < 1000: every env starts this close to the TimeLimit again after each reset
+# is not possible (the TimeLimit is 1000); instead the stagger is compressed so that resets come in bursts: n / PERIOD per step for PERIOD steps
+s0["elapsed"] = 1000 - PERIOD + (torch.arange(n, dtype=torch.int64) * PERIOD // n).numpy()
 env.set_state(s0)
 torch.cuda.synchronize()
 user_stream = torch.cuda.Stream() if os.environ.get("QUICK_STREAM") else None  # the caller works on a created stream instead of the legacy default stream

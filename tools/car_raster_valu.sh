@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the switches used here exist only in the profiling variant: python -m competitive_rl_amd.build --variant abl -DCRL_ABLATION)
+export CRL_LIB_VARIANT=abl
 # VALU / SALU / LDS wave-instructions of car_raster_kernel per (env, viewer) tile under the CRL_CAR_DEBUG ablations
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/car_raster_valu

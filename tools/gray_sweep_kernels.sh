@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the switches used here exist only in the profiling variant: python -m competitive_rl_amd.build --variant abl -DCRL_ABLATION)
+export CRL_LIB_VARIANT=abl
 # per-kernel average duration of the fused-84 step with the address-linear writer (CRL_GRAY_SWEEP=1) under its debug bits
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/gray_sweep_kernels

@@ -1,4 +1,6 @@
-"""Time the opponent-policy kernel alone and the cPongTournament-v0 step around it.
+"""(The CRL_POLICY_* switches exist only in the profiling variant: run with CRL_LIB_VARIANT=abl after
+`python -m competitive_rl_amd.build --variant abl -DCRL_ABLATION`.)
+Time the opponent-policy kernel alone and the cPongTournament-v0 step around it.
 
     python tools/policy_bench.py [num_envs] [calls]
 """
