@@ -49,11 +49,26 @@ def forward(wts, stack_u8):
     return logits.astype(np.float32), value.reshape(-1).astype(np.float32)
 
 
+def forward_full(wts, stack_u8):
+    """ActorCritic.forward (reference utils/network.py:14-50) on stacks [B, 4, 42, 42]: x/255 -> conv1 4->16 k4 s2 -> ReLU -> conv2
+    16->32 k4 s2 pad 2 -> ReLU -> conv3 32->256 k11 -> ReLU -> flatten (256) -> actor_linear (3) / critic_linear (1)."""
+    x = np.asarray(stack_u8).astype(np.float32) / np.float32(255.0)
+    h = np.maximum(_conv(x, wts["conv1_w"], wts["conv1_b"], 2), 0)            # [B, 16, 20, 20]
+    h = np.pad(h, ((0, 0), (0, 0), (2, 2), (2, 2)))
+    h = np.maximum(_conv(h, wts["conv2_w"], wts["conv2_b"], 2), 0)            # [B, 32, 11, 11]
+    h = np.maximum(_conv(h, wts["conv3_w"], wts["conv3_b"], 1), 0)            # [B, 256, 1, 1]
+    f = h.reshape(h.shape[0], -1)
+    logits = f @ wts["actor_w"].T + wts["actor_b"]
+    value = f @ wts["critic_w"].T + wts["critic_b"]
+    return logits.astype(np.float32), value.reshape(-1).astype(np.float32)
+
+
 class PolicyOracle:
     """Policy(…, use_light_model=True) of utils/policy_serving.py as a callable on (N, 1, 42, 42) frames."""
 
-    def __init__(self, weights, num_envs, dtype=np.uint8):
+    def __init__(self, weights, num_envs, dtype=np.uint8, full=False):
         self.w = weights
+        self.fwd = forward_full if full else forward  # full: ActorCritic (STRONG / ALPHA_PONG's model) instead of LightActorCritic
         self.stack = np.zeros((num_envs, 4, 42, 42), dtype)  # (float32: the frames of the reference's unrounded float32 step path)
         self.logits = None
 
@@ -64,5 +79,5 @@ class PolicyOracle:
         obs = np.asarray(obs).reshape(self.stack.shape[0], 42, 42)
         self.stack = np.roll(self.stack, -1, axis=1)
         self.stack[:, -1] = obs
-        self.logits, self.value = forward(self.w, self.stack)
+        self.logits, self.value = self.fwd(self.w, self.stack)
         return self.logits.argmax(1).reshape(-1, 1)

@@ -88,3 +88,17 @@ def test_reference_checkpoint_loader_matches_shipped_weights(name):
     a, b = load_light_weights(pkl), weights(name)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_full_size_network_matches_the_reference_module():
+    """ActorCritic (utils/network.py:14-70; STRONG / ALPHA_PONG's model, no checkpoint in the reference tree): the numpy restatement
+    against logits and values the reference's own torch module produced on seeded weights (tests/golden/gen_policy_full_golden.py)."""
+    from tests.policy_full_weights import make_stacks, make_weights
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "policy_full.npz"))
+    w, x = make_weights(int(g["weight_seed"])), make_stacks(int(g["stack_seed"]))
+    assert int(g["feature_size"]) == 256
+    lg, v = P.forward_full(w, x)
+    assert lg.shape == (len(x), 3) and np.abs(lg - g["logits"]).max() < TOL, float(np.abs(lg - g["logits"]).max())
+    assert np.abs(v - g["values"]).max() < TOL
+    assert np.abs(g["logits"]).max() > 0.1  # (the vectors are not degenerate)
