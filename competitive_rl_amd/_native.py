@@ -23,7 +23,7 @@ SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "cr
            "crl_terminal_observation", "crl_get_state", "crl_set_state", "crl_set_replay", "crl_render_raw",
            "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version",
            "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_get_map", "crl_car_set_replay",
-           "crl_policy_create", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
+           "crl_policy_create", "crl_policy_create_full", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
            "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update", "crl_ctx_last_error",
            "crl_obs_descriptors", "crl_render_frames_dev", "crl_car_cap_hits", "crl_selftest_sincosf"]
 
@@ -119,6 +119,7 @@ def load():
     L.crl_selftest_sincosf.argtypes = [C.c_int32, u64, u64, vp]
     L.crl_car_set_replay.argtypes = [vp, vp, vp, i64]
     L.crl_policy_create.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
+    L.crl_policy_create_full.argtypes = [i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(vp)]
     L.crl_policy_destroy.argtypes = [vp]
     L.crl_policy_destroy.restype = None
     L.crl_policy_reset.argtypes = [vp, vp]

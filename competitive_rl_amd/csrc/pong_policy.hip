@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "crl_internal.h"
+#include "pong_policy_full.h"
 
 namespace crl {
 
@@ -34,6 +35,7 @@ static constexpr int kPlane = kDim * kDim;             // 1764 bytes
 static constexpr int kPlaneWords = kPlane / 4;         // 441
 static constexpr int kPlanePad = 1776;                 // a plane in the ring / in LDS: 111 16-byte chunks (12 bytes of padding)
 static constexpr int kPlaneChunks = kPlanePad / 16;    // 111
+static_assert(kPlanePad == kRingPlanePad, "pong_policy_full.hip reads the same ring");
 static constexpr int kRingBytes = CRL_POLICY_STACK * kPlanePad;  // 7104 per env
 static constexpr int kEnvsPerWg = 5;
 static constexpr int kPos = 100;                       // 10 x 10 conv2 positions
@@ -771,6 +773,7 @@ struct crl_policy {
     PolicyWeights W{};
     float *raw = nullptr;        // the checkpoint tensors in torch layout (MFMA kernel): w1 1024 | b1 16 | w2 1024 | b2 16 | wa 4800 | ba 3
     PolicyWeightsM WM{};
+    PolicyFull *full = nullptr;  // crl_policy_create_full: ActorCritic instead of LightActorCritic (pong_policy_full.hip)
 };
 
 extern "C" {
@@ -827,9 +830,30 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w, co
     return CRL_OK;
 }
 
+int crl_policy_create_full(int32_t device, int64_t num_envs, const float *conv1_w, const float *conv1_b, const float *conv2_w,
+                           const float *conv2_b, const float *conv3_w, const float *conv3_b, const float *actor_w, const float *actor_b,
+                           crl_policy **out) {
+    crl_fail_no_ctx();
+    if (!out || num_envs <= 0 || !conv1_w || !conv1_b || !conv2_w || !conv2_b || !conv3_w || !conv3_b || !actor_w || !actor_b)
+        return crl_fail(CRL_EINVAL, "crl_policy_create_full: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    crl_policy *p = new crl_policy();
+    p->device = device, p->n = num_envs;
+    hipError_t e = hipMalloc(&p->ring, (size_t)num_envs * kRingBytes);
+    if (e == hipSuccess) e = hipMemset(p->ring, 0, (size_t)num_envs * kRingBytes);
+    if (e == hipSuccess) e = policy_full_create(&p->full, num_envs, conv1_w, conv1_b, conv2_w, conv2_b, conv3_w, conv3_b, actor_w, actor_b);
+    if (e != hipSuccess) {
+        crl_policy_destroy(p);
+        return crl_fail(e == hipErrorOutOfMemory ? CRL_ENOMEM : CRL_EHIP, "crl_policy_create_full: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return CRL_OK;
+}
+
 void crl_policy_destroy(crl_policy *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
+    policy_full_destroy(p->full);
     if (p->weights) (void)hipFree(p->weights);
     if (p->raw) (void)hipFree(p->raw);
     if (p->ring) (void)hipFree(p->ring);
@@ -851,8 +875,13 @@ int crl_policy_act(crl_policy *p, const uint8_t *frame_dev, int64_t frame_stride
     if (!p || !frame_dev || !actions_dev) return crl_fail(CRL_EINVAL, "crl_policy_act: null argument");
     if (frame_stride < kPlane || (frame_stride & 3) || ((uintptr_t)frame_dev & 3) || action_stride < 1)
         return crl_fail(CRL_EINVAL, "crl_policy_act: frame_stride must be a multiple of 4 and >= 1764, frames 4-byte aligned");
-    HIP_TRY(hipMemsetAsync(p->ticket, 0, sizeof(unsigned), (hipStream_t)stream));
     hipStream_t main_st = (hipStream_t)stream;
+    if (p->full) {
+        HIP_TRY(policy_full_act(p->full, p->ring, p->head, p->n, frame_dev, frame_stride, actions_dev, action_stride, logits_dev, main_st));
+        p->head = (p->head + 1) & 3;
+        return CRL_OK;
+    }
+    HIP_TRY(hipMemsetAsync(p->ticket, 0, sizeof(unsigned), main_st));
     // The matrix-pipe kernel, conv1 as three exact bf16 products per tap (430 us at 65 536 envs).  Profiling build only
     // (CRL_POLICY_MFMA): 1 = the same kernel with conv1 on the fp32 matrix instruction (757 us), 0 = the packed-FMA kernel of
     // round 1 (725-805 us); CRL_POLICY_DEBUG / CRL_POLICY_MFMA_DEBUG skip phases (wrong outputs).

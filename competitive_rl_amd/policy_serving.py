@@ -2,11 +2,13 @@
 utils/network.py:73-93, pong/builtin_policies.py:61-91).
 
 ``Policy`` has the reference's constructor and call protocol.  The forward pass -- the policy's own
-four-frame stack, LightActorCritic, argmax -- is ONE hand-written HIP kernel behind the C ABI
-(``crl_policy_*`` in include/crl.h); there is no torch model and no CPU path in this module.
+four-frame stack, the network, argmax -- is hand-written HIP behind the C ABI (``crl_policy_*`` in
+include/crl.h); there is no torch model and no CPU path in this module.
 
-Only ``use_light_model=True`` is served: that is what WEAK and MEDIUM use, and the checkpoints of the
-two ActorCritic opponents (STRONG, ALPHA_PONG) are not in the reference tree.
+``use_light_model=True``: LightActorCritic (WEAK, MEDIUM; one fused kernel).  ``use_light_model=False``: the
+full-size ActorCritic (network.py:14-50; three fp32 MFMA GEMM kernels, csrc/pong_policy_full.hip) for checkpoints a
+user trained with the reference -- the reference tree itself ships none for it (STRONG / ALPHA_PONG's files
+are missing), so without a checkpoint it starts from the reference's orthogonal initialisation.
 """
 import ctypes as C
 import logging
@@ -44,6 +46,44 @@ def load_light_weights(checkpoint_path):
     return w
 
 
+_FULL_KEYS = ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "actor_w", "actor_b")
+_FULL_SHAPES = {"conv1_w": (16, 4, 4, 4), "conv1_b": (16,), "conv2_w": (32, 16, 4, 4), "conv2_b": (32,), "conv3_w": (256, 32, 11, 11),
+                "conv3_b": (256,), "actor_w": (3, 256), "actor_b": (3,)}
+
+
+def load_full_weights(checkpoint_path):
+    """ActorCritic tensors from an ``.npz`` with the keys of ``_FULL_KEYS`` or from a reference checkpoint."""
+    assert os.path.isfile(checkpoint_path), checkpoint_path
+    if checkpoint_path.endswith(".npz"):
+        z = np.load(checkpoint_path)
+        w = {k: z[k] for k in _FULL_KEYS}
+    else:
+        sd = torch.load(checkpoint_path, map_location="cpu", weights_only=False)["model"]
+        names = {"conv1": "conv1", "conv2": "conv2", "conv3": "conv3", "actor": "actor_linear"}
+        w = {}
+        for short, long in names.items():
+            w[short + "_w"], w[short + "_b"] = sd[long + ".weight"].detach().cpu().numpy(), sd[long + ".bias"].detach().cpu().numpy()
+    return check_full_weights(w, checkpoint_path)
+
+
+def check_full_weights(w, origin="weights"):
+    w = {k: np.ascontiguousarray(w[k], np.float32) for k in _FULL_KEYS}
+    for k in _FULL_KEYS:
+        if w[k].shape != _FULL_SHAPES[k]:
+            raise ValueError(f"{origin}: {k} has shape {w[k].shape}, ActorCritic on (4, 42, 42) needs {_FULL_SHAPES[k]}")
+    return w
+
+
+def _random_full_weights():
+    """No checkpoint: orthogonal weights (gain sqrt 2 for the convolutions, 0.01 for the actor), zero biases (network.py:18-38)."""
+    w = {}
+    for k, gain in (("conv1", 2.0 ** 0.5), ("conv2", 2.0 ** 0.5), ("conv3", 2.0 ** 0.5), ("actor", 0.01)):
+        t = torch.empty(_FULL_SHAPES[k + "_w"])
+        torch.nn.init.orthogonal_(t, gain=gain)
+        w[k + "_w"], w[k + "_b"] = t.numpy(), np.zeros(_FULL_SHAPES[k + "_b"], np.float32)
+    return check_full_weights(w)
+
+
 def _random_light_weights():
     """No checkpoint: the reference builds the model with torch's default initialisation."""
     c1, c2, fc = torch.nn.Conv2d(4, 16, 4, 2), torch.nn.Conv2d(16, 16, 2, 2), torch.nn.Linear(1600, 3)
@@ -53,12 +93,10 @@ def _random_light_weights():
 
 class Policy:
     def __init__(self, single_obs_space, single_action_space, num_envs, checkpoint_path="", frame_stack=4, use_light_model=False,
-                 device=None):
+                 device=None, weights=None):
+        """``weights``: optional dict of float32 arrays in torch layout instead of a checkpoint file (tests)."""
         if not torch.cuda.is_available():
             raise RuntimeError("competitive_rl_amd.Policy needs a ROCm GPU; there is no CPU fallback")
-        if not use_light_model:
-            raise NotImplementedError("only LightActorCritic opponents (WEAK, MEDIUM) are served: the reference tree has no "
-                                      "ActorCritic checkpoint (checkpoint-strong.pkl / checkpoint-alphapong.pkl are missing)")
         self.num_envs = int(num_envs)
         self.obs_shape = tuple(single_obs_space.shape)
         if self.obs_shape != (1, 42, 42) or frame_stack != 4 or single_action_space.n != 3:
@@ -66,16 +104,21 @@ class Policy:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        if checkpoint_path:
-            self.weights = load_light_weights(checkpoint_path)
+        self.use_light_model = bool(use_light_model)
+        if weights is not None:
+            self.weights = ({k: np.ascontiguousarray(weights[k], np.float32) for k in _KEYS} if use_light_model
+                            else check_full_weights(weights))
+        elif checkpoint_path:
+            self.weights = load_light_weights(checkpoint_path) if use_light_model else load_full_weights(checkpoint_path)
         else:
             logging.warning("Loading a policy without checkpoint!")
-            self.weights = _random_light_weights()
+            self.weights = _random_light_weights() if use_light_model else _random_full_weights()
         self._L = N.load()
         h = C.c_void_p()
-        ptr = [self.weights[k].ctypes.data_as(C.c_void_p) for k in _KEYS]
+        ptr = [self.weights[k].ctypes.data_as(C.c_void_p) for k in (_KEYS if use_light_model else _FULL_KEYS)]
+        create = self._L.crl_policy_create if use_light_model else self._L.crl_policy_create_full
         with torch.cuda.device(self.device):
-            N.check(self._L.crl_policy_create(self.device.index or 0, self.num_envs, *ptr, C.byref(h)))
+            N.check(create(self.device.index or 0, self.num_envs, *ptr, C.byref(h)))
         self._h = h
         self._actions = torch.zeros((self.num_envs,), dtype=torch.int32, device=self.device)
         self._logits = torch.zeros((self.num_envs, 3), dtype=torch.float32, device=self.device)

@@ -357,6 +357,14 @@ int crl_policy_create(int32_t device, int64_t num_envs, const float *conv1_w_hos
                       const float *conv1_b_host /*[16]*/, const float *conv2_w_host /*[16,16,2,2]*/,
                       const float *conv2_b_host /*[16]*/, const float *actor_w_host /*[3,1600]*/,
                       const float *actor_b_host /*[3]*/, crl_policy **out);
+/* Policy(..., use_light_model=False) (policy_serving.py:21-25): ActorCritic (utils/network.py:14-50: conv 4->16 k4 s2, conv 16->32 k4
+ * s2 pad 2, conv 32->256 k11, actor 256->3) -- the model of the reference's STRONG / ALPHA_PONG opponents -- behind the same
+ * handle: crl_policy_reset / _act / _get_stack / _set_stack / _destroy work on it unchanged. */
+int crl_policy_create_full(int32_t device, int64_t num_envs, const float *conv1_w_host /*[16,4,4,4]*/,
+                           const float *conv1_b_host /*[16]*/, const float *conv2_w_host /*[32,16,4,4]*/,
+                           const float *conv2_b_host /*[32]*/, const float *conv3_w_host /*[256,32,11,11]*/,
+                           const float *conv3_b_host /*[256]*/, const float *actor_w_host /*[3,256]*/,
+                           const float *actor_b_host /*[3]*/, crl_policy **out);
 void crl_policy_destroy(crl_policy *p);
 /* Policy.reset (policy_serving.py:46-47): zero the frame stack. */
 int crl_policy_reset(crl_policy *p, void *stream);
