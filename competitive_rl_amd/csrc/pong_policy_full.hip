@@ -5,17 +5,21 @@
 //   x / 255 -> conv1 4->16 k4 s2 (20x20) -> ReLU -> conv2 16->32 k4 s2 pad 2 (11x11) -> ReLU -> conv3 32->256 k11 (1x1) -> ReLU
 //   -> actor_linear 256->3, argmax.        4.79 MFLOP per env: conv1 0.82, conv2 1.98, conv3 1.98.
 //
-// All three convolutions are GEMMs on the fp32 matrix instruction v_mfma_f32_16x16x4_f32 (exact f32 products, f32
-// accumulation: the reference is fp32 and close calls between two logits decide the action, so no bf16 / fp8 here):
-//   conv1  C[(env, pos) x 16]  = im2col(stack)[.. x 64]   x W1^T   weights in 16 VGPRs, bytes gathered from the ring
-//   conv2  C[(env, pos) x 32]  = im2col(act1)[.. x 256]   x W2^T   weights in LDS (33 KB), act1 gathered as float2
-//   conv3  C[env x 256]        = act2[env x 3872]         x W3^T   128 x 128 x 16 LDS tiles, double buffered
+// All three convolutions are GEMMs on the matrix pipe with fp32 results (the reference is fp32 and close calls between two
+// logits decide the action, so no bf16 / fp8 activations):
+//   front kernel, one env per workgroup pass, act1 stays in LDS:
+//     conv1  C[16 x (env, pos)]  = W1 x im2col(stack)[64 x ..]    v_mfma_f32_16x16x32_bf16 on exact operands (bytes; weights as
+//                                                                  three bf16 terms), bytes prefetched one env ahead
+//     conv2  C[32 x (env, pos)]  = W2 x im2col(act1)[256 x ..]    v_mfma_f32_16x16x4_f32, weights (33 KB) and act1 (37 KB) in LDS
+//   conv3    C[env x 256]        = act2[env x 3872] x W3^T        v_mfma_f32_16x16x4_f32, 128 x 128 x 16 LDS tiles, double buffered
+//   actor    one wavefront per env: 3 dot products of 256, argmax
 // The k index inside a group of 16 is dealt kq-major (lane kq of the instruction's four k lanes takes k = 16 g + 4 kq + j in
-// step j): a sum does not care about the order of its terms, and this way every operand fetch is one 8- or 16-byte load of
+// step j): a sum does not care about the order of its terms, and this way every operand fetch is one 8- or 16-byte read of
 // CONSECUTIVE k (a row of the 4x4 window / four consecutive columns of a K-contiguous matrix) with no transposed copy of
-// anything.  Activations go through HBM scratch (25.6 + 15.5 + 1 KB per env, sized for one chunk of envs): 4.8 MFLOP against
-// 82 KB of traffic per env is 58 FLOP / byte, compute bound on the 157 TFLOP/s fp32 matrix pipe (HBM share: 0.7 of 2 ms at
-// 65 536 envs).
+// anything.  HBM traffic per env: 7 KB stack in, 15.5 KB act2 out and in again, 1 KB features: 4.8 MFLOP against 40 KB is
+// compute bound on the 157 TFLOP/s fp32 matrix pipe.  Measured at 65 536 envs (profiles/r04_policy_full_stats.csv): front
+// 1.34 ms (ideal 0.94), conv3 1.00 ms (ideal 0.83), actor 0.017 ms = 2.36 ms per call; the first version (conv1 and conv2
+// as separate kernels through HBM, byte / 255 divisions on the vector pipe) took 4.4.
 #include "pong_policy_full.h"
 
 #include <string.h>
@@ -35,7 +39,6 @@ static constexpr int kC1 = 16, kP1 = 400;        // conv1: 16 channels x 20 x 20
 static constexpr int kC2 = 32, kP2 = 121;        // conv2: 32 channels x 11 x 11
 static constexpr int kK3 = kC2 * kP2;            // 3872 = conv3's receptive field: the whole of act2
 static constexpr int kC3 = 256;
-static constexpr int kAct1 = kC1 * kP1;          // 6400 floats per env
 static constexpr int64_t kChunk = 65536;         // envs per pass (scratch: 42 KB per env)
 
 static constexpr int kOffW1 = 0, kOffB1 = kOffW1 + 1024, kOffW2 = kOffB1 + 16, kOffB2 = kOffW2 + kC2 * 256, kOffW3 = kOffB2 + 32;
@@ -45,102 +48,143 @@ struct PolicyFull {
     int64_t n = 0, chunk = 0;
     int cus = 256;
     float *w = nullptr;     // w1 | b1 | w2 | b2 | w3 | b3 | wa | ba, torch layouts
-    float *act1 = nullptr;  // [chunk][16][400] after ReLU
     float *act2 = nullptr;  // [chunk][32][121] after ReLU = [chunk][3872]
     float *feat = nullptr;  // [chunk][256] after ReLU
 };
 
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// the new frame replaces the oldest plane of the ring (FrameStackTensor.update without a mask, utils/utils.py:159-170)
-__global__ __launch_bounds__(256) void policy_full_push_kernel(uint8_t *__restrict__ ring, int head, const uint8_t *__restrict__ frame,
-                                                               int64_t frame_stride, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n * (kFDim * kFDim / 4)) return;
-    const int64_t env = i / (kFDim * kFDim / 4);
-    const int w = (int)(i - env * (kFDim * kFDim / 4));
-    reinterpret_cast<uint32_t *>(ring + env * kFRingBytes + head * kFPlanePad)[w] =
-        reinterpret_cast<const uint32_t *>(frame + env * frame_stride)[w];
+// conv1 + ReLU + conv2 + ReLU of one env per workgroup pass, act1 never leaves the CU.
+//   conv1 on the bf16 matrix instruction at fp32 accuracy, like the light opponents' kernel: the inputs are integers 0..255 --
+//   exact in bf16 -- and each weight (pre-divided by 255) is the sum of three bf16 terms, so all products are exact and
+//   v_mfma_f32_16x16x32_bf16 accumulates them in fp32: 6 instructions x 16 cycles per tile of 16 positions instead of 16 x 32.
+//   A = pixels (lane: position li; k block lk = plane pair member lk >> 1, window rows 2 (lk & 1) + {0, 1}, four columns), B =
+//   weights in k order 32 h + 8 lk + j = torch's own.  The 20 x 20 x 16 result goes to LDS inside a zero border of two (the
+//   padding of conv2), so conv2's window reads need no bounds tests.
+//   conv2: a wavefront owns two tiles of 16 positions (121 = 8 tiles, the last one ragged): per input channel four 8-byte LDS
+//   reads of the window rows (A) and two 16-byte reads of the weights (B) feed 16 fp32 matrix instructions on four accumulators.
+// The new frame is read straight from the caller's buffer (plane 3 of the stack) and copied over the oldest ring plane here.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline uint32_t pk_bytes_bf16(uint32_t two) {  // the two low bytes of `two` as a pair of bf16
+    const bf2 v = {(__bf16)(float)(two & 255u), (__bf16)(float)((two >> 8) & 255u)};
+    return __builtin_bit_cast(uint32_t, v);
 }
-
-// conv1 + ReLU.  One wavefront per tile of 16 positions of one env (25 tiles); A = pixels / 255 (lane: position li, window row
-// lk, the row's four pixels in the four steps), B = weights (lane: channel li), D: positions 4 lk + r x channel li.
-__global__ __launch_bounds__(256) void policy_full_conv1_kernel(const uint8_t *__restrict__ ring, int head, const float *__restrict__ w1,
-                                                                const float *__restrict__ b1, float *__restrict__ act1, int64_t n) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
-    f4 wr[4];
-#pragma unroll
-    for (int g = 0; g < 4; g++) wr[g] = *reinterpret_cast<const f4 *>(w1 + li * 64 + g * 16 + lk * 4);
-    const float bias = b1[li];
-    const int64_t tiles = n * (kP1 / 16);
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t env = t / (kP1 / 16);
-        const int tl = (int)(t - env * (kP1 / 16));
-        const int p = tl * 16 + li, y = p / 20, x = p - y * 20;
-        const uint8_t *base = ring + env * kFRingBytes + (2 * y + lk) * kFDim + 2 * x;
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < 4; g++) {  // plane g of the stack (oldest first) is ring plane (head + 1 + g) & 3 once the frame is in
-            const uint8_t *q = base + ((head + 1 + g) & 3) * kFPlanePad;
-            const uint32_t lo = *reinterpret_cast<const uint16_t *>(q), hi = *reinterpret_cast<const uint16_t *>(q + 2);
-            acc = MFMA4((float)(lo & 255u) / 255.0f, wr[g][0], acc);
-            acc = MFMA4((float)(lo >> 8) / 255.0f, wr[g][1], acc);
-            acc = MFMA4((float)(hi & 255u) / 255.0f, wr[g][2], acc);
-            acc = MFMA4((float)(hi >> 8) / 255.0f, wr[g][3], acc);
-        }
-        f4 o;
-#pragma unroll
-        for (int r = 0; r < 4; r++) o[r] = fmaxf(acc[r] + bias, 0.f);
-        *reinterpret_cast<f4 *>(act1 + env * kAct1 + li * kP1 + tl * 16 + 4 * lk) = o;
-    }
-}
-
-// conv2 (k4 s2 pad 2) + ReLU.  Tiles of 16 positions q = env * 121 + pos; A = act1 (lane: position li, window row lk: two
-// float2 loads per input channel, zero outside the 20 x 20 plane -- the window's column pairs are either inside or outside as
-// a whole), B = weights from LDS (one 16-byte read per channel block and input channel).
+static constexpr int kS1Rows = 24, kS1Pitch = 580;  // padded plane 24 x 24 = 576 floats + 4: channels start 4 banks apart
 static constexpr int kW2Pitch = 260;  // floats per output channel in LDS: 65 x 16 bytes, odd -> the 16 lanes of a read phase hit 16 bank groups
-__global__ __launch_bounds__(256) void policy_full_conv2_kernel(const float *__restrict__ act1, const float *__restrict__ w2,
+__global__ __launch_bounds__(256) void policy_full_front_kernel(uint8_t *__restrict__ ring, int head, const uint8_t *__restrict__ frame,
+                                                                int64_t frame_stride, const float *__restrict__ w1,
+                                                                const float *__restrict__ b1, const float *__restrict__ w2,
                                                                 const float *__restrict__ b2, float *__restrict__ act2, int64_t n) {
     __shared__ __attribute__((aligned(16))) float sw[kC2 * kW2Pitch];
-    for (int i = threadIdx.x; i < kC2 * 64; i += 256) {
+    __shared__ __attribute__((aligned(16))) float s1[kC1 * kS1Pitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    for (int i = tid; i < kC2 * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
         *reinterpret_cast<f4 *>(sw + r * kW2Pitch + 4 * c) = *reinterpret_cast<const f4 *>(w2 + r * 256 + 4 * c);
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
-    const float bias0 = b2[li], bias1 = b2[16 + li];
-    const float *swa = sw + li * kW2Pitch + 4 * lk, *swb = swa + 16 * kW2Pitch;
-    const int64_t total = n * kP2, tiles = (total + 15) / 16;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < tiles; t += (int64_t)gridDim.x * 4) {
-        int64_t q = t * 16 + li;
-        if (q >= total) q = total - 1;  // the last tile's spare rows repeat a valid position; their results are not stored
-        const int64_t env = q / kP2;
-        const int pos = (int)(q - env * kP2), y = pos / 11, x = pos - y * 11;
-        const int row = 2 * y - 2 + lk;
-        const bool rok = row >= 0 && row < 20, ok01 = rok && x > 0, ok23 = rok && x < 10;
-        const float *base = act1 + env * kAct1 + row * 20 + 2 * x - 2;
-        f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int g = 0; g < kC1; g++) {
-            f2 v01 = {0.f, 0.f}, v23 = {0.f, 0.f};
-            if (ok01) v01 = *reinterpret_cast<const f2 *>(base + g * kP1);
-            if (ok23) v23 = *reinterpret_cast<const f2 *>(base + g * kP1 + 2);
-            const f4 wa = *reinterpret_cast<const f4 *>(swa + 16 * g), wb = *reinterpret_cast<const f4 *>(swb + 16 * g);
-            acc0 = MFMA4(v01[0], wa[0], acc0), acc1 = MFMA4(v01[0], wb[0], acc1);
-            acc0 = MFMA4(v01[1], wa[1], acc0), acc1 = MFMA4(v01[1], wb[1], acc1);
-            acc0 = MFMA4(v23[0], wa[2], acc0), acc1 = MFMA4(v23[0], wb[2], acc1);
-            acc0 = MFMA4(v23[1], wa[3], acc0), acc1 = MFMA4(v23[1], wb[3], acc1);
-        }
+    for (int i = tid; i < kC1 * kS1Pitch; i += 256) s1[i] = 0.f;  // the border stays zero
+    bf8 wB[3][2];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int64_t q2 = t * 16 + 4 * lk + r;
-            if (q2 < total) {
-                const int64_t e2 = q2 / kP2;
-                float *o = act2 + e2 * kK3 + (q2 - e2 * kP2);
-                o[li * kP2] = fmaxf(acc0[r] + bias0, 0.f);
-                o[(16 + li) * kP2] = fmaxf(acc1[r] + bias1, 0.f);
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float w = w1[li * 64 + 32 * h + 8 * lk + j] / 255.0f;
+            const __bf16 t0 = (__bf16)w;
+            const float r1 = w - (float)t0;  // exact
+            const __bf16 t1 = (__bf16)r1;
+            const float r2 = r1 - (float)t1;  // exact
+            wB[0][h][j] = t0, wB[1][h][j] = t1, wB[2][h][j] = (__bf16)r2;
+        }
+    f4 bias1, bias2[2];  // D rows = channels 4 lk + r
+#pragma unroll
+    for (int r = 0; r < 4; r++) bias1[r] = b1[4 * lk + r], bias2[0][r] = b2[4 * lk + r], bias2[1][r] = b2[16 + 4 * lk + r];
+    const float *swa = sw + li * kW2Pitch + 4 * lk, *swb = swa + 16 * kW2Pitch;
+    int ao[2];  // conv2: the window row lk of position 32 wave + 16 u + li in the padded plane
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int pos = min(32 * wave + 16 * u + li, kP2 - 1), y = pos / 11, x = pos - 11 * y;
+        ao[u] = (2 * y + lk) * kS1Rows + 2 * x;
+    }
+    // conv1's input of one env: per tile two planes x two window rows x four bytes (2-byte aligned), fetched one env AHEAD -- the
+    // loads are in flight while conv2 of the current env runs (a wavefront's seven tiles one after the other, each waiting for
+    // its own loads, cost 0.86 ms of the kernel's 1.63 at 65 536 envs)
+    uint32_t raw[7][2][2];
+    auto prefetch = [&](int64_t env) {
+        const uint8_t *fr = frame + env * frame_stride, *rg = ring + env * kFRingBytes;
+        const int win = (2 * (lk & 1)) * kFDim;
+        const uint8_t *pl[2] = {rg + ((head + 1 + (lk >> 1)) & 3) * kFPlanePad + win,                 // plane lk >> 1
+                                ((lk >> 1) ? fr : rg + ((head + 3) & 3) * kFPlanePad) + win};          // plane 2 + (lk >> 1); 3 = the new frame
+#pragma unroll
+        for (int it = 0; it < 7; it++) {  // 25 tiles over 4 wavefronts: the spare turns repeat tile 24 (same values, same addresses)
+            const int tl = min(wave + 4 * it, kP1 / 16 - 1);
+            const int p = tl * 16 + li, y = p / 20, x = p - y * 20, off = 2 * y * kFDim + 2 * x;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                __builtin_memcpy(&raw[it][h][0], pl[h] + off, 4);
+                __builtin_memcpy(&raw[it][h][1], pl[h] + off + kFDim, 4);
             }
         }
+    };
+    __syncthreads();
+    if ((int64_t)blockIdx.x < n) prefetch(blockIdx.x);
+    for (int64_t env = blockIdx.x; env < n; env += gridDim.x) {
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            const int tl = min(wave + 4 * it, kP1 / 16 - 1);
+            bf8 ax[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t a = raw[it][h][0], c = raw[it][h][1];
+                const u32x4 v = {pk_bytes_bf16(a), pk_bytes_bf16(a >> 16), pk_bytes_bf16(c), pk_bytes_bf16(c >> 16)};
+                ax[h] = __builtin_bit_cast(bf8, v);
+            }
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tm = 2; tm >= 0; tm--)  // smallest weight term first
+#pragma unroll
+                for (int h = 0; h < 2; h++) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wB[tm][h], ax[h], acc, 0, 0, 0);
+            const int p = tl * 16 + li, y = p / 20, x = p - y * 20;  // D: channels 4 lk + r x position li
+            float *o = s1 + 4 * lk * kS1Pitch + (y + 2) * kS1Rows + x + 2;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r * kS1Pitch] = fmaxf(acc[r] + bias1[r], 0.f);
+        }
+        __syncthreads();
+        if (env + gridDim.x < n) prefetch(env + gridDim.x);
+        f4 acc[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) acc[u][0] = f4{0.f, 0.f, 0.f, 0.f}, acc[u][1] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int g = 0; g < kC1; g++) {
+            const f4 wa = *reinterpret_cast<const f4 *>(swa + 16 * g), wb = *reinterpret_cast<const f4 *>(swb + 16 * g);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const f2 v01 = *reinterpret_cast<const f2 *>(s1 + g * kS1Pitch + ao[u]);
+                const f2 v23 = *reinterpret_cast<const f2 *>(s1 + g * kS1Pitch + ao[u] + 2);
+                acc[u][0] = MFMA4(wa[0], v01[0], acc[u][0]), acc[u][1] = MFMA4(wb[0], v01[0], acc[u][1]);
+                acc[u][0] = MFMA4(wa[1], v01[1], acc[u][0]), acc[u][1] = MFMA4(wb[1], v01[1], acc[u][1]);
+                acc[u][0] = MFMA4(wa[2], v23[0], acc[u][0]), acc[u][1] = MFMA4(wb[2], v23[0], acc[u][1]);
+                acc[u][0] = MFMA4(wa[3], v23[1], acc[u][0]), acc[u][1] = MFMA4(wb[3], v23[1], acc[u][1]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {  // D: channels 16 nb + 4 lk + r x position li: the 16 lanes of a row store 64 consecutive bytes
+            const int pos = 32 * wave + 16 * u + li;
+            if (pos < kP2) {
+                float *o = act2 + env * kK3 + 4 * lk * kP2 + pos;
+#pragma unroll
+                for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[(16 * nb + r) * kP2] = fmaxf(acc[u][nb][r] + bias2[nb][r], 0.f);
+            }
+        }
+        {  // the new frame replaces the oldest plane of the ring (FrameStackTensor.update without a mask, utils/utils.py:159-170)
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(frame + env * frame_stride);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(ring + env * kFRingBytes + head * kFPlanePad);
+            for (int i = tid; i < kFDim * kFDim / 4; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();  // s1 is rewritten by the next env's conv1
     }
 }
 
@@ -148,7 +192,7 @@ __global__ __launch_bounds__(256) void policy_full_conv2_kernel(const float *__r
 // x 128 channels, 2 x 2 wavefronts of 64 x 64 (16 accumulators), K in slabs of 16 through two LDS buffers; a wavefront reads
 // each operand of a slab with one 16-byte LDS read per 16-row block (4 + 4 reads for 64 matrix instructions).
 static constexpr int kGM = 128, kGN = 128, kGPitch = 20;  // pitch 20 floats = 5 x 16 bytes, odd: conflict-free 16-lane read phases
-__global__ __launch_bounds__(256) void policy_full_conv3_kernel(const float *__restrict__ act2, const float *__restrict__ w3,
+__global__ __launch_bounds__(256, 4) void policy_full_conv3_kernel(const float *__restrict__ act2, const float *__restrict__ w3,
                                                                 const float *__restrict__ b3, float *__restrict__ feat, int64_t n) {
     __shared__ __attribute__((aligned(16))) float sA[2][kGM * kGPitch];
     __shared__ __attribute__((aligned(16))) float sB[2][kGN * kGPitch];
@@ -253,7 +297,6 @@ hipError_t policy_full_create(PolicyFull **out, int64_t num_envs, const float *c
     memcpy(blob.data() + kOffWa, actor_w, (size_t)3 * kC3 * sizeof(float)), memcpy(blob.data() + kOffBa, actor_b, 3 * sizeof(float));
     hipError_t e = hipMalloc(&f->w, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(f->w, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&f->act1, (size_t)f->chunk * kAct1 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&f->act2, (size_t)f->chunk * kK3 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(&f->feat, (size_t)f->chunk * kC3 * sizeof(float));
     if (e != hipSuccess) {
@@ -267,7 +310,6 @@ hipError_t policy_full_create(PolicyFull **out, int64_t num_envs, const float *c
 void policy_full_destroy(PolicyFull *f) {
     if (!f) return;
     if (f->w) (void)hipFree(f->w);
-    if (f->act1) (void)hipFree(f->act1);
     if (f->act2) (void)hipFree(f->act2);
     if (f->feat) (void)hipFree(f->feat);
     delete f;
@@ -275,14 +317,10 @@ void policy_full_destroy(PolicyFull *f) {
 
 hipError_t policy_full_act(PolicyFull *f, uint8_t *ring, int head, int64_t n, const uint8_t *frame_dev, int64_t frame_stride,
                            int32_t *actions_dev, int64_t action_stride, float *logits_dev, hipStream_t st) {
-    const int64_t words = n * (kFDim * kFDim / 4);
-    hipLaunchKernelGGL(policy_full_push_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ring, head, frame_dev, frame_stride, n);
     for (int64_t e0 = 0; e0 < n; e0 += f->chunk) {
         const int64_t c = std::min<int64_t>(f->chunk, n - e0);
-        const int64_t t1 = (c * (kP1 / 16) + 3) / 4, t2 = ((c * kP2 + 15) / 16 + 3) / 4;
-        hipLaunchKernelGGL(policy_full_conv1_kernel, dim3((unsigned)std::min<int64_t>(t1, (int64_t)f->cus * 8)), dim3(256), 0, st,
-                           ring + e0 * kFRingBytes, head, f->w + kOffW1, f->w + kOffB1, f->act1, c);
-        hipLaunchKernelGGL(policy_full_conv2_kernel, dim3((unsigned)std::min<int64_t>(t2, (int64_t)f->cus * 4)), dim3(256), 0, st, f->act1,
+        hipLaunchKernelGGL(policy_full_front_kernel, dim3((unsigned)std::min<int64_t>(c, (int64_t)f->cus * 2)), dim3(256), 0, st,
+                           ring + e0 * kFRingBytes, head, frame_dev + e0 * frame_stride, frame_stride, f->w + kOffW1, f->w + kOffB1,
                            f->w + kOffW2, f->w + kOffB2, f->act2, c);
         hipLaunchKernelGGL(policy_full_conv3_kernel, dim3((unsigned)((c + kGM - 1) / kGM), kC3 / kGN), dim3(256), 0, st, f->act2,
                            f->w + kOffW3, f->w + kOffB3, f->feat, c);

@@ -6,7 +6,9 @@ RULE_BASED.  WEAK / MEDIUM are the reference's LightActorCritic checkpoints serv
 (policy_serving.Policy: frame in, action out, straight into the right-hand column of the device
 action array -- no host round trip).  RULE_BASED is action 999, resolved by the step kernel
 (= auto_action).  STRONG is listed by the reference but its checkpoint is not in the reference tree
-(the reference's own wrapper asserts on the missing file), so it is not offered here.
+(the reference's own wrapper asserts on the missing file), so it is not offered here; its MODEL (the
+full-size ActorCritic) is served -- ``Policy(..., use_light_model=False)`` -- and ``add_agent`` puts
+such a policy into the pool.
 """
 import random
 
@@ -73,6 +75,16 @@ class TournamentEnvWrapper:
         name = random.choice(self.agent_names) if agent_name is None else agent_name
         assert name in self.agent_names, self.agent_names
         self._select(name)
+
+    def add_agent(self, name, compute_action):
+        """Beyond the reference: add an opponent of one's own to the pool -- a ``policy_serving.Policy`` (e.g. a full-size
+        ActorCritic checkpoint trained with the reference, ``use_light_model=False``; its actions stay on the device) or any
+        callable obs -> (N,) actions on the host."""
+        assert name not in self.agents, name
+        if isinstance(compute_action, Policy):
+            assert compute_action.num_envs == self.num_envs and compute_action.device == self._act.device
+        self.agents[name] = compute_action
+        self.agent_names.append(name)
 
     def _fill_actions(self, mine_i32):
         """column 0 <- the caller's actions, column 1 <- the current opponent's: written in place by the policy kernel

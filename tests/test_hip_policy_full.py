@@ -101,3 +101,44 @@ def test_full_network_default_initialisation_and_call_protocol():
     ora(f)
     assert np.abs(pol.logits().cpu().numpy() - ora.logits).max() < TOL
     pol.close()
+
+
+def test_tournament_against_a_full_size_opponent_matches_oracle_game(atlas):
+    """A full-size ActorCritic added to the tournament pool (TournamentEnvWrapper.add_agent) plays the same game as the CPU
+    oracle env with the numpy network on the right-hand paddle (near-ties follow the device's choice, as in
+    test_hip_policy_parity.py)."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from oracle import policy_oracle as P
+    from oracle import pong_oracle as po
+    from tests.policy_full_weights import make_weights
+
+    n, T = 5, 150
+    tour = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=33)
+    w = make_weights(5)
+    tour.add_agent("MINE", make_policy(n, w))
+    assert tour.get_agent_names()[-1] == "MINE"
+    tour.reset_opponent("MINE")
+    env = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=33)
+    ora = P.PolicyOracle(w, n, full=True)
+    o_h = tour.reset()
+    o_c = env.reset().copy()
+    assert np.array_equal(o_h.cpu().numpy(), o_c[:, 0])
+    rs = np.random.RandomState(6)
+    nclear = 0
+    for t in range(T):
+        mine = rs.randint(0, 3, n)
+        opp = ora(o_c[:, 1]).reshape(-1)
+        o_h, r_h, d_h, _ = tour.step(mine)
+        played = tour._act[:, 1].cpu().numpy()
+        srt = np.sort(ora.logits, 1)
+        clear = (srt[:, 2] - srt[:, 1]) > 10 * TOL
+        assert np.array_equal(played[clear], opp[clear]), t
+        nclear += int(clear.sum())
+        o_c, r_c, d_c = env.step(np.stack([mine, played], 1))
+        o_c = o_c.copy()
+        assert np.array_equal(o_h.cpu().numpy(), o_c[:, 0]), t
+        assert np.array_equal(r_h.cpu().numpy().reshape(-1), r_c[:, 0]), t
+    assert nclear > 0.9 * n * T
+    tour.close()
+    env.close()
