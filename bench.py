@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the cPongDouble hot path on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|raw|fused84|fused84_f32|fused84_newest|car|tournament]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|raw|fused84|fused84_f32|fused84_newest|car|tournament|tournament_full]
                     [--envs E] [--gather none|scalars|obs|descriptors] [--no-cpu-baseline]
 
 A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated, device-resident) random
@@ -36,6 +36,7 @@ CAR_BYTES = 24900                          # obs 18 432 + state r/w ~
 HBM_PEAK = 8.0e12                          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a float4 copy sustains)
 FP32_PEAK = 157.3e12                       # fp32 vector = fp32 matrix peak (MI355X_MICROARCH.md)
 POLICY_FLOP = 2 * 516800                   # LightActorCritic: conv1 409 600 + conv2 102 400 + actor 4 800 multiply-adds
+POLICY_FULL_FLOP = 2 * (409600 + 991232 + 991232 + 768)  # ActorCritic: conv1 20x20x16x64, conv2 11x11x32x256, conv3 256x3872, actor 3x256
 # cCarRacingDouble f32 FLOP per env-step, counted from the code paths (DESIGN.md 4b "FLOP model"): island solve
 # 2 cars x (180 velocity iterations x 4 joints x 58 + joint init 4 x 70 + positions ~3 x 4 x 120 + integration 5 x 14)
 # = 87 600; wheel model 2 x 4 x 64 (f64, counted once); sensor contacts ~2 x (300 AABB tests x 4 + 6 narrow pairs x 820)
@@ -50,7 +51,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "raw", "fused84", "fused84_f32", "fused84_newest", "car", "tournament"])
+                    choices=["all", "raw", "fused84", "fused84_f32", "fused84_newest", "car", "tournament", "tournament_full"])
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
     ap.add_argument("--gather", choices=["none", "scalars", "obs", "descriptors"], default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,6 +123,8 @@ def cpu_baselines(workloads, budget_s=8.0):
             b = subproc("car", "Box2D-style step + two 96x96 renders per env-step")
         elif wl == "tournament":
             b = cpu_baseline_tournament(po, atlas, cores, budget_s * 0.8)
+        elif wl == "tournament_full":
+            b = cpu_baseline_tournament(po, atlas, cores, budget_s * 0.8, full=True)
         else:
             continue
         out[wl] = b
@@ -133,8 +136,22 @@ def cpu_baselines(workloads, budget_s=8.0):
     return out
 
 
-def cpu_baseline_tournament(po, atlas, cores, budget_s):
-    """CPU restatement of the tournament loop: oracle Pong env (42x42) + numpy LightActorCritic opponent."""
+def full_policy_weights(seed=0):
+    """Random-init ActorCritic tensors (He-normal weights, small biases) for the tournament_full workload: the reference tree
+    ships no checkpoint of that network, and the forward pass costs the same whatever the values."""
+    import numpy as np
+
+    rs = np.random.RandomState(seed)
+    shapes = {"conv1": (16, 4, 4, 4), "conv2": (32, 16, 4, 4), "conv3": (256, 32, 11, 11), "actor": (3, 256), "critic": (1, 256)}
+    w = {}
+    for k, shp in shapes.items():
+        w[k + "_w"] = (rs.standard_normal(shp) * np.sqrt(2.0 / np.prod(shp[1:]))).astype(np.float32)
+        w[k + "_b"] = (rs.standard_normal(shp[0]) * 0.1).astype(np.float32)
+    return w
+
+
+def cpu_baseline_tournament(po, atlas, cores, budget_s, full=False):
+    """CPU restatement of the tournament loop: oracle Pong env (42x42) + numpy LightActorCritic / ActorCritic opponent."""
     import numpy as np
 
     from oracle import policy_oracle as P
@@ -142,7 +159,10 @@ def cpu_baseline_tournament(po, atlas, cores, budget_s):
     n = 256
     env = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=42, frame_stack=1, seed=0)
     env.set_threads(cores)
-    pol = P.PolicyOracle(P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_medium.npz")), n)
+    if full:
+        pol = P.PolicyOracle(full_policy_weights(), n, full=True)
+    else:
+        pol = P.PolicyOracle(P.load_weights(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_policy_medium.npz")), n)
     obs = env.reset().copy()
     rs = np.random.RandomState(0)
     t0, k = time.perf_counter(), 0
@@ -175,9 +195,14 @@ def run_workload(name, args, G):
     base = rank * n
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     policy_events = None
-    if name == "tournament":
+    if name in ("tournament", "tournament_full"):
         env = crl.make_envs("cPongTournament-v0", num_envs=n, log_dir=None, seed=0, device=dev, env_id_base=base)
-        env.reset_opponent("MEDIUM")
+        if name == "tournament_full":
+            env.add_agent("FULL", crl.Policy(crl.tournament.single_obs_space, crl.tournament.single_act_space, n, use_light_model=False, device=dev,
+                                             weights=full_policy_weights()))
+            env.reset_opponent("FULL")
+        else:
+            env.reset_opponent("MEDIUM")
         pool = [torch.randint(0, 3, (n,), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
         pol, act = env.current_agent, env.current_agent.act_device
         policy_events = []
@@ -199,6 +224,10 @@ def run_workload(name, args, G):
         inner = env.env
         desc = (f"cPongTournament-v0 {n} envs/GPU, 42x42 obs, opponent = reference checkpoint-medium (LightActorCritic) served by the "
                 "HIP policy kernel, 1 step = 4 frames + 1 opponent forward pass (SURVEY 8f N2+N4)")
+        if name == "tournament_full":
+            desc = (f"cPongTournament-v0 {n} envs/GPU, 42x42 obs, opponent = the full-size ActorCritic (utils/network.py:14-50, the model of "
+                    "STRONG / ALPHA_PONG; random-init weights, the reference tree has no checkpoint of it) served by the HIP MFMA kernels, "
+                    "1 step = 4 frames + 1 opponent forward pass")
         kernel, dtype, actions_desc = "pong_policy_light_kernel", "f32", "uniform {0,1,2}"
     elif name == "car":
         env = inner = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=base)
@@ -294,6 +323,16 @@ def run_workload(name, args, G):
         res["config"]["steady_state"] = "TimeLimit counters staggered over [0, 1000) + 1000 un-timed steps before the warm-up"
     if rank != 0:
         return res
+    if name == "tournament_full":
+        k_us = sum(a.elapsed_time(b) for a, b in policy_events) / max(len(policy_events), 1) * 1e3
+        ach = POLICY_FULL_FLOP * n / (k_us * 1e-6)
+        res["roofline"] = {"bound": "mfma", "kernel": "policy_full_front_kernel + policy_full_conv3_kernel + policy_full_actor_kernel",
+                           "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": None,
+                           "flop_per_launch": POLICY_FULL_FLOP * n, "avg_kernel_us": k_us, "launches_timed": len(policy_events),
+                           "note": "the network's own 4.79 MFLOP per env (fp32 multiply-adds x 2) over the HIP-event time of one forward pass "
+                                   "(three kernels) against the fp32 matrix peak; conv1 (17 % of the FLOP) runs as three exact bf16 products per "
+                                   "tap, conv2 / conv3 on v_mfma_f32_16x16x4_f32"}
+        return res
     if name == "tournament":
         k_us = sum(a.elapsed_time(b) for a, b in policy_events) / max(len(policy_events), 1) * 1e3
         traffic, tsrc = traffic_of(name)
@@ -362,7 +401,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     multi = args.workload == "all" and world == 1
-    names = ["raw", "fused84", "fused84_f32", "car", "tournament"] if multi else [("raw" if args.workload == "all" else args.workload)]
+    names = ["raw", "fused84", "fused84_f32", "car", "tournament", "tournament_full"] if multi else [("raw" if args.workload == "all" else args.workload)]
     # the CPU baselines run first: worker processes are started while this process has not initialised the GPU
     cpu = {}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -391,7 +430,8 @@ def main():
     if rank == 0:
         head = results[names[0]]
         metric = {"car": "env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU",
-                  "tournament": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent"}.get(
+                  "tournament": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent",
+                  "tournament_full": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs a full-size ActorCritic opponent"}.get(
             names[0], "env-steps/sec (whole node), cPongDouble 65536 envs per GPU")
         line = {"metric": metric, "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"],

@@ -17,3 +17,20 @@ def test_subproc_architecture_steps(kind):
 def test_dummy_architecture_steps(kind):
     rate, steps, dt = sb.time_dummy(kind, 2, 3)
     assert steps == 3 and rate > 0
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_tournament_baseline_leg_runs(full):
+    """bench.py's CPU restatement of the tournament loop (oracle Pong env + numpy opponent network), light and full-size."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oracle import pong_oracle as po
+
+    atlas = np.load(os.path.join(root, "competitive_rl_amd", "assets", "pong_score_atlas.npz"))["atlas"]
+    b = bench.cpu_baseline_tournament(po, atlas, 2, 0.5, full=full)
+    assert b["value"] > 0 and b["kind"] == "port"
