@@ -142,3 +142,25 @@ def test_tournament_against_a_full_size_opponent_matches_oracle_game(atlas):
     assert nclear > 0.9 * n * T
     tour.close()
     env.close()
+
+
+def test_full_network_more_envs_than_one_pass():
+    """The activation scratch holds 65 536 envs; a larger policy runs in passes.  Envs on both sides of the boundary against the oracle."""
+    _need_gpu()
+    from oracle import policy_oracle as P
+    from tests.policy_full_weights import make_weights
+
+    n, probe = 65536 + 192, [0, 65535, 65536, 65536 + 191]
+    w = make_weights(3)
+    pol = make_policy(n, w)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ora = P.PolicyOracle(w, len(probe), full=True)
+    for t in range(5):
+        f = torch.randint(0, 256, (n, 1, 42, 42), dtype=torch.uint8, device="cuda", generator=g)
+        a = pol.act_device(f, want_logits=True)
+        ao = ora(f[probe].cpu().numpy())
+        assert np.abs(pol.logits()[probe].cpu().numpy() - ora.logits).max() < TOL, t
+        srt = np.sort(ora.logits, 1)
+        clear = (srt[:, 2] - srt[:, 1]) > 10 * TOL
+        assert np.array_equal(a[probe].cpu().numpy()[clear], ao.reshape(-1)[clear]), t
+    pol.close()
