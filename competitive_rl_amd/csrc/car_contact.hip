@@ -290,7 +290,8 @@ __device__ inline V2 rel_vel(const BRef &A, const BRef &B, V2 rA, V2 rB) {
 // impulses are carried over from last step's manifolds by contact id (warm starting).  The env goes to one of two lists:
 // `touch` (one island with contacts: car_touch_kernel) or `near` (the boxes overlap but nothing touches: two islands of
 // their own, car_near_kernel = the per-car solve).
-__global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, int urgent) {
+__global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, int urgent, const float *__restrict__ fresh_body,
+                                                        const uint8_t *__restrict__ cls) {
     // (the fixture tables are indexed per lane at run time: a by-value kernel argument would first be copied to every lane's
     // scratch, and reading them from device memory makes every vertex a dependent ~200-cycle load: stage them in LDS)
     __shared__ CarConsts Ks;
@@ -343,6 +344,9 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
         unsigned long long sb = sa;
 #endif
         const int64_t env = s.coupled_list[slot];
+        // (collide-ahead) an env that finished while coupled: its new episode's bodies, still staged; no manifolds to warm-start from
+        const bool fresh = cls && cls[env] == 3;
+        const float *body = fresh ? fresh_body : s.body;
         const int fa = lane >> 3, fb = lane & 7;
         const bool active = !(fa >= 4 && fb >= 4);
         Contact c;
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
                 const int f = k ? fb : fa;
                 const int64_t ci = k * s.n + env;
                 const int o = f < 4 ? 0 : 6 + 6 * (f - 4);
-                const float bx = s.body[(o + 0) * M + ci], by = s.body[(o + 1) * M + ci], ba = s.body[(o + 2) * M + ci];
+                const float bx = body[(o + 0) * M + ci], by = body[(o + 1) * M + ci], ba = body[(o + 2) * M + ci];
                 crl_sincosf(ba, &xf[k].s, &xf[k].c);
                 const V2 lc = f < 4 ? mk(K.hull_lc[0], K.hull_lc[1]) : mk(0.f, 0.f);
                 xf[k].p = mk(bx, by) - rotv(xf[k].s, xf[k].c, lc);
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
         const int nc = min((int)__popcll(m), kMaxContacts);
         if (hit && rank < kMaxContacts) {
             const float *old = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
-            const int n_old = s.n_contact[env];
+            const int n_old = fresh ? 0 : s.n_contact[env];
             for (int k = 0; k < n_old; k++) {
                 const float *o = old + k * kContactWords;
                 if (__float_as_int(o[0]) != c.pair) continue;
@@ -932,9 +936,9 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
 }
 
 // world.Step of the coupled envs.  `near_st` (may equal `st`): where the near-only envs are solved, beside the touching ones.
-void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent) {
+void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent, const float *fresh_body, const uint8_t *cls) {
     const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
-    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k, urgent ? 1 : 0);
+    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k, urgent ? 1 : 0, fresh_body, cls);
 }
 
 // skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous step); the caller has ordered `st`,

@@ -213,8 +213,9 @@ void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSr
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st);
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st, bool do_broad = true);
-void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st);
-void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent);
+void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body = nullptr, const uint8_t *cls = nullptr);
+void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent, const float *fresh_body = nullptr,
+                       const uint8_t *cls = nullptr);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 // near_st == nullptr: everything on st.  skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous

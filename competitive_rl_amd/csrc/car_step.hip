@@ -307,15 +307,18 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
 // left: Car.step moves nothing): one lane per env, the same two tests as in car_step_kernel, the coupled flags and the compacted
 // list into the next step's counter block.  car_narrow_kernel follows on the same stream -- the step's longest chain then starts
 // with the touching solve instead of with two more kernels.
-__global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K) {
+// fresh_body / cls (optional): an env of class 3 (finished while coupled) is collided on its STAGED bodies -- the new episode, which
+// its commit is about to make current on another stream.
+__global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K, const float *__restrict__ fresh_body,
+                                                       const uint8_t *__restrict__ cls) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t M = 2 * s.n;
     bool coupled = false;
     if (env < s.n) {
         const int64_t c0 = env, c1 = s.n + env;
-        coupled = cars_near(K, s.body[0 * M + c0], s.body[1 * M + c0], s.body[2 * M + c0], s.body[0 * M + c1], s.body[1 * M + c1],
-                            s.body[2 * M + c1]);
-        if (coupled) coupled = fixtures_near(s.body, K, M, c0, c1);
+        const float *body = (cls && cls[env] == 3) ? fresh_body : s.body;
+        coupled = cars_near(K, body[0 * M + c0], body[1 * M + c0], body[2 * M + c0], body[0 * M + c1], body[1 * M + c1], body[2 * M + c1]);
+        if (coupled) coupled = fixtures_near(body, K, M, c0, c1);
         s.coupled[env] = coupled ? 1 : 0;
     }
     const unsigned long long m = __ballot(coupled);
@@ -328,8 +331,8 @@ __global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K) {
     }
 }
 
-void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st) {
-    hipLaunchKernelGGL(car_broad_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k);
+void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body, const uint8_t *cls) {
+    hipLaunchKernelGGL(car_broad_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k, fresh_body, cls);
 }
 
 // world.Step's Collide for the wheel sensors (FrictionDetector, crmp:111-153): Begin / EndContact of every wheel with the

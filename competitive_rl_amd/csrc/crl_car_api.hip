@@ -15,7 +15,7 @@ struct crl_car_ctx {
     int64_t n;
     CarSoA s{};
     CarSoA stage{};  // only the per-car arrays a reset writes: their staged copies (car_commit_list_kernel)
-    hipEvent_t ev_early3 = nullptr, ev_collide = nullptr;
+    hipEvent_t ev_early3 = nullptr, ev_collide = nullptr, ev_c3 = nullptr;
     bool collide_valid = false;  // the NEXT step's broadphase + narrow phase already ran, at the end of the last step (car_broad_kernel)
     bool collide_dirty = false;  // ... was enqueued and not consumed yet: its counter block has to be cleared if the results are not used
     int32_t *coupled2 = nullptr, *lists2 = nullptr;  // [2][n] coupled flags, [2][6][n] near / touch lists: one block per step parity
@@ -305,6 +305,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     if (hipEventCreateWithFlags(&c->ev_narrow, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_post, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_early3, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_collide, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_c3, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin3, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess ||
@@ -362,6 +363,7 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_narrow) hipEventDestroy(c->ev_narrow);
     if (c->ev_post) hipEventDestroy(c->ev_post);
     if (c->ev_early3) hipEventDestroy(c->ev_early3);
+    if (c->ev_c3) hipEventDestroy(c->ev_c3);
     if (c->ev_collide) hipEventDestroy(c->ev_collide);
     if (c->one) hipStreamDestroy(c->one);
     if (c->ev_fin3) hipEventDestroy(c->ev_fin3);
@@ -632,30 +634,41 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         } else {
             finish_chain(c->side2, 2, exp_done, c->class_count_hdev + 1);
         }
+        // Behind the touching solve: (a) the envs that finished while coupled (class 3, a handful): terminal frames + commit; (b) the
+        // NEXT step's Collide (every solve of this step is in); (c) the touching envs' frames on the caller's stream (above).
+        // early_collide: (a) on the high-priority stream and (b) on side2 at once -- the Collide reads the class-3 envs' new episode
+        // from the staging arrays, which (a)'s commit is copying from, and takes no manifolds over for them -- instead of (a), the
+        // join, then (b) in a row in front of the next step's touching solve.
+        static const bool late_collide = CRL_ABL(getenv("CRL_CAR_COLLIDE_LATE") != nullptr);
+        const bool early_collide = can_ahead && staged && !late_collide;
+        auto collide_next = [&](bool fresh) {
+            CarSoA nx = c->s;
+            point_parity(c, nx, c->parity ^ 1);
+            launch_car_broad(nx, c->K_, c->side2, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr);
+            launch_car_narrow(nx, c->K_, c->side2, false, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr);
+            hipEventRecord(c->ev_collide, c->side2);
+            c->collide_valid = c->collide_dirty = true;
+        };
         hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve
-        if (staged) {
+        if (early_collide) {
+            hipStreamWaitEvent(c->one, c->ev_coupled, 0);
+            terminal_frames(c->one, 3, 8, nullptr);
+            launch_car_commit_list(c->s, sv, list_of(3), count_of(3), 8, c->one);
+            hipEventRecord(c->ev_c3, c->one);
+            collide_next(true);
+            hipStreamWaitEvent(c->side2, c->ev_c3, 0);
+        } else if (staged) {
             terminal_frames(c->side2, 3, 8, nullptr);
             launch_car_commit_list(c->s, sv, list_of(3), count_of(3), 8, c->side2);
         } else {
             finish_chain(c->side2, 3, 8, nullptr);
         }
-        // join: side2 collects the bulk stream (and, through ev_early3, the high-priority one) behind its own last kernel, so that the
-        // caller's stream -- whose last kernel is usually the last of the step -- passes ONE barrier instead of three
+        // join: side2 collects the bulk stream (and, through ev_early3 / ev_c3, the high-priority one) behind its own last kernel, so
+        // that the caller's stream -- whose last kernel is usually the last of the step -- passes ONE barrier instead of three
         hipEventRecord(c->ev_join, c->side);
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
         hipEventRecord(c->ev_fin3, c->side2);
-        if (can_ahead) {
-            // every solve of this step is in (side2 is behind the near-only and the touching solve and ev_term: the per-car solve) and
-            // every finished env is committed: the next step's Collide, into the other parity block, beside this step's last frames
-            // and the next car_step_kernel.  (Measured, round 4: earlier -- right behind the solves, reading the finished envs' staged
-            // bodies -- or inside the join, so that the next step needs no barrier for it: both slower, docs/LAB_NOTES_r04.md.)
-            CarSoA nx = c->s;
-            point_parity(c, nx, c->parity ^ 1);
-            launch_car_broad(nx, c->K_, c->side2);
-            launch_car_narrow(nx, c->K_, c->side2, false);
-            hipEventRecord(c->ev_collide, c->side2);
-            c->collide_valid = c->collide_dirty = true;
-        }
+        if (can_ahead && !early_collide) collide_next(false);  // (beside this step's last frames and the next car_step_kernel)
         queue_walk_ahead(c, c->side2);
         hipStreamWaitEvent(st, c->ev_fin3, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
