@@ -11,6 +11,7 @@ import competitive_rl_amd as crl
 
 n, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, int(sys.argv[2]) if len(sys.argv) > 2 else 300
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 50  # steps between host synchronisations
+early_stream = torch.cuda.Stream() if os.environ.get("QUICK_STREAM") == "early" else None  # created BEFORE the env's own streams
 env = crl.HipCarVecEnv(n, seed=int(os.environ.get("QUICK_SEED", "0")))
 st = None
 env.reset()
@@ -25,7 +26,7 @@ PERIOD = int(os.environ.get("QUICK_EPISODE", "1000"))  # < 1000: every env start
 s0["elapsed"] = 1000 - PERIOD + (torch.arange(n, dtype=torch.int64) * PERIOD // n).numpy()
 env.set_state(s0)
 torch.cuda.synchronize()
-user_stream = torch.cuda.Stream() if os.environ.get("QUICK_STREAM") else None  # the caller works on a created stream instead of the legacy default stream
+user_stream = early_stream if early_stream is not None else (torch.cuda.Stream() if os.environ.get("QUICK_STREAM") else None)  # the caller works on a created stream instead of the legacy default stream
 if user_stream is not None:
     torch.cuda.set_stream(user_stream)
 for blk in range(steps // K):
