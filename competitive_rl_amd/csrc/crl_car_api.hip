@@ -18,6 +18,8 @@ struct crl_car_ctx {
     hipEvent_t ev_early3 = nullptr, ev_collide = nullptr, ev_c3 = nullptr;
     bool collide_valid = false;  // the NEXT step's broadphase + narrow phase already ran, at the end of the last step (car_broad_kernel)
     bool collide_dirty = false;  // ... was enqueued and not consumed yet: its counter block has to be cleared if the results are not used
+    hipStream_t collide_joined = nullptr;  // ... and the step's join already stood behind it: this caller's stream needs no barrier for it
+    bool collide_is_joined = false;
     int32_t *coupled2 = nullptr, *lists2 = nullptr;  // [2][n] coupled flags, [2][6][n] near / touch lists: one block per step parity
     hipStream_t one = nullptr;  // HIGH priority (a queue class of its own): the wheel sensors, then the finished envs' early chain
     CarConsts K_{};
@@ -517,7 +519,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
     // state was changed from outside (reset, set_state), not in the one-stream mode.  CRL_CAR_NO_COLLIDE_AHEAD=1: A/B, twin tests
     const bool can_ahead = c->collide_ahead && fork && c->repeat == 1 && contacts;
     const bool ahead = can_ahead && c->collide_valid;
-    c->collide_valid = false;
+    const bool collide_joined = c->collide_is_joined && c->collide_joined == st;  // (the last step's join on this stream stood behind the Collide)
+    c->collide_valid = c->collide_is_joined = false;
     if (!ahead && c->collide_dirty) {  // results of a collide-ahead that will not be used (the state was changed in between): its counters go
         hipStreamWaitEvent(st, c->ev_collide, 0);
         hipMemsetAsync(c->counters + 16 * (c->parity ^ 1), 0, 8 * sizeof(int32_t), st);  // (the block this step is about to use)
@@ -568,10 +571,10 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         launch_car_post(c->s, c->done_car, c->done_env, done_dev, c->slow_env, c->info_steps, c->info_elapsed, 1000, c->car0_only, c->side2, c->class_list,
                         c->class_count);
         hipEventRecord(c->ev_post, c->side2);  // classes, class lists, done flags: what the frame launches and the finished-env chains filter by
-        if (ahead) {  // (side2 ran the narrow phase itself, at the end of the last step; crit and bulk wait for it)
+        if (ahead && !collide_joined) {  // (side2 ran the narrow phase itself, at the end of the last step)
             hipStreamWaitEvent(crit, c->ev_collide, 0);
             hipStreamWaitEvent(bulk, c->ev_collide, 0);
-        }
+        }  // (else: two barriers less, one of them on the step's longest chain)
         if (contacts && !ahead) {  // narrow phase at the head of crit; the sensor kernel beside it doubles both: sensors behind it
             launch_car_narrow(c->s, c->K_, crit, true);
             hipEventRecord(c->ev_narrow, crit);
@@ -669,6 +672,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
         hipEventRecord(c->ev_fin3, c->side2);
         if (can_ahead && !early_collide) collide_next(false);  // (beside this step's last frames and the next car_step_kernel)
+        if (early_collide && !CRL_ABL(getenv("CRL_CAR_COLLIDE_WAIT") != nullptr)) c->collide_is_joined = true, c->collide_joined = st;  // (ev_fin3 was recorded behind the Collide on side2)
         queue_walk_ahead(c, c->side2);
         hipStreamWaitEvent(st, c->ev_fin3, 0);
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
