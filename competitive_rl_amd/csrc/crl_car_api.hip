@@ -614,7 +614,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         auto count_of = [&](int cls) { return c->class_count + (cls - 1); };
         auto terminal_frames = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {
             if (c->analytic) launch_car_raster_list(c->s, c->K_, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
-            else launch_car_obs_list(c->s, c->K_, c->term, q, list_of(cls), count_of(cls), count_to_host, expected, c->slow_env, cls);
+            else launch_car_obs_list(c->s, c->K_, c->term, q, list_of(cls), count_of(cls), count_to_host, expected, c->slow_env, cls,
+                                     cls == 3 && !CRL_ABL(getenv("CRL_CAR_C3_CALM") != nullptr));  // (class 3: behind the touching solve, beside 2 300 other tiles)
         };
         auto finish_chain = [&](hipStream_t q, int cls, int64_t expected, int32_t *count_to_host) {  // everything in place, in order
             frames_list(c, c->s, c->term, q, list_of(cls), count_of(cls), count_to_host, expected);
