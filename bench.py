@@ -284,8 +284,17 @@ def run_workload(name, args, G):
                 gather_state.wait(materialize=False)  # at most one collective in flight: gather(t) overlaps simulate(t+1)
                 gather_state.launch(out if args.gather == "obs" else out[1:])
 
+    warm_resets = None
+    if name == "car":
+        # the episode counters BEFORE the warm-up (reading the state takes the host a while; between the warm-up and the timed
+        # region it would leave the GPU idle long enough for its first kernels to start 10-20 ms late -- measured: a 20-step window
+        # then reads 1.3-2.1 ms per step instead of 0.9); the warm-up's own resets are counted on the device and subtracted
+        episodes_before = env.get_state()["episode"].astype("int64").sum()
+        warm_resets = torch.zeros((), dtype=torch.int64, device=dev)
     for i in range(args.warmup):
         step(i)
+        if warm_resets is not None:
+            warm_resets += inner._done.sum()  # (the env's device-side done flags of this step; same stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -293,14 +302,19 @@ def run_workload(name, args, G):
     inner.kernel_timing(not os.environ.get("CRL_BENCH_NO_KERNEL_TIMING"))  # (A/B: what the hipEvent brackets themselves cost)
     if policy_events is not None:
         timed_act.on = True
-    if name == "car":
-        episodes_before = env.get_state()["episode"].astype("int64").sum()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     if world > 1 and args.gather != "none":
         gather_state.wait(materialize=args.gather == "descriptors")
+    if os.environ.get("CRL_BENCH_DEBUG"):  # (where a short window's time goes: the host's enqueueing, the caller's stream, the rest of the device)
+        t_host = time.perf_counter() - t0
+        torch.cuda.current_stream().synchronize()
+        t_stream = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        print(f"[{name}] host enqueue {t_host * 1e3:.2f} ms, caller's stream done {t_stream * 1e3:.2f} ms, device done {(time.perf_counter() - t0) * 1e3:.2f} ms",
+              file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -313,7 +327,7 @@ def run_workload(name, args, G):
     dyn_ms, dyn_n = inner.kernel_time_ms(0)
     ras_ms, ras_n = inner.kernel_time_ms(1)
     final_state = env.get_state() if episodes_before is not None else None
-    resets = int(final_state["episode"].astype("int64").sum() - episodes_before) if episodes_before is not None else None
+    resets = int(final_state["episode"].astype("int64").sum() - episodes_before - int(warm_resets.item())) if episodes_before is not None else None
     env.close()
     res = {"value": world * n * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3, "dtype": dtype,
            "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",

@@ -39,6 +39,7 @@ static constexpr int kMapSurface = 10000;
 enum { kPalGrass = 0, kPalLight = 1, kPalRoad0 = 2, kPalWhite = 5, kPalRed = 6 };
 // per (env, viewer) tile, written by car_view_kernel and read by car_obs_kernel
 static constexpr int kViewWords = 20;     // struct ViewParams (16 words) + the float32 camera (sin, cos, offset x, y)
+static constexpr int kWalkSaveWords = 18;
 static constexpr int kSpanSlots = 16;     // scanline spans one car polygon can produce (a polygon is <= 5.3 px across: <= 8)
 static constexpr int kViewRecWords = 16 * kSpanSlots;
 
@@ -102,6 +103,7 @@ struct CarSoA {
     uint32_t *walk_tag;     // [n] episode index the stored walk belongs to (0xFFFFFFFF = none); written last, device-scope release
     int32_t *walk_list, *walk_count;  // [n], [1]: the envs the current walk-ahead launch has to walk, compacted
     int32_t *walk_len, *walk_first, *walk_swap;  // [n] lap length, its first point, birth-place swap of the stored walk
+    uint32_t *walk_save;    // [n][kWalkSaveWords] an unfinished walk-ahead's state between two bounded launches (car_track.hip WalkSave)
     const uint32_t *text_bits;  // reward read-out bitmaps [CRL_CAR_TEXT_STRINGS][CRL_CAR_TEXT_ROWS] or nullptr
     // ---- car-car contacts (players == 2)
     int contacts_enabled;
@@ -210,7 +212,7 @@ void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &sr
 void launch_car_commit_list(const CarSoA &live, const CarSoA &stage, const int32_t *list, const int32_t *list_count, int64_t expected, hipStream_t st);
 void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, const int32_t *list, const int32_t *list_count,
                            int64_t expected, hipStream_t st);
-void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st);
+void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st, int budget = 0);  // budget: walk iterations per env (<= 0: to the end)
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st, bool do_broad = true);
 void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body = nullptr, const uint8_t *cls = nullptr);

@@ -202,6 +202,59 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
             bgpal = (b >> ((rx & 1) * 4)) & 15u;
         }
     }
+    if (!CHECK) {
+        // Every source pixel is inside the window and the crop: the byte's address comes straight from the 16.16 coordinates (all
+        // non-negative): block row dy >> 20, block column dx >> 20, row in block bits 16-19 of dy, byte in row bits 17-19 of dx,
+        // nibble bit 16 of dx; a 32-bit unsigned offset from the env's map base (uniform), so the load takes base + offset without
+        // 64-bit address arithmetic per pixel.  Two regions in flight: the next region's 16 loads are issued before this region's
+        // bytes are unpacked -- a tile is a chain of dependent load rounds (30 cycles per vector instruction), not issue slots.
+        auto fetch = [&](int it, uint32_t (&raw)[16]) {
+            const int X0 = 32 * (it % 3) + 4 * (lane & 7), Y0 = 32 * (it / 3) + 4 * (lane >> 3);
+            int dxr = dx00 + icos * X0 - isin * Y0, dyr = dy00 + isin * X0 + icos * Y0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int dx = dxr, dy = dyr;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t udx = (uint32_t)dx, udy = (uint32_t)dy;
+                    const uint32_t blk = (udy >> 20) * (uint32_t)kMapBlocks + (udx >> 20);
+                    const uint32_t off = (blk << 7) | ((udy >> 13) & 0x78u) | __builtin_amdgcn_ubfe(udx, 17, 3);
+                    raw[4 * j + i] = map[off];
+                    dx += icos, dy += isin;
+                }
+                dxr -= isin, dyr += icos;
+            }
+        };
+        auto unpack = [&](int it, const uint32_t (&raw)[16]) {
+            const int X0 = 32 * (it % 3) + 4 * (lane & 7), Y0 = 32 * (it / 3) + 4 * (lane >> 3);
+            int dxr = dx00 + icos * X0 - isin * Y0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int dx = dxr;
+                uint32_t sel = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    sel |= __builtin_amdgcn_ubfe(raw[4 * j + i], ((uint32_t)dx >> 14) & 4u, 4) << (8 * i);
+                    dx += icos;
+                }
+                tile[(Y0 + j) * kPitch + (X0 >> 2)] = __builtin_amdgcn_perm(kLutHi, kLutLo, sel);
+                dxr -= isin;
+            }
+        };
+        uint32_t cur[16], nxt[16];
+        if (it0 < 9) fetch(it0, cur);
+#pragma unroll 1
+        for (int it = it0; it < 9; it += it_step) {
+            const bool more = it + it_step < 9;
+            if (more) fetch(it + it_step, nxt);
+            unpack(it, cur);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) cur[k] = nxt[k];
+            }
+        }
+        return;
+    }
 #pragma unroll 1
     for (int it = it0; it < 9; it += it_step) {
         // a wavefront iteration covers a 32 x 32-pixel region: lane = a 4 x 4 patch, so one load instruction reads 64 pixels
@@ -215,25 +268,12 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int sx = dx >> 16, sy = dy >> 16;
-                uint32_t p;
-                if (!CHECK) {
-                    // straight from the 16.16 coordinates (all non-negative here): block row dy >> 20, block column dx >> 20, row in
-                    // block bits 16-19 of dy, byte in row bits 17-19 of dx, nibble bit 16 of dx; a 32-bit unsigned offset from
-                    // the env's map base (uniform), so the load takes base + offset without 64-bit address arithmetic per pixel
-                    const uint32_t udx = (uint32_t)dx, udy = (uint32_t)dy;
-                    const uint32_t blk = (udy >> 20) * (uint32_t)kMapBlocks + (udx >> 20);
-                    const uint32_t off = (blk << 7) | ((udy >> 13) & 0x78u) | __builtin_amdgcn_ubfe(udx, 17, 3);
-                    const uint32_t b = map[off];
-                    p = __builtin_amdgcn_ubfe(b, (udx >> 14) & 4u, 4);
-                } else {
-                    const int ux = dx - rx * 65536, uy = dy - ry * 65536;  // position inside the 192 x 192 crop
-                    const bool in_crop = !(ux < 0 || uy < 0 || ux > (192 << 16) - 1 || uy > (192 << 16) - 1);
-                    const bool in_win = sx >= 0 && sy >= 0 && sx < kMapW && sy < kMapW;
-                    uint32_t b = 0;
-                    if (in_crop && in_win) b = map[((sy >> 4) * kMapBlocks + (sx >> 4)) * 128 + (sy & 15) * 8 + ((sx & 15) >> 1)];
-                    p = !in_crop ? bgpal : (in_win ? ((b >> ((sx & 1) * 4)) & 15u) : (uint32_t)kPalGrass);
-                }
-                nib[4 * j + i] = p;
+                const int ux = dx - rx * 65536, uy = dy - ry * 65536;  // position inside the 192 x 192 crop
+                const bool in_crop = !(ux < 0 || uy < 0 || ux > (192 << 16) - 1 || uy > (192 << 16) - 1);
+                const bool in_win = sx >= 0 && sy >= 0 && sx < kMapW && sy < kMapW;
+                uint32_t b = 0;
+                if (in_crop && in_win) b = map[((sy >> 4) * kMapBlocks + (sx >> 4)) * 128 + (sy & 15) * 8 + ((sx & 15) >> 1)];
+                nib[4 * j + i] = !in_crop ? bgpal : (in_win ? ((b >> ((sx & 1) * 4)) & 15u) : (uint32_t)kPalGrass);
                 dx += icos, dy += isin;
             }
             dxr -= isin, dyr += icos;

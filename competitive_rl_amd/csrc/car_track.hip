@@ -76,9 +76,8 @@ __device__ inline void walk_init(Walk &w) {
 // 80 KB per env buys not having to repeat the ~2 500-step f64 walk once the lap's end points are known).
 // On success returns the lap length and, in *first, the index of its first point; 0 otherwise.
 static constexpr int kWalkMax = 2500;
-__device__ int create_track(const double u[24], double *__restrict__ pts, int64_t stride, int *first) {
+__device__ inline void make_checkpoints(const double u[24], Checkpoints &cp) {
     const double PI = 3.141592653589793;
-    Checkpoints cp;
     cp.start_alpha = 0;
     for (int c = 0; c < 12; c++) {
         const double noise = 0 + (2 * PI * 1 / 12 - 0) * u[2 * c];
@@ -88,23 +87,37 @@ __device__ int create_track(const double u[24], double *__restrict__ pts, int64_
         if (c == 11) alpha = 2 * PI * c / 12, cp.start_alpha = 2 * PI * (-0.5) / 12, rad = 1.5 * CAR_TRACK_RAD;
         cp.a[c] = alpha, cp.x[c] = rad * crl_cos_fast(alpha), cp.y[c] = rad * crl_sin_fast(alpha);
     }
+}
+
+// one attempt's walk as a resumable run: the walk-ahead advances it a bounded number of iterations per launch
+struct WalkRun {
     Walk w;
-    walk_init(w);
-    int n = 0, cross_last = -1, cross_prev = -1, no_freeze = kWalkMax;
-    double prev_alpha = 0;
-    for (;;) {
+    int n, cross_last, cross_prev, no_freeze;
+    double prev_alpha;
+};
+__device__ inline void walk_run_init(WalkRun &r) {
+    walk_init(r.w);
+    r.n = 0, r.cross_last = -1, r.cross_prev = -1, r.no_freeze = kWalkMax, r.prev_alpha = 0;
+}
+// at most `budget` iterations; true when the walk has ended (five laps, or kWalkMax points)
+__device__ inline bool walk_run(const Checkpoints &cp, WalkRun &r, double *__restrict__ pts, int64_t stride, int budget) {
+    for (; budget > 0; budget--) {
         double p[4];
-        walk_step(cp, w, p);
+        walk_step(cp, r.w, p);
 #pragma unroll
-        for (int q = 0; q < 4; q++) pts[((int64_t)n * 4 + q) * stride] = p[q];
-        if (n > 0 && p[0] > cp.start_alpha && prev_alpha <= cp.start_alpha) cross_prev = cross_last, cross_last = n;
-        prev_alpha = p[0];
-        n++;
-        if (w.laps > 4) break;
-        if (--no_freeze == 0) break;
+        for (int q = 0; q < 4; q++) pts[((int64_t)r.n * 4 + q) * stride] = p[q];
+        if (r.n > 0 && p[0] > cp.start_alpha && r.prev_alpha <= cp.start_alpha) r.cross_prev = r.cross_last, r.cross_last = r.n;
+        r.prev_alpha = p[0];
+        r.n++;
+        if (r.w.laps > 4) return true;
+        if (--r.no_freeze == 0) return true;
     }
+    return false;
+}
+// the finished walk's lap: its length and, in *first, the index of its first point; 0 = the attempt failed
+__device__ inline int walk_close(const WalkRun &r, const double *__restrict__ pts, int64_t stride, int *first) {
     // the reference scans i = n-1 .. 1 and fails at i == 0 before testing it
-    const int i2 = cross_last, i1 = cross_prev;
+    const int i2 = r.cross_last, i1 = r.cross_prev;
     if (i2 < 1 || i1 < 1) return 0;
     const int len = (i2 - 1) - i1;  // points i1 .. i2-2
     if (len <= 0 || len > kCarMaxTiles) return 0;
@@ -115,6 +128,14 @@ __device__ int create_track(const double u[24], double *__restrict__ pts, int64_
     if (sqrt(a * a + b * b) > CAR_TRACK_DETAIL_STEP) return 0;
     *first = i1;
     return len;
+}
+__device__ int create_track(const double u[24], double *__restrict__ pts, int64_t stride, int *first) {
+    Checkpoints cp;
+    make_checkpoints(u, cp);
+    WalkRun r;
+    walk_run_init(r);
+    walk_run(cp, r, pts, stride, 0x7fffffff);
+    return walk_close(r, pts, stride, first);
 }
 
 __device__ inline void store_poly_ccw(const double (*v)[2], int nv, float *dst, int64_t stride, float *aabb) {
@@ -270,29 +291,34 @@ __device__ void finish_reset(CarSoA &s, const CarConsts &K, int64_t env, const d
 // The attempts loop of CarRacing.reset (crmp:454-525): fresh draws until a lap closes.  The draws of attempt a
 // only depend on (seed, global env id, episode, a) -- or on the replay stream -- so the walk of an env's NEXT
 // episode can be generated at any time before that reset.
+// the 24 uniform draws + the birth-place swap of attempt `attempt` of episode `episode` of an env
+__device__ inline void draw_attempt(const CarTrackSrc &src, int64_t env, uint32_t episode, int attempt, double u[24], int *swap) {
+    if (src.attempts > 0) {
+        const int64_t a = ((int64_t)episode * 16 + attempt) % src.attempts;
+        for (int k = 0; k < 24; k++) u[k] = src.ru[(env * src.attempts + a) * 24 + k];
+        *swap = src.rshuffle[env * src.attempts + a];
+    } else {
+        const uint64_t gid = (uint64_t)(src.env_id_base + env);
+        for (int k = 0; k < 13; k++) {
+            uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (episode << 12) | ((uint32_t)attempt << 4) | (uint32_t)k,
+                             0x43415253u /* "CARS" */};
+            philox4x32_10c(c, (uint32_t)src.seed, (uint32_t)(src.seed >> 32));
+            if (k < 12) {
+                u[2 * k] = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);
+                u[2 * k + 1] = (double)((((uint64_t)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0);
+            } else {
+                *swap = c[0] & 1;
+            }
+        }
+    }
+}
+static constexpr int kMaxAttempts = 256;
 __device__ void gen_walk(const CarSoA &s, const CarTrackSrc &src, int64_t env, uint32_t episode, double *pts, int *len_out,
                          int *first_out, int *swap_out) {
     int len = 0, swap = 0, first = 0;
-    for (int attempt = 0; attempt < 256 && len == 0; attempt++) {
+    for (int attempt = 0; attempt < kMaxAttempts && len == 0; attempt++) {
         double u[24];
-        if (src.attempts > 0) {
-            const int64_t a = ((int64_t)episode * 16 + attempt) % src.attempts;
-            for (int k = 0; k < 24; k++) u[k] = src.ru[(env * src.attempts + a) * 24 + k];
-            swap = src.rshuffle[env * src.attempts + a];
-        } else {
-            const uint64_t gid = (uint64_t)(src.env_id_base + env);
-            for (int k = 0; k < 13; k++) {
-                uint32_t c[4] = {(uint32_t)gid, (uint32_t)(gid >> 32), (episode << 12) | ((uint32_t)attempt << 4) | (uint32_t)k,
-                                 0x43415253u /* "CARS" */};
-                philox4x32_10c(c, (uint32_t)src.seed, (uint32_t)(src.seed >> 32));
-                if (k < 12) {
-                    u[2 * k] = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);
-                    u[2 * k + 1] = (double)((((uint64_t)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0);
-                } else {
-                    swap = c[0] & 1;
-                }
-            }
-        }
+        draw_attempt(src, env, episode, attempt, u, &swap);
         len = create_track(u, pts, 1, &first);
     }
     *len_out = len, *first_out = first, *swap_out = swap;
@@ -367,17 +393,63 @@ __global__ __launch_bounds__(256) void car_walk_mark_kernel(CarSoA s, int32_t *_
     if (need) list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
 }
 
+// What a walk-ahead launch leaves behind for the next one: the attempt it is in and that attempt's walk (72 bytes per env).
+struct WalkSave {
+    uint32_t episode;  // the episode this state belongs to (anything else: start from attempt 0)
+    int32_t attempt, n, cross_last, cross_prev, no_freeze, laps, visited_other_side;
+    int64_t dest_i;
+    double prev_alpha, x, y, beta;
+};
+static_assert(sizeof(WalkSave) == kWalkSaveWords * 4, "WalkSave words");
+
+// `budget` walk iterations per lane and launch (<= 0: to the end).  The step pipeline queues one bounded launch per step on its
+// low-priority stream: a walk of 2 500 iterations x a few attempts is 5-17 ms of ONE lane's latency, and a kernel of that length
+// was what a device-wide synchronise at the end of a short timed window waited for (up to 0.85 ms per step of a 20-step window).
 __global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSrc src, const int32_t *__restrict__ list,
-                                                            const int32_t *__restrict__ count) {
+                                                            const int32_t *__restrict__ count, int budget) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *count) return;
     const int64_t env = list[i];
     const uint32_t episode = __hip_atomic_load(&s.episode[env], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == episode) return;
-    int len, first, swap;
-    gen_walk(s, src, env, episode, s.track_scratch + env * (int64_t)(kWalkMax * 4), &len, &first, &swap);
-    s.walk_len[env] = len, s.walk_first[env] = first, s.walk_swap[env] = swap;
-    __hip_atomic_store(&s.walk_tag[env], episode, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    WalkSave *save = reinterpret_cast<WalkSave *>(s.walk_save) + env;
+    double *pts = s.track_scratch + env * (int64_t)(kWalkMax * 4);
+    WalkRun r;
+    int attempt = 0;
+    if (budget > 0 && save->episode == episode) {
+        attempt = save->attempt;
+        r.n = save->n, r.cross_last = save->cross_last, r.cross_prev = save->cross_prev, r.no_freeze = save->no_freeze;
+        r.w.laps = save->laps, r.w.visited_other_side = save->visited_other_side, r.w.dest_i = (long)save->dest_i;
+        r.prev_alpha = save->prev_alpha, r.w.x = save->x, r.w.y = save->y, r.w.beta = save->beta;
+    } else {
+        walk_run_init(r);
+    }
+    int left = budget > 0 ? budget : 0x7fffffff;
+    for (;;) {
+        double u[24];
+        int swap = 0;
+        draw_attempt(src, env, episode, attempt, u, &swap);
+        Checkpoints cp;
+        make_checkpoints(u, cp);
+        const int n0 = r.n;
+        const bool ended = walk_run(cp, r, pts, 1, left);
+        left -= r.n - n0;
+        if (!ended) break;  // out of budget in the middle of an attempt
+        int first = 0;
+        const int len = walk_close(r, pts, 1, &first);
+        if (len > 0 || attempt + 1 >= kMaxAttempts) {  // (gen_walk: the lap, or nothing after the last attempt)
+            s.walk_len[env] = len, s.walk_first[env] = first, s.walk_swap[env] = swap;
+            __hip_atomic_store(&s.walk_tag[env], episode, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        attempt++;
+        walk_run_init(r);
+        if (left <= 0) break;
+    }
+    save->episode = episode, save->attempt = attempt;
+    save->n = r.n, save->cross_last = r.cross_last, save->cross_prev = r.cross_prev, save->no_freeze = r.no_freeze;
+    save->laps = r.w.laps, save->visited_other_side = r.w.visited_other_side, save->dest_i = (int64_t)r.w.dest_i;
+    save->prev_alpha = r.prev_alpha, save->x = r.w.x, save->y = r.w.y, save->beta = r.w.beta;
 }
 
 void launch_car_reset(const CarSoA &s, const CarConsts &k, const CarTrackSrc &src, bool only_done, const uint8_t *done_env,
@@ -424,10 +496,10 @@ void launch_car_commit_list(const CarSoA &live, const CarSoA &stage, const int32
     hipLaunchKernelGGL(car_commit_list_kernel, dim3((unsigned)want), dim3(64), 0, st, live, stage, list, list_count);
 }
 
-void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st) {
+void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st, int budget) {
     hipMemsetAsync(s.walk_count, 0, sizeof(int32_t), st);
     hipLaunchKernelGGL(car_walk_mark_kernel, dim3((unsigned)((s.n + 255) / 256)), dim3(256), 0, st, s, s.walk_list, s.walk_count);
-    hipLaunchKernelGGL(car_walk_ahead_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, src, s.walk_list, s.walk_count);
+    hipLaunchKernelGGL(car_walk_ahead_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, src, s.walk_list, s.walk_count, budget);
 }
 
 }  // namespace crl

@@ -16,6 +16,8 @@ struct crl_car_ctx {
     CarSoA s{};
     CarSoA stage{};  // only the per-car arrays a reset writes: their staged copies (car_commit_list_kernel)
     hipEvent_t ev_early3 = nullptr, ev_collide = nullptr, ev_c3 = nullptr;
+    hipEvent_t ev_walk[2] = {nullptr, nullptr};  // behind the last two walk-ahead pieces: no third one is queued while both are pending
+    uint64_t walk_turn = 0;
     bool collide_valid = false;  // the NEXT step's broadphase + narrow phase already ran, at the end of the last step (car_broad_kernel)
     bool collide_dirty = false;  // ... was enqueued and not consumed yet: its counter block has to be cleared if the results are not used
     hipStream_t collide_joined = nullptr;  // ... and the step's join already stood behind it: this caller's stream needs no barrier for it
@@ -50,8 +52,6 @@ struct crl_car_ctx {
     hipStream_t gen = nullptr;  // walk-ahead of the next episode's track, beside the steps
     std::vector<hipStream_t> pads;  // idle streams that only occupy hardware-queue slots (crl_car_create)
     hipEvent_t ev_reset = nullptr;
-    hipEvent_t ev_walk = nullptr;  // recorded behind every walk-ahead launch: no new one is queued while it is pending
-    bool walk_pending = false;
     int32_t *info_steps = nullptr;  // [n] CarRacing.step_count after the step, before the auto-reset (info["num_steps"])
     int32_t *info_elapsed = nullptr;  // [n] gym TimeLimit._elapsed_steps after the step, before the auto-reset (info["TimeLimit.truncated"])
     bool car0_only = false;         // crl_opts.done_policy == CRL_CAR_DONE_CAR0
@@ -204,7 +204,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     A(border_poly, (size_t)kCarMaxTiles * 8 * n); A(border, (size_t)kCarMaxTiles * n); A(start_pose, 3 * n);
     A(track_scratch, (size_t)2500 * 4 * n);    // every point of a walk (car_track.hip: kWalkMax), f64: walk-ahead ...
     A(track_scratch_b, (size_t)2500 * 4 * n);  // ... and inline walks
-    A(walk_tag, n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
+    A(walk_tag, n); A(walk_save, (size_t)kWalkSaveWords * n); A(walk_list, n); A(walk_count, 4); A(walk_len, n); A(walk_first, n); A(walk_swap, n);
     A(wforce, 8 * M); A(wsnap, 12 * M); A(sensor_ovf, M); A(sleep, 5 * M); A(coupled_list, n); A(cap_hits, 4); A(stamps, 64); A(nc_new, n); A(contact_new, (size_t)n * kMaxContacts * kContactWords); A(n_contact, n); A(contact, (size_t)n * kMaxContacts * kContactWords);
     A(tile_aabb_em, (size_t)kCarMaxTiles * n); A(tile_poly_em, (size_t)kCarMaxTiles * 10 * n);
     A(border_poly_em, (size_t)kCarMaxTiles * 8 * n); A(border_em, (size_t)kCarMaxTiles * n);
@@ -310,9 +310,10 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         hipEventCreateWithFlags(&c->ev_c3, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fin3, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_sens, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_walk, kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_reset, kEvFlags) != hipSuccess || hipEventCreateWithFlags(&c->ev_walk[0], kEvFlags) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_walk[1], kEvFlags) != hipSuccess ||
         hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(c->s.walk_save, 0xFF, (size_t)c->n * kWalkSaveWords * sizeof(uint32_t)) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_coupled, kEvFlags) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_term, kEvFlags) != hipSuccess ||
@@ -366,6 +367,8 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->ev_post) hipEventDestroy(c->ev_post);
     if (c->ev_early3) hipEventDestroy(c->ev_early3);
     if (c->ev_c3) hipEventDestroy(c->ev_c3);
+    for (hipEvent_t e : c->ev_walk)
+        if (e) hipEventDestroy(e);
     if (c->ev_collide) hipEventDestroy(c->ev_collide);
     if (c->one) hipStreamDestroy(c->one);
     if (c->ev_fin3) hipEventDestroy(c->ev_fin3);
@@ -373,7 +376,6 @@ void crl_car_destroy(crl_car_ctx *c) {
     if (c->gen) hipStreamDestroy(c->gen);
     for (hipStream_t p : c->pads) hipStreamDestroy(p);
     if (c->ev_reset) hipEventDestroy(c->ev_reset);
-    if (c->ev_walk) hipEventDestroy(c->ev_walk);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_coupled) hipEventDestroy(c->ev_coupled);
     if (c->ev_term) hipEventDestroy(c->ev_term);
@@ -389,23 +391,25 @@ void crl_car_destroy(crl_car_ctx *c) {
 static void invalidate_walks(crl_car_ctx *c) {
     hipDeviceSynchronize();
     hipMemset(c->s.walk_tag, 0xFF, (size_t)c->n * sizeof(uint32_t));
+    hipMemset(c->s.walk_save, 0xFF, (size_t)c->n * kWalkSaveWords * sizeof(uint32_t));  // (episode 0xFFFFFFFF: no unfinished walk)
 }
-// Queues the walk-ahead of every env whose stored walk is not the one its next reset needs, on the context's own
-// stream, after the reset that `after` has just been given.  A launch that finds work runs for milliseconds (one
-// serial f64 walk per lane) while a step takes ~2 ms, so launches are NOT queued behind one another: while the
-// previous one is still pending nothing is added -- it, or the next launch after it, picks up every env that was
-// reset in the meantime (a reset that comes too early for its walk simply walks inline; results never depend on it).
-static void queue_walk_ahead(crl_car_ctx *c, hipStream_t after, bool force = false) {
+// Queues a BOUNDED piece of the walk-ahead (every env whose stored walk is not the one its next reset needs advances by
+// kWalkBudget iterations of its walk) on the context's own low-priority stream.  At most one piece per step and two in flight:
+// ~0.3 ms of a few wavefronts (0.7 beside a step), against one lane's 5-17 ms when a launch walked to the end -- whatever
+// synchronises the device (the end of a timed window, reset, set_state) waits for a millisecond, not for a walk (a 20-step window
+// used to end with up to 17 ms of it: 0.85 ms per step).  The pieces are NOT ordered behind the step that asked for them: the
+// kernels find their work through the episode / tag words (acquire / release), so a host that runs hundreds of steps ahead of
+// the GPU does not starve the walks.  A walk is needed ~1 000 steps after it is asked for and takes 20-80 pieces; a reset that
+// comes too early for its walk simply walks inline (results never depend on it).
+static constexpr int kWalkBudget = 160;
+static void queue_walk_ahead(crl_car_ctx *c, hipStream_t, bool = false) {
     if (!c->overlap) return;
-    if (c->walk_pending && !force) {
-        if (hipEventQuery(c->ev_walk) == hipErrorNotReady) return;
-        c->walk_pending = false;
-    }
-    hipEventRecord(c->ev_reset, after);
-    hipStreamWaitEvent(c->gen, c->ev_reset, 0);
-    launch_car_walk_ahead(c->s, c->src, c->gen);
-    hipEventRecord(c->ev_walk, c->gen);
-    c->walk_pending = true;
+    static const int budget = CRL_ABL(getenv("CRL_CAR_WALK_BUDGET") != nullptr) ? atoi(getenv("CRL_CAR_WALK_BUDGET")) : kWalkBudget;
+    hipEvent_t &ev = c->ev_walk[c->walk_turn & 1];
+    if (c->walk_turn >= 2 && hipEventQuery(ev) == hipErrorNotReady) return;  // two pieces are still queued
+    launch_car_walk_ahead(c->s, c->src, c->gen, budget);
+    hipEventRecord(ev, c->gen);
+    c->walk_turn++;
 }
 void crl_car_seed(crl_car_ctx *c, uint64_t seed) {
     invalidate_walks(c);

@@ -33,7 +33,8 @@ for blk in range(steps // K):
     t0 = time.time()
     for t in range(K):
         env.step_device(acts[(blk * K + t) % NA])
+    th = (time.time() - t0) / K * 1e3  # the host's share: enqueueing a step (the GPU runs behind)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / K * 1e3
-    print(f"steps {blk * K:5d}-{blk * K + K - 1:5d}: {dt:8.3f} ms/step  cap_hits {env.cap_hits()}", flush=True)
+    print(f"steps {blk * K:5d}-{blk * K + K - 1:5d}: {dt:8.3f} ms/step  (host enqueue {th:.3f})  cap_hits {env.cap_hits()}", flush=True)
 env.close()
