@@ -535,3 +535,47 @@ env.close()
         assert r.returncode == 0 and "checksum" in r.stdout, (order, r.stdout[-500:], r.stderr[-1500:])
         sums.add(r.stdout.strip().splitlines()[-1])
     assert len(sums) == 1, sums
+
+
+def test_car_walk_ahead_pieces_give_the_same_tracks():
+    """The walk-ahead advances every pending track walk by a bounded number of iterations per launch and resumes it from its saved
+    state (csrc/car_track.hip WalkSave).  Whatever the piece size -- 7 iterations (hundreds of resumes per walk, mid-attempt and
+    across failed attempts), the default, or unbounded -- and however far the walks have got when an env is reset (a reset
+    that comes too early walks inline), the envs must see the same tracks: episodes of 60 steps, five resets per env (child
+    processes of the profiling build: the piece size is read once)."""
+    _need_gpu()
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import competitive_rl_amd as crl
+n = 48
+g = torch.Generator(device="cuda").manual_seed(2)
+acts = torch.rand((16, n, 2, 2), generator=g, device="cuda") * 2 - 1
+env = crl.HipCarVecEnv(n, seed=5)
+env.reset()
+st = env.get_state()
+st["elapsed"] = (1000 - 60 + np.arange(n) %% 60).astype(st["elapsed"].dtype)   # every env ends within 60 steps, then every 1000
+env.set_state(st)
+tot = torch.zeros((), dtype=torch.int64, device="cuda")
+for rnd in range(5):
+    for t in range(70):
+        o, r, d = env.step_device(acts[t %% 16])
+        tot += o.to(torch.int64).sum() + d.to(torch.int64).sum() * 7
+    st = env.get_state()
+    st["elapsed"] = (1000 - 60 + np.arange(n) %% 60).astype(st["elapsed"].dtype)
+    env.set_state(st)
+trk = sum(float(np.asarray(env.get_track(i)["tile_poly"], np.float64).sum()) for i in range(0, n, 5))
+print("checksum", int(tot), repr(trk), int(env.get_state()["episode"].astype("int64").sum()))
+env.close()
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = set()
+    for budget in ("7", "160", "0"):
+        env = dict(os.environ, CRL_LIB_VARIANT="abl", CRL_CAR_WALK_BUDGET=budget)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "checksum" in r.stdout, (budget, r.stdout[-500:], r.stderr[-1500:])
+        outs.add(r.stdout.strip().splitlines()[-1])
+    assert len(outs) == 1, outs
