@@ -558,15 +558,15 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         //   bulk   per-car solve -> camera, polygons -> frames of class 0 (the big launch)
         //   side2  env bookkeeping; the coupled envs where nothing touches (two islands of their own) -> their frames; the terminal
         //          frames of the finished envs on their own as soon as the per-car solve is in, their commit once the new episode is
-        //          staged; behind the touching solve the terminal frames + commit of the envs that are finished AND coupled; the
-        //          step's join; the NEXT step's Collide
+        //          staged; behind the touching solve the NEXT step's Collide; the step's join
         //   one    (HIGH priority) the wheel sensors (tile rewards, road_visited: they read the transforms the step started from and
         //          feed nothing into its solve; every frame shows the reward, so every frame launch waits for them), then the finished
-        //          envs' NEW episode, prepared early on the staged view: reset, map, first frame.  Round 4: the sensors used to have a
+        //          envs' NEW episode, prepared early on the staged view: reset, map, first frame; behind the touching solve the
+        //          terminal frames + commit of the few envs that are finished AND coupled.  Round 4: the sensors used to have a
         //          normal-priority stream of their own and finished at ~350 us; here they are done at ~135-250 us, everything that
         //          waits for them starts earlier, and the context needs one stream less (1.03 -> 0.93 ms per step, same box)
         // (streams of one priority share four hardware queues, and two streams that share one wait for each other's kernels;
-        // the milliseconds-long walk-ahead has a priority class of its own)
+        // the walk-ahead's pieces have a priority class of their own)
         uint8_t *target = c->K == 1 ? obs_dev : c->frame;
         hipEventRecord(c->ev_fork, st);
         hipStreamWaitEvent(c->side, c->ev_fork, 0);
