@@ -247,7 +247,7 @@ def run_workload(name, args, G):
                            "(BASELINE config #3)",
                 "fused84_f32": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack, float32 output (N,2,4,84,84): the "
                                "uint8 values widened to the dtype DummyVecEnv's buffers have (SURVEY 8d config-3 variant, 225 792 B/env; the "
-                               "reference's own UNROUNDED float32 values are obs_dtype='float32_ref', 2.4 M env-steps/s, not benchmarked here), "
+                               "reference's own UNROUNDED float32 values are obs_dtype='float32_ref', 8.6 M env-steps/s, not benchmarked here), "
                                "1 step = 4 frames",
                 "fused84_newest": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA, newest plane only (N,2,1,84,84) u8, "
                                   "1 step = 4 frames (variant of BASELINE config #3)"}[name]

@@ -100,6 +100,8 @@ struct crl_ctx {
     uint8_t *tab_blob = nullptr;
     GrayTabOfs tofs{};
     uint8_t *tile_hdr = nullptr;  // [n * views * K] 64-byte tile headers of the address-linear gray writer
+    float *f32_top = nullptr, *f32_bot = nullptr;  // CRL_OBS_F32_REF: court-without-objects tables (GrayParams)
+    int f32_bot0 = 0, f32_xtaps = 0, f32_ytaps = 0;
     // replay
     double *ru = nullptr;
     uint8_t *rbx = nullptr, *rby = nullptr;
@@ -282,6 +284,14 @@ static int setup_gray(crl_ctx *c) {
     launch_pong_gray_templates(p, c->x_first, c->x_last, c->y_first, c->y_last, c->band_rows, c->band_chunks, c->band,
                                c->rest, nullptr);
     HIP_TRY(hipGetLastError());
+    if (c->o.obs_dtype == CRL_OBS_F32_REF) {  // the unrounded float32 path's tables: 484 score pairs x 2 views x {unrounded, rounded}
+        c->f32_bot0 = yf[CRL_PONG_BOTTOM], c->f32_xtaps = (int)xt.si.size(), c->f32_ytaps = (int)yt.si.size();
+        p.band_rows = c->band_rows, p.f32_bot0 = c->f32_bot0;
+        if ((rc = dev_alloc(c, &c->f32_top, (size_t)484 * 4 * c->band_rows * R))) return rc;
+        if ((rc = dev_alloc(c, &c->f32_bot, (size_t)2 * (R - c->f32_bot0) * R))) return rc;
+        launch_pong_gray_f32ref_tables(p, c->f32_top, c->f32_bot, nullptr);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipDeviceSynchronize());
     // longest run of all-zero template rows below the score rows = the empty court
     std::vector<uint8_t> rest((size_t)R * R);
@@ -450,6 +460,7 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype, p.hdr = c->tile_hdr;
+        p.f32_top = c->f32_top, p.f32_bot = c->f32_bot, p.f32_bot0 = c->f32_bot0, p.f32_xtaps = c->f32_xtaps, p.f32_ytaps = c->f32_ytaps;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
@@ -566,6 +577,7 @@ static int render_ring(crl_ctx *c, const uint64_t *ring_dev, int64_t m, uint8_t 
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = out_dev, p.obs_f32 = c->o.obs_dtype;
+        p.f32_top = c->f32_top, p.f32_bot = c->f32_bot, p.f32_bot0 = c->f32_bot0, p.f32_xtaps = c->f32_xtaps, p.f32_ytaps = c->f32_ytaps;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
@@ -668,6 +680,7 @@ int crl_render_frames_dev(crl_ctx *c, const crl_pong_frame *desc_dev, int64_t co
         p.atlas_gray = c->atlas_gray, p.band = c->band, p.band_rows = c->band_rows;
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = out_dev, p.obs_f32 = c->o.obs_dtype;
+        p.f32_top = c->f32_top, p.f32_bot = c->f32_bot, p.f32_bot0 = c->f32_bot0, p.f32_xtaps = c->f32_xtaps, p.f32_ytaps = c->f32_ytaps;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }

@@ -238,7 +238,13 @@ struct GrayParams {
     uint8_t *obs;                   // [n][2][K][R][R]
     int obs_f32;                    // crl_obs_dtype of obs: 1 = float32, same values, widened in the store epilogue; 2 = the reference's unrounded float32 path
     void *hdr;                      // scratch for the address-linear writer: 64 B per (env, view, plane) tile, or nullptr
+    // CRL_OBS_F32_REF: the planes of a court WITHOUT ball and bats, per score pair (pong_raster_gray.hip pong_gray_f32ref_kernel)
+    const float *f32_top;           // [484][2 views][2: unrounded, rounded][band_rows][R] output rows fed by the score band
+    const float *f32_bot;           // [2][R - f32_bot0][R] output rows fed by the white band under the court (score-independent)
+    int f32_bot0;                   // first output row with a tap under the court
+    int f32_xtaps, f32_ytaps;       // entries of xsi / ysi (the kernel stages the tap tables in LDS)
 };
+void launch_pong_gray_f32ref_tables(const GrayParams &p, float *top, float *bot, hipStream_t st);
 void launch_pong_raster_gray(const GrayParams &p, hipStream_t st);
 
 }  // namespace crl

@@ -879,15 +879,90 @@ void pong_gray_print_ticks() {
 // kept frames are the same frame is such a reset observation (consecutive frames of a running game differ in the ball's x).
 // One wavefront per (env, view, plane) tile, lanes over the output columns, every tap evaluated from the frame descriptors in
 // OpenCV's accumulation order (eval_pixel's); source rows of the empty court are skipped (wave-uniform).  This is the exact
-// mode, not the fast one (milliseconds per step at 65 536 envs against 2.7 ms for the widened uint8 values, CRL_OBS_F32).
+// mode, not the fast one (7.6 ms per step at 65 536 envs against 2.7 ms for the widened uint8 values, CRL_OBS_F32).
 __device__ inline float gray_of_f32(int v) {
     const float f = (float)v;
     return f * 0.299f + f * 0.587f + f * 0.114f;  // (one rounding per operation: -ffp-contract=off)
 }
 
-__global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g, int R, int K, int views,
+// one output pixel of that path, OpenCV's accumulation order (eval_pixel's); rounded: a reset observation (the uint8 image)
+__device__ inline float f32ref_pixel(const GrayCtx &g, const Frame &fa, const Frame &fb, int view, int dy, int dx, bool rounded) {
+    const int j0 = g.yofs[dy], j1 = g.yofs[dy + 1];
+    const int k0 = g.xofs[dx], k1 = g.xofs[dx + 1];
+    float sum = 0.f;
+    for (int j = j0; j < j1; j++) {
+        const int r = g.ysi[j];
+        float buf = 0.f;
+        for (int k = k0; k < k1; k++) {
+            const int c = g.xsi[k];
+            const int sv = max(px_view(fa, g.atlas_gray, view, r, c), px_view(fb, g.atlas_gray, view, r, c));
+            buf = buf + (rounded ? (float)sv : gray_of_f32(sv)) * g.xalpha[k];
+        }
+        const float tj = g.yalpha[j] * buf;
+        sum = (j == j0) ? tj : sum + tj;
+    }
+    if (rounded) {
+        const int v = (int)rintf(sum);
+        sum = (float)min(max(v, 0), 255);
+    }
+    return sum;
+}
+
+// a frame with the given scores whose ball and bats are parked in the middle of the court: what the top / bottom band tables are
+// drawn from (an output pixel of a real plane differs from them only where its taps touch a ball or a bat: those are re-drawn)
+__device__ inline Frame parked_frame(int sl, int sr) {
+    Frame f;
+    f.sl = sl, f.sr = sr, f.x = 78, f.y = 112, f.bl = 100, f.br = 100;
+    return f;
+}
+
+__global__ __launch_bounds__(256) void pong_gray_f32ref_table_kernel(GrayCtx g, int R, int band_rows, int bot0, float *__restrict__ top,
+                                                                     float *__restrict__ bot) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ntop = (int64_t)484 * 2 * 2 * band_rows * R, nbot = (int64_t)2 * (R - bot0) * R;
+    if (i < ntop) {
+        const int dx = (int)(i % R), dy = (int)(i / R % band_rows), rnd = (int)(i / ((int64_t)R * band_rows) % 2);
+        const int view = (int)(i / ((int64_t)R * band_rows * 2) % 2), pair = (int)(i / ((int64_t)R * band_rows * 4));
+        const Frame f = parked_frame(pair / 22, pair % 22);
+        top[i] = f32ref_pixel(g, f, f, view, dy, dx, rnd != 0);
+    } else if (i < ntop + nbot) {
+        const int64_t q = i - ntop;
+        const int dx = (int)(q % R), dy = bot0 + (int)(q / R % (R - bot0)), rnd = (int)(q / ((int64_t)R * (R - bot0)));
+        const Frame f = parked_frame(0, 0);
+        bot[q] = f32ref_pixel(g, f, f, 0, dy, dx, rnd != 0);
+    }
+}
+
+void launch_pong_gray_f32ref_tables(const GrayParams &p, float *top, float *bot, hipStream_t st) {
+    GrayCtx g = {p.atlas_gray, p.xofs, p.yofs, p.xsi, p.ysi, p.xalpha, p.yalpha};
+    const int64_t total = (int64_t)484 * 4 * p.band_rows * p.R + (int64_t)2 * (p.R - p.f32_bot0) * p.R;
+    hipLaunchKernelGGL(pong_gray_f32ref_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, p.R, p.band_rows, p.f32_bot0, top, bot);
+}
+
+// One wavefront per (env, view, plane) tile.  Usual case (both kept frames show the same scores): the plane is the score pair's
+// band rows + an empty court + the white band, copied, and the few dozen output pixels whose taps touch the ball or a bat of
+// either frame, re-drawn exactly -- every other pixel sees the same source values as in the table.  Otherwise (a point was
+// scored between the two frames) every pixel is evaluated.  The tap tables are staged in LDS once per workgroup (an output
+// pixel's evaluation is a chain of ~25 dependent table reads).
+struct F32RefGeom {
+    const float *top, *bot;
+    int band_rows, bot0;
+    const uint8_t *x_first, *x_last, *y_first, *y_last;
+    int xtaps, ytaps;  // entries of the x / y tap tables
+};
+static constexpr int kF32MaxR = 84, kF32MaxTaps = 3 * kF32MaxR + 8;
+__global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx gg, F32RefGeom q, int R, int K, int views,
                                                                float *__restrict__ obs) {
-    constexpr int MAXT = 6;  // taps per output pixel and axis (R >= 8: at most ceil(210 / 8) ... the tables of crl_create never exceed 5; checked below)
+    __shared__ int32_t s_xofs[kF32MaxR + 1], s_yofs[kF32MaxR + 1], s_xsi[kF32MaxTaps], s_ysi[kF32MaxTaps];
+    __shared__ float s_xalpha[kF32MaxTaps], s_yalpha[kF32MaxTaps];
+    GrayCtx g = gg;
+    if (R <= kF32MaxR && q.xtaps <= kF32MaxTaps && q.ytaps <= kF32MaxTaps) {  // (uniform)
+        for (int i = threadIdx.x; i <= R; i += 256) s_xofs[i] = gg.xofs[i], s_yofs[i] = gg.yofs[i];
+        for (int i = threadIdx.x; i < q.xtaps; i += 256) s_xsi[i] = gg.xsi[i], s_xalpha[i] = gg.xalpha[i];
+        for (int i = threadIdx.x; i < q.ytaps; i += 256) s_ysi[i] = gg.ysi[i], s_yalpha[i] = gg.yalpha[i];
+        g.xofs = s_xofs, g.yofs = s_yofs, g.xsi = s_xsi, g.ysi = s_ysi, g.xalpha = s_xalpha, g.yalpha = s_yalpha;
+    }
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int tiles_per_env = views * K;
@@ -904,49 +979,55 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
     const bool rounded = pa == pb || fa.sl == 255 || fb.sl == 255;  // a reset observation: the uint8 path
     if (fa.sl == 255) fa = fb;
     else if (fb.sl == 255) fb = fa;
-    // court rows that hold a ball or a bat of either frame (view coordinates do not change rows)
-    auto row_live = [&](int r) {
-        if (r < CRL_PONG_TOP || r >= CRL_PONG_BOTTOM) return true;
-        return (unsigned)(r - fa.y) < (unsigned)CRL_PONG_BALL || (unsigned)(r - fb.y) < (unsigned)CRL_PONG_BALL ||
-               (unsigned)(r - fa.bl) < (unsigned)CRL_PONG_BAT_H || (unsigned)(r - fb.bl) < (unsigned)CRL_PONG_BAT_H ||
-               (unsigned)(r - fa.br) < (unsigned)CRL_PONG_BAT_H || (unsigned)(r - fb.br) < (unsigned)CRL_PONG_BAT_H;
-    };
-#pragma unroll 1
-    for (int dx = lane; dx < R; dx += 64) {  // this lane's column: its taps stay in registers for the whole tile
-        const int k0 = g.xofs[dx], nk = g.xofs[dx + 1] - k0;
-        int cs[MAXT];
-        float al[MAXT];
+    if (fa.sl != fb.sl || fa.sr != fb.sr || q.band_rows > q.bot0) {  // different score texts in the two frames (or a tiny R): every pixel
+        for (int i = lane; i < R * R; i += 64) out[i] = f32ref_pixel(g, fa, fb, view, i / R, i - (i / R) * R, rounded);
+        return;
+    }
+    {
+        const float *top = q.top + ((((int64_t)(fa.sl * 22 + fa.sr) * 2 + view) * 2 + (rounded ? 1 : 0)) * q.band_rows) * R;
+        const float *bot = q.bot + (int64_t)(rounded ? 1 : 0) * (R - q.bot0) * R;
+        const int ntop = q.band_rows * R, nbot0 = q.bot0 * R;
+        for (int i = lane; i < ntop; i += 64) out[i] = top[i];
+        for (int i = ntop + lane; i < nbot0; i += 64) out[i] = 0.0f;
+        for (int i = nbot0 + lane; i < R * R; i += 64) out[i] = bot[i - nbot0];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the re-drawn pixels below overwrite what other lanes have just stored: those stores first
+    // ball, left bat, right bat of both frames: source rectangle -> the output pixels it feeds; one list over the six rectangles
+    // (where two of them overlap a pixel is drawn twice, to the same value)
+    int rdx0[6], rwx[6], rdy0[6], rend[6], total = 0;
 #pragma unroll
-        for (int k = 0; k < MAXT; k++) cs[k] = k < nk ? g.xsi[k0 + k] : 0, al[k] = k < nk ? g.xalpha[k0 + k] : 0.f;
-#pragma unroll 1
-        for (int dy = 0; dy < R; dy++) {
-            const int j0 = g.yofs[dy], j1 = g.yofs[dy + 1];
-            float sum = 0.f;
-            for (int j = j0; j < j1; j++) {
-                const int r = g.ysi[j];  // (wave-uniform, like the row tests)
-                float buf = 0.f;
-                if (row_live(r)) {
-#pragma unroll
-                    for (int k = 0; k < MAXT; k++) {
-                        if (k < nk) {
-                            const int sv = max(px_view(fa, g.atlas_gray, view, r, cs[k]), px_view(fb, g.atlas_gray, view, r, cs[k]));
-                            buf = buf + (rounded ? (float)sv : gray_of_f32(sv)) * al[k];
-                        }
-                    }
-                    for (int k = MAXT; k < nk; k++) {  // (never with crl_create's sizes; kept exact for any table)
-                        const int sv = max(px_view(fa, g.atlas_gray, view, r, g.xsi[k0 + k]), px_view(fb, g.atlas_gray, view, r, g.xsi[k0 + k]));
-                        buf = buf + (rounded ? (float)sv : gray_of_f32(sv)) * g.xalpha[k0 + k];
-                    }
-                }
-                const float tj = g.yalpha[j] * buf;
-                sum = (j == j0) ? tj : sum + tj;
+    for (int o = 0; o < 6; o++) {
+        const Frame &f = o < 3 ? fa : fb;
+        const int k = o % 3;
+        int x0 = k == 0 ? f.x : k == 1 ? CRL_PONG_BATL_X : CRL_PONG_BATR_X, w = k == 0 ? CRL_PONG_BALL : CRL_PONG_BAT_W;
+        int y0 = k == 0 ? f.y : k == 1 ? f.bl : f.br, h = k == 0 ? CRL_PONG_BALL : CRL_PONG_BAT_H;
+        int x1 = min(x0 + w - 1, CRL_PONG_W - 1), y1 = min(y0 + h - 1, CRL_PONG_BOTTOM - 1);
+        x0 = max(x0, 0), y0 = max(y0, CRL_PONG_TOP);  // (px_view draws the court's rows only)
+        int npx = 0;
+        rdx0[o] = rwx[o] = rdy0[o] = 0;
+        const bool twice = o >= 3 && (k == 0 ? (fb.x == fa.x && fb.y == fa.y) : k == 1 ? fb.bl == fa.bl : fb.br == fa.br);  // the same rectangle as in frame a
+        if (x0 <= x1 && y0 <= y1 && !twice) {
+            if (view == 1) {  // court rows are mirrored in the second view
+                const int m0 = CRL_PONG_W - 1 - x1, m1 = CRL_PONG_W - 1 - x0;
+                x0 = m0, x1 = m1;
             }
-            if (rounded) {
-                const int v = (int)rintf(sum);
-                sum = (float)min(max(v, 0), 255);
-            }
-            out[dy * R + dx] = sum;
+            const int dx0 = q.x_first[x0], dx1 = q.x_last[x1], dy0 = q.y_first[y0], dy1 = q.y_last[y1];
+            rdx0[o] = dx0, rwx[o] = dx1 - dx0 + 1, rdy0[o] = dy0, npx = rwx[o] * (dy1 - dy0 + 1);
         }
+        total += npx;
+        rend[o] = total;
+    }
+    for (int i = lane; i < total; i += 64) {
+        int o = 0, base = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (i >= rend[k]) o = k + 1, base = rend[k];
+        int dx0 = rdx0[0], wx = rwx[0], dy0 = rdy0[0];
+#pragma unroll
+        for (int k = 1; k < 6; k++)
+            if (o == k) dx0 = rdx0[k], wx = rwx[k], dy0 = rdy0[k];
+        const int j = i - base, dy = dy0 + j / wx, dx = dx0 + j % wx;
+        out[dy * R + dx] = f32ref_pixel(g, fa, fb, view, dy, dx, rounded);
     }
 }
 
@@ -969,7 +1050,8 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     if (p.obs_f32 == 2) {  // CRL_OBS_F32_REF
         const int views = p.views > 0 ? p.views : 2;
         const int64_t tiles = p.n * views * p.K;
-        hipLaunchKernelGGL(pong_gray_f32ref_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, p.R, p.K, views,
+        const F32RefGeom fq = {p.f32_top, p.f32_bot, p.band_rows, p.f32_bot0, x_first, x_last, y_first, y_last, p.f32_xtaps, p.f32_ytaps};
+        hipLaunchKernelGGL(pong_gray_f32ref_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, fq, p.R, p.K, views,
                            reinterpret_cast<float *>(p.obs));
         return;
     }
