@@ -877,9 +877,8 @@ void pong_gray_print_ticks() {
 // cv2.cvtColor computes gray = R * 0.299f + G * 0.587f + B * 0.114f in float32 and cv2.resize(INTER_AREA) returns the UNROUNDED
 // area average of that; reset() and the auto-reset of a finished env go through the uint8 image (rounded).  A plane whose two
 // kept frames are the same frame is such a reset observation (consecutive frames of a running game differ in the ball's x).
-// One wavefront per (env, view, plane) tile, lanes over the output columns, every tap evaluated from the frame descriptors in
-// OpenCV's accumulation order (eval_pixel's); source rows of the empty court are skipped (wave-uniform).  This is the exact
-// mode, not the fast one (7.6 ms per step at 65 536 envs against 2.7 ms for the widened uint8 values, CRL_OBS_F32).
+// Every tap is evaluated from the frame descriptors in OpenCV's accumulation order (eval_pixel's).  This is the exact mode, not
+// the fast one (7.6 ms per step at 65 536 envs against 2.7 ms for the widened uint8 values, CRL_OBS_F32).
 __device__ inline float gray_of_f32(int v) {
     const float f = (float)v;
     return f * 0.299f + f * 0.587f + f * 0.114f;  // (one rounding per operation: -ffp-contract=off)
