@@ -605,7 +605,8 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         if (contacts) {  // crit again: the touching envs' frames, behind their solve (wave priority 3: beside the big launch's 32 768 wavefronts)
             hipStreamWaitEvent(crit, c->ev_sens, 0);
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
-            else launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, true);
+            else if (!CRL_ABL(getenv("CRL_CAR_ABL_NO_TOUCH_FRAMES") != nullptr))  // (timing ablation, WRONG frames: what the step costs without them)
+                launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, true);
         }
         // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
         // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared
@@ -660,7 +661,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve
         if (early_collide) {
             hipStreamWaitEvent(c->one, c->ev_coupled, 0);
-            terminal_frames(c->one, 3, 8, nullptr);
+            if (!CRL_ABL(getenv("CRL_CAR_ABL_NO_C3") != nullptr)) terminal_frames(c->one, 3, 8, nullptr);  // (timing ablation: no terminal frames for class 3)
             launch_car_commit_list(c->s, sv, list_of(3), count_of(3), 8, c->one);
             hipEventRecord(c->ev_c3, c->one);
             collide_next(true);
