@@ -707,7 +707,14 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     int nc_wave = nc;  // contacts past NK: the wavefront's loop runs to the largest count in it
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) nc_wave = max(nc_wave, __shfl_xor(nc_wave, d));
-    if (me == 0) {  // this step's manifolds, from the narrow phase
+    constexpr int kCW = (int)(sizeof(Contact) / 4);  // a Contact is its first 17 persisted words, in order (kContactWords = the stride in memory)
+    static_assert(sizeof(Contact) == 17 * 4 && kCW <= kContactWords, "Contact layout");
+    if (EPW == 1) {  // one env per wavefront: every lane mirrors it -- the words of its manifolds go one per lane (a lone lane's
+                     // 17 loads per manifold, one after the other, were a quarter of the setup of an eight-manifold island)
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(s.contact_new + env * (int64_t)(kMaxContacts * kContactWords));
+        uint32_t *dst = reinterpret_cast<uint32_t *>(ct);
+        for (int i = threadIdx.x; i < nc * kCW; i += 64) dst[i] = in[(i / kCW) * kContactWords + i % kCW];
+    } else if (me == 0) {  // this step's manifolds, from the narrow phase
         const float *in = s.contact_new + env * (int64_t)(kMaxContacts * kContactWords);
         for (int k = 0; k < nc; k++) {
             const float *o = in + k * kContactWords;
@@ -733,8 +740,9 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 #pragma unroll
         for (int w = 0; w < 4; w++) mW[w].vx = r.W[w].vx, mW[w].vy = r.W[w].vy, mW[w].w = r.W[w].w;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (me == 0) {
-            for (int k = 0; k < nc; k++) {
+        // EPW == 1: manifold k's constraint rows by lane k (they depend on the poses and the manifold only); else lane 0 of the pair
+        if (EPW == 1 ? (int)threadIdx.x < nc : me == 0) {
+            for (int k = EPW == 1 ? (int)threadIdx.x : 0; k < (EPW == 1 ? (int)threadIdx.x + 1 : nc); k++) {
                 Contact &c = ct[k];
                 ContactVC q;
                 const BRef A = body_of(car[0], K, c.pair >> 3), B = body_of(car[1], K, c.pair & 7);
@@ -780,6 +788,9 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
                 t.k10 = q.K[1][0], t.k11 = q.K[1][1], t.ik00 = q.invK[0][0], t.ik01 = q.invK[0][1];
                 t.ik10 = q.invK[1][0], t.ik11 = q.invK[1][1], t.count = q.count, t.pair = c.pair;
             }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (me == 0) {  // warm start: in contact order (the bodies' velocities chain through it)
             for (int k = 0; k < nc; k++) {
                 const TouchC &t = tc[k];
                 const BRef A = body_of(car[0], K, t.pair >> 3), B = body_of(car[1], K, t.pair & 7);
@@ -879,16 +890,27 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     const float mm = isl_sleep_scan(r, slp, h);
     const float mo = __shfl_xor(mm, 1);
     if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(r, slp);
+#ifdef CRL_ABLATION
+    const unsigned long long st3b = __builtin_readcyclecounter();
+#endif
+    if (EPW == 1) {  // the manifolds with their impulses, one word per lane (every lane mirrors the env)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(ct);
+        uint32_t *out = reinterpret_cast<uint32_t *>(s.contact + env * (int64_t)(kMaxContacts * kContactWords));
+        for (int i = threadIdx.x; i < nc * kCW; i += 64) out[(i / kCW) * kContactWords + i % kCW] = src[i];
+    }
     if (!live) return;
     for (int b = 0; b < 5; b++) s.sleep[b * M + me * s.n + env] = slp[b];
 
     // ---- store bodies, joints and the manifolds with their impulses
     store_car(s, M, me * s.n + env, r);
     s.first_step[me * s.n + env] = 0;
+#ifdef CRL_ABLATION
+    const unsigned long long st3c = __builtin_readcyclecounter();
+#endif
     if (me != 0) return;
     s.n_contact[env] = nc;
     float *out = s.contact + env * (int64_t)(kMaxContacts * kContactWords);
-    for (int k = 0; k < nc; k++) {
+    for (int k = 0; k < (EPW == 1 ? 0 : nc); k++) {
         float *o = out + k * kContactWords;
         const Contact &c = ct[k];
         o[0] = __int_as_float(c.pair), o[1] = __int_as_float(c.count), o[2] = __int_as_float(c.type);
@@ -902,7 +924,7 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         const unsigned long long st4 = __builtin_readcyclecounter();
         unsigned long long *q = s.stamps + 8 * (NK - 1);
         atomicAdd(q + 0, st1 - st0), atomicAdd(q + 1, st2 - st1), atomicAdd(q + 2, st3 - st2), atomicAdd(q + 3, st4 - st3);
-        atomicAdd(q + 4, (unsigned long long)pi_wave), atomicMax(q + 5, st4 - st0), atomicAdd(q + 7, 1ull);
+        atomicAdd(q + 4, (unsigned long long)pi_wave), atomicMax(q + 5, st4 - st0), atomicAdd(q + 6, st3c - st3b), atomicAdd(q + 7, 1ull);
     }
 #endif
 }

@@ -348,8 +348,8 @@ void crl_car_destroy(crl_car_ctx *c) {
         for (int cls = 0; cls < 3; cls++) {
             const unsigned long long *q = h + 8 * cls;
             const double w = q[7] ? (double)q[7] : 1.0;
-            fprintf(stderr, "touch class %d: %llu waves; mean cycles setup %.0f | velocity %.0f | position %.0f (%.1f iterations) | store %.0f | max total %llu\n", cls + 1,
-                    q[7], q[0] / w, q[1] / w, q[2] / w, q[4] / w, q[3] / w, q[5]);
+            fprintf(stderr, "touch class %d: %llu waves; mean cycles setup %.0f | velocity %.0f | position %.0f (%.1f iterations) | store %.0f (sleep scan %.0f) | max total %llu\n", cls + 1,
+                    q[7], q[0] / w, q[1] / w, q[2] / w, q[4] / w, q[3] / w, q[6] / w, q[5]);
         }
         const unsigned long long *q = h + 32;
         const double w = q[7] ? (double)q[7] : 1.0;
