@@ -494,8 +494,8 @@ struct KC {  // one contact in registers
     int bi;     // this lane's body of the contact: 0 = hull, 1..4 = wheels 0..3
     float mA, iA, mB, iB;
     bool ok;  // the env has this contact (k < nc)
-    int ccount, ctype;  // manifold (position pass)
-    float lnx, lny, lpx, lpy, pt0x, pt0y, pt1x, pt1y;
+    // (the manifold itself -- what the position pass needs -- stays in its LDS row: ten registers per contact that nothing reads in
+    // the 180 velocity iterations were what the allocator spilled to scratch and reloaded one by one afterwards)
 };
 
 __device__ __forceinline__ float lane_swap(float x) {  // the value of the other lane of the pair (DPP quad_perm [1,0,3,2])
@@ -535,8 +535,7 @@ __device__ __forceinline__ KC kc_load(const TouchC &t, const Contact &c, int me,
     q.mA = fA < 4 ? K.hull_inv_mass : K.wheel_inv_mass, q.iA = fA < 4 ? K.hull_inv_I : K.wheel_inv_I;
     q.mB = fB < 4 ? K.hull_inv_mass : K.wheel_inv_mass, q.iB = fB < 4 ? K.hull_inv_I : K.wheel_inv_I;
     q.ok = ok;
-    q.ccount = c.count, q.ctype = c.type, q.lnx = c.ln[0], q.lny = c.ln[1], q.lpx = c.lp[0], q.lpy = c.lp[1];
-    q.pt0x = c.pt[0][0], q.pt0y = c.pt[0][1], q.pt1x = c.pt[1][0], q.pt1y = c.pt[1][1];
+    (void)c;
     return q;
 }
 
@@ -624,13 +623,15 @@ __device__ __forceinline__ void contact_vel(CarRegs &r, KC &q, const int me, con
 }
 
 // b2ContactSolver::SolvePositionConstraints for one contact (both manifold points)
-__device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const int me, const V2 hlc, float &minSep) {
+__device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const Contact &c, const int me, const V2 hlc, float &minSep) {
     const int bi = q.bi;
+    const int ccount = c.count, ctype = c.type;
+    const float lnx = c.ln[0], lny = c.ln[1], lpx = c.lp[0], lpy = c.lp[1];
     const float mA = q.mA, iA = q.iA, mB = q.mB, iB = q.iB;
     const V2 mylc = bi == 0 ? hlc : mk(0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const bool ok = q.ok && j < q.ccount;
+        const bool ok = q.ok && j < ccount;
         if (!__any(ok)) continue;  // (no island of this wavefront has this point: with one env per wavefront, exactly this island)
         // this lane's body (centre, angle) -> its transform; the partner's through DPP
         const float ocx = CRL_SEL(cx, bi), ocy = CRL_SEL(cy, bi), oa = CRL_SEL(a, bi);
@@ -643,16 +644,16 @@ __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const int m
         const XF xa = me ? px : ox, xb = me ? ox : px;
         V2 cA = me ? mk(pcx, pcy) : mk(ocx, ocy), cB = me ? mk(ocx, ocy) : mk(pcx, pcy);
         float aA = me ? pa : oa, aB = me ? oa : pa;
-        const V2 lpt = j ? mk(q.pt1x, q.pt1y) : mk(q.pt0x, q.pt0y);
+        const V2 lpt = mk(c.pt[j][0], c.pt[j][1]);
         V2 normal, point;
         float sep;
-        if (q.ctype == 0) {
-            normal = rotv(xa.s, xa.c, mk(q.lnx, q.lny));
-            const V2 plane = xmul(xa, mk(q.lpx, q.lpy)), clip = xmul(xb, lpt);
+        if (ctype == 0) {
+            normal = rotv(xa.s, xa.c, mk(lnx, lny));
+            const V2 plane = xmul(xa, mk(lpx, lpy)), clip = xmul(xb, lpt);
             sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
         } else {
-            normal = rotv(xb.s, xb.c, mk(q.lnx, q.lny));
-            const V2 plane = xmul(xb, mk(q.lpx, q.lpy)), clip = xmul(xa, lpt);
+            normal = rotv(xb.s, xb.c, mk(lnx, lny));
+            const V2 plane = xmul(xb, mk(lpx, lpy)), clip = xmul(xa, lpt);
             sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
             normal = -1.0f * normal;
         }
@@ -728,8 +729,6 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-    float slp[5];  // b2Body::m_sleepTime of this lane's car
-    for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + me * s.n + env];
     CarRegs r = car[me];
     Body &mH = car[me].H;
     Body(&mW)[4] = car[me].W;
@@ -852,7 +851,20 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     const unsigned long long st2 = __builtin_readcyclecounter();
     int pos_iters = 0;
 #endif
-    isl_integrate_pos(r, h);
+    // (the poses did not change since the car was loaded: from the LDS copy again, so that they need no registers across the
+    // velocity iterations)
+    r.H.cx = mH.cx, r.H.cy = mH.cy, r.H.a = mH.a;
+#pragma unroll
+    for (int w = 0; w < 4; w++) r.W[w].cx = mW[w].cx, r.W[w].cy = mW[w].cy, r.W[w].a = mW[w].a;
+    // Behind the position integration velocities, joint impulses and limit states are final: stored then, while they are in registers (the position
+    // iterations need every register for their sines and cosines; what they do not touch went to scratch and came back one
+    // value at a time for the stores at the end: 30-45 k cycles behind the last iteration of the step's slowest islands).
+    // The island's sleep scan only reads the velocities: here as well.
+    isl_integrate_pos(r, h);  // (clamps velocities that would move a body too far in one step: final only now)
+    if (live) store_car_vel(s, M, me * s.n + env, r);
+    float slp[5];  // b2Body::m_sleepTime of this lane's car
+    for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + me * s.n + env];
+    const float mm = isl_sleep_scan(r, slp, h);
     bool solved = false;
     const V2 hlc = mk(K.hull_lc[0], K.hull_lc[1]);
 #pragma unroll 1
@@ -862,13 +874,13 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         pos_iters = it + 1;
 #endif
 #pragma unroll
-        for (int k = 0; k < NK; k++) contact_pos(r, kc[k], me, hlc, minSep);
+        for (int k = 0; k < NK; k++) contact_pos(r, kc[k], ct[k < nc ? k : 0], me, hlc, minSep);
         if (TAIL) {
 #pragma unroll 1
             for (int k = NK; k < nc_wave; k++) {
                 const bool ok = k < nc;
                 const KC q = kc_load(tc[ok ? k : 0], ct[ok ? k : 0], me, ok, K);
-                contact_pos(r, q, me, hlc, minSep);
+                contact_pos(r, q, ct[ok ? k : 0], me, hlc, minSep);
             }
         }
         const bool cok = minSep >= -3.0f * LINEAR_SLOP;
@@ -887,22 +899,24 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     for (int d = 1; d < 64; d <<= 1) pi_wave = max(pi_wave, __shfl_xor(pi_wave, d));
 #endif
     // one island: it sleeps only when all ten bodies have been still long enough
-    const float mm = isl_sleep_scan(r, slp, h);
     const float mo = __shfl_xor(mm, 1);
-    if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(r, slp);
-#ifdef CRL_ABLATION
-    const unsigned long long st3b = __builtin_readcyclecounter();
-#endif
+    if (fminf(mm, mo) >= TIME_TO_SLEEP && solved) {
+        isl_put_to_sleep(r, slp);
+        if (live) store_car_vel(s, M, me * s.n + env, r);  // (the velocities again: zero)
+    }
     if (EPW == 1) {  // the manifolds with their impulses, one word per lane (every lane mirrors the env)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(ct);
         uint32_t *out = reinterpret_cast<uint32_t *>(s.contact + env * (int64_t)(kMaxContacts * kContactWords));
         for (int i = threadIdx.x; i < nc * kCW; i += 64) out[(i / kCW) * kContactWords + i % kCW] = src[i];
     }
     if (!live) return;
+#ifdef CRL_ABLATION
+    const unsigned long long st3b = __builtin_readcyclecounter();
+#endif
     for (int b = 0; b < 5; b++) s.sleep[b * M + me * s.n + env] = slp[b];
 
     // ---- store bodies, joints and the manifolds with their impulses
-    store_car(s, M, me * s.n + env, r);
+    store_car_pos(s, M, me * s.n + env, r);
     s.first_step[me * s.n + env] = 0;
 #ifdef CRL_ABLATION
     const unsigned long long st3c = __builtin_readcyclecounter();

@@ -360,6 +360,27 @@ __device__ inline float isl_sleep_scan(const CarRegs &c, float *sleep, float h) 
     }
     return min_sleep;
 }
+// the same in two halves: what the velocity iterations leave final (velocities, joint impulses and states) and the poses
+__device__ inline void store_car_vel(const CarSoA &s, int64_t M, int64_t ci, const CarRegs &c) {
+    float *b = s.body + ci;
+    b[3 * M] = c.H.vx, b[4 * M] = c.H.vy, b[5 * M] = c.H.w;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int o = 6 + 6 * w;
+        b[(o + 3) * M] = c.W[w].vx, b[(o + 4) * M] = c.W[w].vy, b[(o + 5) * M] = c.W[w].w;
+        s.jimp[(3 * w + 0) * M + ci] = c.imp[w][0], s.jimp[(3 * w + 1) * M + ci] = c.imp[w][1], s.jimp[(3 * w + 2) * M + ci] = c.imp[w][2];
+        s.jmotor[w * M + ci] = c.motor_imp[w], s.jspeed[w * M + ci] = c.motor_speed[w], s.jlimit[w * M + ci] = c.lim[w];
+    }
+}
+__device__ inline void store_car_pos(const CarSoA &s, int64_t M, int64_t ci, const CarRegs &c) {
+    float *b = s.body + ci;
+    b[0 * M] = c.H.cx, b[1 * M] = c.H.cy, b[2 * M] = c.H.a;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int o = 6 + 6 * w;
+        b[(o + 0) * M] = c.W[w].cx, b[(o + 1) * M] = c.W[w].cy, b[(o + 2) * M] = c.W[w].a;
+    }
+}
 __device__ inline void isl_put_to_sleep(CarRegs &c, float *sleep) {
     c.H.vx = c.H.vy = c.H.w = 0.0f;
 #pragma unroll

@@ -402,11 +402,21 @@ static void invalidate_walks(crl_car_ctx *c) {
 // the GPU does not starve the walks.  A walk is needed ~1 000 steps after it is asked for and takes 20-80 pieces; a reset that
 // comes too early for its walk simply walks inline (results never depend on it).
 static constexpr int kWalkBudget = 160;
-static void queue_walk_ahead(crl_car_ctx *c, hipStream_t, bool = false) {
+// (behind_reset: after a FULL reset the piece is ordered behind it -- that reset walks every env itself, on the caller's stream and
+// into the same scratch, and a piece that started another attempt of the same walk beside it would overwrite its points)
+static void queue_walk_ahead(crl_car_ctx *c, hipStream_t after, bool behind_reset = false) {
     if (!c->overlap) return;
     static const int budget = CRL_ABL(getenv("CRL_CAR_WALK_BUDGET") != nullptr) ? atoi(getenv("CRL_CAR_WALK_BUDGET")) : kWalkBudget;
     hipEvent_t &ev = c->ev_walk[c->walk_turn & 1];
-    if (c->walk_turn >= 2 && hipEventQuery(ev) == hipErrorNotReady) return;  // two pieces are still queued
+#ifdef CRL_TEST_WALK_UNORDERED  // (a test build reproduces the race tests/test_hip_round2.py guards against)
+    behind_reset = false;
+#endif
+    if (behind_reset) {
+        hipEventRecord(c->ev_reset, after);
+        hipStreamWaitEvent(c->gen, c->ev_reset, 0);
+    } else if (c->walk_turn >= 2 && hipEventQuery(ev) == hipErrorNotReady) {
+        return;  // two pieces are still queued
+    }
     launch_car_walk_ahead(c->s, c->src, c->gen, budget);
     hipEventRecord(ev, c->gen);
     c->walk_turn++;
