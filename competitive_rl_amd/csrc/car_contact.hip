@@ -332,7 +332,9 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
         }
     }
     __syncthreads();
-    __shared__ WPoly wp[64][2];
+    // the 16 fixtures of the env in world space (car 0's at [f], car 1's at [8 + f]): built once by 16 lanes, read by every pair.
+    // (One copy per PAIR -- 17 KB per workgroup -- allowed eight workgroups per CU: 2 300 coupled envs took two rounds of the kernel.)
+    __shared__ WPoly wp[16];
     const int count = *s.coupled_count;
     const int64_t M = 2 * s.n;
 #ifdef CRL_ABLATION
@@ -378,17 +380,22 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
             const bool cand = !(dx * dx + dy * dy > rr * rr);
             // (wave-uniform: does any candidate pair of this env involve the hull's octagon?)
             const bool big = __any(cand && (shape_of(K, fa).n > 4 || shape_of(K, fb).n > 4));
-            if (cand) {
+            if (__any(cand)) {  // (wave-uniform) every fixture into world space once: vertices, and normals as rotv(q, local normal)
 #pragma unroll
-                for (int k = 0; k < 2; k++) {  // both fixtures into world space once: vertices, and normals as rotv(q, local normal)
-                    const int f = k ? fb : fa;
-                    const Shape sh = shape_of(K, f);
-                    WPoly &w = wp[lane][k];
-                    w.cnt = sh.n;
-                    for (int i = 0; i < sh.n; i++) w.w[i] = xmul(xf[k], shape_vertex(sh, i)), w.n[i] = rotv(xf[k].s, xf[k].c, nl[f < 4 ? f : 4][i]);
+                for (int k = 0; k < 2; k++) {
+                    if (k == 0 ? fb == 0 : fa == 0) {  // this lane builds car k's fixture (pairs (fa, 0) and (0, fb) are active ones)
+                        const int f = k ? fb : fa;
+                        const Shape sh = shape_of(K, f);
+                        WPoly &w = wp[8 * k + f];
+                        w.cnt = sh.n;
+                        for (int i = 0; i < sh.n; i++) w.w[i] = xmul(xf[k], shape_vertex(sh, i)), w.n[i] = rotv(xf[k].s, xf[k].c, nl[f < 4 ? f : 4][i]);
+                    }
                 }
-                if (big) collide_polygons_w<8>(c, shape_of(K, fa), xf[0], wp[lane][0], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[lane][1], nl[fb < 4 ? fb : 4]);
-                else collide_polygons_w<4>(c, shape_of(K, fa), xf[0], wp[lane][0], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[lane][1], nl[fb < 4 ? fb : 4]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (cand) {
+                if (big) collide_polygons_w<8>(c, shape_of(K, fa), xf[0], wp[fa], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[8 + fb], nl[fb < 4 ? fb : 4]);
+                else collide_polygons_w<4>(c, shape_of(K, fa), xf[0], wp[fa], nl[fa < 4 ? fa : 4], shape_of(K, fb), xf[1], wp[8 + fb], nl[fb < 4 ? fb : 4]);
             }
         }
 #ifdef CRL_ABLATION
