@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) void car_obs_kernel(CarSoA s, uint8_t *__restri
 // The envs of a compacted list (the small env classes of a step): camera, polygons and tile in ONE launch, one wavefront per
 // tile -- every lane computes the (uniform) camera, lanes 0-15 the polygons, everything handed over through LDS.  Three
 // dependent launches of a few hundred wavefronts each cost three launch latencies at the end of a step.
-__global__ __launch_bounds__(64) void car_obs_list_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
+__global__ __launch_bounds__(64, 3) void car_obs_list_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
                                                           const int32_t *__restrict__ list_count, int32_t *__restrict__ count_to_host,
                                                           const uint8_t *__restrict__ filter, int want, int urgent) {
     if (urgent) __builtin_amdgcn_s_setprio(3);  // the launch at the end of the step's longest chain, beside the big frame launch's 32 768 wavefronts
