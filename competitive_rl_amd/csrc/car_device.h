@@ -215,7 +215,8 @@ void launch_car_reset_list(const CarSoA &s, const CarConsts &k, const CarTrackSr
 void launch_car_walk_ahead(const CarSoA &s, const CarTrackSrc &src, hipStream_t st, int budget = 0);  // budget: walk iterations per env (<= 0: to the end)
 void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, float *rew, uint8_t *done_car, int sub, int repeat,
                      hipStream_t st, bool do_broad = true);
-void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body = nullptr, const uint8_t *cls = nullptr);
+void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body = nullptr, const uint8_t *cls = nullptr,
+                      const int32_t *touching_now = nullptr, const int32_t *manifolds_now = nullptr);
 void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent, const float *fresh_body = nullptr,
                        const uint8_t *cls = nullptr);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);

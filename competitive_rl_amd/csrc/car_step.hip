@@ -309,16 +309,26 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
 // with the touching solve instead of with two more kernels.
 // fresh_body / cls (optional): an env of class 3 (finished while coupled) is collided on its STAGED bodies -- the new episode, which
 // its commit is about to make current on another stream.
+// touching_now / manifolds_now (optional): the kernel runs BEFORE this step's touching solve is in (beside it, so that only the
+// narrow phase follows the solve): an env whose cars touch in this step -- its poses are not final yet -- is filed as coupled
+// without a test.  The flag only routes: the narrow phase decides what touches, and a coupled env in which nothing does is solved
+// as two islands of their own, bit for bit like the per-car kernel.
 __global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K, const float *__restrict__ fresh_body,
-                                                       const uint8_t *__restrict__ cls) {
+                                                       const uint8_t *__restrict__ cls, const int32_t *__restrict__ touching_now,
+                                                       const int32_t *__restrict__ manifolds_now) {
     const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t M = 2 * s.n;
     bool coupled = false;
     if (env < s.n) {
         const int64_t c0 = env, c1 = s.n + env;
-        const float *body = (cls && cls[env] == 3) ? fresh_body : s.body;
-        coupled = cars_near(K, body[0 * M + c0], body[1 * M + c0], body[2 * M + c0], body[0 * M + c1], body[1 * M + c1], body[2 * M + c1]);
-        if (coupled) coupled = fixtures_near(body, K, M, c0, c1);
+        const bool fresh = cls && cls[env] == 3;
+        const float *body = fresh ? fresh_body : s.body;
+        if (!fresh && touching_now && touching_now[env] && manifolds_now[env] > 0) {
+            coupled = true;
+        } else {
+            coupled = cars_near(K, body[0 * M + c0], body[1 * M + c0], body[2 * M + c0], body[0 * M + c1], body[1 * M + c1], body[2 * M + c1]);
+            if (coupled) coupled = fixtures_near(body, K, M, c0, c1);
+        }
         s.coupled[env] = coupled ? 1 : 0;
     }
     const unsigned long long m = __ballot(coupled);
@@ -331,8 +341,9 @@ __global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K, co
     }
 }
 
-void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body, const uint8_t *cls) {
-    hipLaunchKernelGGL(car_broad_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k, fresh_body, cls);
+void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body, const uint8_t *cls,
+                      const int32_t *touching_now, const int32_t *manifolds_now) {
+    hipLaunchKernelGGL(car_broad_kernel, dim3((unsigned)((s.n + 63) / 64)), dim3(64), 0, st, s, k, fresh_body, cls, touching_now, manifolds_now);
 }
 
 // world.Step's Collide for the wheel sensors (FrictionDetector, crmp:111-153): Begin / EndContact of every wheel with the

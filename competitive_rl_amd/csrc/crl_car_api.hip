@@ -639,6 +639,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             frames_list(c, c->s, target, q, list_of(cls), count_of(cls), nullptr, expected);
         };
         const bool staged = !c->analytic;  // (the analytic raster reads the track arrays themselves: it needs them until the terminal frame is drawn)
+        const bool early_broad = can_ahead && staged && !CRL_ABL(getenv("CRL_CAR_COLLIDE_LATE") != nullptr) && !CRL_ABL(getenv("CRL_CAR_BROAD_LATE") != nullptr);
         hipStreamWaitEvent(c->side2, c->ev_term, 0);
         if (staged) {
             // early chain, every finished env (class 2 and 3 alike), at high priority: the map build's small workgroups get CU slots
@@ -650,6 +651,14 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             terminal_frames(c->side2, 2, exp_done, c->class_count_hdev + 1);  // (side2 idles between the near-only envs' frames and the touching solve)
             hipStreamWaitEvent(c->side2, c->ev_early3, 0);
             launch_car_commit_list(c->s, sv, list_of(2), count_of(2), exp_done, c->side2);
+            if (early_broad) {
+                // The NEXT step's broadphase already here: every pose but the touching islands' is final (per-car solve: ev_term; near-only
+                // solve and class-2 commit: this stream; class 3: staged), and an env that touches now is filed as coupled untested --
+                // behind the touching solve only the narrow phase is left.
+                CarSoA nx = c->s;
+                point_parity(c, nx, c->parity ^ 1);
+                launch_car_broad(nx, c->K_, c->side2, c->stage.body, c->slow_env, c->s.coupled, c->s.nc_new);
+            }
         } else {
             finish_chain(c->side2, 2, exp_done, c->class_count_hdev + 1);
         }
@@ -663,7 +672,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         auto collide_next = [&](bool fresh) {
             CarSoA nx = c->s;
             point_parity(c, nx, c->parity ^ 1);
-            launch_car_broad(nx, c->K_, c->side2, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr);
+            if (!(fresh && early_broad)) launch_car_broad(nx, c->K_, c->side2, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr);
             launch_car_narrow(nx, c->K_, c->side2, false, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr);
             hipEventRecord(c->ev_collide, c->side2);
             c->collide_valid = c->collide_dirty = true;

@@ -295,7 +295,7 @@ typedef struct crl_car_env_state {
     int32_t elapsed;  /* gym TimeLimit._elapsed_steps */
     uint32_t episode; /* resets so far                */
     int32_t n_contact;
-    int32_t coupled; /* (get only) 1 = the cars' boxes met and the last step solved them in one kernel */
+    int32_t coupled; /* (get only) 1 = the step filed the env for the narrow phase: the cars' boxes met, or the cars touched in the step before */
     crl_car_contact contact[CRL_CAR_MAX_CONTACTS];
 } crl_car_env_state;
 
