@@ -568,7 +568,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         //   bulk   per-car solve -> camera, polygons -> frames of class 0 (the big launch)
         //   side2  env bookkeeping; the coupled envs where nothing touches (two islands of their own) -> their frames; the terminal
         //          frames of the finished envs on their own as soon as the per-car solve is in, their commit once the new episode is
-        //          staged; behind the touching solve the NEXT step's Collide; the step's join
+        //          staged, then the NEXT step's broadphase; behind the touching solve its narrow phase; the step's join
         //   one    (HIGH priority) the wheel sensors (tile rewards, road_visited: they read the transforms the step started from and
         //          feed nothing into its solve; every frame shows the reward, so every frame launch waits for them), then the finished
         //          envs' NEW episode, prepared early on the staged view: reset, map, first frame; behind the touching solve the
