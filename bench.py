@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "raw", "fused84", "fused84_f32", "fused84_newest", "car", "tournament", "tournament_full"])
+                    choices=["all", "raw", "fused84", "fused84_f32", "fused84_newest", "car", "car_fma", "tournament", "tournament_full"])
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
     ap.add_argument("--gather", choices=["none", "scalars", "obs", "descriptors"], default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,7 +119,7 @@ def cpu_baselines(workloads, budget_s=8.0):
         elif wl in ("fused84", "fused84_f32", "fused84_newest"):
             b = subproc("gray_84", "skip-4 + max-2 + gray + 84x84 INTER_AREA, 2 x (1,84,84) per env-step")
             b["openmp_port"] = openmp_port("fused84", 16 * cores)
-        elif wl == "car":
+        elif wl in ("car", "car_fma"):
             b = subproc("car", "Box2D-style step + two 96x96 renders per env-step")
         elif wl == "tournament":
             b = cpu_baseline_tournament(po, atlas, cores, budget_s * 0.8)
@@ -191,7 +191,8 @@ def run_workload(name, args, G):
     """Builds the env for `name`, does W warm-up steps, times exactly K steps (barrier + synchronize on both sides, max
     over ranks) and returns the result dict (value, ms_per_step, roofline ...)."""
     torch, crl, dist, dev, world, rank = G["torch"], G["crl"], G["dist"], G["dev"], G["world"], G["rank"]
-    n = args.envs or (16384 if name == "car" else 65536)
+    is_car = name in ("car", "car_fma")
+    n = args.envs or (16384 if is_car else 65536)
     base = rank * n
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     policy_events = None
@@ -229,8 +230,8 @@ def run_workload(name, args, G):
                     "STRONG / ALPHA_PONG; random-init weights, the reference tree has no checkpoint of it) served by the HIP MFMA kernels, "
                     "1 step = 4 frames + 1 opponent forward pass")
         kernel, dtype, actions_desc = "pong_policy_light_kernel", "f32", "uniform {0,1,2}"
-    elif name == "car":
-        env = inner = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=base)
+    elif is_car:
+        env = inner = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=base, solver="fma" if name == "car_fma" else "box2d")
         pool = [torch.rand((n, 2, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
         desc = (f"cCarRacingDouble-v0 {n} envs/GPU, (N,2,96,96) u8 obs + Box2D-style car dynamics with car-car contacts, "
                 "1 step = 1 CarRacing.step (BASELINE config #4)")
@@ -255,7 +256,7 @@ def run_workload(name, args, G):
         dtype, actions_desc = ("f32" if name == "fused84_f32" else "u8"), "uniform {0,1,2}"
     env.reset()
     episodes_before = None
-    if name == "car":
+    if is_car:
         # Steady state, un-timed: gym's TimeLimit counters staggered uniformly over [0, 1000) and ONE episode length of pre-roll, so
         # that every env has been reset once at a different time -- the batch then holds cars of every age (spread over their
         # tracks, ~10 % of the envs with overlapping cars), and every timed step carries its ~n/1000 resets (terminal frames,
@@ -270,7 +271,7 @@ def run_workload(name, args, G):
     gather_state = G.get("gather")
 
     def step(i):
-        if world > 1 and args.gather == "obs" and name != "car" and name != "tournament":
+        if world > 1 and args.gather == "obs" and not is_car and name != "tournament":
             # the env draws straight into the collective's send buffer (two of them, alternating: gather(t) still reads one)
             out = env.step_device(pool[i % 16], obs_out=gather_state.obs_slot(inner._obs[0].shape, inner._obs[0].dtype, dev))
         else:
@@ -285,7 +286,7 @@ def run_workload(name, args, G):
                 gather_state.launch(out if args.gather == "obs" else out[1:])
 
     warm_resets = None
-    if name == "car":
+    if is_car:
         # the episode counters BEFORE the warm-up (reading the state takes the host a while; between the warm-up and the timed
         # region it would leave the GPU idle long enough for its first kernels to start 10-20 ms late -- measured: a 20-step window
         # then reads 1.3-2.1 ms per step instead of 0.9); the warm-up's own resets are counted on the device and subtracted
@@ -376,9 +377,9 @@ def run_workload(name, args, G):
                                    "VALU share one 157.3 TFLOP/s peak (MI355X_MICROARCH.md)"}
         return res
     ras_s = ras_ms / max(ras_n, 1) * 1e-3
-    bytes_per_env = {"raw": RAW_BYTES, "fused84": FUSED_BYTES, "fused84_f32": FUSED_F32_BYTES, "fused84_newest": NEWEST_BYTES, "car": CAR_BYTES}[name]
+    bytes_per_env = {"raw": RAW_BYTES, "fused84": FUSED_BYTES, "fused84_f32": FUSED_F32_BYTES, "fused84_newest": NEWEST_BYTES, "car": CAR_BYTES, "car_fma": CAR_BYTES}[name]
     drawn = 1.0
-    if name == "car":
+    if is_car:
         # the timed launch draws the envs that are neither coupled nor finished (the others' wavefronts exit at once; their frames come
         # from the list-driven launches): count only what it draws.  coupled: the last step's flags; finished: resets per step.
         drawn = 1.0 - float((final_state["coupled"] != 0).mean()) - resets / max(args.steps, 1) / n
@@ -387,7 +388,7 @@ def run_workload(name, args, G):
     res["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                        "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": bytes_per_env * n * drawn, "avg_kernel_us": ras_s * 1e6,
                        "launches_timed": ras_n, "dynamics_kernel_avg_us": dyn_ms / max(dyn_n, 1) * 1e3}
-    if name == "car":
+    if is_car:
         flop, fsrc = CAR_FLOP_MODEL, "bench.py CAR_FLOP_MODEL (counted from the code paths, DESIGN.md 4b)"
         ff = os.path.join(ROOT, "profiles", "flops_car.json")
         if os.path.exists(ff):
@@ -444,6 +445,7 @@ def main():
     if rank == 0:
         head = results[names[0]]
         metric = {"car": "env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU",
+                  "car_fma": "env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU, island solver in fused multiply-adds",
                   "tournament": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent",
                   "tournament_full": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs a full-size ActorCritic opponent"}.get(
             names[0], "env-steps/sec (whole node), cPongDouble 65536 envs per GPU")

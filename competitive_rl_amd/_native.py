@@ -50,6 +50,7 @@ CAR_CONTACT_DT = np.dtype([("pair", "<i4"), ("count", "<i4"), ("type", "<i4"), (
 CAR_ENV_STATE_DT = np.dtype([("car", CAR_STATE_DT, (2,)), ("elapsed", "<i4"), ("episode", "<u4"), ("n_contact", "<i4"), ("coupled", "<i4"),
                              ("contact", CAR_CONTACT_DT, (8,))], align=True)
 CRL_FLAG_CAR_NO_CONTACTS = 2
+CRL_FLAG_CAR_FMA = 4
 CRL_CAR_DONE_ANY, CRL_CAR_DONE_CAR0 = 0, 1
 CRL_OBS_U8, CRL_OBS_F32, CRL_OBS_F32_REF = 0, 1, 2
 CRL_EACTION = -5

@@ -448,6 +448,7 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
 
 // ---- (2) envs whose boxes overlap but where nothing touches: two islands of their own, exactly the per-car kernel,
 // two lanes per env over the compacted list
+template <bool FM>
 __global__ __launch_bounds__(64) void car_near_kernel(CarSoA s, CarConsts K) {
     const int64_t M = 2 * s.n;
     const int count = s.coupled_count[1];
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(64) void car_near_kernel(CarSoA s, CarConsts K) {
         float slp[5];
 #pragma unroll
         for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + ci];
-        island_solve(cr, K, h, dt_ratio, slp);
+        island_solve<FM>(cr, K, h, dt_ratio, slp);
 #pragma unroll
         for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = slp[b];
         store_car(s, M, ci, cr);
@@ -548,6 +549,7 @@ __device__ __forceinline__ KC kc_load(const TouchC &t, const Contact &c, int me,
 
 // b2ContactSolver::SolveVelocityConstraints for one contact: friction per point, then the normal constraint (one point, or
 // the two-point block solver), in Box2D's order.  any1 / any2: some lane of the wavefront has a one- / two-point constraint.
+template <bool FM>
 __device__ __forceinline__ void contact_vel(CarRegs &r, KC &q, const int me, const float friction, const bool any1, const bool any2) {
     const int bi = q.bi;
     const float ovx = CRL_SEL(vx, bi), ovy = CRL_SEL(vy, bi), ow = CRL_SEL(w, bi);
@@ -558,56 +560,59 @@ __device__ __forceinline__ void contact_vel(CarRegs &r, KC &q, const int me, con
     const V2 normal = mk(q.nx, q.ny), tangent = mk(normal.y, -normal.x);
     const V2 rA0 = mk(q.rA0x, q.rA0y), rB0 = mk(q.rB0x, q.rB0y), rA1 = mk(q.rA1x, q.rA1y), rB1 = mk(q.rB1x, q.rB1y);
     const int count = q.count;
-    auto relv = [&](V2 ra, V2 rb) { return ((vB + scross(wB, rb)) - vA) - scross(wA, ra); };
+    // ((vB + wB x rb) - vA) - wA x ra,  w x r = (-w r.y, w r.x)   (mad / nmad: car_solver.h)
+    auto relv = [&](V2 ra, V2 rb) {
+        return mk(nmad<FM>(-wA, ra.y, nmad<FM>(wB, rb.y, vB.x) - vA.x), nmad<FM>(wA, ra.x, mad<FM>(wB, rb.x, vB.y) - vA.y));
+    };
     auto apply = [&](V2 ra, V2 rb, V2 P) {
-        vA.x -= mA * P.x, vA.y -= mA * P.y, wA -= iA * cross(ra, P);
-        vB.x += mB * P.x, vB.y += mB * P.y, wB += iB * cross(rb, P);
+        vA.x = nmad<FM>(mA, P.x, vA.x), vA.y = nmad<FM>(mA, P.y, vA.y), wA = nmad<FM>(iA, fcross<FM>(ra, P), wA);
+        vB.x = mad<FM>(mB, P.x, vB.x), vB.y = mad<FM>(mB, P.y, vB.y), wB = mad<FM>(iB, fcross<FM>(rb, P), wB);
     };
     {  // friction, point 0 (every constraint has it)
-        const float vt = dot(relv(rA0, rB0), tangent);
-        float lambda = q.tm0 * (-vt);
+        const float vt = fdot<FM>(relv(rA0, rB0), tangent);
         const float maxF = friction * q.nimp0;
-        float ni = q.timp0 + lambda;
-        ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
-        lambda = ni - q.timp0, q.timp0 = ni;
+        float ni = mad<FM>(q.tm0, -vt, q.timp0);
+        ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;  // (maxF may be +0: the compare chain keeps the limit's sign, a median would not)
+        const float lambda = ni - q.timp0;
+        q.timp0 = ni;
         apply(rA0, rB0, lambda * tangent);
     }
     if (any2) {
         if (count == 2) {  // friction, point 1
-            const float vt = dot(relv(rA1, rB1), tangent);
-            float lambda = q.tm1 * (-vt);
+            const float vt = fdot<FM>(relv(rA1, rB1), tangent);
             const float maxF = friction * q.nimp1;
-            float ni = q.timp1 + lambda;
+            float ni = mad<FM>(q.tm1, -vt, q.timp1);
             ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
-            lambda = ni - q.timp1, q.timp1 = ni;
+            const float lambda = ni - q.timp1;
+            q.timp1 = ni;
             apply(rA1, rB1, lambda * tangent);
         }
     }
     if (any1) {
         if (count == 1) {
-            const float vn = dot(relv(rA0, rB0), normal);
-            float lambda = -q.nm0 * (vn - 0.0f);
-            const float ni = fmaxf(q.nimp0 + lambda, 0.0f);
-            lambda = ni - q.nimp0, q.nimp0 = ni;
+            const float vn = fdot<FM>(relv(rA0, rB0), normal);
+            const float ni = fmaxf(mad<FM>(-q.nm0, vn - 0.0f, q.nimp0), 0.0f);
+            const float lambda = ni - q.nimp0;
+            q.nimp0 = ni;
             apply(rA0, rB0, lambda * normal);
         }
     }
     if (any2) {
         if (count == 2) {
             const V2 a = mk(q.nimp0, q.nimp1);
-            float vn1 = dot(relv(rA0, rB0), normal), vn2 = dot(relv(rA1, rB1), normal);
+            float vn1 = fdot<FM>(relv(rA0, rB0), normal), vn2 = fdot<FM>(relv(rA1, rB1), normal);
             V2 b = mk(vn1 - 0.0f, vn2 - 0.0f);
-            b = b - mk(q.k00 * a.x + q.k10 * a.y, q.k01 * a.x + q.k11 * a.y);
-            V2 x = mk(-(q.ik00 * b.x + q.ik10 * b.y), -(q.ik01 * b.x + q.ik11 * b.y));
+            b = b - mk(mad<FM>(q.k00, a.x, q.k10 * a.y), mad<FM>(q.k01, a.x, q.k11 * a.y));
+            V2 x = mk(-mad<FM>(q.ik00, b.x, q.ik10 * b.y), -mad<FM>(q.ik01, b.x, q.ik11 * b.y));
             bool solved = x.x >= 0.0f && x.y >= 0.0f;
             if (!solved) {
                 x = mk(-q.nm0 * b.x, 0.0f);
-                vn2 = q.k01 * x.x + b.y;
+                vn2 = mad<FM>(q.k01, x.x, b.y);
                 solved = x.x >= 0.0f && vn2 >= 0.0f;
             }
             if (!solved) {
                 x = mk(0.0f, -q.nm1 * b.y);
-                vn1 = q.k10 * x.y + b.x;
+                vn1 = mad<FM>(q.k10, x.y, b.x);
                 solved = x.y >= 0.0f && vn1 >= 0.0f;
             }
             if (!solved) {
@@ -617,10 +622,10 @@ __device__ __forceinline__ void contact_vel(CarRegs &r, KC &q, const int me, con
             if (solved) {
                 const V2 d = x - a;
                 const V2 P1 = d.x * normal, P2 = d.y * normal;
-                vA.x -= mA * (P1.x + P2.x), vA.y -= mA * (P1.y + P2.y);
-                wA -= iA * (cross(rA0, P1) + cross(rA1, P2));
-                vB.x += mB * (P1.x + P2.x), vB.y += mB * (P1.y + P2.y);
-                wB += iB * (cross(rB0, P1) + cross(rB1, P2));
+                vA.x = nmad<FM>(mA, P1.x + P2.x, vA.x), vA.y = nmad<FM>(mA, P1.y + P2.y, vA.y);
+                wA = nmad<FM>(iA, fcross<FM>(rA0, P1) + fcross<FM>(rA1, P2), wA);
+                vB.x = mad<FM>(mB, P1.x + P2.x, vB.x), vB.y = mad<FM>(mB, P1.y + P2.y, vB.y);
+                wB = mad<FM>(iB, fcross<FM>(rB0, P1) + fcross<FM>(rB1, P2), wB);
                 q.nimp0 = x.x, q.nimp1 = x.y;
             }
         }
@@ -630,6 +635,7 @@ __device__ __forceinline__ void contact_vel(CarRegs &r, KC &q, const int me, con
 }
 
 // b2ContactSolver::SolvePositionConstraints for one contact (both manifold points)
+template <bool FM>
 __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const Contact &c, const int me, const V2 hlc, float &minSep) {
     const int bi = q.bi;
     const int ccount = c.count, ctype = c.type;
@@ -644,7 +650,7 @@ __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const Conta
         const float ocx = CRL_SEL(cx, bi), ocy = CRL_SEL(cy, bi), oa = CRL_SEL(a, bi);
         XF ox;
         crl_sincosf(oa, &ox.s, &ox.c);
-        ox.p = mk(ocx, ocy) - rotv(ox.s, ox.c, mylc);
+        ox.p = mk(ocx, ocy) - frot<FM>(ox.s, ox.c, mylc);
         XF px;
         px.s = lane_swap(ox.s), px.c = lane_swap(ox.c), px.p.x = lane_swap(ox.p.x), px.p.y = lane_swap(ox.p.y);
         const float pcx = lane_swap(ocx), pcy = lane_swap(ocy), pa = lane_swap(oa);
@@ -655,24 +661,24 @@ __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const Conta
         V2 normal, point;
         float sep;
         if (ctype == 0) {
-            normal = rotv(xa.s, xa.c, mk(lnx, lny));
-            const V2 plane = xmul(xa, mk(lpx, lpy)), clip = xmul(xb, lpt);
-            sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
+            normal = frot<FM>(xa.s, xa.c, mk(lnx, lny));
+            const V2 plane = frot<FM>(xa.s, xa.c, mk(lpx, lpy)) + xa.p, clip = frot<FM>(xb.s, xb.c, lpt) + xb.p;
+            sep = fdot<FM>(clip - plane, normal) - 0.01f - 0.01f, point = clip;
         } else {
-            normal = rotv(xb.s, xb.c, mk(lnx, lny));
-            const V2 plane = xmul(xb, mk(lpx, lpy)), clip = xmul(xa, lpt);
-            sep = dot(clip - plane, normal) - 0.01f - 0.01f, point = clip;
+            normal = frot<FM>(xb.s, xb.c, mk(lnx, lny));
+            const V2 plane = frot<FM>(xb.s, xb.c, mk(lpx, lpy)) + xb.p, clip = frot<FM>(xa.s, xa.c, lpt) + xa.p;
+            sep = fdot<FM>(clip - plane, normal) - 0.01f - 0.01f, point = clip;
             normal = -1.0f * normal;
         }
         const V2 rA = point - cA, rB = point - cB;
         if (ok && sep < minSep) minSep = sep;
         const float C = fminf(fmaxf(0.2f * (sep + LINEAR_SLOP), -0.2f), 0.0f);
-        const float rnA = cross(rA, normal), rnB = cross(rB, normal);
-        const float Kn = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+        const float rnA = fcross<FM>(rA, normal), rnB = fcross<FM>(rB, normal);
+        const float Kn = mad<FM>(iB * rnB, rnB, mad<FM>(iA * rnA, rnA, mA + mB));
         const float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
         const V2 P = impulse * normal;
-        cA.x -= mA * P.x, cA.y -= mA * P.y, aA -= iA * cross(rA, P);
-        cB.x += mB * P.x, cB.y += mB * P.y, aB += iB * cross(rB, P);
+        cA.x = nmad<FM>(mA, P.x, cA.x), cA.y = nmad<FM>(mA, P.y, cA.y), aA = nmad<FM>(iA, fcross<FM>(rA, P), aA);
+        cB.x = mad<FM>(mB, P.x, cB.x), cB.y = mad<FM>(mB, P.y, cB.y), aB = mad<FM>(iB, fcross<FM>(rB, P), aB);
         const float ncx = me ? cB.x : cA.x, ncy = me ? cB.y : cA.y, na = me ? aB : aA;
         CRL_PUT(cx, bi, ok, ncx) CRL_PUT(cy, bi, ok, ncy) CRL_PUT(a, bi, ok, na)
     }
@@ -686,7 +692,7 @@ __device__ __forceinline__ void contact_pos(CarRegs &r, const KC &q, const Conta
 // TAIL: the env may have more manifolds than the NK kept in registers; those go through their LDS rows every iteration
 // (44 LDS reads per row and iteration -- still far cheaper than what the register allocator does when three rows, five bodies and
 // four joints do not fit 512 registers: NK = 3 spilled 167 of them, 66 scratch accesses inside the velocity loop)
-template <int NK, int EPW, bool TAIL>
+template <int NK, int EPW, bool TAIL, bool FM>
 __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K, const int32_t *list, const int list_count, const int slot_base,
                                             CarRegs (*sh_car)[2], Contact (*sh_ct)[kMaxContacts], TouchC (*sh_tc)[kMaxContacts]) {
     const int me = threadIdx.x & 1;
@@ -740,7 +746,7 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     Body &mH = car[me].H;
     Body(&mW)[4] = car[me].W;
     JointTmp jt;
-    isl_integrate_vel(r, K, h);
+    isl_integrate_vel<FM>(r, K, h);
     {  // b2ContactSolver::InitializeVelocityConstraints + WarmStart, once per step: even lane, on an LDS copy of both cars
         mH.vx = r.H.vx, mH.vy = r.H.vy, mH.w = r.H.w;
 #pragma unroll
@@ -833,15 +839,15 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     const int jmode = isl_joint_mode(r);
 #pragma unroll 1
     for (int it = 0; it < 180; it++) {
-        isl_joints_vel_mode(jmode, r, jt, K, h);
+        isl_joints_vel_mode<FM>(jmode, r, jt, K, h);
 #pragma unroll
-        for (int k = 0; k < NK; k++) contact_vel(r, kc[k], me, friction, any1, any2);
+        for (int k = 0; k < NK; k++) contact_vel<FM>(r, kc[k], me, friction, any1, any2);
         if (TAIL) {
 #pragma unroll 1
             for (int k = NK; k < nc_wave; k++) {
                 const bool ok = k < nc;
                 KC q = kc_load(tc[ok ? k : 0], ct[ok ? k : 0], me, ok, K);
-                contact_vel(r, q, me, friction, tail1, tail2);
+                contact_vel<FM>(r, q, me, friction, tail1, tail2);
                 if (ok && me == 0) tc[k].nimp0 = q.nimp0, tc[k].nimp1 = q.nimp1, tc[k].timp0 = q.timp0, tc[k].timp1 = q.timp1;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
@@ -867,7 +873,7 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
     // iterations need every register for their sines and cosines; what they do not touch went to scratch and came back one
     // value at a time for the stores at the end: 30-45 k cycles behind the last iteration of the step's slowest islands).
     // The island's sleep scan only reads the velocities: here as well.
-    isl_integrate_pos(r, h);  // (clamps velocities that would move a body too far in one step: final only now)
+    isl_integrate_pos<FM>(r, h);  // (clamps velocities that would move a body too far in one step: final only now)
     if (live) store_car_vel(s, M, me * s.n + env, r);
     float slp[5];  // b2Body::m_sleepTime of this lane's car
     for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + me * s.n + env];
@@ -881,17 +887,17 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         pos_iters = it + 1;
 #endif
 #pragma unroll
-        for (int k = 0; k < NK; k++) contact_pos(r, kc[k], ct[k < nc ? k : 0], me, hlc, minSep);
+        for (int k = 0; k < NK; k++) contact_pos<FM>(r, kc[k], ct[k < nc ? k : 0], me, hlc, minSep);
         if (TAIL) {
 #pragma unroll 1
             for (int k = NK; k < nc_wave; k++) {
                 const bool ok = k < nc;
                 const KC q = kc_load(tc[ok ? k : 0], ct[ok ? k : 0], me, ok, K);
-                contact_pos(r, q, ct[ok ? k : 0], me, hlc, minSep);
+                contact_pos<FM>(r, q, ct[ok ? k : 0], me, hlc, minSep);
             }
         }
         const bool cok = minSep >= -3.0f * LINEAR_SLOP;
-        const bool jok = isl_joints_pos(r, K);
+        const bool jok = isl_joints_pos<FM>(r, K);
         // contactsOkay && jointsOkay of the whole island: combine the pair
         const int mine = (cok ? 1 : 0) & (jok ? 1 : 0);
         const int other = __shfl_xor(mine, 1);
@@ -946,6 +952,8 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
         unsigned long long *q = s.stamps + 8 * (NK - 1);
         atomicAdd(q + 0, st1 - st0), atomicAdd(q + 1, st2 - st1), atomicAdd(q + 2, st3 - st2), atomicAdd(q + 3, st4 - st3);
         atomicAdd(q + 4, (unsigned long long)pi_wave), atomicMax(q + 5, st4 - st0), atomicAdd(q + 6, st3c - st3b), atomicAdd(q + 7, 1ull);
+        unsigned long long *m = s.stamps + 40 + 4 * (NK - 1);  // per class: longest velocity phase, longest position phase, wavefronts that ran all 60 position iterations
+        atomicMax(m + 0, st2 - st1), atomicMax(m + 1, st3 - st2), atomicAdd(m + 2, pi_wave >= 60 ? 1ull : 0ull), atomicMax(m + 3, st1 - st0);
     }
 #endif
 }
@@ -959,7 +967,7 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 // published by the wheel sensors' stream: one tile takes a lone wavefront ~75 us, so two or eight tiles in a row behind a solve are
 // slower than the list launch that draws them side by side -- and a kernel that spins on another kernel's output deadlocks as soon
 // as both are only partly dispatched.  docs/LAB_NOTES_r04.md.)
-template <int EPW1, int NK2, int NK3>
+template <int EPW1, int NK2, int NK3, bool FM>
 __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, int cls0) {
     const int cls = cls0 + blockIdx.y;
     const int count = s.coupled_count[2 + cls];
@@ -971,9 +979,9 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
     __shared__ __attribute__((aligned(16))) TouchC sh_tc[EPW1][kMaxContacts];
     const int32_t *list = s.touch_list + (int64_t)cls * s.n;
     for (int base = blockIdx.x * epw; base < count; base += gridDim.x * epw) {
-        if (cls == 0) touch_solve<1, EPW1, false>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
-        else if (cls == 1) touch_solve<NK2, 1, (NK2 < 2)>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
-        else touch_solve<NK3, 1, true>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        if (cls == 0) touch_solve<1, EPW1, false, FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        else if (cls == 1) touch_solve<NK2, 1, (NK2 < 2), FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+        else touch_solve<NK3, 1, true, FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
 }
@@ -996,9 +1004,15 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hip
             hipStreamWaitEvent(near_st, ev_narrow, 0);
         }
     }
-    hipLaunchKernelGGL(car_near_kernel, dim3((unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512)), dim3(64), 0, near_st, s, k);
+    const unsigned gn = (unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512);
     const unsigned g = (unsigned)((s.n + 31) / 32 < 256 ? (s.n + 31) / 32 : 256);
-    hipLaunchKernelGGL((car_touch_kernel<8, 2, 3>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
+    if (s.fma) {  // CRL_FLAG_CAR_FMA: the iterations in fused multiply-adds (car_solver.h)
+        hipLaunchKernelGGL(car_near_kernel<true>, dim3(gn), dim3(64), 0, near_st, s, k);
+        hipLaunchKernelGGL((car_touch_kernel<8, 2, 3, true>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
+    } else {
+        hipLaunchKernelGGL(car_near_kernel<false>, dim3(gn), dim3(64), 0, near_st, s, k);
+        hipLaunchKernelGGL((car_touch_kernel<8, 2, 3, false>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
+    }
 }
 
 }  // namespace crl

@@ -107,6 +107,9 @@ struct CarSoA {
     const uint32_t *text_bits;  // reward read-out bitmaps [CRL_CAR_TEXT_STRINGS][CRL_CAR_TEXT_ROWS] or nullptr
     // ---- car-car contacts (players == 2)
     int contacts_enabled;
+    int abl_keep_tag;       // profiling build only (CRL_CAR_ABL_KEEP_TAG): a walk-ahead does not void the stored walk's tag before overwriting it
+    int abl_no_walk;        // profiling build only (CRL_CAR_ABL_NO_WALK): resets reuse the stored walk, no walk-ahead kernel is launched
+    int fma;                // CRL_FLAG_CAR_FMA: the island solver's iterations in fused multiply-adds (car_solver.h: FM)
     float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
     float *wsnap;           // [12][M] wheel transforms (cx, cy, angle) the step starts from, for car_sensor_kernel
     uint8_t *sensor_ovf;    // [M] 1 = car_sensor_kernel's lists overflowed for this car: car_sensor_serial_kernel redoes it

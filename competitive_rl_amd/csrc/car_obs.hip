@@ -20,6 +20,7 @@
 
 #include "car_device.h"
 #include "car_obs_tile.h"
+#include "crl_internal.h"
 
 namespace crl {
 
@@ -213,6 +214,28 @@ __global__ __launch_bounds__(64) void car_poly_kernel(CarSoA s, CarConsts K, con
     if (filter && filter[env] != want) return;
     car_poly_tile(s, K, env, (int)(t % s.players), threadIdx.x & 15);
 }
+// Camera AND polygons of a tile in one launch (round 5, profiling build only: measured, not kept): 16 lanes per tile, every lane
+// evaluates the tile's (uniform) camera itself, lane 0 stores the view, then lane q its polygon -- the same two device functions, one
+// launch boundary and one trip through memory less on the bulk stream's chain per-car solve -> view -> frames.
+#ifdef CRL_ABLATION
+__global__ __launch_bounds__(64) void car_view_kernel(CarSoA s, CarConsts K, const uint8_t *__restrict__ filter, int want) {
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (t >= s.n * s.players) return;
+    const int64_t env = t / s.players;
+    if (filter && filter[env] != want) return;
+    const int viewer = (int)(t % s.players), q = threadIdx.x & 15;
+    ViewParams vp;
+    float4 cam;
+    camera_compute(s, K, env, viewer, vp, cam);
+    int32_t *dst = s.view + t * kViewWords;
+    if (q == 0) {
+        const int32_t *src = reinterpret_cast<const int32_t *>(&vp);
+        for (int i = 0; i < 8; i++) dst[i] = src[i];
+        reinterpret_cast<float4 *>(dst)[4] = cam;
+    }
+    s.view_cnt[t * 16 + q] = (uint8_t)poly_compute(s, K, env, viewer, q, cam, reinterpret_cast<uint32_t *>(dst) + 8, s.view_rec + (t * 16 + q) * kSpanSlots);
+}
+#endif
 // Tile slot b -> (position i = 8 (b / 16) + b % 8, viewer (b % 16) / 8) when there are two views: workgroups b and b + 8 run on
 // the same XCD, so the two views of an env (which look at neighbouring parts of the same map) share that XCD's L2.
 __global__ __launch_bounds__(64) void car_obs_kernel(CarSoA s, uint8_t *__restrict__ obs, const uint8_t *__restrict__ only_env, int want) {
@@ -266,6 +289,16 @@ __global__ __launch_bounds__(64, 3) void car_obs_list_kernel(CarSoA s, CarConsts
 // camera + car polygons of every env (or of the envs with only_env[e] == want): what launch_car_obs reads
 void launch_car_view(const CarSoA &s, const CarConsts &k, hipStream_t st, const uint8_t *only_env, int want) {
     const int64_t tiles = s.n * s.players;
+    // (profiling build, round 5: camera + polygons in ONE launch, 16 lanes per tile -- bit-exact, and 1 % slower per step in three A/B
+    // pairs: 16 x the wavefronts walk through the double-double camera while the solves need the issue slots; docs/LAB_NOTES_r05.md)
+    static const bool merged = CRL_ABL(getenv("CRL_CAR_VIEW_MERGED") != nullptr);
+#ifdef CRL_ABLATION
+    if (merged) {
+        hipLaunchKernelGGL(car_view_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(64), 0, st, s, k, only_env, want);
+        return;
+    }
+#endif
+    (void)merged;
     hipLaunchKernelGGL(car_camera_kernel, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, st, s, k, only_env, want);
     hipLaunchKernelGGL(car_poly_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(64), 0, st, s, k, only_env, want);
 }

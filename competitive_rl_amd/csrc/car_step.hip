@@ -109,6 +109,7 @@ __device__ inline bool fixtures_near(const float *__restrict__ body, const CarCo
 // world.Step -> b2Island::Solve for every car that is an island of its own (one lane per car
 // instance, state in registers); the cars flagged by car_step_kernel are solved together in
 // car_coupled_kernel instead.
+template <bool FM>
 __global__ __launch_bounds__(64) void car_solve_kernel(CarSoA s, CarConsts K) {
     const int64_t M = (int64_t)s.players * s.n;
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64) void car_solve_kernel(CarSoA s, CarConsts K) {
     float slp[5];  // b2Body::m_sleepTime
 #pragma unroll
     for (int b = 0; b < 5; b++) slp[b] = s.sleep[b * M + ci];
-    island_solve(cr, K, h, dt_ratio, slp);
+    island_solve<FM>(cr, K, h, dt_ratio, slp);
 #pragma unroll
     for (int b = 0; b < 5; b++) s.sleep[b * M + ci] = slp[b];
     store_car(s, M, ci, cr);
@@ -674,7 +675,8 @@ void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st) {
 
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st) {
     const int64_t M = (int64_t)s.players * s.n;
-    hipLaunchKernelGGL(car_solve_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
+    if (s.fma) hipLaunchKernelGGL(car_solve_kernel<true>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
+    else hipLaunchKernelGGL(car_solve_kernel<false>, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, st, s, k);
 }
 
 void launch_car_post(const CarSoA &s, const uint8_t *done_car, uint8_t *done_env, uint8_t *done_out, uint8_t *slow_env, int32_t *info_steps,

@@ -368,6 +368,12 @@ __device__ inline void reset_one_env(CarSoA &s, const CarConsts &K, const CarTra
     // every lane has consumed the stored walk -- a walk-ahead wavefront that starts while this reset is still reading
     // `track_scratch` sees the old index (tag == episode: nothing to do) and cannot overwrite the points under it.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifdef CRL_ABLATION
+    // timing ablation (WRONG tracks: every episode of an env replays the walk it has): no walk-ahead kernel ever runs; what a step costs
+    // without one in flight (CRL_CAR_ABL_NO_WALK, docs/LAB_NOTES_r05.md)
+    if (s.abl_no_walk && lane == 0 && pts == s.track_scratch + env * (int64_t)(kWalkMax * 4))
+        __hip_atomic_store(&s.walk_tag[env], episode + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     if (lane == 0) __hip_atomic_store(&s.episode[env], episode + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -414,6 +420,14 @@ __global__ __launch_bounds__(64) void car_walk_ahead_kernel(CarSoA s, CarTrackSr
     if (__hip_atomic_load(&s.walk_tag[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == episode) return;
     WalkSave *save = reinterpret_cast<WalkSave *>(s.walk_save) + env;
     double *pts = s.track_scratch + env * (int64_t)(kWalkMax * 4);
+    // The stored walk (of an EARLIER episode: the tag differs from the one the next reset asks for) is about to be overwritten, in pieces
+    // over the next 20-80 steps: from here on it must not be taken for anybody's walk -- a set_state that puts `episode` back to the
+    // stored walk's index would otherwise find tag == episode and build its track from points partly replaced by this one.
+    // With the tag void such a reset walks inline into the other scratch, like any reset that comes before its walk-ahead has finished.
+#ifdef CRL_ABLATION
+    if (!s.abl_keep_tag)  // (profiling build, CRL_CAR_ABL_KEEP_TAG: round 4's behaviour, to show that the test of this hazard detects it)
+#endif
+    __hip_atomic_store(&s.walk_tag[env], 0xFFFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     WalkRun r;
     int attempt = 0;
     if (budget > 0 && save->episode == episode) {

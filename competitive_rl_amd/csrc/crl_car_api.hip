@@ -183,6 +183,9 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
     CarSoA &s = c->s;
     s.n = n, s.players = players;
     s.contacts_enabled = (players == 2 && !(opts->flags & CRL_FLAG_CAR_NO_CONTACTS)) ? 1 : 0;
+    s.fma = (opts->flags & CRL_FLAG_CAR_FMA) ? 1 : 0;
+    s.abl_no_walk = CRL_ABL(getenv("CRL_CAR_ABL_NO_WALK") != nullptr) ? 1 : 0;
+    s.abl_keep_tag = CRL_ABL(getenv("CRL_CAR_ABL_KEEP_TAG") != nullptr) ? 1 : 0;
     int rc = 0;
     c->overlap = !getenv("CRL_CAR_NO_OVERLAP");
     c->collide_ahead = !getenv("CRL_CAR_NO_COLLIDE_AHEAD");
@@ -287,6 +290,7 @@ int crl_car_create(const crl_opts *opts, const uint32_t *text_bits_host, crl_car
         for (const char *q = order; *q && ok; q++) {
             hipStream_t pad = nullptr;
             if (*q == 's' && !c->side) ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, 0) == hipSuccess;  // the bulk of a step
+            else if (*q == 'S' && !c->side) ok = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_lo) == hipSuccess;  // (experiment: the bulk at low dispatch priority)
             else if (*q == '2' && !c->side2) ok = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) == hipSuccess;
             else if (*q == 'o' && !c->one) ok = hipStreamCreateWithPriority(&c->one, hipStreamNonBlocking, prio_hi) == hipSuccess;
             else if (*q == 'g' && !c->gen) ok = hipStreamCreateWithPriority(&c->gen, hipStreamNonBlocking, prio_lo) == hipSuccess;  // milliseconds-long walks: a priority class of its own
@@ -350,6 +354,8 @@ void crl_car_destroy(crl_car_ctx *c) {
             const double w = q[7] ? (double)q[7] : 1.0;
             fprintf(stderr, "touch class %d: %llu waves; mean cycles setup %.0f | velocity %.0f | position %.0f (%.1f iterations) | store %.0f (sleep scan %.0f) | max total %llu\n", cls + 1,
                     q[7], q[0] / w, q[1] / w, q[2] / w, q[4] / w, q[3] / w, q[6] / w, q[5]);
+            fprintf(stderr, "              longest: setup %llu | velocity %llu | position %llu; wavefronts with all 60 position iterations %llu\n", h[40 + 4 * cls + 3],
+                    h[40 + 4 * cls + 0], h[40 + 4 * cls + 1], h[40 + 4 * cls + 2]);
         }
         const unsigned long long *q = h + 32;
         const double w = q[7] ? (double)q[7] : 1.0;
@@ -406,6 +412,7 @@ static constexpr int kWalkBudget = 160;
 // into the same scratch, and a piece that started another attempt of the same walk beside it would overwrite its points)
 static void queue_walk_ahead(crl_car_ctx *c, hipStream_t after, bool behind_reset = false) {
     if (!c->overlap) return;
+    if (c->s.abl_no_walk && !behind_reset) return;  // (profiling build: the step without a walk-ahead piece in flight)
     static const int budget = CRL_ABL(getenv("CRL_CAR_WALK_BUDGET") != nullptr) ? atoi(getenv("CRL_CAR_WALK_BUDGET")) : kWalkBudget;
     hipEvent_t &ev = c->ev_walk[c->walk_turn & 1];
 #ifdef CRL_TEST_WALK_UNORDERED  // (a test build reproduces the race tests/test_hip_round2.py guards against)

@@ -70,7 +70,7 @@ class CarLazyInfos:
 
 class HipCarVecEnv(VecEnv):
     def __init__(self, num_envs, seed=0, device=None, env_id_base=0, output="torch", dones="dummy", action_repeat=None,
-                 frame_stack=None, players=2, car_contacts=True, done_policy="any"):
+                 frame_stack=None, players=2, car_contacts=True, done_policy="any", solver="box2d"):
         if not torch.cuda.is_available():
             raise RuntimeError("HipCarVecEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -84,11 +84,15 @@ class HipCarVecEnv(VecEnv):
         self.output, self.dones_kind, self.closed = output, dones, False
         self.K = 1 if frame_stack is None else int(frame_stack)
         assert players in (1, 2)
+        # solver="fma": world.Step's island iterations in fused multiply-adds (include/crl.h CRL_FLAG_CAR_FMA): 0.46 x the instructions of
+        # the step's longest chain; checked against its own build of the CPU checker (tolerance 0), velocities within 2.7e-5 of Box2D's roundings after one step
+        assert solver in ("box2d", "fma")
+        self.solver = solver
         self.P = int(players)  # 2 = cCarRacingDouble-v0, 1 = cCarRacing-v0
         opts = N.CrlOpts(env_kind=N.CRL_ENV_CAR_DOUBLE if players == 2 else N.CRL_ENV_CAR_SINGLE, obs_mode=0,
                          resized_dim=0, frame_stack=self.K, num_envs=int(num_envs),
                          env_id_base=int(env_id_base), seed=int(seed) & (2 ** 64 - 1), device=self.device.index or 0,
-                         flags=0 if car_contacts else N.CRL_FLAG_CAR_NO_CONTACTS, action_repeat=self.action_repeat,
+                         flags=(0 if car_contacts else N.CRL_FLAG_CAR_NO_CONTACTS) | (N.CRL_FLAG_CAR_FMA if solver == "fma" else 0), action_repeat=self.action_repeat,
                          done_policy=N.CRL_CAR_DONE_CAR0 if done_policy == "car0" else N.CRL_CAR_DONE_ANY)
         h = C.c_void_p()
         self._text = N.load_car_text()  # reward read-out bitmaps of the indicator strip

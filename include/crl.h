@@ -67,6 +67,13 @@ enum crl_env_kind {
 /* crl_opts.flags */
 #define CRL_FLAG_CAR_NO_CONTACTS 2  /* cCarRacingDouble: skip the car-car contact constraints (cars pass
                                       through each other); default is to solve them */
+#define CRL_FLAG_CAR_FMA 4          /* cCarRacing*: b2World.Step's island solver (car_racing_multi_players.py:600 -> b2Island::Solve:
+                                      integrators, the 180 velocity and <= 60 position iterations of joints and contacts)
+                                      evaluates every a*b+c in ONE fused multiply-add instead of Box2D's two roundings:
+                                      0.46 x the instructions of the step's longest dependent chain.  Checked at tolerance 0
+                                      against the CPU checker's -DCRL_FMA build (the same sites as MAD / NMAD); one step away from the
+                                      checker's libm build by <= 2.7e-5 relative on velocities (default: 5.6e-6),
+                                      which is why it is opt-in */
 #define CRL_FLAG_STACK_REPLICATE 1 /* FrameStack wrapper semantics (utils/atari_wrappers.py:243-247):
                                       reset fills all K planes with the first frame, instead of
                                       FrameStackTensor's zeroed history */

@@ -203,6 +203,31 @@ static inline float vcross(v2 a, v2 b) { return a.x * b.y - a.y * b.x; }
 static inline v2 scross(float s, v2 a) { return V(-s * a.y, s * a.x); } /* b2Cross(float, vec) */
 static inline v2 rot(float s, float c, v2 v) { return V(c * v.x - s * v.y, s * v.x + c * v.y); }
 
+/* ---- the CONTRACTED arithmetic of the island solver: -DCRL_FMA (liboracle_fma.so, `make -C oracle fma`).
+ * Scope: b2Island::Solve's integrators and the bodies of the velocity / position iterations (revolute joints and contacts);
+ * constraint initialisation, warm start, Collide and everything outside world.Step are the same in both builds.  Inside
+ * that scope every `a * b + c` / `c - a * b` site below is ONE fused multiply-add (a single rounding) in the FMA build and
+ * two roundings in the default build, and the terms that are exactly zero because a wheel's joint anchor is its centre
+ * (rB = 0) are not evaluated in the FMA build.  MAD / NMAD expand to the default build's ORIGINAL expressions (IEEE addition
+ * and multiplication commute exactly and x + (-y) == x - y): tools/oracle_regress.py keeps a digest of the default
+ * build's states from before the macros went in.  The HIP kernels follow the same definition behind CRL_FLAG_CAR_FMA
+ * (csrc/car_solver.h, car_contact.hip: template parameter FM), so HIP(fma) == liboracle_fma.so at tolerance 0. */
+#if defined(CRL_FMA) && !defined(CRL_NO_RB)
+#define CRL_NO_RB 1 /* the exactly-zero rB terms of the wheel joints are not evaluated (alone: `make -C oracle norb`, a default build
+                     * without them -- tests/test_oracle_car_physics.py shows its states are the default build's, bit for bit) */
+#endif
+#ifdef CRL_FMA
+#define MAD(a, b, c) fmaf((a), (b), (c))   /* a * b + c */
+#define NMAD(a, b, c) fmaf(-(a), (b), (c)) /* c - a * b */
+#else
+#define MAD(a, b, c) ((a) * (b) + (c))
+#define NMAD(a, b, c) ((c) - (a) * (b))
+#endif
+/* dot, cross and rotation inside the scope: the FIRST product is the fused one */
+static inline float fdot(v2 a, v2 b) { return MAD(a.x, b.x, a.y * b.y); }
+static inline float fcross(v2 a, v2 b) { return MAD(a.x, b.y, -(a.y * b.x)); }
+static inline v2 frot(float s, float c, v2 v) { return V(MAD(c, v.x, -(s * v.y)), MAD(s, v.x, c * v.y)); }
+
 /* b2PolygonShape::ComputeMass: mass, centroid, inertia about the shape origin */
 static void poly_mass(const v2 *vs, int n, float density, float *mass, v2 *center, float *I) {
     v2 c = V(0, 0), s = V(0, 0);
@@ -416,9 +441,9 @@ typedef struct {
 
 static v2 solve22(const float m[3][3], v2 b) {
     float a11 = m[0][0], a12 = m[1][0], a21 = m[0][1], a22 = m[1][1];
-    float det = a11 * a22 - a12 * a21;
+    float det = a11 * a22 - a12 * a21; /* (matrix only: not contracted -- the GPU takes it out of the velocity loop) */
     if (det != 0.0f) det = 1.0f / det;
-    return V(det * (a22 * b.x - a12 * b.y), det * (a11 * b.y - a21 * b.x));
+    return V(det * MAD(a22, b.x, -(a12 * b.y)), det * MAD(a11, b.y, -(a21 * b.x)));
 }
 
 static void solve33(const float m[3][3], const float b[3], float x[3]) {
@@ -426,11 +451,11 @@ static void solve33(const float m[3][3], const float b[3], float x[3]) {
     float cyz[3] = {ey[1] * ez[2] - ey[2] * ez[1], ey[2] * ez[0] - ey[0] * ez[2], ey[0] * ez[1] - ey[1] * ez[0]};
     float det = ex[0] * cyz[0] + ex[1] * cyz[1] + ex[2] * cyz[2];
     if (det != 0.0f) det = 1.0f / det;
-    float cbz[3] = {b[1] * ez[2] - b[2] * ez[1], b[2] * ez[0] - b[0] * ez[2], b[0] * ez[1] - b[1] * ez[0]};
-    float cyb[3] = {ey[1] * b[2] - ey[2] * b[1], ey[2] * b[0] - ey[0] * b[2], ey[0] * b[1] - ey[1] * b[0]};
-    x[0] = det * (b[0] * cyz[0] + b[1] * cyz[1] + b[2] * cyz[2]);
-    x[1] = det * (ex[0] * cbz[0] + ex[1] * cbz[1] + ex[2] * cbz[2]);
-    x[2] = det * (ex[0] * cyb[0] + ex[1] * cyb[1] + ex[2] * cyb[2]);
+    float cbz[3] = {MAD(b[1], ez[2], -(b[2] * ez[1])), MAD(b[2], ez[0], -(b[0] * ez[2])), MAD(b[0], ez[1], -(b[1] * ez[0]))};
+    float cyb[3] = {MAD(ey[1], b[2], -(ey[2] * b[1])), MAD(ey[2], b[0], -(ey[0] * b[2])), MAD(ey[0], b[1], -(ey[1] * b[0]))};
+    x[0] = det * MAD(b[2], cyz[2], MAD(b[1], cyz[1], b[0] * cyz[0]));
+    x[1] = det * MAD(ex[2], cbz[2], MAD(ex[1], cbz[1], ex[0] * cbz[0]));
+    x[2] = det * MAD(ex[2], cyb[2], MAD(ex[1], cyb[1], ex[0] * cyb[0]));
 }
 
 /* b2Island::Solve, split into its phases so that one car (the usual case) and two cars coupled by
@@ -445,8 +470,11 @@ static void solve33(const float m[3][3], const float b[3], float x[3]) {
 /* integrate velocities: v += h * invMass * F (no gravity, no damping, no torque) */
 static void isl_integrate_vel(car_state *car, float h) {
     ISL_CONSTS;
-    H->vx += h * (mA * H->fx), H->vy += h * (mA * H->fy);
-    for (int w = 0; w < 4; w++) car->wheel[w].vx += h * (mB * car->wheel[w].fx), car->wheel[w].vy += h * (mB * car->wheel[w].fy);
+    H->vx = MAD(h, mA * H->fx, H->vx), H->vy = MAD(h, mA * H->fy, H->vy);
+    for (int w = 0; w < 4; w++) {
+        car_body *B = &car->wheel[w];
+        B->vx = MAD(h, mB * B->fx, B->vx), B->vy = MAD(h, mB * B->fy, B->vy);
+    }
 }
 
 /* b2RevoluteJoint::InitVelocityConstraints (+ warm start) for the 4 joints */
@@ -490,6 +518,17 @@ static void isl_joints_init(car_state *car, joint_tmp *jt, float dt_ratio) {
     }
 }
 
+/* vB + wB x rB - vA - wA x rA at a wheel joint; rB = 0 (the anchor is the wheel's centre) */
+static inline v2 joint_rel_vel(const car_body *H, const car_body *B, v2 rA, v2 rB) {
+#ifdef CRL_NO_RB
+    (void)rB;
+    return V(MAD(H->w, rA.y, B->vx - H->vx), NMAD(H->w, rA.x, B->vy - H->vy));
+#else
+    v2 vA = V(H->vx, H->vy), vB = V(B->vx, B->vy);
+    return vsub(vsub(vadd(vB, scross(B->w, rB)), vA), scross(H->w, rA));
+#endif
+}
+
 /* one velocity iteration: b2RevoluteJoint::SolveVelocityConstraints for the 4 joints */
 static void isl_joints_vel(car_state *car, joint_tmp *jt, float h) {
     ISL_CONSTS;
@@ -500,16 +539,15 @@ static void isl_joints_vel(car_state *car, joint_tmp *jt, float h) {
             v2 rA = j->rA, rB = j->rB;
             { /* motor */
                 float Cdot = B->w - H->w - car->motor_speed[w];
-                float impulse = -j->motorMass * Cdot, old = car->motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
-                float ni = old + impulse;
+                float old = car->motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
+                float ni = MAD(-j->motorMass, Cdot, old);
                 ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
                 car->motor_imp[w] = ni;
-                impulse = ni - old;
-                H->w -= iA * impulse, B->w += iB * impulse;
+                float impulse = ni - old;
+                H->w = NMAD(iA, impulse, H->w), B->w = MAD(iB, impulse, B->w);
             }
-            v2 vA = V(H->vx, H->vy), vB = V(B->vx, B->vy);
             if (car->limit_state[w] != LIM_INACTIVE) {
-                v2 Cdot1 = vsub(vsub(vadd(vB, scross(B->w, rB)), vA), scross(H->w, rA));
+                v2 Cdot1 = joint_rel_vel(H, B, rA, rB);
                 float Cdot2 = B->w - H->w;
                 float b[3] = {Cdot1.x, Cdot1.y, Cdot2}, imp[3];
                 solve33(j->m, b, imp);
@@ -517,7 +555,7 @@ static void isl_joints_vel(car_state *car, joint_tmp *jt, float h) {
                 float newI = car->imp[w][2] + imp[2];
                 int lower = car->limit_state[w] == LIM_LOWER;
                 if (lower ? newI < 0.0f : newI > 0.0f) {
-                    v2 rhs = vadd(vmul(-1.0f, Cdot1), vmul(car->imp[w][2], V(j->m[2][0], j->m[2][1])));
+                    v2 rhs = V(MAD(car->imp[w][2], j->m[2][0], -Cdot1.x), MAD(car->imp[w][2], j->m[2][1], -Cdot1.y));
                     v2 red = solve22(j->m, rhs);
                     imp[0] = red.x, imp[1] = red.y, imp[2] = -car->imp[w][2];
                     car->imp[w][0] += red.x, car->imp[w][1] += red.y, car->imp[w][2] = 0;
@@ -525,14 +563,22 @@ static void isl_joints_vel(car_state *car, joint_tmp *jt, float h) {
                     car->imp[w][0] += imp[0], car->imp[w][1] += imp[1], car->imp[w][2] += imp[2];
                 }
                 v2 P = V(imp[0], imp[1]);
-                H->vx -= mA * P.x, H->vy -= mA * P.y, H->w -= iA * (vcross(rA, P) + imp[2]);
-                B->vx += mB * P.x, B->vy += mB * P.y, B->w += iB * (vcross(rB, P) + imp[2]);
+                H->vx = NMAD(mA, P.x, H->vx), H->vy = NMAD(mA, P.y, H->vy), H->w = NMAD(iA, fcross(rA, P) + imp[2], H->w);
+                B->vx = MAD(mB, P.x, B->vx), B->vy = MAD(mB, P.y, B->vy);
+#ifdef CRL_NO_RB
+                B->w = MAD(iB, imp[2], B->w);
+#else
+                B->w += iB * (vcross(rB, P) + imp[2]);
+#endif
             } else {
-                v2 Cdot = vsub(vsub(vadd(vB, scross(B->w, rB)), vA), scross(H->w, rA));
+                v2 Cdot = joint_rel_vel(H, B, rA, rB);
                 v2 imp = solve22(j->m, vmul(-1.0f, Cdot));
                 car->imp[w][0] += imp.x, car->imp[w][1] += imp.y;
-                H->vx -= mA * imp.x, H->vy -= mA * imp.y, H->w -= iA * vcross(rA, imp);
-                B->vx += mB * imp.x, B->vy += mB * imp.y, B->w += iB * vcross(rB, imp);
+                H->vx = NMAD(mA, imp.x, H->vx), H->vy = NMAD(mA, imp.y, H->vy), H->w = NMAD(iA, fcross(rA, imp), H->w);
+                B->vx = MAD(mB, imp.x, B->vx), B->vy = MAD(mB, imp.y, B->vy);
+#ifndef CRL_NO_RB
+                B->w += iB * vcross(rB, imp);
+#endif
             }
         }
 }
@@ -544,13 +590,13 @@ static void isl_integrate_pos(car_state *car, float h) {
     for (int k = 0; k < 5; k++) {
         car_body *b = all[k];
         v2 tr = V(h * b->vx, h * b->vy);
-        if (vdot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) {
-            float ratio = MAX_TRANSLATION / sqrtf(vdot(tr, tr));
+        if (fdot(tr, tr) > MAX_TRANSLATION * MAX_TRANSLATION) {
+            float ratio = MAX_TRANSLATION / sqrtf(fdot(tr, tr));
             b->vx *= ratio, b->vy *= ratio;
         }
         float ro = h * b->w;
         if (ro * ro > MAX_ROTATION * MAX_ROTATION) b->w *= MAX_ROTATION / fabsf(ro);
-        b->cx += h * b->vx, b->cy += h * b->vy, b->a += h * b->w;
+        b->cx = MAD(h, b->vx, b->cx), b->cy = MAD(h, b->vy, b->cy), b->a = MAD(h, b->w, b->a);
     }
 }
 
@@ -574,21 +620,33 @@ static int isl_joints_pos(car_state *car) {
                     C = fminf(fmaxf(C - ANGULAR_SLOP, 0.0f), MAX_ANGULAR_CORRECTION);
                 }
                 li = -mm * C;
-                H->a -= iA * li, B->a += iB * li;
+                H->a = NMAD(iA, li, H->a), B->a = MAD(iB, li, B->a);
             }
             float sA, cA;
             rot_sincosf(H->a, &sA, &cA);
-            v2 rA = rot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA)), rB = V(0, 0);
-            v2 C = vsub(vsub(vadd(V(B->cx, B->cy), rB), V(H->cx, H->cy)), rA);
-            float posErr = sqrtf(vdot(C, C));
+            v2 rA = frot(sA, cA, vsub(V(K.anchor[w][0], K.anchor[w][1]), lcA));
             float k[3][3];
+#ifdef CRL_NO_RB
+            v2 C = vsub(vsub(V(B->cx, B->cy), V(H->cx, H->cy)), rA);
+            k[0][0] = MAD(iA * rA.y, rA.y, mA + mB);
+            k[0][1] = -iA * rA.x * rA.y;
+            k[1][0] = k[0][1];
+            k[1][1] = MAD(iA * rA.x, rA.x, mA + mB);
+#else
+            v2 rB = V(0, 0);
+            v2 C = vsub(vsub(vadd(V(B->cx, B->cy), rB), V(H->cx, H->cy)), rA);
             k[0][0] = mA + mB + iA * rA.y * rA.y + iB * rB.y * rB.y;
             k[0][1] = -iA * rA.x * rA.y - iB * rB.x * rB.y;
             k[1][0] = k[0][1];
             k[1][1] = mA + mB + iA * rA.x * rA.x + iB * rB.x * rB.x;
+#endif
+            float posErr = sqrtf(fdot(C, C));
             v2 imp = vmul(-1.0f, solve22(k, C));
-            H->cx -= mA * imp.x, H->cy -= mA * imp.y, H->a -= iA * vcross(rA, imp);
-            B->cx += mB * imp.x, B->cy += mB * imp.y, B->a += iB * vcross(rB, imp);
+            H->cx = NMAD(mA, imp.x, H->cx), H->cy = NMAD(mA, imp.y, H->cy), H->a = NMAD(iA, fcross(rA, imp), H->a);
+            B->cx = MAD(mB, imp.x, B->cx), B->cy = MAD(mB, imp.y, B->cy);
+#ifndef CRL_NO_RB
+            B->a += iB * vcross(rB, imp);
+#endif
             ok &= posErr <= LINEAR_SLOP && angErr <= ANGULAR_SLOP;
         }
     return ok;
@@ -702,6 +760,14 @@ static xform xf_of(const bref *r) {
     t.p = vsub(V(r->b->cx, r->b->cy), rot(t.s, t.c, r->lc));
     return t;
 }
+/* the same inside the position iterations (the scope of the contracted arithmetic, see MAD) */
+static xform xf_of_f(const bref *r) {
+    xform t;
+    rot_sincosf(r->b->a, &t.s, &t.c);
+    t.p = vsub(V(r->b->cx, r->b->cy), frot(t.s, t.c, r->lc));
+    return t;
+}
+static inline v2 xmul_f(xform t, v2 v) { return vadd(frot(t.s, t.c, v), t.p); }
 
 /* b2FindMaxSeparation: which published form?  box2d-py ~=2.3.5 is not in the reference tree, and Box2D changed this function
  * between 2.3.0 and 2.3.1; DESIGN.md section 9 tabulates what is assumed per function.  CRL_B2_COLLIDE selects (compile time):
@@ -981,11 +1047,14 @@ static void contacts_init(car_env *e, contact_vc *vc, float dt_ratio) {
 }
 
 static void apply_imp(contact_vc *q, int j, v2 P) {
-    q->A.b->vx -= q->A.im * P.x, q->A.b->vy -= q->A.im * P.y, q->A.b->w -= q->A.ii * vcross(q->rA[j], P);
-    q->B.b->vx += q->B.im * P.x, q->B.b->vy += q->B.im * P.y, q->B.b->w += q->B.ii * vcross(q->rB[j], P);
+    car_body *A = q->A.b, *B = q->B.b;
+    A->vx = NMAD(q->A.im, P.x, A->vx), A->vy = NMAD(q->A.im, P.y, A->vy), A->w = NMAD(q->A.ii, fcross(q->rA[j], P), A->w);
+    B->vx = MAD(q->B.im, P.x, B->vx), B->vy = MAD(q->B.im, P.y, B->vy), B->w = MAD(q->B.ii, fcross(q->rB[j], P), B->w);
 }
-static v2 rel_vel(const contact_vc *q, int j) {
-    return vsub(vsub(vadd(bvel(q->B.b), scross(q->B.b->w, q->rB[j])), bvel(q->A.b)), scross(q->A.b->w, q->rA[j]));
+static v2 rel_vel(const contact_vc *q, int j) { /* ((vB + wB x rB) - vA) - wA x rA,  w x r = (-w r.y, w r.x) */
+    const car_body *A = q->A.b, *B = q->B.b;
+    const v2 rA = q->rA[j], rB = q->rB[j];
+    return V(NMAD(-A->w, rA.y, NMAD(B->w, rB.y, B->vx) - A->vx), NMAD(A->w, rA.x, MAD(B->w, rB.x, B->vy) - A->vy));
 }
 
 /* b2ContactSolver::SolveVelocityConstraints, one iteration */
@@ -996,36 +1065,37 @@ static void contacts_vel(car_env *e, contact_vc *vc) {
         contact_vc *q = &vc[k];
         v2 normal = q->normal, tangent = V(normal.y, -normal.x);
         for (int j = 0; j < q->count; j++) { /* friction first */
-            float vt = vdot(rel_vel(q, j), tangent);
-            float lambda = q->tmass[j] * (-vt), maxF = friction * c->nimp[j];
-            float ni = c->timp[j] + lambda;
+            float vt = fdot(rel_vel(q, j), tangent);
+            float maxF = friction * c->nimp[j];
+            float ni = MAD(q->tmass[j], -vt, c->timp[j]);
             ni = ni < -maxF ? -maxF : ni > maxF ? maxF : ni;
-            lambda = ni - c->timp[j], c->timp[j] = ni;
+            float lambda = ni - c->timp[j];
+            c->timp[j] = ni;
             apply_imp(q, j, vmul(lambda, tangent));
         }
         if (q->count == 1) {
-            float vn = vdot(rel_vel(q, 0), normal);
-            float lambda = -q->nmass[0] * (vn - q->bias[0]);
-            float ni = fmaxf(c->nimp[0] + lambda, 0.0f);
-            lambda = ni - c->nimp[0], c->nimp[0] = ni;
+            float vn = fdot(rel_vel(q, 0), normal);
+            float ni = fmaxf(MAD(-q->nmass[0], vn - q->bias[0], c->nimp[0]), 0.0f);
+            float lambda = ni - c->nimp[0];
+            c->nimp[0] = ni;
             apply_imp(q, 0, vmul(lambda, normal));
         } else if (q->count == 2) { /* block solver */
             v2 a = V(c->nimp[0], c->nimp[1]);
-            float vn1 = vdot(rel_vel(q, 0), normal), vn2 = vdot(rel_vel(q, 1), normal);
+            float vn1 = fdot(rel_vel(q, 0), normal), vn2 = fdot(rel_vel(q, 1), normal);
             v2 b = V(vn1 - q->bias[0], vn2 - q->bias[1]);
-            b = vsub(b, V(q->K[0][0] * a.x + q->K[1][0] * a.y, q->K[0][1] * a.x + q->K[1][1] * a.y));
+            b = vsub(b, V(MAD(q->K[0][0], a.x, q->K[1][0] * a.y), MAD(q->K[0][1], a.x, q->K[1][1] * a.y)));
             v2 x;
             int solved = 0;
-            x = V(-(q->invK[0][0] * b.x + q->invK[1][0] * b.y), -(q->invK[0][1] * b.x + q->invK[1][1] * b.y));
+            x = V(-MAD(q->invK[0][0], b.x, q->invK[1][0] * b.y), -MAD(q->invK[0][1], b.x, q->invK[1][1] * b.y));
             if (x.x >= 0.0f && x.y >= 0.0f) solved = 1;
             if (!solved) {
                 x = V(-q->nmass[0] * b.x, 0.0f);
-                vn2 = q->K[0][1] * x.x + b.y;
+                vn2 = MAD(q->K[0][1], x.x, b.y);
                 if (x.x >= 0.0f && vn2 >= 0.0f) solved = 1;
             }
             if (!solved) {
                 x = V(0.0f, -q->nmass[1] * b.y);
-                vn1 = q->K[1][0] * x.y + b.x;
+                vn1 = MAD(q->K[1][0], x.y, b.x);
                 if (x.y >= 0.0f && vn1 >= 0.0f) solved = 1;
             }
             if (!solved) {
@@ -1035,10 +1105,11 @@ static void contacts_vel(car_env *e, contact_vc *vc) {
             if (solved) {
                 v2 d = vsub(x, a);
                 v2 P1 = vmul(d.x, normal), P2 = vmul(d.y, normal);
-                q->A.b->vx -= q->A.im * (P1.x + P2.x), q->A.b->vy -= q->A.im * (P1.y + P2.y);
-                q->A.b->w -= q->A.ii * (vcross(q->rA[0], P1) + vcross(q->rA[1], P2));
-                q->B.b->vx += q->B.im * (P1.x + P2.x), q->B.b->vy += q->B.im * (P1.y + P2.y);
-                q->B.b->w += q->B.ii * (vcross(q->rB[0], P1) + vcross(q->rB[1], P2));
+                car_body *A = q->A.b, *B = q->B.b;
+                A->vx = NMAD(q->A.im, P1.x + P2.x, A->vx), A->vy = NMAD(q->A.im, P1.y + P2.y, A->vy);
+                A->w = NMAD(q->A.ii, fcross(q->rA[0], P1) + fcross(q->rA[1], P2), A->w);
+                B->vx = MAD(q->B.im, P1.x + P2.x, B->vx), B->vy = MAD(q->B.im, P1.y + P2.y, B->vy);
+                B->w = MAD(q->B.ii, fcross(q->rB[0], P1) + fcross(q->rB[1], P2), B->w);
                 c->nimp[0] = x.x, c->nimp[1] = x.y;
             }
         }
@@ -1052,28 +1123,28 @@ static int contacts_pos(car_env *e) {
         car_contact *c = &e->contact[k];
         bref A = body_of(e, 0, c->pair >> 3), B = body_of(e, 1, c->pair & 7);
         for (int j = 0; j < c->count; j++) {
-            xform xa = xf_of(&A), xb = xf_of(&B);
+            xform xa = xf_of_f(&A), xb = xf_of_f(&B);
             v2 normal, point;
             float sep;
             if (c->type == 0) {
-                normal = rot(xa.s, xa.c, V(c->ln[0], c->ln[1]));
-                v2 plane = xmul(xa, V(c->lp[0], c->lp[1])), clip = xmul(xb, V(c->pt[j][0], c->pt[j][1]));
-                sep = vdot(vsub(clip, plane), normal) - 0.01f - 0.01f, point = clip;
+                normal = frot(xa.s, xa.c, V(c->ln[0], c->ln[1]));
+                v2 plane = xmul_f(xa, V(c->lp[0], c->lp[1])), clip = xmul_f(xb, V(c->pt[j][0], c->pt[j][1]));
+                sep = fdot(vsub(clip, plane), normal) - 0.01f - 0.01f, point = clip;
             } else {
-                normal = rot(xb.s, xb.c, V(c->ln[0], c->ln[1]));
-                v2 plane = xmul(xb, V(c->lp[0], c->lp[1])), clip = xmul(xa, V(c->pt[j][0], c->pt[j][1]));
-                sep = vdot(vsub(clip, plane), normal) - 0.01f - 0.01f, point = clip;
+                normal = frot(xb.s, xb.c, V(c->ln[0], c->ln[1]));
+                v2 plane = xmul_f(xb, V(c->lp[0], c->lp[1])), clip = xmul_f(xa, V(c->pt[j][0], c->pt[j][1]));
+                sep = fdot(vsub(clip, plane), normal) - 0.01f - 0.01f, point = clip;
                 normal = vmul(-1.0f, normal);
             }
             v2 rA = vsub(point, V(A.b->cx, A.b->cy)), rB = vsub(point, V(B.b->cx, B.b->cy));
             if (sep < minSep) minSep = sep;
             float C = fminf(fmaxf(0.2f * (sep + LINEAR_SLOP), -0.2f), 0.0f);
-            float rnA = vcross(rA, normal), rnB = vcross(rB, normal);
-            float Kn = A.im + B.im + A.ii * rnA * rnA + B.ii * rnB * rnB;
+            float rnA = fcross(rA, normal), rnB = fcross(rB, normal);
+            float Kn = MAD(B.ii * rnB, rnB, MAD(A.ii * rnA, rnA, A.im + B.im));
             float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
             v2 P = vmul(impulse, normal);
-            A.b->cx -= A.im * P.x, A.b->cy -= A.im * P.y, A.b->a -= A.ii * vcross(rA, P);
-            B.b->cx += B.im * P.x, B.b->cy += B.im * P.y, B.b->a += B.ii * vcross(rB, P);
+            A.b->cx = NMAD(A.im, P.x, A.b->cx), A.b->cy = NMAD(A.im, P.y, A.b->cy), A.b->a = NMAD(A.ii, fcross(rA, P), A.b->a);
+            B.b->cx = MAD(B.im, P.x, B.b->cx), B.b->cy = MAD(B.im, P.y, B.b->cy), B.b->a = MAD(B.ii, fcross(rB, P), B.b->a);
         }
     }
     return minSep >= -3.0f * LINEAR_SLOP;
@@ -1082,26 +1153,104 @@ static int contacts_pos(car_env *e) {
 /* b2Island::Solve for the two cars joined by touching contacts: contacts are initialised and
  * warm-started before the joints; each velocity iteration solves joints (car 1, car 0) then
  * contacts; each position iteration contacts then joints. */
+#ifdef CRL_CYCLE_STATS
+/* Experiment (tools/cycle_stats.py, `make -C oracle cyc`; docs/LAB_NOTES_r05.md): does the iteration state of a touching island
+ * come back to an EARLIER state bit for bit (a cycle of period <= 8)?  Then every later iteration is known without running it.
+ * stats: [0] islands, [1 + p] islands whose velocity iterations enter a period-p cycle (p = 1..8), [10] sum of the iteration
+ * index where it is first seen, [11] islands that run all 60 position iterations, [12 + p] of those, the ones whose position
+ * iterations enter a period-p cycle, [21] sum of the iteration index, [22 + k] histogram of position iterations used (k = 1..60),
+ * [90 + nc] islands by manifold count; [100..] the same block again for the islands with >= 2 manifolds */
+static long cyc_stats[256];
+void car_oracle_cycle_stats(long *out) { memcpy(out, cyc_stats, sizeof(cyc_stats)); }
+static int cyc_snap_vel(const car_env *e, float *b) {
+    int n = 0;
+    for (int c = 0; c < 2; c++) {
+        const car_state *q = &e->car[c];
+        b[n++] = q->hull.vx, b[n++] = q->hull.vy, b[n++] = q->hull.w;
+        for (int w = 0; w < 4; w++) {
+            b[n++] = q->wheel[w].vx, b[n++] = q->wheel[w].vy, b[n++] = q->wheel[w].w;
+            b[n++] = q->imp[w][0], b[n++] = q->imp[w][1], b[n++] = q->imp[w][2], b[n++] = q->motor_imp[w];
+        }
+    }
+    for (int k = 0; k < e->n_contact; k++)
+        for (int j = 0; j < 2; j++) b[n++] = e->contact[k].nimp[j], b[n++] = e->contact[k].timp[j];
+    return n;
+}
+static int cyc_snap_pos(const car_env *e, float *b) {
+    int n = 0;
+    for (int c = 0; c < 2; c++) {
+        const car_state *q = &e->car[c];
+        b[n++] = q->hull.cx, b[n++] = q->hull.cy, b[n++] = q->hull.a;
+        for (int w = 0; w < 4; w++) b[n++] = q->wheel[w].cx, b[n++] = q->wheel[w].cy, b[n++] = q->wheel[w].a;
+    }
+    return n;
+}
+#endif
+
 static void island_solve_coupled(car_env *e, float h, float dt_ratio, int vel_iters, int pos_iters) {
     joint_tmp jt[2][4];
     contact_vc vc[CAR_MAX_CONTACTS];
     isl_integrate_vel(&e->car[1], h), isl_integrate_vel(&e->car[0], h);
     contacts_init(e, vc, dt_ratio);
     isl_joints_init(&e->car[1], jt[1], dt_ratio), isl_joints_init(&e->car[0], jt[0], dt_ratio);
+#ifdef CRL_CYCLE_STATS
+    float ring[9][128];
+    int found_p = 0, found_it = 0;
+    const int blk = e->n_contact >= 2 ? 100 : 0;
+#endif
     for (int it = 0; it < vel_iters; it++) {
         isl_joints_vel(&e->car[1], jt[1], h), isl_joints_vel(&e->car[0], jt[0], h);
         contacts_vel(e, vc);
+#ifdef CRL_CYCLE_STATS
+        const int nw = cyc_snap_vel(e, ring[it % 9]);
+        for (int p = 1; p <= 8 && p <= it && !found_p; p++)
+            if (memcmp(ring[it % 9], ring[(it - p) % 9], nw * sizeof(float)) == 0) found_p = p, found_it = it;
+#endif
     }
+#ifdef CRL_CYCLE_STATS
+#pragma omp critical
+    {
+        cyc_stats[0]++, cyc_stats[90 + (e->n_contact > 8 ? 8 : e->n_contact)]++;
+        if (blk) cyc_stats[100]++;
+        if (found_p) {
+            cyc_stats[1 + found_p]++, cyc_stats[10] += found_it;
+            if (blk) cyc_stats[blk + 1 + found_p]++, cyc_stats[blk + 10] += found_it;
+        }
+    }
+    found_p = found_it = 0;
+    int used = pos_iters;
+#endif
     isl_integrate_pos(&e->car[1], h), isl_integrate_pos(&e->car[0], h);
     int solved = 0;
     for (int it = 0; it < pos_iters; it++) {
         int cok = contacts_pos(e);
         int j1 = isl_joints_pos(&e->car[1]), j0 = isl_joints_pos(&e->car[0]);
+#ifdef CRL_CYCLE_STATS
+        const int nw = cyc_snap_pos(e, ring[it % 9]);
+        for (int p = 1; p <= 8 && p <= it && !found_p; p++)
+            if (memcmp(ring[it % 9], ring[(it - p) % 9], nw * sizeof(float)) == 0) found_p = p, found_it = it;
+        if (cok && j1 && j0) used = it + 1;
+#endif
         if (cok && j1 && j0) {
             solved = 1;
             break;
         }
     }
+#ifdef CRL_CYCLE_STATS
+#pragma omp critical
+    {
+        cyc_stats[22 + used]++;
+        if (blk) cyc_stats[blk + 22 + used]++;
+        if (!solved) {
+            cyc_stats[11]++;
+            if (blk) cyc_stats[blk + 11]++;
+            if (found_p) {
+                cyc_stats[12 + found_p]++, cyc_stats[21] += found_it;
+                if (blk) cyc_stats[blk + 12 + found_p]++, cyc_stats[blk + 21] += found_it;
+            }
+        }
+    }
+#endif
     isl_clear_forces(&e->car[1]), isl_clear_forces(&e->car[0]);
     const float m1 = isl_sleep_scan(&e->car[1], h), m0 = isl_sleep_scan(&e->car[0], h);
     if (fminf(m1, m0) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(&e->car[1]), isl_put_to_sleep(&e->car[0]);
@@ -1299,6 +1448,14 @@ void car_oracle_collide_batch(car_env *e, long n) {
     for (long i = 0; i < n; i++) collide_cars(&e[i]);
 }
 int car_oracle_collide_variant(void) { return CRL_B2_COLLIDE; }
+/* 1: this build solves the islands in the contracted arithmetic (-DCRL_FMA, see MAD above) */
+int car_oracle_fma(void) {
+#ifdef CRL_FMA
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 void car_oracle_hull_position(const car_env *e, int c, float out[3]) {
     float s, co;

@@ -66,12 +66,20 @@ def _configure(L):
 
 
 def lib(libm=False):
-    """liboracle.so (sin / cos / atan2 shared with the HIP kernels) or, libm=True, liboracle_libm.so (the
-    host libm, like the reference): same sources, see oracle/Makefile."""
-    key = bool(libm)
+    """liboracle.so (sin / cos / atan2 shared with the HIP kernels); libm=True: liboracle_libm.so (the host libm, like the
+    reference); libm="fma": liboracle_fma.so (liboracle.so with the island solver's iterations in fused multiply-adds, the
+    checker of CRL_FLAG_CAR_FMA contexts).  Same sources, see oracle/Makefile."""
+    key = libm if libm in ("fma", "norb") else bool(libm)
     if key not in _libs:
-        L = _po.lib()  # builds both
-        _libs[key] = _configure(C.CDLL(_po.LIB_LIBM) if libm else L)
+        L = _po.lib()  # builds the first three
+        if key == "norb":  # the default build without the wheel joints' exactly-zero rB terms (oracle/Makefile): a counting variant
+            import os
+            import subprocess
+
+            subprocess.check_call(["make", "-C", _po.HERE, "norb"], stdout=subprocess.DEVNULL)
+            L = C.CDLL(os.path.join(_po.HERE, "liboracle_norb.so"))
+        _libs[key] = _configure(L if key in (False, "norb") else C.CDLL(_po.LIB_FMA) if key == "fma" else C.CDLL(_po.LIB_LIBM))
+        assert _libs[key].car_oracle_fma() == (1 if key == "fma" else 0)
     return _libs[key]
 
 
@@ -86,7 +94,7 @@ def set_text(bits):
     """Reward read-out bitmaps u32 [3001, 10] (kept alive here); None turns the text off."""
     global _text
     _text = None if bits is None else np.ascontiguousarray(bits, np.uint32)
-    for libm in (False, True):
+    for libm in (False, True, "fma"):
         lib(libm).car_oracle_set_text(None if _text is None else _p(_text))
 
 

@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _SUFFIX = os.environ.get("CRL_ORACLE_SUFFIX", "")
 LIB = os.path.join(HERE, "liboracle%s.so" % _SUFFIX)
 LIB_LIBM = os.path.join(HERE, "liboracle_libm%s.so" % _SUFFIX)  # same sources with -DCRL_LIBM: the host libm's sin / cos / atan2
+LIB_FMA = os.path.join(HERE, "liboracle_fma.so")  # -DCRL_FMA: the island solver's iterations in fused multiply-adds (CRL_FLAG_CAR_FMA contexts)
 
 RAW, GRAY = 0, 1
 
@@ -43,7 +44,7 @@ def build(force=False):
     want = h.hexdigest()
     with open(os.path.join(HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        for lib_ in (LIB, LIB_LIBM):
+        for lib_ in (LIB, LIB_LIBM) + (() if _SUFFIX else (LIB_FMA,)):
             stamp = lib_ + ".stamp"
             have = open(stamp).read().strip() if os.path.exists(stamp) else ""
             if force or not os.path.exists(lib_) or have != want:

@@ -88,7 +88,13 @@ def _park_beside(E, idx, gap=2.6):
     c1["wheel"]["cx"][idx], c1["wheel"]["cy"][idx] = c0["wheel"]["cx"][idx] + dx[:, None], c0["wheel"]["cy"][idx] + dy[:, None]
 
 
-def test_pipelined_step_equals_the_oracle_through_episode_ends():
+# the island solver's two arithmetics, each against its own oracle build (tests/test_hip_car_parity.py: SOLVERS)
+SOLVERS = pytest.mark.parametrize("solver", ["box2d", "fma"])
+ORACLE_OF = {"box2d": False, "fma": "fma"}
+
+
+@SOLVERS
+def test_pipelined_step_equals_the_oracle_through_episode_ends(solver):
     _need_gpu()
     import competitive_rl_amd as crl
     from competitive_rl_amd import _native as N
@@ -99,9 +105,9 @@ def test_pipelined_step_equals_the_oracle_through_episode_ends():
     rs = np.random.RandomState(77)
     u = rs.random_sample((n, (phases + 1) * A, 24))
     swap = rs.randint(0, 2, (n, (phases + 1) * A)).astype(np.uint8)
-    hip = crl.HipCarVecEnv(n, seed=1)  # default context: the pipelined step
+    hip = crl.HipCarVecEnv(n, seed=1, solver=solver)  # default context: the pipelined step
     hip.set_replay(u, swap)
-    B = co.CarBatch(n)
+    B = co.CarBatch(n, libm=ORACLE_OF[solver])
     episode = np.zeros(n, np.int64)
 
     def oracle_reset(i):
@@ -175,7 +181,8 @@ def test_pipelined_step_equals_the_oracle_through_episode_ends():
     hip.close()
 
 
-def test_teacher_forced_soak_2048_envs_200_steps():
+@SOLVERS
+def test_teacher_forced_soak_2048_envs_200_steps(solver):
     """tools/car_teacher_soak.py as a test, at scale: every step starts from the oracle's state (pushed as a whole), both
     sides step once -- the oracle over the host's cores (car_oracle_step_batch) --, and the complete state is compared with
     tolerance 0: bodies, joint impulses, sleep timers, wheel model, tile bookkeeping, manifolds and their impulses.  An env whose
@@ -186,12 +193,12 @@ def test_teacher_forced_soak_2048_envs_200_steps():
     from tests.car_scenarios import make_oracle_envs
 
     n, steps, base = 2048, 200, 32
-    seeds = make_oracle_envs(base, seed0=5)  # 32 distinct tracks; env i starts from seed i % 32, then diverges (own actions)
-    B = co.CarBatch(n)
+    seeds = make_oracle_envs(base, seed0=5, libm=ORACLE_OF[solver])  # 32 distinct tracks; env i starts from seed i % 32, then diverges (own actions)
+    B = co.CarBatch(n, libm=ORACLE_OF[solver])
     for i in range(n):
         B.E[i] = seeds[i % base].e
     start = B.E.copy()
-    hip = crl.HipCarVecEnv(n)
+    hip = crl.HipCarVecEnv(n, solver=solver)
     hip.reset()
 
     def push_track(j):

@@ -12,7 +12,7 @@ import competitive_rl_amd as crl
 n, steps = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, int(sys.argv[2]) if len(sys.argv) > 2 else 300
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 50  # steps between host synchronisations
 early_stream = torch.cuda.Stream() if os.environ.get("QUICK_STREAM") == "early" else None  # created BEFORE the env's own streams
-env = crl.HipCarVecEnv(n, seed=int(os.environ.get("QUICK_SEED", "0")))
+env = crl.HipCarVecEnv(n, seed=int(os.environ.get("QUICK_SEED", "0")), solver=os.environ.get("QUICK_SOLVER", "box2d"))
 st = None
 env.reset()
 g = torch.Generator(device="cuda").manual_seed(3)

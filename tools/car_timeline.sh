@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/car_timeline
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $REPO/bench.py --workload car --steps ${CAR_STEPS:-30} --warmup ${CAR_WARMUP:-5} --no-cpu-baseline > $OUT/b.json 2> $OUT/err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $REPO/bench.py --workload ${CAR_WORKLOAD:-car} --steps ${CAR_STEPS:-30} --warmup ${CAR_WARMUP:-5} --no-cpu-baseline > $OUT/b.json 2> $OUT/err
 cd $REPO
 python3 - $OUT <<'PY'
 import sys, glob, csv

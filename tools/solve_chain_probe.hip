@@ -1,7 +1,8 @@
 // How fast can ONE wavefront run the 180 velocity iterations of a car's four revolute joints?  (the per-car
 // solve and the touching solve are dependent-instruction chains of lone wavefronts.)  Runs the production loop body
 // (car_solver.h) and restructured variants on the same synthetic cars and prints time per iteration and a checksum of the
-// resulting state: a variant only counts if its checksum equals V0's bit for bit.
+// resulting state: a variant only counts if its checksum equals V0's bit for bit
+// (the FM = true variants: V3's).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I include tools/solve_chain_probe.hip -o tools/solve_chain_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -11,85 +12,10 @@
 
 using namespace crl;
 
-// ---- V1: every limit inactive, the four joints in ONE basic block
-__device__ __forceinline__ void vel_inactive(CarRegs &c, const JointTmp &j, const CarConsts &K, float h) {
-    ISL_CONSTS;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int w = 3 - q;
-        const V2 r = j.rA[w], rB = mk(0.f, 0.f);
-        {
-            const float Cdot = c.W[w].w - c.H.w - c.motor_speed[w];
-            float impulse = -j.motorMass * Cdot;
-            const float old = c.motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
-            float ni = old + impulse;
-            ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
-            c.motor_imp[w] = ni;
-            impulse = ni - old;
-            c.H.w -= iA * impulse, c.W[w].w += iB * impulse;
-        }
-        const V2 vA = mk(c.H.vx, c.H.vy), vB = mk(c.W[w].vx, c.W[w].vy);
-        const V2 Cdot = ((vB + scross(c.W[w].w, rB)) - vA) - scross(c.H.w, r);
-        const V2 im = solve22_pre(j.mass[w], j.det22[w], -1.0f * Cdot);
-        c.imp[w][0] += im.x, c.imp[w][1] += im.y;
-        c.H.vx -= mA * im.x, c.H.vy -= mA * im.y, c.H.w -= iA * cross(r, im);
-        c.W[w].vx += mB * im.x, c.W[w].vy += mB * im.y, c.W[w].w += iB * cross(rB, im);
-    }
-}
-
-// ---- V2: limits handled with selects (both the 3x3 and the 2x2 answer are computed for the two steered joints; the rear
-// joints never reach their limits and take the 2x2 path), one basic block
-__device__ __forceinline__ void vel_select(CarRegs &c, const JointTmp &j, const CarConsts &K, float h) {
-    ISL_CONSTS;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int w = 3 - q;
-        const V2 r = j.rA[w], rB = mk(0.f, 0.f);
-        {
-            const float Cdot = c.W[w].w - c.H.w - c.motor_speed[w];
-            float impulse = -j.motorMass * Cdot;
-            const float old = c.motor_imp[w], maxI = h * MAX_MOTOR_TORQUE;
-            float ni = old + impulse;
-            ni = ni < -maxI ? -maxI : ni > maxI ? maxI : ni;
-            c.motor_imp[w] = ni;
-            impulse = ni - old;
-            c.H.w -= iA * impulse, c.W[w].w += iB * impulse;
-        }
-        const V2 vA = mk(c.H.vx, c.H.vy), vB = mk(c.W[w].vx, c.W[w].vy);
-        const V2 Cdot1 = ((vB + scross(c.W[w].w, rB)) - vA) - scross(c.H.w, r);
-        // inactive answer
-        const V2 im2 = solve22_pre(j.mass[w], j.det22[w], -1.0f * Cdot1);
-        float ix = im2.x, iy = im2.y, iz = 0.0f;
-        float n0 = c.imp[w][0] + im2.x, n1 = c.imp[w][1] + im2.y, n2 = c.imp[w][2];
-        bool act = false;
-        if (w < 2) {
-            act = c.lim[w] != LIM_INACTIVE;
-            const float Cdot2 = c.W[w].w - c.H.w;
-            const float b[3] = {Cdot1.x, Cdot1.y, Cdot2};
-            float im[3];
-            solve33_pre(j.mass[w], j.cyz[w], j.det33[w], b, im);
-            im[0] = -im[0], im[1] = -im[1], im[2] = -im[2];
-            const float newI = c.imp[w][2] + im[2];
-            const bool lower = c.lim[w] == LIM_LOWER;
-            const bool clampz = lower ? newI < 0.0f : newI > 0.0f;
-            const V2 rhs = (-1.0f * Cdot1) + c.imp[w][2] * mk(j.mass[w].ez[0], j.mass[w].ez[1]);
-            const V2 red = solve22_pre(j.mass[w], j.det22[w], rhs);
-            const float ax = clampz ? red.x : im[0], ay = clampz ? red.y : im[1], az = clampz ? -c.imp[w][2] : im[2];
-            const float a0 = c.imp[w][0] + ax, a1 = c.imp[w][1] + ay, a2 = clampz ? 0.0f : c.imp[w][2] + im[2];
-            ix = act ? ax : ix, iy = act ? ay : iy, iz = act ? az : iz;
-            n0 = act ? a0 : n0, n1 = act ? a1 : n1, n2 = act ? a2 : n2;
-        }
-        c.imp[w][0] = n0, c.imp[w][1] = n1, c.imp[w][2] = n2;
-        const V2 P = mk(ix, iy);
-        // (the two paths apply the impulse with the same operations except for the + im[2] of the 3x3 one)
-        const float hw_act = c.H.w - iA * (cross(r, P) + iz), hw_in = c.H.w - iA * cross(r, P);
-        const float ww_act = c.W[w].w + iB * (cross(rB, P) + iz), ww_in = c.W[w].w + iB * cross(rB, P);
-        c.H.vx -= mA * P.x, c.H.vy -= mA * P.y;
-        c.W[w].vx += mB * P.x, c.W[w].vy += mB * P.y;
-        c.H.w = act ? hw_act : hw_in, c.W[w].w = act ? ww_act : ww_in;
-    }
-}
-
+// Variants (round 5: the loop bodies are car_solver.h's own, template parameter FM = fused multiply-adds):
+//   V0 isl_joints_vel<false> (branches per joint)   V1 isl_joints_vel_in<false> (no limit code)   V2 isl_joints_vel_sel<false> (selects)
+//   V3 isl_joints_vel_in<true>                      V4 isl_joints_vel_sel<true>                   V5 isl_joints_vel<true>
+// The checksum of V3-V5 differs from V0-V2's by design (one rounding per a*b+c instead of two); within a group it must agree.
 template <int V>
 __global__ __launch_bounds__(64) void probe(const CarConsts *Kp, int iters, int with_limits, uint32_t *sum, unsigned long long *ticks) {
     const CarConsts K = *Kp;
@@ -105,16 +31,19 @@ __global__ __launch_bounds__(64) void probe(const CarConsts *Kp, int iters, int 
     }
     JointTmp j;
     const float h = 1.0f / 50.0f;
-    isl_integrate_vel(c, K, h);
+    isl_integrate_vel<false>(c, K, h);
     isl_joints_init(c, j, K, 1.0f);
     if (!with_limits)
         for (int w = 0; w < 4; w++) c.lim[w] = LIM_INACTIVE, c.imp[w][2] = 0.f;
     const unsigned long long t0 = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
-        if (V == 0) isl_joints_vel(c, j, K, h);
-        if (V == 1) vel_inactive(c, j, K, h);
-        if (V == 2) vel_select(c, j, K, h);
+        if (V == 0) isl_joints_vel<false>(c, j, K, h);
+        if (V == 1) isl_joints_vel_in<false>(c, j, K, h);
+        if (V == 2) isl_joints_vel_sel<false>(c, j, K, h);
+        if (V == 3) isl_joints_vel_in<true>(c, j, K, h);
+        if (V == 4) isl_joints_vel_sel<true>(c, j, K, h);
+        if (V == 5) isl_joints_vel<true>(c, j, K, h);
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     uint32_t x = __float_as_uint(c.H.vx) ^ (__float_as_uint(c.H.vy) * 3u) ^ (__float_as_uint(c.H.w) * 5u);
@@ -140,8 +69,8 @@ int main() {
     hipEventCreate(&e0), hipEventCreate(&e1);
     const int iters = 1800;
     for (int lim = 0; lim < 2; lim++)
-        for (int v = 0; v < 3; v++) {
-            if (v == 1 && lim) continue;
+        for (int v = 0; v < 6; v++) {
+            if ((v == 1 || v == 3) && lim) continue;
             for (int blocks : {512, 16}) {
                 float best = 1e9f;
                 uint32_t hs = 0;
@@ -152,6 +81,9 @@ int main() {
                     if (v == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(64), 0, 0, Kd, iters, lim, sum, ticks);
                     if (v == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(64), 0, 0, Kd, iters, lim, sum, ticks);
                     if (v == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(64), 0, 0, Kd, iters, lim, sum, ticks);
+                    if (v == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(64), 0, 0, Kd, iters, lim, sum, ticks);
+                    if (v == 4) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(64), 0, 0, Kd, iters, lim, sum, ticks);
+                    if (v == 5) hipLaunchKernelGGL(probe<5>, dim3(blocks), dim3(64), 0, 0, Kd, iters, lim, sum, ticks);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     float ms;
