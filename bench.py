@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the cPongDouble hot path on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|raw|fused84|fused84_f32|fused84_newest|car|tournament|tournament_full]
-                    [--envs E] [--gather none|scalars|obs|descriptors] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload all|raw|fused84|fused84_f32|fused84_f32_ref|fused84_newest|car|car_fma|
+                    tournament|tournament_full|protocol] [--envs E] [--gather none|scalars|obs|descriptors] [--no-cpu-baseline]
 
 A "step" is one VecEnv.step over this rank's shard of envs with synthetic (pre-generated, device-resident) random
 actions, auto-reset included, no host sync inside the timed loop.  The headline (``metric`` / ``value``) is
 BASELINE.json configs[1]: cPongDouble-v0, 65 536 envs per GPU, raw (N, 2, 210, 160, 3) uint8 observations, 1 env-step =
 1 frame.  With the default ``--workload all`` on one GPU the same process then measures every other single-GPU
 configuration (fused gray+84x84+4-stack u8 and its float32 variant, cCarRacingDouble, the tournament loop) the same way
-and attaches them under ``"configs"``, each with its own ``roofline`` and ``cpu_baseline``.  ONE JSON line on rank 0.
+and attaches them under ``"configs"``, each with its own ``roofline`` and ``cpu_baseline``, plus a flat ``"configs_brief"``
+{name: [env-steps/s, ms/step, roofline frac]}.  ONE JSON line on rank 0, numbers only (< 6 KB: the driver keeps 8 KB of stdout);
+what the numbers mean -- workload definitions, roofline models, CPU baseline samples -- is DESIGN.md section 7.
 
 ``--gpus N`` without a launcher starts N fresh worker processes itself (one per GPU, before anything touches the GPU);
 under ``torch.distributed.run`` the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* of the environment are used.  Envs shard
@@ -30,7 +32,7 @@ sys.path.insert(0, ROOT)
 # ---- algorithmic HBM bytes per env per launch of the dominant kernel (DESIGN.md "Kernels")
 RAW_BYTES = 2 * 100800 + 8                 # both RGB views stored + the 8-byte frame descriptor read
 FUSED_BYTES = 2 * 4 * 84 * 84 + 8 * 8      # (2, 4, 84, 84) u8 stored + the eight descriptors of the stack
-FUSED_F32_BYTES = 4 * 2 * 4 * 84 * 84 + 8 * 8
+FUSED_F32_BYTES = 4 * 2 * 4 * 84 * 84 + 8 * 8   # float32 output (both the widened and the reference's unrounded values)
 NEWEST_BYTES = 2 * 84 * 84 + 16
 CAR_BYTES = 24900                          # obs 18 432 + state r/w ~1 600 + track read ~4 700 + visited bits
 HBM_PEAK = 8.0e12                          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s is what a float4 copy sustains)
@@ -51,7 +53,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="all",
-                    choices=["all", "raw", "fused84", "fused84_f32", "fused84_newest", "car", "car_fma", "tournament", "tournament_full"])
+                    choices=["all", "raw", "fused84", "fused84_f32", "fused84_f32_ref", "fused84_newest", "car", "car_fma", "tournament", "tournament_full", "protocol"])
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default 65536; 16384 for car)")
     ap.add_argument("--gather", choices=["none", "scalars", "obs", "descriptors"], default="none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,24 +105,29 @@ def cpu_baselines(workloads, budget_s=8.0):
             k += 1
         dt = time.perf_counter() - t0
         env.close()
-        return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-                "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c ({kind}) as one OpenMP batch over {cores} threads, {dt:.1f} s"}
+        return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port", "sample": f"{k} steps x {n} envs, one OpenMP batch, {dt:.1f} s"}
 
     def subproc(kind, label):
         v, k, dt = sb.time_subproc(kind, cores, budget_s)
-        return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port", "architecture": "subproc-arch",
-                "sample": f"{k} lock-steps x {cores} one-env worker processes ({label}), duplex pipes, pickled obs per step "
-                          f"(architecture of utils/subproc_vec_env.py:11-118), {dt:.1f} s"}
+        return {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port", "architecture": "subproc",
+                "sample": f"{k} lock-steps x {cores} one-env worker processes ({label}), {dt:.1f} s"}
+
+    cache = {}
+
+    def once(key, fn):  # fused84 / fused84_f32 / fused84_f32_ref share one CPU workload, car / car_fma another
+        if key not in cache:
+            cache[key] = fn()
+        return cache[key]
 
     for wl in workloads:
         if wl == "raw":
-            b = subproc("raw", "raw 2 x (210,160,3) u8 per env-step")
-            b["openmp_port"] = openmp_port("raw", 64 * cores)
-        elif wl in ("fused84", "fused84_f32", "fused84_newest"):
-            b = subproc("gray_84", "skip-4 + max-2 + gray + 84x84 INTER_AREA, 2 x (1,84,84) per env-step")
-            b["openmp_port"] = openmp_port("fused84", 16 * cores)
+            b = dict(once("raw", lambda: subproc("raw", "raw 2x(210,160,3) u8")))
+            b["openmp_port"] = once("raw_omp", lambda: openmp_port("raw", 64 * cores))
+        elif wl in ("fused84", "fused84_f32", "fused84_f32_ref", "fused84_newest", "protocol"):
+            b = dict(once("gray", lambda: subproc("gray_84", "skip4+max2+gray+84x84")))
+            b["openmp_port"] = once("gray_omp", lambda: openmp_port("fused84", 16 * cores))
         elif wl in ("car", "car_fma"):
-            b = subproc("car", "Box2D-style step + two 96x96 renders per env-step")
+            b = once("car", lambda: subproc("car", "Box2D-style step + two 96x96 renders"))
         elif wl == "tournament":
             b = cpu_baseline_tournament(po, atlas, cores, budget_s * 0.8)
         elif wl == "tournament_full":
@@ -130,9 +137,7 @@ def cpu_baselines(workloads, budget_s=8.0):
         out[wl] = b
     if "raw" in workloads:  # BASELINE config #1: make_envs(num_envs=4, asynchronous=False), 42x42, 1000 steps
         v, k, dt = sb.time_dummy("gray_42", 4, 1000)
-        out["raw"]["config1_dummy_n4"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port", "architecture": "dummy-arch",
-                                          "sample": f"{k} steps x 4 envs in one process (DummyVecEnv loop, utils/dummy_vec_env.py:51-63), "
-                                                    f"resized_dim 42, {dt:.1f} s"}
+        out["raw"]["config1_dummy_n4"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": f"{k} steps x 4 envs, one process, {dt:.1f} s"}
     return out
 
 
@@ -172,8 +177,7 @@ def cpu_baseline_tournament(po, atlas, cores, budget_s, full=False):
         k += 1
     dt = time.perf_counter() - t0
     env.close()
-    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{k} steps x {n} envs, oracle/pong_oracle.c (42x42, OpenMP) + oracle/policy_oracle.py (numpy/BLAS), {dt:.1f} s"}
+    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port", "sample": f"{k} steps x {n} envs, C env (OpenMP) + numpy policy, {dt:.1f} s"}
 
 
 # =============================================================================================== GPU workloads
@@ -182,14 +186,105 @@ def traffic_of(name):
     measured in a separate profiled run of this same command, not in this process."""
     f = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
     if not os.path.exists(f):
-        return None, None
-    d = json.load(open(f))
-    return d.get("hbm_bytes_per_launch"), f"profiles/traffic_{name}.json: {d.get('source', 'rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE')}"
+        return None
+    return json.load(open(f)).get("hbm_bytes_per_launch")
+
+
+# one short line per workload (what each one is, in full: DESIGN.md section 7)
+WORKLOADS = {
+    "raw": "cPongDouble-v0 raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)",
+    "fused84": "cPongDouble-v0 fused skip4+max2+gray+84x84+4-stack (N,2,4,84,84) u8, 1 step = 4 frames (config #3)",
+    "fused84_f32": "config #3 with float32 output: the uint8 values widened",
+    "fused84_f32_ref": "config #3 with float32 output: the reference's own unrounded step() values (obs_dtype=float32_ref)",
+    "fused84_newest": "config #3, newest plane only (N,2,1,84,84) u8",
+    "car": "cCarRacingDouble-v0 (N,2,96,96) u8 + Box2D-style dynamics with car-car contacts (config #4), steady state",
+    "car_fma": "config #4, island solver iterations in fused multiply-adds (CRL_FLAG_CAR_FMA), steady state",
+    "tournament": "cPongTournament-v0 42x42, MEDIUM LightActorCritic opponent on the HIP policy kernel",
+    "tournament_full": "cPongTournament-v0 42x42, full-size ActorCritic opponent (random-init weights) on the HIP MFMA kernels",
+    "protocol": "cPongDouble-v0 84x84 through the drop-in protocol: make_envs().step(), then step_envs + FrameStackTensor(4)",
+}
+
+
+def _r(x, nd=5):
+    """numbers of the JSON line: 5 significant digits"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def timed_loop(G, args, step, after=None):
+    """W warm-up calls of step(i), then exactly K timed ones between barrier + synchronize on both sides; max over ranks."""
+    torch, dist, dev, world = G["torch"], G["dist"], G["dev"], G["world"]
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if after:
+        after()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    return t0
+
+
+def run_protocol(args, G):
+    """The reference-shaped calls around the same env: (a) step_device, the library's hot-loop entry;
+    (b) make_envs(...).step(device actions) -- VecEnv.step_async / step_wait with cloned outputs and lazy infos; (c) the same with
+    infos[i] read for the envs that finished (one host copy of the done flags per step, the terminal observations drawn by one call);
+    (d) step_envs + FrameStackTensor.update (reference utils/utils.py:23-60, 145-173): the trainer's books, observation stack of
+    agent 0 as float32 (N, 4, 84, 84) kept on the device."""
+    torch, crl, dev, rank = G["torch"], G["crl"], G["dev"], G["rank"]
+    import numpy as np
+
+    n = args.envs or 65536
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pool = [torch.randint(0, 3, (n, 2), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
+    env = crl.make_envs("cPongDouble-v0", num_envs=n, log_dir=None, seed=0, resized_dim=84, frame_stack=None, device=dev, env_id_base=rank * n)
+    env.reset()
+    fst = crl.FrameStackTensor(n, (1, 84, 84), 4, dev)
+    books = dict(ep=torch.zeros((n, 2), dtype=torch.float32, device=dev), rr=[], lr=[], steps=0, episodes=0)
+    sink = [0]
+
+    def leg_device(i):
+        env.step_device(pool[i % 16])
+
+    def leg_step(i):
+        env.step(pool[i % 16])
+
+    def leg_infos(i):
+        obs, rew, done, infos = env.step(pool[i % 16])
+        for j in np.flatnonzero(done[:, 0].cpu().numpy()):
+            sink[0] += len(infos[int(j)]["terminal_observation"])
+
+    def leg_step_envs(i):
+        out = crl.step_envs(pool[i % 16], env, books["ep"], fst, books["rr"], books["lr"], books["steps"], books["episodes"], dev, False)
+        books["episodes"], books["steps"] = out[5], out[6]
+
+    res = {}
+    for key, leg in (("step_device", leg_device), ("vec_env_step", leg_step), ("vec_env_step_infos", leg_infos), ("step_envs", leg_step_envs)):
+        t0 = timed_loop(G, args, leg)
+        torch.cuda.synchronize()
+        res[key] = (time.perf_counter() - t0) / args.steps * 1e3
+    env.close()
+    base = res["step_device"]
+    out = {"value": G["world"] * n * args.steps / (res["step_envs"] * 1e-3 * args.steps), "unit": "env-steps/s", "ms_per_step": res["step_envs"], "dtype": "u8",
+           "config": {"workload": WORKLOADS["protocol"], "envs_per_gpu": n},
+           "legs_ms_per_step": res, "overhead_us_per_step": {k: (v - base) * 1e3 for k, v in res.items() if k != "step_device"},
+           "episodes_recorded": books["episodes"]}
+    return out
 
 
 def run_workload(name, args, G):
     """Builds the env for `name`, does W warm-up steps, times exactly K steps (barrier + synchronize on both sides, max
     over ranks) and returns the result dict (value, ms_per_step, roofline ...)."""
+    if name == "protocol":
+        return run_protocol(args, G)
     torch, crl, dist, dev, world, rank = G["torch"], G["crl"], G["dist"], G["dev"], G["world"], G["rank"]
     is_car = name in ("car", "car_fma")
     n = args.envs or (16384 if is_car else 65536)
@@ -207,7 +302,6 @@ def run_workload(name, args, G):
         pool = [torch.randint(0, 3, (n,), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
         pol, act = env.current_agent, env.current_agent.act_device
         policy_events = []
-
         event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]  # made before the timed loop
 
         def timed_act(*a, **k):  # HIP events around the policy kernel, on the stream it is launched on (torch's current)
@@ -223,37 +317,21 @@ def run_workload(name, args, G):
         timed_act.on = False
         pol.act_device = timed_act
         inner = env.env
-        desc = (f"cPongTournament-v0 {n} envs/GPU, 42x42 obs, opponent = reference checkpoint-medium (LightActorCritic) served by the "
-                "HIP policy kernel, 1 step = 4 frames + 1 opponent forward pass (SURVEY 8f N2+N4)")
-        if name == "tournament_full":
-            desc = (f"cPongTournament-v0 {n} envs/GPU, 42x42 obs, opponent = the full-size ActorCritic (utils/network.py:14-50, the model of "
-                    "STRONG / ALPHA_PONG; random-init weights, the reference tree has no checkpoint of it) served by the HIP MFMA kernels, "
-                    "1 step = 4 frames + 1 opponent forward pass")
-        kernel, dtype, actions_desc = "pong_policy_light_kernel", "f32", "uniform {0,1,2}"
+        kernel, dtype = "pong_policy_mfma_kernel", "f32"
     elif is_car:
         env = inner = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=base, solver="fma" if name == "car_fma" else "box2d")
         pool = [torch.rand((n, 2, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
-        desc = (f"cCarRacingDouble-v0 {n} envs/GPU, (N,2,96,96) u8 obs + Box2D-style car dynamics with car-car contacts, "
-                "1 step = 1 CarRacing.step (BASELINE config #4)")
-        kernel, dtype, actions_desc = "car_obs_kernel", "f32", "uniform [-1,1]^2 per car"
+        kernel, dtype = "car_obs_kernel", "f32"
     else:
         kw = {"raw": dict(mode="raw"),
               "fused84": dict(mode="wrapped", resized_dim=84, frame_stack=4),
               "fused84_f32": dict(mode="wrapped", resized_dim=84, frame_stack=4, obs_dtype="float32"),
+              "fused84_f32_ref": dict(mode="wrapped", resized_dim=84, frame_stack=4, obs_dtype="float32_ref"),
               "fused84_newest": dict(mode="wrapped", resized_dim=84, frame_stack=1)}[name]
         env = inner = crl.HipPongVecEnv(n, seed=0, device=dev, env_id_base=base, **kw)
         pool = [torch.randint(0, 3, (n, 2), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
-        desc = {"raw": f"cPongDouble-v0 {n} envs/GPU raw (N,2,210,160,3) u8, 1 step = 1 frame (BASELINE config #2)",
-                "fused84": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack (N,2,4,84,84) u8, 1 step = 4 frames "
-                           "(BASELINE config #3)",
-                "fused84_f32": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA+4-stack, float32 output (N,2,4,84,84): the "
-                               "uint8 values widened to the dtype DummyVecEnv's buffers have (SURVEY 8d config-3 variant, 225 792 B/env; the "
-                               "reference's own UNROUNDED float32 values are obs_dtype='float32_ref', 8.6 M env-steps/s, not benchmarked here), "
-                               "1 step = 4 frames",
-                "fused84_newest": f"cPongDouble-v0 {n} envs/GPU fused skip4+max2+gray+84x84 INTER_AREA, newest plane only (N,2,1,84,84) u8, "
-                                  "1 step = 4 frames (variant of BASELINE config #3)"}[name]
         kernel = "pong_raster_raw_sweep_kernel" if name == "raw" else "pong_raster_gray_env_kernel"
-        dtype, actions_desc = ("f32" if name == "fused84_f32" else "u8"), "uniform {0,1,2}"
+        dtype = "f32" if name in ("fused84_f32", "fused84_f32_ref") else "u8"
     env.reset()
     episodes_before = None
     if is_car:
@@ -271,7 +349,7 @@ def run_workload(name, args, G):
     gather_state = G.get("gather")
 
     def step(i):
-        if world > 1 and args.gather == "obs" and not is_car and name != "tournament":
+        if world > 1 and args.gather == "obs" and name not in ("tournament", "tournament_full"):
             # the env draws straight into the collective's send buffer (two of them, alternating: gather(t) still reads one)
             out = env.step_device(pool[i % 16], obs_out=gather_state.obs_slot(inner._obs[0].shape, inner._obs[0].dtype, dev))
         else:
@@ -292,6 +370,7 @@ def run_workload(name, args, G):
         # then reads 1.3-2.1 ms per step instead of 0.9); the warm-up's own resets are counted on the device and subtracted
         episodes_before = env.get_state()["episode"].astype("int64").sum()
         warm_resets = torch.zeros((), dtype=torch.int64, device=dev)
+
     for i in range(args.warmup):
         step(i)
         if warm_resets is not None:
@@ -331,81 +410,55 @@ def run_workload(name, args, G):
     resets = int(final_state["episode"].astype("int64").sum() - episodes_before - int(warm_resets.item())) if episodes_before is not None else None
     env.close()
     res = {"value": world * n * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3, "dtype": dtype,
-           "config": {"workload": desc, "envs_per_gpu": n, "gather": args.gather if world > 1 else "n/a",
-                      "actions": actions_desc + ", pre-generated on device", "auto_reset": True}}
+           "config": {"workload": WORKLOADS[name], "envs_per_gpu": n}}
     if resets is not None:
         res["config"]["resets_in_timed_region"] = resets
-        res["config"]["steady_state"] = "TimeLimit counters staggered over [0, 1000) + 1000 un-timed steps before the warm-up"
     if rank != 0:
         return res
     if name == "tournament_full":
         k_us = sum(a.elapsed_time(b) for a, b in policy_events) / max(len(policy_events), 1) * 1e3
         ach = POLICY_FULL_FLOP * n / (k_us * 1e-6)
-        res["roofline"] = {"bound": "mfma", "kernel": "policy_full_front_kernel + policy_full_conv3_kernel + policy_full_actor_kernel",
-                           "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": None,
-                           "flop_per_launch": POLICY_FULL_FLOP * n, "avg_kernel_us": k_us, "launches_timed": len(policy_events),
-                           "note": "the network's own 4.79 MFLOP per env (fp32 multiply-adds x 2) over the HIP-event time of one forward pass "
-                                   "(three kernels) against the fp32 matrix peak; conv1 (17 % of the FLOP) runs as three exact bf16 products per "
-                                   "tap, conv2 / conv3 on v_mfma_f32_16x16x4_f32"}
+        res["roofline"] = {"bound": "mfma", "kernel": "policy_full_front+conv3+actor", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
+                           "frac": ach / FP32_PEAK, "traffic": None, "avg_kernel_us": k_us, "launches_timed": len(policy_events)}
         return res
     if name == "tournament":
         k_us = sum(a.elapsed_time(b) for a, b in policy_events) / max(len(policy_events), 1) * 1e3
-        traffic, tsrc = traffic_of(name)
-        mode = os.environ.get("CRL_POLICY_MFMA", "3")
-        if mode in ("1", "3"):
-            # matrix-pipe kernel: per tile of 16 conv2 positions (6.25 tiles per env) conv1 = 24 v_mfma_f32_16x16x32_bf16 (three exact
-            # bf16 products per tap, 16 cycles each) or 64 v_mfma_f32_16x16x4_f32 (32 cycles), conv2 = 16 v_mfma_f32_16x16x4_f32
-            tiles = n * 100 / 16
-            c1_n, c1_flop, c1_cyc = (24, 16 * 16 * 32 * 2, 16) if mode == "3" else (64, 16 * 16 * 4 * 2, 32)
-            exec_flop = tiles * (c1_n * c1_flop + 16 * 2048)
-            floor_s = tiles * (c1_n * c1_cyc + 16 * 32) / (1024 * 2.4e9)  # 1 024 SIMDs, 2.4 GHz (the clock the launch runs at)
-            ach, peak = exec_flop / (k_us * 1e-6), exec_flop / floor_s
-            res["roofline"] = {"bound": "mfma", "kernel": "pong_policy_mfma_kernel", "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc, "flop_per_launch": exec_flop,
-                               "avg_kernel_us": k_us, "launches_timed": len(policy_events),
-                               "fp32_equivalent_tflops": POLICY_FLOP * n / (k_us * 1e-6) / 1e12,
-                               "note": "EXECUTED matrix FLOP (bf16 conv1 passes + fp32 conv2) against the issue-rate peak of that same instruction mix "
-                                       "(16 cycles per 16x16x32 bf16, 32 per 16x16x4 f32 MFMA, MI355X_MICROARCH.md); frac = matrix-pipe time / kernel time.  "
-                                       "fp32_equivalent_tflops = the network's own 1.03 MFLOP per env over the same time (round 1's packed-FMA "
-                                       "kernel: 84-93 against the 157.3 TFLOP/s fp32 peak)"}
-            return res
-        ach = POLICY_FLOP * n / (k_us * 1e-6)
-        res["roofline"] = {"bound": "valu_fp32", "kernel": kernel, "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
-                           "frac": ach / FP32_PEAK, "traffic": traffic, "traffic_source": tsrc, "flop_per_launch": POLICY_FLOP * n,
-                           "avg_kernel_us": k_us, "launches_timed": len(policy_events),
-                           "note": "fp32 (exact products; the reference plays the argmax of fp32 logits): fp32 MFMA and packed fp32 "
-                                   "VALU share one 157.3 TFLOP/s peak (MI355X_MICROARCH.md)"}
+        # matrix-pipe kernel: per tile of 16 conv2 positions (6.25 tiles per env) conv1 = 24 v_mfma_f32_16x16x32_bf16 (three exact
+        # bf16 products per tap, 16 cycles each), conv2 = 16 v_mfma_f32_16x16x4_f32 (32 cycles): EXECUTED matrix FLOP against the issue-rate
+        # peak of that instruction mix, i.e. frac = matrix-pipe time / kernel time; fp32_equivalent = the network's own 1.03 MFLOP per env
+        tiles = n * 100 / 16
+        exec_flop = tiles * (24 * 16 * 16 * 32 * 2 + 16 * 2048)
+        floor_s = tiles * (24 * 16 + 16 * 32) / (1024 * 2.4e9)  # 1 024 SIMDs, 2.4 GHz (the clock the launch runs at)
+        ach, peak = exec_flop / (k_us * 1e-6), exec_flop / floor_s
+        res["roofline"] = {"bound": "mfma", "kernel": kernel, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+                           "traffic": traffic_of(name), "avg_kernel_us": k_us, "launches_timed": len(policy_events),
+                           "fp32_equivalent_tflops": POLICY_FLOP * n / (k_us * 1e-6) / 1e12}
         return res
     ras_s = ras_ms / max(ras_n, 1) * 1e-3
-    bytes_per_env = {"raw": RAW_BYTES, "fused84": FUSED_BYTES, "fused84_f32": FUSED_F32_BYTES, "fused84_newest": NEWEST_BYTES, "car": CAR_BYTES, "car_fma": CAR_BYTES}[name]
+    bytes_per_env = {"raw": RAW_BYTES, "fused84": FUSED_BYTES, "fused84_f32": FUSED_F32_BYTES, "fused84_f32_ref": FUSED_F32_BYTES,
+                     "fused84_newest": NEWEST_BYTES, "car": CAR_BYTES, "car_fma": CAR_BYTES}[name]
     drawn = 1.0
     if is_car:
         # the timed launch draws the envs that are neither coupled nor finished (the others' wavefronts exit at once; their frames come
         # from the list-driven launches): count only what it draws.  coupled: the last step's flags; finished: resets per step.
         drawn = 1.0 - float((final_state["coupled"] != 0).mean()) - resets / max(args.steps, 1) / n
     ach = bytes_per_env * n * drawn / ras_s if ras_s > 0 else 0.0
-    traffic, tsrc = traffic_of(name)
     res["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                       "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": bytes_per_env * n * drawn, "avg_kernel_us": ras_s * 1e6,
+                       "traffic": traffic_of("car" if is_car else name), "bytes_per_launch": bytes_per_env * n * drawn, "avg_kernel_us": ras_s * 1e6,
                        "launches_timed": ras_n, "dynamics_kernel_avg_us": dyn_ms / max(dyn_n, 1) * 1e3}
     if is_car:
-        flop, fsrc = CAR_FLOP_MODEL, "bench.py CAR_FLOP_MODEL (counted from the code paths, DESIGN.md 4b)"
+        flop = CAR_FLOP_MODEL
         ff = os.path.join(ROOT, "profiles", "flops_car.json")
         if os.path.exists(ff):
-            d = json.load(open(ff))
-            flop, fsrc = d["f32_flop_per_env_step"], "profiles/flops_car.json: " + d.get("source", "")
+            flop = json.load(open(ff))["f32_flop_per_env_step"]
         fl = flop * res["value"] / world
         res["roofline"]["envs_drawn_by_timed_launch"] = drawn
-        res["roofline"]["note"] = ("car_obs_kernel = the per-pixel gather from the pre-rastered map for the envs that are neither coupled nor finished "
-                                   "(envs_drawn_by_timed_launch of the batch: bytes_per_launch counts those; `traffic` is the PMC figure of a launch "
-                                   "that draws every env); vector-issue bound (250 instructions per 16 pixels of a lane), not bandwidth bound; the step "
-                                   "itself ends with the touching cars' island solve, see roofline_valu and DESIGN.md 4.4")
         res["roofline_valu"] = {"bound": "valu_fp32", "achieved": fl / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / FP32_PEAK,
-                                "flop_per_env_step": flop, "flop_source": fsrc,
-                                "limiter": "neither roof: the island solves are 180 x 4 Gauss-Seidel joint updates per car on one lane each (a lone "
-                                           "wavefront issues one instruction per ~5.3 cycles: 900-1 800 cycles per iteration), a touching pair of cars adds "
-                                           "~1 350 cycles per contact and iteration, and the step ends with the slowest such island; see DESIGN.md 4.2 / 4.4"}
+                                "flop_per_env_step": flop}
     return res
+
+
+ALL = ["raw", "fused84", "fused84_f32", "fused84_f32_ref", "car", "car_fma", "tournament", "tournament_full", "protocol"]
 
 
 def main():
@@ -416,7 +469,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     multi = args.workload == "all" and world == 1
-    names = ["raw", "fused84", "fused84_f32", "car", "tournament", "tournament_full"] if multi else [("raw" if args.workload == "all" else args.workload)]
+    names = ALL if multi else [("raw" if args.workload == "all" else args.workload)]
     # the CPU baselines run first: worker processes are started while this process has not initialised the GPU
     cpu = {}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -447,15 +500,24 @@ def main():
         metric = {"car": "env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU",
                   "car_fma": "env-steps/sec (whole node), cCarRacingDouble 16384 envs per GPU, island solver in fused multiply-adds",
                   "tournament": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs the MEDIUM CNN opponent",
-                  "tournament_full": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs a full-size ActorCritic opponent"}.get(
+                  "tournament_full": "env-steps/sec (whole node), cPongTournament 65536 envs per GPU vs a full-size ActorCritic opponent",
+                  "protocol": "env-steps/sec (whole node), cPongDouble 65536 envs per GPU through make_envs().step + step_envs"}.get(
             names[0], "env-steps/sec (whole node), cPongDouble 65536 envs per GPU")
         line = {"metric": metric, "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"],
-                "data": "synthetic", "config": head["config"], "roofline": head.get("roofline")}
-        if "roofline_valu" in head:
-            line["roofline_valu"] = head["roofline_valu"]
-        # what ran where: one process per GPU, contiguous env ranges by global id, no data-path collective unless
-        # --gather asks for the config-#5 all-gather; the collective library the ranks would use
+                "data": "synthetic", "config": dict(head["config"], gather=args.gather if world > 1 else "n/a", actions="uniform random, pre-generated on device",
+                                                    auto_reset=True),
+                "roofline": head.get("roofline")}
+        for k in ("roofline_valu", "legs_ms_per_step", "overhead_us_per_step"):
+            if k in head:
+                line[k] = head[k]
+        if names[0] in cpu:
+            line["cpu_baseline"] = cpu[names[0]]
+        if multi:
+            # every configuration where a parser that keeps only top-level scalars / short lists still finds it: [env-steps/s, ms/step, roofline frac]
+            line["configs_brief"] = {nm: [results[nm]["value"], results[nm]["ms_per_step"], (results[nm].get("roofline") or {}).get("frac")] for nm in names}
+        # what ran where: one process per GPU, contiguous env ranges by global id, no data-path collective unless --gather asks for the
+        # config-#5 all-gather; the collective library the ranks would use
         npg = head["config"]["envs_per_gpu"]
         try:
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -463,21 +525,20 @@ def main():
             rccl = f"unavailable ({type(exc).__name__})"
         line["comm"] = {"backend": "nccl (= RCCL on ROCm)" if world > 1 else "none (one rank)", "rccl_version": rccl, "world": world,
                         "env_ranges": [[r * npg, (r + 1) * npg] for r in range(world)], "gather": args.gather}
-        if world > 1 and args.gather != "none":
-            line["config"]["gather"] = args.gather + (" (64 bytes of frame descriptors per env in one packed all_gather_into_tensor per step; every rank re-draws all shards' observations)"
-                                                      if args.gather == "descriptors" else
-                                                      " (one packed all_gather_into_tensor per step on a side stream, overlapped with the next step)")
-        if names[0] in cpu:
-            line["cpu_baseline"] = cpu[names[0]]
         if multi:
             line["configs"] = {}
-            for nm in names[1:]:
-                r = dict(results[nm])
-                r["steps"], r["warmup"] = args.steps, args.warmup
+            for nm in names[1:]:  # slim: the name is the key of WORKLOADS / DESIGN.md section 7, numbers only
+                r = {k: v for k, v in results[nm].items() if k != "unit"}
+                r["config"] = {k: v for k, v in r["config"].items() if k != "workload"}
+                if r.get("roofline"):
+                    r["roofline"] = {k: v for k, v in r["roofline"].items() if k not in ("bytes_per_launch", "launches_timed", "dynamics_kernel_avg_us")}
                 if nm in cpu:
-                    r["cpu_baseline"] = cpu[nm]
+                    b = {k: v for k, v in cpu[nm].items() if k in ("value", "unit", "cores", "kind", "sample")}
+                    if "openmp_port" in cpu[nm]:
+                        b["openmp_port_value"] = cpu[nm]["openmp_port"]["value"]
+                    r["cpu_baseline"] = b
                 line["configs"][nm] = r
-        print(json.dumps(line), flush=True)
+        print(json.dumps(_r(line), separators=(",", ":")), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

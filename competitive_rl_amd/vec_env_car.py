@@ -110,7 +110,7 @@ class HipCarVecEnv(VecEnv):
         self._done = torch.zeros((n,), dtype=torch.uint8, device=dev)
         self._actions = torch.zeros((n, self.P, 2), dtype=torch.float32, device=dev)
         self._serial = 0
-        self._prev_buf = self._obs[1]
+        self._prev_buf = self._cur_out = self._obs[1]
         self.envs = _EnvList(self)
 
     def _stream(self):
@@ -148,17 +148,29 @@ class HipCarVecEnv(VecEnv):
             raise AssertionError(f"actions must have shape ({self.num_envs}, {self.P}, 2), got {tuple(a.shape)}")
         self._actions = a.contiguous()
 
-    def step_device(self, actions_f32, render=True):
-        """Hot-loop entry: float32 (N, 2, 2) device tensor in, device tensors out, no sync."""
+    def step_device(self, actions_f32, render=True, obs_out=None):
+        """Hot-loop entry: float32 (N, 2, 2) device tensor in, device tensors out, no sync.  ``obs_out``: draw the observation straight
+        into the caller's tensor (e.g. its slot of a collective's send buffer, sharding.StepGather.obs_slot) instead of the env's
+        double buffer; the caller keeps it intact until the next step has been issued (a stacked env's terminal observations read it)."""
         if not (actions_f32.is_contiguous() and actions_f32.dtype == torch.float32 and actions_f32.device == self.device):
             raise AssertionError("step_device needs a contiguous float32 tensor on the env's device")
+        if obs_out is not None:
+            if not (obs_out.is_contiguous() and obs_out.dtype == torch.uint8 and obs_out.device == self.device
+                    and obs_out.numel() == self._obs[0].numel()):
+                raise AssertionError("obs_out must be a contiguous uint8 tensor of the observation buffer's size on the env's device")
+            N.check(self._L.crl_step(self._h, C.c_void_p(actions_f32.data_ptr()), C.c_void_p(obs_out.data_ptr()),
+                                     C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+            self._serial += 1
+            self._prev_buf, self._cur_out = self._cur_out, obs_out.view(self._obs[0].shape)
+            return self._cur_out, self._rew, self._done
         buf = self._obs[self._flip]
         N.check(self._L.crl_step(self._h, C.c_void_p(actions_f32.data_ptr()), C.c_void_p(buf.data_ptr()) if render else None,
                                  C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
         self._serial += 1
         if not render:  # nothing was drawn: the buffers stay as they are, and there is no observation to hand out
             return None, self._rew, self._done
-        self._prev_buf = self._obs[self._flip ^ 1]  # observation before this step (the stack's older planes)
+        self._prev_buf = self._cur_out  # observation before this step (the stack's older planes)
+        self._cur_out = buf
         self._flip ^= 1
         return buf, self._rew, self._done
 

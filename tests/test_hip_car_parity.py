@@ -823,21 +823,53 @@ def test_set_state_that_rewinds_the_episode_does_not_reuse_an_overwritten_walk()
         run(1)
 
     run(130)  # the walks of episode 1 (started behind the full reset, one piece per step) are in
-    snap_a, snap_b = a.get_state(), b.get_state()
-    assert snap_a.tobytes() == snap_b.tobytes()
-    ep0 = snap_a["episode"].copy()
-    finish_picked()
-    assert (a.get_state()["episode"][pick] == ep0[pick] + 1).all()
-    run(20)  # the walk-ahead of the picked envs' NEXT episode is now overwriting the scratch their last walk lived in
-    a.set_state(snap_a), b.set_state(snap_b)
-    assert (a.get_state()["episode"] == ep0).all()
-    finish_picked()  # resets with the rewound episode index
-    sa, sb = a.get_state(), b.get_state()
-    assert (sa["episode"][pick] == ep0[pick] + 1).all()
-    assert sa.tobytes() == sb.tobytes()
-    for i in np.nonzero(pick)[0]:
-        ta, tb = a.get_track(int(i)), b.get_track(int(i))
-        assert ta["n"] == tb["n"] and np.array_equal(ta["tile_poly"], tb["tile_poly"]), int(i)
-    run(5)
-    assert torch.equal(a.render_current(), b.render_current())
+    for delay in (2, 5, 9, 14):  # steps between the reset and the restore: the next walk (2 500 iterations, 160 per step) is under way
+        snap_a, snap_b = a.get_state(), b.get_state()
+        assert snap_a.tobytes() == snap_b.tobytes()
+        ep0 = snap_a["episode"].copy()
+        finish_picked()
+        assert (a.get_state()["episode"][pick] == ep0[pick] + 1).all()
+        run(delay)  # the walk-ahead of the picked envs' NEXT episode is now overwriting the scratch their last walk lived in
+        a.set_state(snap_a), b.set_state(snap_b)
+        assert (a.get_state()["episode"] == ep0).all()
+        finish_picked()  # resets with the rewound episode index
+        sa, sb = a.get_state(), b.get_state()
+        assert (sa["episode"][pick] == ep0[pick] + 1).all()
+        for i in np.nonzero(pick)[0]:
+            ta, tb = a.get_track(int(i)), b.get_track(int(i))
+            assert ta["n"] == tb["n"] and np.array_equal(ta["tile_poly"], tb["tile_poly"]), (delay, int(i))
+        assert sa.tobytes() == sb.tobytes(), delay
+        run(5)
+        assert torch.equal(a.render_current(), b.render_current())
+        run(60)  # (the walks of the next episode finish: the next round starts from tag == episode again)
     a.close(), b.close()
+
+
+def test_car_step_device_draws_into_the_callers_tensor():
+    """``step_device(obs_out=)`` (the zero-copy slot of sharding.StepGather for config #5): same frames as the
+    env's own double buffer, with and without a frame stack, terminal observations included."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    for K in (None, 3):
+        n = 40
+        a, b = crl.HipCarVecEnv(n, seed=4, frame_stack=K), crl.HipCarVecEnv(n, seed=4, frame_stack=K)
+        a.reset(), b.reset()
+        for env in (a, b):
+            st = env.get_state()
+            st["elapsed"][::5] = 994
+            env.set_state(st)
+        g = torch.Generator(device="cuda").manual_seed(6)
+        slots = [torch.empty_like(a._obs[0]) for _ in range(2)]
+        with pytest.raises(AssertionError):
+            a.step_device(torch.zeros((n, 2, 2), device="cuda"), obs_out=torch.empty(7, dtype=torch.uint8, device="cuda"))
+        for t in range(12):
+            act = torch.rand((n, 2, 2), generator=g, device="cuda") * 2 - 1
+            oa, ra, da = a.step_device(act, obs_out=slots[t & 1])
+            ob, rb, db = b.step_device(act)
+            assert oa.data_ptr() == slots[t & 1].data_ptr()
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+            idx = torch.nonzero(da).reshape(-1)
+            if len(idx):
+                assert torch.equal(torch.stack(a.terminal_observation(idx)), torch.stack(b.terminal_observation(idx)))
+        a.close(), b.close()

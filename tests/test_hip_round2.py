@@ -415,6 +415,32 @@ def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
         _check_against_one_batch(tmp_path)
 
 
+def test_bench_line_on_two_gpus_names_the_ranks_and_their_env_ranges():
+    """The first multi-GPU box validates ranks + ranges in one run: ``bench.py --gpus 2 --steps 5`` for the Pong and the
+    CarRacing workload with the config-#5 gather -- world 2, RCCL named, contiguous env ranges by global id, whole-job value.
+    Needs two visible GPUs; skipped on a one-GPU box."""
+    _need_gpu()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for wl, envs in (("fused84", 4096), ("car", 1024)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--workload", wl,
+                              "--envs", str(envs), "--gather", "obs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, CRL_BENCH_CAR_PREROLL="50"))
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 5
+        comm = line["comm"]
+        assert comm["world"] == 2 and comm["backend"].startswith("nccl") and comm["gather"] == "obs"
+        assert comm["env_ranges"] == [[0, envs], [envs, 2 * envs]]
+        assert abs(line["value"] - 2 * envs * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-3 * line["value"]  # whole-job: both ranks' envs
+
+
 def test_address_linear_gray_writer_is_bit_exact_too():
     """The address-linear fused-84 writer (header kernel + aligned 1-KiB-block sweep; bit-exact and slower,
     so it lives in the profiling variant only: CRL_LIB_VARIANT=abl CRL_GRAY_SWEEP=1) against the oracle, in a child process

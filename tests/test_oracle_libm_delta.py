@@ -5,6 +5,7 @@ the reference's Box2D / CPython / pygame call: ``b2Rot`` = sinf / cosf at car_ra
 ``_create_track``) are the same sources.  Here both are teacher-forced from IDENTICAL pre-step states, step by step,
 and the distance after one ``world.Step`` is measured: north_star's bar for CarRacing float state is 1e-5."""
 import numpy as np
+import pytest
 
 from oracle import car_oracle as co
 from tests.car_scenarios import crash_actions, make_oracle_envs, park_for_crash
@@ -41,9 +42,18 @@ def _merge(w, x):
         w[k] = max(w.get(k, 0.0), v)
 
 
-def test_free_driving_one_step_distance():
+# "crl": the default build (== the HIP kernels' default path); "fma": the build whose island iterations use fused multiply-adds
+# (== CRL_FLAG_CAR_FMA contexts).  Measured (this test's print-out): positions, angles inside north_star's 1e-5 for both; LINEAR
+# velocities 4.7e-6 / 5.6e-6 for crl but 2.6e-5 for fma (every rounding of the 180 unconverged Gauss-Seidel iterations differs, not just
+# the last bit of a few sines) -- which is why fma is opt-in; wheel spin 2.75e-4 (crl) / 8.6e-5 (fma), joint impulses 3e-5 / 4e-5.
+VEL_BOUND = {False: 1e-5, "fma": 6e-5}
+BUILDS = pytest.mark.parametrize("build", [False, "fma"], ids=["crl", "fma"])
+
+
+@BUILDS
+def test_free_driving_one_step_distance(build):
     n, steps = 12, 160
-    envs, twins = make_oracle_envs(n), [co.CarEnv(libm=True) for _ in range(n)]
+    envs, twins = make_oracle_envs(n, libm=build), [co.CarEnv(libm=True) for _ in range(n)]
     rs = np.random.RandomState(4)
     worst = {}
     for t in range(steps):
@@ -51,18 +61,21 @@ def test_free_driving_one_step_distance():
         if t < 60:
             acts[:, :, 1] = np.abs(acts[:, :, 1])
         _merge(worst, _one_step_distance(envs, twins, acts))
-    print("crl vs libm oracle, one step from identical state, free driving: max relative |d|", worst)
+    print("crl" if not build else build, "vs libm oracle, one step from identical state, free driving: max relative |d|", worst)
     # north_star's 1e-5 holds for positions, angles and linear velocities; a wheel's spin (inverse inertia 134 behind a
     # stiff joint) amplifies ONE unit in the last place of sinf / cosf by three to four orders of magnitude -- no
     # evaluation other than the host's own libm can stay under 1e-5 there; the bound below is the stated deviation
-    for f in ("cx", "cy", "a", "vx", "vy"):
+    for f in ("cx", "cy", "a"):
         assert worst[f] <= 1e-5, (f, worst)
+    for f in ("vx", "vy"):
+        assert worst[f] <= VEL_BOUND[build], (f, worst)
     assert worst["w"] <= 2e-3 and worst["imp"] <= 2e-3, worst
 
 
-def test_touching_cars_one_step_distance():
+@BUILDS
+def test_touching_cars_one_step_distance(build):
     n, steps = 8, 150
-    envs, twins = make_oracle_envs(n, seed0=20), [co.CarEnv(libm=True) for _ in range(n)]
+    envs, twins = make_oracle_envs(n, seed0=20, libm=build), [co.CarEnv(libm=True) for _ in range(n)]
     park_for_crash(envs)
     worst, touched = {}, 0
     for t in range(steps):
@@ -70,13 +83,15 @@ def test_touching_cars_one_step_distance():
         for e, tw in zip(envs, twins):
             touched += int(e.e["n_contact"]) > 0
             assert int(e.e["n_contact"]) == int(tw.e["n_contact"])
-    print("crl vs libm oracle, one step from identical state, cars touching in", touched, "env-steps: max relative |d|", worst)
+    print("crl" if not build else build, "vs libm oracle, one step from identical state, cars touching in", touched, "env-steps: max relative |d|", worst)
     assert touched > 50
     # A touching wheel's spin is where a last-bit difference of sinf / cosf is amplified most (inverse inertia 134):
     # the number is REPORTED for every field; the bar is north_star's 1e-5 on positions / angles / linear velocity,
     # and a looser stated bound on angular velocity.
-    for f in ("cx", "cy", "a", "vx", "vy"):
+    for f in ("cx", "cy", "a"):
         assert worst[f] <= 1e-5, (f, worst)
+    for f in ("vx", "vy"):
+        assert worst[f] <= VEL_BOUND[build], (f, worst)
     assert worst["w"] <= 5e-3, worst
 
 
