@@ -284,10 +284,11 @@ static int setup_gray(crl_ctx *c) {
     launch_pong_gray_templates(p, c->x_first, c->x_last, c->y_first, c->y_last, c->band_rows, c->band_chunks, c->band,
                                c->rest, nullptr);
     HIP_TRY(hipGetLastError());
-    if (c->o.obs_dtype == CRL_OBS_F32_REF) {  // the unrounded float32 path's tables: 484 score pairs x 2 views x {unrounded, rounded}
+    if (c->o.obs_dtype == CRL_OBS_F32_REF) {  // the unrounded float32 path's tables: 484 score pairs x 3 kinds x 2 views x {unrounded, rounded}
         c->f32_bot0 = yf[CRL_PONG_BOTTOM], c->f32_xtaps = (int)xt.si.size(), c->f32_ytaps = (int)yt.si.size();
         p.band_rows = c->band_rows, p.f32_bot0 = c->f32_bot0;
-        if ((rc = dev_alloc(c, &c->f32_top, (size_t)484 * 4 * c->band_rows * R))) return rc;
+        // x 3 "kinds": both kept frames with this score pair | the left / the right score one higher in one of them (a point scored between them)
+        if ((rc = dev_alloc(c, &c->f32_top, (size_t)484 * 3 * 4 * c->band_rows * R))) return rc;
         if ((rc = dev_alloc(c, &c->f32_bot, (size_t)2 * (R - c->f32_bot0) * R))) return rc;
         launch_pong_gray_f32ref_tables(p, c->f32_top, c->f32_bot, nullptr);
         HIP_TRY(hipGetLastError());

@@ -704,9 +704,13 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side2, c->ev_join, 0);
         hipEventRecord(c->ev_fin3, c->side2);
         if (can_ahead && !early_collide) collide_next(false);  // (beside this step's last frames and the next car_step_kernel)
-        if (early_collide && !CRL_ABL(getenv("CRL_CAR_COLLIDE_WAIT") != nullptr)) c->collide_is_joined = true, c->collide_joined = st;  // (ev_fin3 was recorded behind the Collide on side2)
         queue_walk_ahead(c, c->side2);
-        hipStreamWaitEvent(st, c->ev_fin3, 0);
+        // The next step may skip its barriers on ev_collide ONLY because of this order on side2: collide_next(true) [records ev_collide] ...
+        // record(ev_fin3) ... and the caller's stream waits for ev_fin3 here.  Anything added to side2 behind the ev_fin3 record that the next
+        // car_step_kernel must see, or an early return between that record and this wait, breaks it silently: the flag is set
+        // behind the wait, and only when the wait was accepted.
+        const bool joined = hipStreamWaitEvent(st, c->ev_fin3, 0) == hipSuccess;
+        if (joined && early_collide && !CRL_ABL(getenv("CRL_CAR_COLLIDE_WAIT") != nullptr)) c->collide_is_joined = true, c->collide_joined = st;
         if (c->K > 1) launch_car_stack(c->frame, c->stack, obs_dev, c->done_env, false, c->K, c->n, c->s.players, st);
     }
     hipError_t e = hipGetLastError();

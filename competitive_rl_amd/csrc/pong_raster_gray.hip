@@ -878,7 +878,7 @@ void pong_gray_print_ticks() {
 // area average of that; reset() and the auto-reset of a finished env go through the uint8 image (rounded).  A plane whose two
 // kept frames are the same frame is such a reset observation (consecutive frames of a running game differ in the ball's x).
 // Every tap is evaluated from the frame descriptors in OpenCV's accumulation order (eval_pixel's).  This is the exact mode, not
-// the fast one (7.6 ms per step at 65 536 envs against 2.7 ms for the widened uint8 values, CRL_OBS_F32).
+// the fast one (round 4: 7.6 ms per step at 65 536 envs against 2.7 ms for the widened uint8 values, CRL_OBS_F32; round 5: DESIGN.md 7).
 __device__ inline float gray_of_f32(int v) {
     const float f = (float)v;
     return f * 0.299f + f * 0.587f + f * 0.114f;  // (one rounding per operation: -ffp-contract=off)
@@ -918,12 +918,19 @@ __device__ inline Frame parked_frame(int sl, int sr) {
 __global__ __launch_bounds__(256) void pong_gray_f32ref_table_kernel(GrayCtx g, int R, int band_rows, int bot0, float *__restrict__ top,
                                                                      float *__restrict__ bot) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t ntop = (int64_t)484 * 2 * 2 * band_rows * R, nbot = (int64_t)2 * (R - bot0) * R;
+    // top[pair][kind][view][rounded][band_rows][R]; kind 0: both kept frames show the pair; 1 / 2: one of them shows the left / right score
+    // one higher (a point was scored between the two frames: the text under the max is the union of both -- round 4 evaluated every
+    // pixel of such a plane, 2.5 % of the tiles of a random-action batch at 40-100 x the cost of the others: 6.4 of the kernel's 7.6 ms)
+    const int64_t ntop = (int64_t)484 * 3 * 2 * 2 * band_rows * R, nbot = (int64_t)2 * (R - bot0) * R;
     if (i < ntop) {
         const int dx = (int)(i % R), dy = (int)(i / R % band_rows), rnd = (int)(i / ((int64_t)R * band_rows) % 2);
-        const int view = (int)(i / ((int64_t)R * band_rows * 2) % 2), pair = (int)(i / ((int64_t)R * band_rows * 4));
-        const Frame f = parked_frame(pair / 22, pair % 22);
-        top[i] = f32ref_pixel(g, f, f, view, dy, dx, rnd != 0);
+        const int view = (int)(i / ((int64_t)R * band_rows * 2) % 2), kind = (int)(i / ((int64_t)R * band_rows * 4) % 3);
+        const int pair = (int)(i / ((int64_t)R * band_rows * 12)), sl = pair / 22, sr = pair % 22;
+        const Frame f = parked_frame(sl, sr);
+        const int sl2 = sl + (kind == 1), sr2 = sr + (kind == 2);
+        if (sl2 > 21 || sr2 > 21) return;  // (no such score; the slot is never read)
+        const Frame f2 = parked_frame(sl2, sr2);
+        top[i] = f32ref_pixel(g, f, f2, view, dy, dx, rnd != 0);
     } else if (i < ntop + nbot) {
         const int64_t q = i - ntop;
         const int dx = (int)(q % R), dy = bot0 + (int)(q / R % (R - bot0)), rnd = (int)(q / ((int64_t)R * (R - bot0)));
@@ -934,26 +941,29 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_table_kernel(GrayCtx g, 
 
 void launch_pong_gray_f32ref_tables(const GrayParams &p, float *top, float *bot, hipStream_t st) {
     GrayCtx g = {p.atlas_gray, p.xofs, p.yofs, p.xsi, p.ysi, p.xalpha, p.yalpha};
-    const int64_t total = (int64_t)484 * 4 * p.band_rows * p.R + (int64_t)2 * (p.R - p.f32_bot0) * p.R;
+    const int64_t total = (int64_t)484 * 12 * p.band_rows * p.R + (int64_t)2 * (p.R - p.f32_bot0) * p.R;
     hipLaunchKernelGGL(pong_gray_f32ref_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, p.R, p.band_rows, p.f32_bot0, top, bot);
 }
 
 // One wavefront per (env, view, plane) tile.  Usual case (both kept frames show the same scores): the plane is the score pair's
 // band rows + an empty court + the white band, copied, and the few dozen output pixels whose taps touch the ball or a bat of
-// either frame, re-drawn exactly -- every other pixel sees the same source values as in the table.  Otherwise (a point was
-// scored between the two frames) every pixel is evaluated.  The tap tables are staged in LDS once per workgroup (an output
-// pixel's evaluation is a chain of ~25 dependent table reads).
+// either frame, re-drawn exactly -- every other pixel sees the same source values as in the table.  A point scored between the
+// two frames puts two score texts under the max: the tables hold that union too (kind 1 / 2: left / right score one higher in one
+// frame).  Only unrelated score pairs (a set_state can produce them) evaluate every pixel.  The tap tables are staged in LDS once per
+// workgroup (an output pixel's evaluation is a chain of ~25 dependent table reads).
 struct F32RefGeom {
     const float *top, *bot;
     int band_rows, bot0;
     const uint8_t *x_first, *x_last, *y_first, *y_last;
     int xtaps, ytaps;  // entries of the x / y tap tables
+    int debug;         // profiling build: 16 = no re-draw, 32 = no table copy (WRONG pixels: what each phase costs)
 };
 static constexpr int kF32MaxR = 84, kF32MaxTaps = 3 * kF32MaxR + 8;
 __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx gg, F32RefGeom q, int R, int K, int views,
                                                                float *__restrict__ obs) {
     __shared__ int32_t s_xofs[kF32MaxR + 1], s_yofs[kF32MaxR + 1], s_xsi[kF32MaxTaps], s_ysi[kF32MaxTaps];
     __shared__ float s_xalpha[kF32MaxTaps], s_yalpha[kF32MaxTaps];
+    if (q.debug & 64) return;
     GrayCtx g = gg;
     if (R <= kF32MaxR && q.xtaps <= kF32MaxTaps && q.ytaps <= kF32MaxTaps) {  // (uniform)
         for (int i = threadIdx.x; i <= R; i += 256) s_xofs[i] = gg.xofs[i], s_yofs[i] = gg.yofs[i];
@@ -962,6 +972,7 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
         g.xofs = s_xofs, g.yofs = s_yofs, g.xsi = s_xsi, g.ysi = s_ysi, g.xalpha = s_xalpha, g.yalpha = s_yalpha;
     }
     __syncthreads();
+    if (q.debug & 128) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
     const int tiles_per_env = views * K;
@@ -978,19 +989,52 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
     const bool rounded = pa == pb || fa.sl == 255 || fb.sl == 255;  // a reset observation: the uint8 path
     if (fa.sl == 255) fa = fb;
     else if (fb.sl == 255) fb = fa;
-    if (fa.sl != fb.sl || fa.sr != fb.sr || q.band_rows > q.bot0) {  // different score texts in the two frames (or a tiny R): every pixel
+    // which table: the two frames' score pair, or a pair and its successor (the frames in either order)
+    const int slo = min(fa.sl, fb.sl), sro = min(fa.sr, fb.sr), dl = abs(fa.sl - fb.sl), dr = abs(fa.sr - fb.sr);
+    const int kind = (dl == 0 && dr == 0) ? 0 : (dl == 1 && dr == 0) ? 1 : (dl == 0 && dr == 1) ? 2 : -1;
+    if (kind < 0 || max(fa.sl, fb.sl) > 21 || max(fa.sr, fb.sr) > 21 || q.band_rows > q.bot0) {  // unrelated score texts (only a set_state produces them) or a tiny R: every pixel
         for (int i = lane; i < R * R; i += 64) out[i] = f32ref_pixel(g, fa, fb, view, i / R, i - (i / R) * R, rounded);
         return;
     }
-    {
-        const float *top = q.top + ((((int64_t)(fa.sl * 22 + fa.sr) * 2 + view) * 2 + (rounded ? 1 : 0)) * q.band_rows) * R;
+    if (!(q.debug & 32)) {
+        const float *top = q.top + (((((int64_t)(slo * 22 + sro) * 3 + kind) * 2 + view) * 2 + (rounded ? 1 : 0)) * q.band_rows) * R;
         const float *bot = q.bot + (int64_t)(rounded ? 1 : 0) * (R - q.bot0) * R;
         const int ntop = q.band_rows * R, nbot0 = q.bot0 * R;
-        for (int i = lane; i < ntop; i += 64) out[i] = top[i];
-        for (int i = ntop + lane; i < nbot0; i += 64) out[i] = 0.0f;
-        for (int i = nbot0 + lane; i < R * R; i += 64) out[i] = bot[i - nbot0];
+        if (((ntop | nbot0 | (R * R)) & 3) == 0) {  // (uniform; R = 84: always) 16-byte pieces -- a tile is 28 KB, three quarters of it the empty court
+            // (round 4 copied float by float: 110 dependent load -> store pairs per lane and 4-byte stores; round 5: the table reads of a
+            // lane are issued together, 7 of them, and the tile leaves in 1-KiB wave stores)
+            const float4 *top4 = reinterpret_cast<const float4 *>(top), *bot4 = reinterpret_cast<const float4 *>(bot);
+            float4 *out4 = reinterpret_cast<float4 *>(out);
+            const int nt4 = ntop >> 2, nb4 = nbot0 >> 2, nn4 = (R * R) >> 2;
+            constexpr int kU = 6;  // table pieces in flight per lane (band: <= 5 per lane at R = 84, bottom rows: <= 3)
+            for (int i0 = lane; i0 < nt4; i0 += 64 * kU) {
+                float4 v[kU];
+#pragma unroll
+                for (int k = 0; k < kU; k++)
+                    if (i0 + 64 * k < nt4) v[k] = top4[i0 + 64 * k];
+#pragma unroll
+                for (int k = 0; k < kU; k++)
+                    if (i0 + 64 * k < nt4) out4[i0 + 64 * k] = v[k];
+            }
+            for (int i0 = nb4 + lane; i0 < nn4; i0 += 64 * kU) {
+                float4 v[kU];
+#pragma unroll
+                for (int k = 0; k < kU; k++)
+                    if (i0 + 64 * k < nn4) v[k] = bot4[i0 + 64 * k - nb4];
+#pragma unroll
+                for (int k = 0; k < kU; k++)
+                    if (i0 + 64 * k < nn4) out4[i0 + 64 * k] = v[k];
+            }
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = nt4 + lane; i < nb4; i += 64) out4[i] = z;
+        } else {
+            for (int i = lane; i < ntop; i += 64) out[i] = top[i];
+            for (int i = ntop + lane; i < nbot0; i += 64) out[i] = 0.0f;
+            for (int i = nbot0 + lane; i < R * R; i += 64) out[i] = bot[i - nbot0];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the re-drawn pixels below overwrite what other lanes have just stored: those stores first
+    if (q.debug & 16) return;
     // ball, left bat, right bat of both frames: source rectangle -> the output pixels it feeds; one list over the six rectangles
     // (where two of them overlap a pixel is drawn twice, to the same value)
     int rdx0[6], rwx[6], rdy0[6], rend[6], total = 0;
@@ -1049,7 +1093,8 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     if (p.obs_f32 == 2) {  // CRL_OBS_F32_REF
         const int views = p.views > 0 ? p.views : 2;
         const int64_t tiles = p.n * views * p.K;
-        const F32RefGeom fq = {p.f32_top, p.f32_bot, p.band_rows, p.f32_bot0, x_first, x_last, y_first, y_last, p.f32_xtaps, p.f32_ytaps};
+        static const int dbg = CRL_ABL(getenv("CRL_GRAY_DEBUG") != nullptr) ? atoi(getenv("CRL_GRAY_DEBUG")) : 0;
+        const F32RefGeom fq = {p.f32_top, p.f32_bot, p.band_rows, p.f32_bot0, x_first, x_last, y_first, y_last, p.f32_xtaps, p.f32_ytaps, dbg};
         hipLaunchKernelGGL(pong_gray_f32ref_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, fq, p.R, p.K, views,
                            reinterpret_cast<float *>(p.obs));
         return;

@@ -19,8 +19,8 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
               obs_dtype="uint8", env_id_base=0, stack_planes=1, score_atlas=None):
     """Create a vectorised environment.
 
-    :param env_id: "cPongDouble-v0" is served by the HIP backend (other reference ids are
-        not part of this hot path yet and raise NotImplementedError).
+    :param env_id: one of the reference's ids served by the HIP backend: "cPongDouble-v0", "cPong-v0", "cPongTournament-v0",
+        "cCarRacingDouble-v0", "cCarRacing-v0" (register.py / car_racing/register.py); anything else raises NotImplementedError.
     :param seed: random seed; env i is keyed by ``seed`` and its global index.
     :param log_dir: only created, as in the reference (make_envs.py:98-99).
     :param num_envs: number of concurrent environments (any size: one GPU lane per env).
@@ -28,7 +28,8 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
         (make_envs.py:83,114-117).  On the GPU there are no worker processes; the flag only
         selects the Subproc return convention: ``dones`` of shape (N,) instead of (N, 2).
     :param resized_dim: observation is (1, resized_dim, resized_dim) per agent.
-    :param frame_stack: must be None for cPongDouble-v0 (make_envs.py:105-106).
+    :param frame_stack: must be None for cPongDouble-v0 (make_envs.py:105-106); FrameStack / MultipleFrameStack depth for the other ids.
+    :param action_repeat: CarRacing only (car_racing_multi_players.py:576-603).
     :param stack_planes: GPU extra -- fuse FrameStackTensor's K-plane stack into the step
         (obs (N, K, R, R) per agent).
     :param score_atlas: GPU extra -- gray glyph images of the score band (default: the baked FreeSansBold atlas).

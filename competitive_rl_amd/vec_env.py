@@ -382,8 +382,18 @@ class HipPongVecEnv(VecEnv):
         assert len(st) == self.num_envs
         N.check(self._L.crl_set_state(self._h, st.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()))
 
-    state_dict = get_state
-    load_state_dict = set_state
+    def state_dict(self):
+        """Checkpoint of the whole batch in torch's idiom (SURVEY section 5 "checkpoint / resume"): a plain dict that ``torch.save`` /
+        ``numpy.save`` can store -- the structured per-env state (ball, bats, scores, f64 speeds, serve counters, the kept frames and
+        the frame-stack history) plus what the context was created with.  ``load_state_dict`` puts it back; the next step then
+        produces the same bytes as the original run would have (tests/test_hip_pong_parity.py)."""
+        return {"kind": "cPong", "num_envs": self.num_envs, "mode": self.mode, "env_state": self.get_state()}
+
+    def load_state_dict(self, sd):
+        st = sd["env_state"] if isinstance(sd, dict) else sd  # (a bare get_state() array is accepted too)
+        if isinstance(sd, dict) and (sd.get("kind") != "cPong" or int(sd.get("num_envs", -1)) != self.num_envs):
+            raise ValueError(f"state_dict of a {sd.get('kind')} batch of {sd.get('num_envs')} envs does not fit this env")
+        self.set_state(st)
 
     def set_replay(self, u, bx, by):
         """Replay mode of the serve sampler: arrays [N, per_env]."""

@@ -264,7 +264,18 @@ class HipCarVecEnv(VecEnv):
         st = np.ascontiguousarray(st, N.CAR_ENV_STATE_DT)
         N.check(self._L.crl_car_set_state(self._h, st.ctypes.data_as(C.c_void_p), 0, self.num_envs, self._stream()))
 
-    state_dict, load_state_dict = get_state, set_state
+    def state_dict(self):
+        """Checkpoint of the whole batch in torch's idiom: the structured per-env state (bodies, joints, wheel model, tile books,
+        manifolds, TimeLimit and episode counters) as a plain dict.  The current TRACKS are not part of it: they are a function of
+        (seed, global env id, episode) and are rebuilt by the next reset; restore into a context that is on the same episodes (or
+        push tracks with set_track) when the cars' positions matter."""
+        return {"kind": "cCarRacing", "num_envs": self.num_envs, "players": self.P, "solver": self.solver, "env_state": self.get_state()}
+
+    def load_state_dict(self, sd):
+        st = sd["env_state"] if isinstance(sd, dict) else sd  # (a bare get_state() array is accepted too)
+        if isinstance(sd, dict) and (sd.get("kind") != "cCarRacing" or int(sd.get("num_envs", -1)) != self.num_envs or int(sd.get("players", self.P)) != self.P):
+            raise ValueError(f"state_dict of a {sd.get('kind')} batch of {sd.get('num_envs')} envs does not fit this env")
+        self.set_state(st)
 
     def get_track(self, env):
         n = C.c_int32()

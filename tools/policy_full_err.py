@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __file__.rsplit("/", 2)[0] if "/" in __file__ else "..")
 from tests.policy_full_weights import make_weights
 from tests.test_hip_policy_full import make_policy
 from oracle import policy_oracle as P

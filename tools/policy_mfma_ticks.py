@@ -1,5 +1,5 @@
-# (CRL_POLICY_* switches: profiling variant only, CRL_LIB_VARIANT=abl)
 #!/usr/bin/env python3
+# (CRL_POLICY_* switches: profiling variant only, CRL_LIB_VARIANT=abl)
 """CRL_POLICY_MFMA_DEBUG=4: per-phase cycle counters of the fp32-MFMA opponent kernel (first 64 workgroups, all 8 wavefronts).
 Columns per group: 0 ring write-back, 1 tile loop, 2 wait + barrier after it, 3 ticket request, 4 previous group's sums + outputs,
 5 next group's staging requests."""
