@@ -11,6 +11,9 @@
 // not collide with wheels).  friction = sqrt(0.2*0.2), restitution = 0, polygonRadius = 0.01.
 #include <stdlib.h>
 
+#ifdef CRL_ABLATION
+#include "car_obs_tile.h"
+#endif
 #include "car_solver.h"
 
 namespace crl {
@@ -967,6 +970,39 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 // published by the wheel sensors' stream: one tile takes a lone wavefront ~75 us, so two or eight tiles in a row behind a solve are
 // slower than the list launch that draws them side by side -- and a kernel that spins on another kernel's output deadlocks as soon
 // as both are only partly dispatched.  docs/LAB_NOTES_r04.md.)
+#ifdef CRL_ABLATION
+// Epilogue of the touching solve (round 5, profiling build only: measured, not kept -- CRL_CAR_TOUCH_VIEW=1): the wavefront that solved
+// an island also prepares the VIEW of its env's two frames -- camera (double-double atan2 / sincos, ~15 us of latency) and the car
+// polygons' scanline spans (~20 us) -- from the poses it has just stored, into the arrays the bulk path's camera / polygon kernels fill
+// (s.view, s.view_rec, s.view_cnt), so that the frame launch behind the solve only gathers (car_obs_list_kernel<true>: 118 registers,
+// four wavefronts per SIMD).  Bit-exact; 0.922-0.932 against 0.903-0.915 ms per step (fma 0.861-0.872 against 0.854-0.861): the 35 us
+// land on the wavefronts that end the kernel, and the tiles they spare are not what the frame launch waits for.  Restricted to the
+// one-manifold islands (whose wavefronts finish early): +- 1 %, and the frame kernel then needs the manifold counts, which the next
+// step's narrow phase is rewriting at that moment.  docs/LAB_NOTES_r05.md.
+__device__ __forceinline__ void touch_view_epilogue(const CarSoA &s, const CarConsts &K, const int32_t *list, int count, int base, int epw) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the solved poses were stored by this wavefront: completed, and not served from a stale L1 line
+    const int lane = threadIdx.x;
+    const int ntile = 2 * min(epw, count - base);
+    for (int t0 = 0; t0 < ntile; t0 += 4) {
+        const int tl = t0 + (lane >> 4);
+        if (tl >= ntile) continue;
+        const int64_t env = list[base + (tl >> 1)];
+        const int viewer = tl & 1, q = lane & 15;
+        const int64_t t = env * 2 + viewer;
+        ViewParams vp;
+        float4 cam;
+        camera_compute(s, K, env, viewer, vp, cam);
+        int32_t *dst = s.view + t * kViewWords;
+        if (q == 0) {
+            const int32_t *src = reinterpret_cast<const int32_t *>(&vp);
+            for (int i = 0; i < 8; i++) dst[i] = src[i];
+            reinterpret_cast<float4 *>(dst)[4] = cam;
+        }
+        s.view_cnt[t * 16 + q] = (uint8_t)poly_compute(s, K, env, viewer, q, cam, reinterpret_cast<uint32_t *>(dst) + 8, s.view_rec + (t * 16 + q) * kSpanSlots);
+    }
+}
+#endif
+
 template <int EPW1, int NK2, int NK3, bool FM>
 __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, int cls0) {
     const int cls = cls0 + blockIdx.y;
@@ -982,6 +1018,9 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
         if (cls == 0) touch_solve<1, EPW1, false, FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         else if (cls == 1) touch_solve<NK2, 1, (NK2 < 2), FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         else touch_solve<NK3, 1, true, FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
+#ifdef CRL_ABLATION
+        if (s.touch_view) touch_view_epilogue(s, K, list, count, base, epw);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
 }

@@ -109,6 +109,7 @@ struct CarSoA {
     int contacts_enabled;
     int abl_keep_tag;       // profiling build only (CRL_CAR_ABL_KEEP_TAG): a walk-ahead does not void the stored walk's tag before overwriting it
     int abl_no_walk;        // profiling build only (CRL_CAR_ABL_NO_WALK): resets reuse the stored walk, no walk-ahead kernel is launched
+    int touch_view;         // this launch of the touching solve also prepares its envs' views (camera, polygon spans): the step pipeline's last world.Step
     int fma;                // CRL_FLAG_CAR_FMA: the island solver's iterations in fused multiply-adds (car_solver.h: FM)
     float *wforce;          // [8][M] tyre forces of this step, handed to the coupled kernel
     float *wsnap;           // [12][M] wheel transforms (cx, cy, angle) the step starts from, for car_sensor_kernel
@@ -248,7 +249,8 @@ void launch_car_map_build_list(const CarSoA &s, hipStream_t st, const int32_t *l
 void launch_car_view(const CarSoA &s, const CarConsts &k, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env = nullptr, int want = 1);
 void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
-                         int32_t *count_to_host, int64_t expected, const uint8_t *filter = nullptr, int want_cls = 0, bool urgent = false);
+                         int32_t *count_to_host, int64_t expected, const uint8_t *filter = nullptr, int want_cls = 0, bool urgent = false,
+                         int prepared = 0);
 void car_map_light_masks(uint32_t *lightx, uint32_t *lighty);  // host: the squares' columns / rows (kMapW / 32 words each)
 int car_map_coord(double v);                                     // host: (int)(obs_scale * -v + 5000), as the map polygons' vertices
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,

@@ -255,9 +255,12 @@ __global__ __launch_bounds__(64) void car_obs_kernel(CarSoA s, uint8_t *__restri
 // The envs of a compacted list (the small env classes of a step): camera, polygons and tile in ONE launch, one wavefront per
 // tile -- every lane computes the (uniform) camera, lanes 0-15 the polygons, everything handed over through LDS.  Three
 // dependent launches of a few hundred wavefronts each cost three launch latencies at the end of a step.
-__global__ __launch_bounds__(64, 3) void car_obs_list_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
-                                                          const int32_t *__restrict__ list_count, int32_t *__restrict__ count_to_host,
-                                                          const uint8_t *__restrict__ filter, int want, int urgent) {
+// PREPARED (round 5, instantiated in the profiling build only): the envs' views are already in s.view / s.view_rec / s.view_cnt (the
+// touching solve's epilogue put them there, car_contact.hip): gather and overlays only.
+template <bool PREPARED>
+__global__ __launch_bounds__(64, PREPARED ? 4 : 3) void car_obs_list_kernel(CarSoA s, CarConsts K, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
+                                                                         const int32_t *__restrict__ list_count, int32_t *__restrict__ count_to_host,
+                                                                         const uint8_t *__restrict__ filter, int want, int urgent) {
     if (urgent) __builtin_amdgcn_s_setprio(3);  // the launch at the end of the step's longest chain, beside the big frame launch's 32 768 wavefronts
     __shared__ __attribute__((aligned(16))) uint32_t tile[96 * kPitch];
     __shared__ __attribute__((aligned(16))) int32_t vp_s[16];
@@ -270,7 +273,12 @@ __global__ __launch_bounds__(64, 3) void car_obs_list_kernel(CarSoA s, CarConsts
     for (int64_t b = blockIdx.x; b < tiles; b += gridDim.x) {
         const int64_t env = list[b / s.players];
         const int viewer = (int)(b % s.players);
-        if (!filter || filter[env] == want) {
+        if (PREPARED) {
+            if (!filter || filter[env] == want) {
+                const int64_t t = env * s.players + viewer;
+                car_obs_tile(s, obs, env, viewer, tile, s.view + t * kViewWords, s.view_rec + t * kViewRecWords, s.view_cnt + t * 16);
+            }
+        } else if (!filter || filter[env] == want) {
             ViewParams vp;
             float4 cam;
             camera_compute(s, K, env, viewer, vp, cam);
@@ -310,10 +318,17 @@ void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream
 // the envs of a compacted list (its length in device memory; `expected` = the caller's guess of it, only for the grid size),
 // optionally only those with filter[env] == want
 void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
-                         int32_t *count_to_host, int64_t expected, const uint8_t *filter, int want_cls, bool urgent) {
+                         int32_t *count_to_host, int64_t expected, const uint8_t *filter, int want_cls, bool urgent, int prepared) {
     int64_t want = expected + expected / 4 + 32;  // slack: a launch that falls short loops, it does not miss tiles
     want = want > s.n ? s.n : want;
-    hipLaunchKernelGGL(car_obs_list_kernel, dim3((unsigned)(want * s.players)), dim3(64), 0, st, s, k, obs, list, list_count, count_to_host, filter, want_cls, urgent ? 1 : 0);
+#ifdef CRL_ABLATION
+    if (prepared) {  // (profiling build: the touching solve's epilogue has prepared the listed envs' views, car_contact.hip)
+        hipLaunchKernelGGL(car_obs_list_kernel<true>, dim3((unsigned)(want * s.players)), dim3(64), 0, st, s, k, obs, list, list_count, count_to_host, filter, want_cls, urgent ? 1 : 0);
+        return;
+    }
+#endif
+    (void)prepared;
+    hipLaunchKernelGGL(car_obs_list_kernel<false>, dim3((unsigned)(want * s.players)), dim3(64), 0, st, s, k, obs, list, list_count, count_to_host, filter, want_cls, urgent ? 1 : 0);
 }
 
 // MultipleFrameStack + FlattenMultiAgentObservation + WrapPyTorch (reference

@@ -605,7 +605,14 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->one, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the frame launches pass ONE barrier each)
         launch_car_sensors(c->s, c->K_, c->one);
         hipEventRecord(c->ev_sens, c->one);
-        launch_car_coupled(c->s, c->K_, crit, c->side2, nullptr, true);  // near-only solve on side2, touching solve on crit
+        // CRL_CAR_TOUCH_VIEW=1 (profiling build): the touching solve's wavefronts also prepare their envs' views (measured, not kept: car_contact.hip)
+        static const int touch_view_mode = CRL_ABL(getenv("CRL_CAR_TOUCH_VIEW") != nullptr) ? 1 : 0;
+        const int touch_view = contacts && !c->analytic ? touch_view_mode : 0;
+        {
+            CarSoA sv2 = c->s;
+            sv2.touch_view = touch_view;
+            launch_car_coupled(sv2, c->K_, crit, c->side2, nullptr, true);  // near-only solve on side2, touching solve on crit
+        }
         hipEventRecord(c->ev_coupled, crit);
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];
         hipStreamWaitEvent(c->side2, c->ev_sens, 0);  // (every frame shows the reward)
@@ -619,11 +626,20 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(bulk, c->ev_sens, 0);
         crl_timer_end(tm, 0, bulk);
         frames(c, target, bulk, c->slow_env, 0, tm);
-        if (contacts) {  // crit again: the touching envs' frames, behind their solve (wave priority 3: beside the big launch's 32 768 wavefronts)
-            hipStreamWaitEvent(crit, c->ev_sens, 0);
-            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
+        // The touching envs' frames, behind their solve, on the caller's stream (wave priority 3: beside the big launch's 32 768 wavefronts).
+        // (Round 5, profiling build, CRL_CAR_TOUCH_FRAMES_ON_ONE=1: on the HIGH-priority stream instead, in front of the class-3 chain that
+        // waits for the same solve there, so that dispatch priority gets their 2 300 workgroups the CU slots the bulk frame kernel frees --
+        // bit-exact and 5-6 % SLOWER in three A/B pairs (0.885-0.895 against 0.826-0.845 ms; fma 0.823-0.836 against 0.784-0.796): once
+        // more, what ends a step has to sit on the caller's stream.)
+        static const bool touch_frames_on_one = CRL_ABL(getenv("CRL_CAR_TOUCH_FRAMES_ON_ONE") != nullptr);
+        auto touch_frames = [&](hipStream_t q) {
+            if (c->analytic) launch_car_raster_list(c->s, c->K_, target, q, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
             else if (!CRL_ABL(getenv("CRL_CAR_ABL_NO_TOUCH_FRAMES") != nullptr))  // (timing ablation, WRONG frames: what the step costs without them)
-                launch_car_obs_list(c->s, c->K_, target, crit, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, true);
+                launch_car_obs_list(c->s, c->K_, target, q, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, true, touch_view);
+        };
+        if (contacts && !touch_frames_on_one) {  // crit again
+            hipStreamWaitEvent(crit, c->ev_sens, 0);
+            touch_frames(crit);
         }
         // The finished envs.  Their NEW episode (track arrays in place, map into the env's other slot, car state into the staged
         // arrays, first frame straight into the caller's tensor) only needs the step's sensor contacts to be in: it is prepared
@@ -685,8 +701,15 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             c->collide_valid = c->collide_dirty = true;
         };
         hipStreamWaitEvent(c->side2, c->ev_coupled, 0);  // the touching solve
+        if (contacts && touch_frames_on_one && !early_collide) {  // (no class-3 chain on `one` in this mode: the frames go there all the same)
+            hipStreamWaitEvent(c->one, c->ev_coupled, 0);
+            touch_frames(c->one);
+            hipEventRecord(c->ev_c3, c->one);
+            hipStreamWaitEvent(c->side2, c->ev_c3, 0);
+        }
         if (early_collide) {
             hipStreamWaitEvent(c->one, c->ev_coupled, 0);
+            if (contacts && touch_frames_on_one) touch_frames(c->one);  // (`one` ran the sensors itself: no wait for ev_sens)
             if (!CRL_ABL(getenv("CRL_CAR_ABL_NO_C3") != nullptr)) terminal_frames(c->one, 3, 8, nullptr);  // (timing ablation: no terminal frames for class 3)
             launch_car_commit_list(c->s, sv, list_of(3), count_of(3), 8, c->one);
             hipEventRecord(c->ev_c3, c->one);
