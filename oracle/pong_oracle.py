@@ -207,3 +207,11 @@ class PongOracle:
         out = np.empty(shape, np.float32 if self.f32ref else np.uint8)
         lib().pong_oracle_terminal_observation(self.h, int(i), _p(out))
         return out
+
+
+def f32ref_ambiguous():
+    """float32_ref observations so far for which "reset observation" (the explicit flag the oracle rounds by) and "the two kept frames
+    are identical" (what the HIP kernel infers it from) disagreed -- must stay 0."""
+    L = lib()
+    L.pong_oracle_f32ref_ambiguous.restype = C.c_long
+    return int(L.pong_oracle_f32ref_ambiguous())

@@ -115,6 +115,7 @@ def test_float32_ref_equals_the_oracles_unrounded_observation(atlas, R, K):
             assert np.array_equal(got[i, :, -1], np.rint(got[i, :, -1]))  # the auto-reset's observation: rounded again
             seen += 1
     assert fractional > 1000 and (seen > 0 or R != 42)
+    assert po.f32ref_ambiguous() == 0  # (the kernel infers "reset observation" from identical kept frames; the oracle is told: never a disagreement)
     f.close()
 
 

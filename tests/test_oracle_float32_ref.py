@@ -37,6 +37,8 @@ def test_float32_ref_is_the_unrounded_twin_of_the_uint8_observation(atlas, R, K)
             ta, tb = a.terminal_observation(i), b.terminal_observation(i)
             assert np.abs(tb - ta.astype(np.float32)).max() <= 0.5 + 1e-4 and (tb != np.rint(tb)).any(), (t, i)
     assert dones > 0 and 0.005 < np.mean(frac) < 0.2, (dones, np.mean(frac))
+    # "reset observation" (the flag the oracle rounds by) == "the two kept frames are identical" (what the HIP kernel infers it from)
+    assert po.f32ref_ambiguous() == 0
 
 
 def test_float_gray_of_an_achromatic_pixel():
