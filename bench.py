@@ -321,7 +321,7 @@ def run_workload(name, args, G):
     elif is_car:
         env = inner = crl.HipCarVecEnv(n, seed=0, device=dev, env_id_base=base, solver="fma" if name == "car_fma" else "box2d")
         pool = [torch.rand((n, 2, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1 for _ in range(16)]
-        kernel, dtype = "car_obs_kernel", "f32"
+        kernel, dtype = "car_obs_third_kernel", "f32"
     else:
         kw = {"raw": dict(mode="raw"),
               "fused84": dict(mode="wrapped", resized_dim=84, frame_stack=4),

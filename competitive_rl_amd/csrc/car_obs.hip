@@ -252,6 +252,21 @@ __global__ __launch_bounds__(64) void car_obs_kernel(CarSoA s, uint8_t *__restri
     car_obs_tile(s, obs, env, viewer, tile, s.view + t * kViewWords, s.view_rec + t * kViewRecWords, s.view_cnt + t * 16);
 }
 
+// The big launch, one wavefront per THIRD of a tile (car_obs_third): workgroup slot b -> env 8 (b / 48) + b % 8 and item (b % 48) / 8 =
+// 3 viewer + third, so that the six wavefronts of an env (b, b + 8, ...) run on one XCD and share its L2's copy of the map blocks.
+__global__ __launch_bounds__(64) void car_obs_third_kernel(CarSoA s, uint8_t *__restrict__ obs, const uint8_t *__restrict__ only_env, int want) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[32 * kPitch];
+    const int per = 3 * s.players;  // wavefronts per env
+    const int64_t g = blockIdx.x / (8 * per);
+    const int r = (int)(blockIdx.x - g * (8 * per));
+    const int64_t env = g * 8 + (r & 7);
+    const int item = r >> 3, viewer = item / 3, third = item - 3 * viewer;
+    if (env >= s.n) return;
+    if (only_env && only_env[env] != want) return;
+    const int64_t t = env * s.players + viewer;
+    car_obs_third(s, obs, env, viewer, third, tile, s.view + t * kViewWords, s.view_rec + t * kViewRecWords, s.view_cnt + t * 16);
+}
+
 // The envs of a compacted list (the small env classes of a step): camera, polygons and tile in ONE launch, one wavefront per
 // tile -- every lane computes the (uniform) camera, lanes 0-15 the polygons, everything handed over through LDS.  Three
 // dependent launches of a few hundred wavefronts each cost three launch latencies at the end of a step.
@@ -311,6 +326,13 @@ void launch_car_view(const CarSoA &s, const CarConsts &k, hipStream_t st, const 
     hipLaunchKernelGGL(car_poly_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(64), 0, st, s, k, only_env, want);
 }
 void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const uint8_t *only_env, int want) {
+    // (profiling build, CRL_CAR_OBS_WHOLE_TILES=1: rounds 3-4's one wavefront per tile.  Same box, four alternating pairs of 200-step windows:
+    // the frame kernel 267-271 us in thirds against 295-313 whole; the step 0.840-0.842 against 0.838-0.847 ms, fma 0.784-0.791 against 0.793-0.800)
+    static const bool whole = CRL_ABL(getenv("CRL_CAR_OBS_WHOLE_TILES") != nullptr);
+    if (!whole) {
+        hipLaunchKernelGGL(car_obs_third_kernel, dim3((unsigned)((s.n + 7) / 8 * 8 * 3 * s.players)), dim3(64), 0, st, s, obs, only_env, want);
+        return;
+    }
     const unsigned grid = s.players == 2 ? (unsigned)((s.n + 7) / 8 * 16) : (unsigned)s.n;
     hipLaunchKernelGGL(car_obs_kernel, dim3(grid), dim3(64), 0, st, s, obs, only_env, want);
 }

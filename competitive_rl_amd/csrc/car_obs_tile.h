@@ -191,10 +191,13 @@ static constexpr int kPitch = 28;  // dwords per tile row in LDS (96 B of pixels
 
 // CHECK = false: every source pixel is inside the window and inside the crop (ViewParams.flags == 3)
 // it0, it_step: which of the nine 32 x 32-pixel regions this wavefront draws (0, 1: all of them; w, W: every W-th from w on)
+// it_end / row0 (round 5): the iterations stop in front of it_end, and tile row r of the LDS buffer holds screen row row0 + r -- a
+// wavefront that owns one region row (iterations 3 t .. 3 t + 2, screen rows 32 t .. 32 t + 31) needs a 32-row buffer only.
 template <bool CHECK>
 __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, const int dx00, const int dy00, const int isin, const int icos,
-                                               const int rx, const int ry, uint32_t *__restrict__ tile, const int lane, const int it0 = 0,
-                                               const int it_step = 1) {
+                                               const int rx, const int ry, uint32_t *__restrict__ tile_, const int lane, const int it0 = 0,
+                                               const int it_step = 1, const int it_end = 9, const int row0 = 0) {
+    uint32_t *__restrict__ tile = tile_ - row0 * kPitch;
     uint32_t bgpal = 0;
     if (CHECK) {  // rotate()'s background colour = the crop's first pixel
         if (rx >= 0 && ry >= 0 && rx < kMapW && ry < kMapW) {
@@ -242,10 +245,10 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
             }
         };
         uint32_t cur[16], nxt[16];
-        if (it0 < 9) fetch(it0, cur);
+        if (it0 < it_end) fetch(it0, cur);
 #pragma unroll 1
-        for (int it = it0; it < 9; it += it_step) {
-            const bool more = it + it_step < 9;
+        for (int it = it0; it < it_end; it += it_step) {
+            const bool more = it + it_step < it_end;
             if (more) fetch(it + it_step, nxt);
             unpack(it, cur);
             if (more) {
@@ -256,7 +259,7 @@ __device__ __forceinline__ void obs_background(const uint8_t *__restrict__ map, 
         return;
     }
 #pragma unroll 1
-    for (int it = it0; it < 9; it += it_step) {
+    for (int it = it0; it < it_end; it += it_step) {
         // a wavefront iteration covers a 32 x 32-pixel region: lane = a 4 x 4 patch, so one load instruction reads 64 pixels
         // of ONE region (a handful of 128-byte blocks) and a lane's 16 loads stay within one or two blocks
         const int X0 = 32 * (it % 3) + 4 * (lane & 7), Y0 = 32 * (it / 3) + 4 * (lane >> 3);
@@ -362,6 +365,78 @@ __device__ __forceinline__ void car_obs_tile(const CarSoA &s, uint8_t *__restric
     for (int i = 0; i < (9 + WAVES - 1) / WAVES; i++) {
         const int c = (i * WAVES + wave) * 64 + lane, row = c / 6, col = c - row * 6;
         if (WAVES == 1 || c < 576) out[c] = *reinterpret_cast<const uint4 *>(&tile[row * kPitch + col * 4]);
+    }
+}
+
+
+// ---- one THIRD of a frame per wavefront (round 5, the big frame launch): screen rows 32 t .. 32 t + 31.  A whole tile needs 10.5 KB of
+// LDS, which holds the frame kernel at four wavefronts per SIMD; its time is the latency of nine dependent gather rounds, not issue slots,
+// so what it lacks is wavefronts in flight.  A third needs 3.5 KB (seven wavefronts per SIMD at 73 registers), gathers three regions,
+// and paints the overlay spans / rectangles / read-out rows that fall into its rows -- in the same order, so every pixel ends up with the
+// colour of the last layer drawn over it, as in the whole-tile form.
+__device__ __forceinline__ void car_obs_third(const CarSoA &s, uint8_t *__restrict__ obs, const int64_t env, const int viewer, const int third, uint32_t *tile,
+                                              const int32_t *vp, const uint32_t *rec, const uint8_t *cnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = env * s.players + viewer;
+    const int dx00 = vp[0], dy00 = vp[1], isin = vp[2], icos = vp[3], rx = vp[4], ry = vp[5], flags = vp[6];
+    const int r0 = 32 * third;
+    const uint8_t *map = env_map(s, env);
+    uint8_t *tile8 = reinterpret_cast<uint8_t *>(tile);
+    if (flags == 3) {
+        obs_background<false>(map, dx00, dy00, isin, icos, rx, ry, tile, lane, 3 * third, 1, 3 * third + 3, r0);
+    } else if (flags & 4) {
+        for (int i = lane; i < 32 * kPitch; i += 64) tile[i] = G_GRASS * 0x01010101u;
+    } else {
+        obs_background<true>(map, dx00, dy00, isin, icos, rx, ry, tile, lane, 3 * third, 1, 3 * third + 3, r0);
+    }
+    // ---- cars (draw order: car 0 wheels, car 0 hull, car 1 wheels, car 1 hull; LDS operations of one wavefront execute in program order)
+    const uint32_t *cnt32 = reinterpret_cast<const uint32_t *>(cnt);
+    const uint32_t cnt_all[4] = {cnt32[0], cnt32[1], cnt32[2], cnt32[3]};
+#pragma unroll
+    for (int layer = 0; layer < 4; layer++) {
+        if (layer >= 2 * s.players) break;
+        if (cnt_all[layer] == 0u) continue;
+        const int poly = lane >> 4, slot = lane & 15;
+        const int c = (int)((cnt_all[layer] >> (8 * poly)) & 0xFFu);
+        const uint32_t r = rec[(layer * 4 + poly) * kSpanSlots + slot];
+        const int gray = (layer & 1) ? ((layer >> 1) == viewer ? G_OWN : G_OTHER) : 0;
+        const int y = (int)(r & 0xFFu) - r0;
+        if (slot < c && (unsigned)y < 32u) {
+            const int xl = (int)((r >> 8) & 0xFFu), xr = (int)((r >> 16) & 0xFFu);
+            for (int x = xl; x <= xr; x++) tile8[y * (kPitch * 4) + x] = (uint8_t)gray;
+        }
+    }
+    if (third == 2) {  // (the indicator strip and the read-out live in rows 86 .. 95)
+        const uint32_t *rects = reinterpret_cast<const uint32_t *>(vp) + 8;
+        const int rgray[8] = {0, G_BLUE, G_BLUE, G_BLUE, G_ABS_REAR, G_ABS_REAR, G_GREEN, G_RED};
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t q = rects[r];
+            const int x0 = (int)(q & 0xFFu), x1 = (int)((q >> 8) & 0xFFu), y0 = max((int)((q >> 16) & 0xFFu), r0), y1 = (int)(q >> 24);
+            const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+            if (w <= 0 || h <= 0) continue;
+            for (int p = lane; p < w * h; p += 64) {
+                const int yy = p / w, xx = p - yy * w;
+                tile8[(y0 - r0 + yy) * (kPitch * 4) + x0 + xx] = (uint8_t)rgray[r];
+            }
+        }
+        if (s.text_bits && lane < 32) {
+            const double rw = s.reward[(int64_t)viewer * s.n + env];
+            const double rr = rint(rw);  // "%.0f" rounds half to even
+            int idx = (int)rr - CRL_CAR_TEXT_RMIN;
+            if (rr == 0.0 && (rw < 0.0 || (rw == 0.0 && signbit(rw)))) idx = CRL_CAR_TEXT_STRINGS - 1;  // "-0000"
+            const uint32_t *rows = s.text_bits + (int64_t)min(max(idx, 0), CRL_CAR_TEXT_STRINGS - 1) * CRL_CAR_TEXT_ROWS;
+#pragma unroll
+            for (int row = 0; row < 5; row++)
+                if ((rows[row] >> lane) & 1u) tile8[(91 - r0 + row) * (kPitch * 4) + lane] = 255;
+        }
+    }
+    // ---- stream the 32 rows out: 16 B per lane, 1 KiB contiguous per wave store
+    uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + t * (96 * 96) + r0 * 96);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int c = i * 64 + lane, row = c / 6, col = c - row * 6;
+        out[c] = *reinterpret_cast<const uint4 *>(&tile[row * kPitch + col * 4]);
     }
 }
 
