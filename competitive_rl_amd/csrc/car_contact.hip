@@ -1045,12 +1045,15 @@ void launch_car_coupled(const CarSoA &s, const CarConsts &k, hipStream_t st, hip
     }
     const unsigned gn = (unsigned)((s.n + 31) / 32 < 512 ? (s.n + 31) / 32 : 512);
     const unsigned g = (unsigned)((s.n + 31) / 32 < 256 ? (s.n + 31) / 32 : 256);
+#ifndef CRL_EPW1
+#define CRL_EPW1 8  // envs per wavefront of the one-manifold class (build-time experiment switch: python -m competitive_rl_amd.build --variant e4 -DCRL_EPW1=4)
+#endif
     if (s.fma) {  // CRL_FLAG_CAR_FMA: the iterations in fused multiply-adds (car_solver.h)
         hipLaunchKernelGGL(car_near_kernel<true>, dim3(gn), dim3(64), 0, near_st, s, k);
-        hipLaunchKernelGGL((car_touch_kernel<8, 2, 3, true>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
+        hipLaunchKernelGGL((car_touch_kernel<CRL_EPW1, 2, 3, true>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
     } else {
         hipLaunchKernelGGL(car_near_kernel<false>, dim3(gn), dim3(64), 0, near_st, s, k);
-        hipLaunchKernelGGL((car_touch_kernel<8, 2, 3, false>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
+        hipLaunchKernelGGL((car_touch_kernel<CRL_EPW1, 2, 3, false>), dim3(g, 3), dim3(64), 0, st, s, k, 0);
     }
 }
 
