@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = {"raw": "pong_raster_raw_sweep_kernel", "fused84": "pong_raster_gray", "fused84_newest": "pong_raster_gray", "fused84_f32": "pong_raster_gray",
-            "car": "car_obs_kernel", "tournament": "pong_policy_mfma_kernel"}
+            "fused84_f32_ref": "pong_gray_f32ref_kernel", "car": "car_obs_third_kernel", "car_fma": "car_obs_third_kernel", "tournament": "pong_policy_mfma_kernel"}
 
 
 def main():
@@ -33,14 +33,14 @@ def main():
         shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, f"{rnd}_{wl}_bench_under_rocprof.json"))
         pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
         fl = pmc.pop("__flops__", None)
-        if fl and wl == "car":
+        if fl and wl == "car":  # (car_fma: the same kernels with fused multiply-adds; flops_car.json stays the default arithmetic's)
             n_envs = 16384
             json.dump({"f32_flop_per_env_step": fl["f32_flop_per_step"] / n_envs, "f64_flop_per_env_step": fl["f64_flop_per_step"] / n_envs,
                        "valu_wave_insts_per_env_step": fl["valu_insts_per_step"] / n_envs,
                        "source": f"profiles/{rnd}_car_pmc_summary.json: rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA,TRANS}}_F32 over every car_* kernel of "
                                  f"{fl['steps']} steps at {n_envs} envs; 64 lanes per wave-instruction (upper bound), FMA = 2 FLOP"},
                       open(os.path.join(dst, "flops_car.json"), "w"), indent=1)
-        if wl == "car":  # the raster also runs on a handful of envs for terminal frames: take the full-batch launches
+        if wl in ("car", "car_fma"):  # the raster also runs on a handful of envs for terminal frames: take the full-batch launches
             import csv
             for cname, sub in (("WRITE_SIZE", "pmc_write"), ("FETCH_SIZE", "pmc_fetch")):
                 files = sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)

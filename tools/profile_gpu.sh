@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 # CarRacing: the two traffic passes run the step on ONE stream (CRL_CAR_NO_OVERLAP=1), i.e. with one raster launch over all envs, so that
 # "bytes per launch" is the full frame batch (the pipelined step draws three env classes in separate launches)
 # (and from reset, without the 1000 un-timed pre-roll steps of the steady-state bench: the frame kernel's bytes per launch do not depend on it)
-if [ "$WL" = "car" ]; then export CRL_CAR_NO_OVERLAP=1 CRL_BENCH_CAR_PREROLL=0; fi
+if [ "$WL" = "car" ] || [ "$WL" = "car_fma" ]; then export CRL_CAR_NO_OVERLAP=1 CRL_BENCH_CAR_PREROLL=0; fi
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --workload $WL --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
 unset CRL_CAR_NO_OVERLAP
