@@ -971,14 +971,13 @@ __device__ __forceinline__ void touch_solve(const CarSoA &s, const CarConsts &K,
 // slower than the list launch that draws them side by side -- and a kernel that spins on another kernel's output deadlocks as soon
 // as both are only partly dispatched.  docs/LAB_NOTES_r04.md.)
 #ifdef CRL_ABLATION
-// Epilogue of the touching solve (round 5, profiling build only: measured, not kept -- CRL_CAR_TOUCH_VIEW=1): the wavefront that solved
-// an island also prepares the VIEW of its env's two frames -- camera (double-double atan2 / sincos, ~15 us of latency) and the car
-// polygons' scanline spans (~20 us) -- from the poses it has just stored, into the arrays the bulk path's camera / polygon kernels fill
-// (s.view, s.view_rec, s.view_cnt), so that the frame launch behind the solve only gathers (car_obs_list_kernel<true>: 118 registers,
-// four wavefronts per SIMD).  Bit-exact; 0.922-0.932 against 0.903-0.915 ms per step (fma 0.861-0.872 against 0.854-0.861): the 35 us
-// land on the wavefronts that end the kernel, and the tiles they spare are not what the frame launch waits for.  Restricted to the
-// one-manifold islands (whose wavefronts finish early): +- 1 %, and the frame kernel then needs the manifold counts, which the next
-// step's narrow phase is rewriting at that moment.  docs/LAB_NOTES_r05.md.
+// Epilogue of the touching solve (round 5, profiling build only: measured, not kept): the solving wavefront also prepares the VIEWS of its
+// envs' frames -- camera (double-double atan2 / sincos, ~15 us of latency) and the car polygons' scanline spans (~20 us) -- from the poses
+// it has just stored, into the arrays the bulk path's camera / polygon kernels fill (s.view, s.view_rec, s.view_cnt).
+// touch_view == 1: every class, and the frame launch behind the solve only gathers: + 2-3 % per step (the 35 us land on the wavefronts that
+// end the kernel).  touch_view == 2: the one-manifold class only (eight envs per wavefront, done long before the slow islands; behind the
+// solve car_view_list_kernel computes the ~110 multi-manifold envs' views from touch_multi -- THIS step's narrow-phase lists on both sides,
+// no manifold counts read while the next narrow phase rewrites them): +- 0 in four alternating pairs of shipped-flavour builds.
 __device__ __forceinline__ void touch_view_epilogue(const CarSoA &s, const CarConsts &K, const int32_t *list, int count, int base, int epw) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the solved poses were stored by this wavefront: completed, and not served from a stale L1 line
     const int lane = threadIdx.x;
@@ -1019,7 +1018,7 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
         else if (cls == 1) touch_solve<NK2, 1, (NK2 < 2), FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
         else touch_solve<NK3, 1, true, FM>(s, K, list, count, base, sh_car, sh_ct, sh_tc);
 #ifdef CRL_ABLATION
-        if (s.touch_view) touch_view_epilogue(s, K, list, count, base, epw);
+        if (s.touch_view == 1 || (s.touch_view == 2 && cls == 0)) touch_view_epilogue(s, K, list, count, base, epw);
 #endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }

@@ -251,6 +251,8 @@ void launch_car_obs(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream
 void launch_car_obs_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count,
                          int32_t *count_to_host, int64_t expected, const uint8_t *filter = nullptr, int want_cls = 0, bool urgent = false,
                          int prepared = 0);
+void launch_car_obs_long_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count, int64_t expected,
+                              const uint8_t *filter, int want_cls, bool urgent, const int32_t *view_list, const int32_t *view_count, int64_t view_expected);
 void car_map_light_masks(uint32_t *lightx, uint32_t *lighty);  // host: the squares' columns / rows (kMapW / 32 words each)
 int car_map_coord(double v);                                     // host: (int)(obs_scale * -v + 5000), as the map polygons' vertices
 void launch_car_stack(const uint8_t *frame, uint8_t *stack, uint8_t *obs, const uint8_t *fill_env, bool fill_all, int K, int64_t n,

@@ -267,6 +267,68 @@ __global__ __launch_bounds__(64) void car_obs_third_kernel(CarSoA s, uint8_t *__
     car_obs_third(s, obs, env, viewer, third, tile, s.view + t * kViewWords, s.view_rec + t * kViewRecWords, s.view_cnt + t * 16);
 }
 
+// ---- a LONG list (round 5: the touching envs' frames, ~1 150 envs = 2 300 tiles behind the step's longest chain) in TWO light launches
+// instead of the one-wavefront-per-tile list kernel below: (1) camera + polygons of the listed envs into s.view* (16 lanes per tile: the
+// double-double camera, ~15 us, then the polygon spans, ~20 us -- 575 wavefronts); (2) the gather in THIRDS of a tile (63 registers,
+// 3.5 KB of LDS: 6 900 wavefronts, all resident at once).  The list kernel walks camera -> polygons -> nine gather rounds in ONE
+// wavefront at 168 registers (three per SIMD): 75 us per tile alone, 215-295 us for the 2 300 tiles beside the tail of the big frame launch.
+__global__ __launch_bounds__(64) void car_view_list_kernel(CarSoA s, CarConsts K, const int32_t *__restrict__ list, const int32_t *__restrict__ list_count,
+                                                           const uint8_t *__restrict__ filter, int want, int urgent) {
+    if (urgent) __builtin_amdgcn_s_setprio(3);
+    const int64_t tiles = (int64_t)*list_count * s.players;
+    for (int64_t t0 = (int64_t)blockIdx.x * 4; t0 < tiles; t0 += (int64_t)gridDim.x * 4) {
+        const int64_t b = t0 + (threadIdx.x >> 4);
+        if (b >= tiles) continue;
+        const int64_t env = list[b / s.players];
+        if (filter && filter[env] != want) continue;
+        const int viewer = (int)(b % s.players), q = threadIdx.x & 15;
+        const int64_t t = env * s.players + viewer;
+        ViewParams vp;
+        float4 cam;
+        camera_compute(s, K, env, viewer, vp, cam);
+        int32_t *dst = s.view + t * kViewWords;
+        if (q == 0) {
+            const int32_t *src = reinterpret_cast<const int32_t *>(&vp);
+            for (int i = 0; i < 8; i++) dst[i] = src[i];
+            reinterpret_cast<float4 *>(dst)[4] = cam;
+        }
+        s.view_cnt[t * 16 + q] = (uint8_t)poly_compute(s, K, env, viewer, q, cam, reinterpret_cast<uint32_t *>(dst) + 8, s.view_rec + (t * 16 + q) * kSpanSlots);
+    }
+}
+// slot b -> list position 8 (b / 8 per) + b % 8 and item (b % 8 per) / 8 = 3 viewer + third (per = 3 players): an env's wavefronts on one XCD
+__global__ __launch_bounds__(64) void car_obs_third_list_kernel(CarSoA s, uint8_t *__restrict__ obs, const int32_t *__restrict__ list,
+                                                                const int32_t *__restrict__ list_count, const uint8_t *__restrict__ filter, int want, int urgent) {
+    if (urgent) __builtin_amdgcn_s_setprio(3);
+    __shared__ __attribute__((aligned(16))) uint32_t tile[32 * kPitch];
+    const int per = 3 * s.players;
+    const int64_t count = *list_count, slots = (count + 7) / 8 * 8 * per;
+    for (int64_t b = blockIdx.x; b < slots; b += gridDim.x) {
+        const int64_t g = b / (8 * per);
+        const int r = (int)(b - g * (8 * per));
+        const int64_t pos = g * 8 + (r & 7);
+        if (pos < count) {
+            const int64_t env = list[pos];
+            if (!filter || filter[env] == want) {
+                const int item = r >> 3, viewer = item / 3, third = item - 3 * viewer;
+                const int64_t t = env * s.players + viewer;
+                car_obs_third(s, obs, env, viewer, third, tile, s.view + t * kViewWords, s.view_rec + t * kViewRecWords, s.view_cnt + t * 16);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (a looping workgroup reuses the LDS rows)
+    }
+}
+// view_list / view_count: the envs whose views are still to be computed (the whole list, or -- when the touching solve's one-manifold wavefronts
+// have prepared theirs -- the envs with two manifolds or more)
+void launch_car_obs_long_list(const CarSoA &s, const CarConsts &k, uint8_t *obs, hipStream_t st, const int32_t *list, const int32_t *list_count, int64_t expected,
+                              const uint8_t *filter, int want_cls, bool urgent, const int32_t *view_list, const int32_t *view_count, int64_t view_expected) {
+    int64_t want = expected + expected / 4 + 32;  // slack: a launch that falls short loops, it does not miss tiles
+    want = want > s.n ? s.n : want;
+    int64_t vwant = view_expected + view_expected / 4 + 32;
+    vwant = vwant > s.n ? s.n : vwant;
+    hipLaunchKernelGGL(car_view_list_kernel, dim3((unsigned)((vwant * s.players + 3) / 4)), dim3(64), 0, st, s, k, view_list, view_count, filter, want_cls, urgent ? 1 : 0);
+    hipLaunchKernelGGL(car_obs_third_list_kernel, dim3((unsigned)((want + 7) / 8 * 8 * 3 * s.players)), dim3(64), 0, st, s, obs, list, list_count, filter, want_cls, urgent ? 1 : 0);
+}
+
 // The envs of a compacted list (the small env classes of a step): camera, polygons and tile in ONE launch, one wavefront per
 // tile -- every lane computes the (uniform) camera, lanes 0-15 the polygons, everything handed over through LDS.  Three
 // dependent launches of a few hundred wavefronts each cost three launch latencies at the end of a step.

@@ -605,8 +605,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->one, c->ev_post, 0);  // (a 6 us kernel, long done: ev_sens then stands for the bookkeeping as well, and the frame launches pass ONE barrier each)
         launch_car_sensors(c->s, c->K_, c->one);
         hipEventRecord(c->ev_sens, c->one);
-        // CRL_CAR_TOUCH_VIEW=1 (profiling build): the touching solve's wavefronts also prepare their envs' views (measured, not kept: car_contact.hip)
-        static const int touch_view_mode = CRL_ABL(getenv("CRL_CAR_TOUCH_VIEW") != nullptr) ? 1 : 0;
+        // CRL_CAR_TOUCH_VIEW (profiling build; measured, not kept, docs/LAB_NOTES_r05.md): 1 = every wavefront of the touching solve prepares its envs'
+        // views (+ 2-3 %), 2 = the one-manifold wavefronts do and only the multi-manifold envs' views are computed behind the solve (+- 0)
+        static const int touch_view_mode = CRL_ABL(getenv("CRL_CAR_TOUCH_VIEW") != nullptr) ? atoi(getenv("CRL_CAR_TOUCH_VIEW")) : 0;
         const int touch_view = contacts && !c->analytic ? touch_view_mode : 0;
         {
             CarSoA sv2 = c->s;
@@ -635,7 +636,15 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         auto touch_frames = [&](hipStream_t q) {
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, q, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled);
             else if (!CRL_ABL(getenv("CRL_CAR_ABL_NO_TOUCH_FRAMES") != nullptr))  // (timing ablation, WRONG frames: what the step costs without them)
-                launch_car_obs_list(c->s, c->K_, target, q, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, true, touch_view);
+            {
+                static const bool one_launch = CRL_ABL(getenv("CRL_CAR_TOUCH_FRAMES_LIST") != nullptr);  // (profiling build: rounds 3-4's one-wavefront-per-tile list kernel)
+                if (touch_view == 1 || one_launch) launch_car_obs_list(c->s, c->K_, target, q, c->s.touch_all, c->s.coupled_count + 5, nullptr, exp_coupled, c->slow_env, 1, true, touch_view == 1 ? 1 : 0);
+                else if (touch_view == 2)  // views: only the envs with two manifolds or more are left (a tenth of the touching envs); frames: all, in thirds
+                    launch_car_obs_long_list(c->s, c->K_, target, q, c->s.touch_all, c->s.coupled_count + 5, exp_coupled, c->slow_env, 1, true, c->s.touch_multi,
+                                             c->s.coupled_count + 6, exp_coupled / 4);
+                else launch_car_obs_long_list(c->s, c->K_, target, q, c->s.touch_all, c->s.coupled_count + 5, exp_coupled, c->slow_env, 1, true, c->s.touch_all,
+                                              c->s.coupled_count + 5, exp_coupled);
+            }
         };
         if (contacts && !touch_frames_on_one) {  // crit again
             hipStreamWaitEvent(crit, c->ev_sens, 0);
