@@ -293,8 +293,11 @@ __device__ inline V2 rel_vel(const BRef &A, const BRef &B, V2 rA, V2 rB) {
 // impulses are carried over from last step's manifolds by contact id (warm starting).  The env goes to one of two lists:
 // `touch` (one island with contacts: car_touch_kernel) or `near` (the boxes overlap but nothing touches: two islands of
 // their own, car_near_kernel = the per-car solve).
+// phase (round 5): the broadphase that runs ahead files the coupled envs in two lists -- front: poses final (count [0]), back: envs that touch in
+// the current step (count [7], car_broad_kernel).  0: both lists; 1: the front list only (beside the touching solve); 2: the back list only
+// (behind it).  The output lists are appended to in any order, so two launches fill them like one.
 __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, int urgent, const float *__restrict__ fresh_body,
-                                                        const uint8_t *__restrict__ cls) {
+                                                        const uint8_t *__restrict__ cls, int phase) {
     // (the fixture tables are indexed per lane at run time: a by-value kernel argument would first be copied to every lane's
     // scratch, and reading them from device memory makes every vertex a dependent ~200-cycle load: stage them in LDS)
     __shared__ CarConsts Ks;
@@ -305,10 +308,11 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
 #endif
     if (urgent) __builtin_amdgcn_s_setprio(3);  // in front of the touching solve it heads the step's critical path; run ahead, at the end of the
                                                 // previous step, it must not take issue slots from that step's last frames and the next car_step_kernel
+    const int n_front = s.coupled_count[0], n_back = s.coupled_count[7];
+    const int slot0 = phase == 2 ? n_front : 0, slot1 = phase == 1 ? n_front : n_front + n_back;  // slots [0, n_front) = the front list, then the back list
     {
-        const int count0 = *s.coupled_count;
-        if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host) *s.coupled_to_host = count0;
-        if ((int)blockIdx.x >= count0) return;  // (before the tables are staged: most of the grid has nothing to do)
+        if (blockIdx.x == 0 && lane == 0 && s.coupled_to_host && phase != 1) *s.coupled_to_host = n_front + n_back;
+        if ((int)blockIdx.x >= slot1 - slot0) return;  // (before the tables are staged: most of the grid has nothing to do)
     }
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(s.consts_dev);
@@ -338,17 +342,16 @@ __global__ __launch_bounds__(64) void car_narrow_kernel(CarSoA s, CarConsts Kv, 
     // the 16 fixtures of the env in world space (car 0's at [f], car 1's at [8 + f]): built once by 16 lanes, read by every pair.
     // (One copy per PAIR -- 17 KB per workgroup -- allowed eight workgroups per CU: 2 300 coupled envs took two rounds of the kernel.)
     __shared__ WPoly wp[16];
-    const int count = *s.coupled_count;
     const int64_t M = 2 * s.n;
 #ifdef CRL_ABLATION
     const unsigned long long sn1 = __builtin_readcyclecounter();
 #endif
-    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+    for (int slot = slot0 + (int)blockIdx.x; slot < slot1; slot += gridDim.x) {
 #ifdef CRL_ABLATION
         const unsigned long long sa = __builtin_readcyclecounter();
         unsigned long long sb = sa;
 #endif
-        const int64_t env = s.coupled_list[slot];
+        const int64_t env = slot < n_front ? s.coupled_list[slot] : s.coupled_list[s.n - 1 - (slot - n_front)];
         // (collide-ahead) an env that finished while coupled: its new episode's bodies, still staged; no manifolds to warm-start from
         const bool fresh = cls && cls[env] == 3;
         const float *body = fresh ? fresh_body : s.body;
@@ -1025,9 +1028,9 @@ __global__ __launch_bounds__(64) void car_touch_kernel(CarSoA s, CarConsts K, in
 }
 
 // world.Step of the coupled envs.  `near_st` (may equal `st`): where the near-only envs are solved, beside the touching ones.
-void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent, const float *fresh_body, const uint8_t *cls) {
+void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent, const float *fresh_body, const uint8_t *cls, int phase) {
     const unsigned cap = (unsigned)(s.n < 4096 ? s.n : 4096);
-    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k, urgent ? 1 : 0, fresh_body, cls);
+    hipLaunchKernelGGL(car_narrow_kernel, dim3(cap), dim3(64), 0, st, s, k, urgent ? 1 : 0, fresh_body, cls, phase);
 }
 
 // skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous step); the caller has ordered `st`,

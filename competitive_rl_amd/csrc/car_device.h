@@ -120,7 +120,7 @@ struct CarSoA {
     float *sleep;           // [5][M] b2Body::m_sleepTime of hull, wheels 0-3
     int32_t *coupled;       // [n] 1 = the two cars are solved together this step
     int32_t *coupled_list;  // [n] the coupled envs of this step, compacted (any order), and
-    int32_t *coupled_count; // [8] how many: [0] coupled (car_step_kernel), then the narrow phase's split: [1] near-only, [2..4] touching
+    int32_t *coupled_count; // [8] how many: [0] coupled (car_step_kernel; car_broad_kernel run ahead: those with final poses, the envs that touch now: [7], from the list's end), then the narrow phase's split: [1] near-only, [2..4] touching
                             //     with one / two / three-or-more manifolds
     int32_t *near_list, *touch_list;  // [n], [3][n]
     int32_t *touch_all;     // [n] every touching env (any manifold count), [5] of coupled_count: their frames
@@ -222,7 +222,7 @@ void launch_car_step(const CarSoA &s, const CarConsts &k, const float *actions, 
 void launch_car_broad(const CarSoA &s, const CarConsts &k, hipStream_t st, const float *fresh_body = nullptr, const uint8_t *cls = nullptr,
                       const int32_t *touching_now = nullptr, const int32_t *manifolds_now = nullptr);
 void launch_car_narrow(const CarSoA &s, const CarConsts &k, hipStream_t st, bool urgent, const float *fresh_body = nullptr,
-                       const uint8_t *cls = nullptr);
+                       const uint8_t *cls = nullptr, int phase = 0);
 void launch_car_solve(const CarSoA &s, const CarConsts &k, hipStream_t st);
 void launch_car_sensors(const CarSoA &s, const CarConsts &k, hipStream_t st);
 // near_st == nullptr: everything on st.  skip_narrow: the narrow phase of this step already ran (ahead, at the end of the previous

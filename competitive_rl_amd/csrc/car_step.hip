@@ -332,13 +332,23 @@ __global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K, co
         }
         s.coupled[env] = coupled ? 1 : 0;
     }
-    const unsigned long long m = __ballot(coupled);
+    // Two lists in one array (round 5): the envs whose poses are FINAL now go to the front (count [0]) -- their narrow phase runs right
+    // behind this kernel, beside the touching solve --, the envs that touch in this step (filed untested above) to the back, from the end
+    // downwards (count [7]): only their narrow phase is left behind the solve.
+    const bool late = coupled && touching_now && !(cls && cls[env] == 3) && touching_now[env] && manifolds_now[env] > 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(coupled && !late), ml = __ballot(late);
     if (m) {
-        const int lane = threadIdx.x & 63;
         int base = 0;
         if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(s.coupled_count, (int)__popcll(m));
         base = __shfl(base, (int)__ffsll((long long)m) - 1);
-        if (coupled) s.coupled_list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
+        if (coupled && !late) s.coupled_list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int32_t)env;
+    }
+    if (ml) {
+        int base = 0;
+        if (lane == (int)__ffsll((long long)ml) - 1) base = atomicAdd(s.coupled_count + 7, (int)__popcll(ml));
+        base = __shfl(base, (int)__ffsll((long long)ml) - 1);
+        if (late) s.coupled_list[s.n - 1 - (base + (int)__popcll(ml & ((1ull << lane) - 1ull)))] = (int32_t)env;
     }
 }
 

@@ -619,7 +619,12 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         hipStreamWaitEvent(c->side2, c->ev_sens, 0);  // (every frame shows the reward)
         if (contacts) {  // frames of the near-only envs
             if (c->analytic) launch_car_raster_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled);
-            else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
+            else {  // (round 5: as a view launch + a gather-in-thirds launch, like the touching envs' frames: - 0.5 %; CRL_CAR_NEAR_LIST=1 in the profiling build: the list kernel)
+                static const bool near_list_kernel = CRL_ABL(getenv("CRL_CAR_NEAR_LIST") != nullptr);
+                if (!near_list_kernel) launch_car_obs_long_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, exp_coupled, c->slow_env, 1, false,
+                                                                c->s.near_list, c->s.coupled_count + 1, exp_coupled);
+                else launch_car_obs_list(c->s, c->K_, target, c->side2, c->s.near_list, c->s.coupled_count + 1, nullptr, exp_coupled, c->slow_env, 1);
+            }
         }
         // bulk: the per-car solve, then the frames of every env that is neither coupled nor finished
         launch_car_solve(c->s, c->K_, bulk);
@@ -670,6 +675,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             launch_car_map_build_list(c->s, q, list_of(cls), count_of(cls), expected);
             frames_list(c, c->s, target, q, list_of(cls), count_of(cls), nullptr, expected);
         };
+        bool split_narrow = false;
         const bool staged = !c->analytic;  // (the analytic raster reads the track arrays themselves: it needs them until the terminal frame is drawn)
         const bool early_broad = can_ahead && staged && !CRL_ABL(getenv("CRL_CAR_COLLIDE_LATE") != nullptr) && !CRL_ABL(getenv("CRL_CAR_BROAD_LATE") != nullptr);
         hipStreamWaitEvent(c->side2, c->ev_term, 0);
@@ -690,6 +696,11 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
                 CarSoA nx = c->s;
                 point_parity(c, nx, c->parity ^ 1);
                 launch_car_broad(nx, c->K_, c->side2, c->stage.body, c->slow_env, c->s.coupled, c->s.nc_new);
+                // ... and the narrow phase of the envs whose poses ARE final (round 5: everything but the envs that touch in this step --
+                // half of the 2 300 coupled envs), beside the touching solve instead of behind it (CRL_CAR_NARROW_LATE=1, profiling build: all behind)
+                static const bool narrow_late = CRL_ABL(getenv("CRL_CAR_NARROW_LATE") != nullptr);
+                split_narrow = !narrow_late;
+                if (split_narrow) launch_car_narrow(nx, c->K_, c->side2, false, c->stage.body, c->slow_env, 1);
             }
         } else {
             finish_chain(c->side2, 2, exp_done, c->class_count_hdev + 1);
@@ -705,7 +716,7 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
             CarSoA nx = c->s;
             point_parity(c, nx, c->parity ^ 1);
             if (!(fresh && early_broad)) launch_car_broad(nx, c->K_, c->side2, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr);
-            launch_car_narrow(nx, c->K_, c->side2, false, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr);
+            launch_car_narrow(nx, c->K_, c->side2, false, fresh ? c->stage.body : nullptr, fresh ? c->slow_env : nullptr, fresh && early_broad && split_narrow ? 2 : 0);
             hipEventRecord(c->ev_collide, c->side2);
             c->collide_valid = c->collide_dirty = true;
         };
