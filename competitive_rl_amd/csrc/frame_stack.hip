@@ -27,11 +27,25 @@ __global__ __launch_bounds__(256) void frame_stack_update_kernel(float *__restri
     const float m = mask ? mask[env] : 1.0f;
     float *base = stack + env * planes * hw + x;
     if (VEC == 4) {
-#pragma unroll 4
-        for (int p = 0; p < keep; p++) {
-            float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)(p + c) * hw);
-            if (mask) v.x *= m, v.y *= m, v.z *= m, v.w *= m;
-            *reinterpret_cast<float4 *>(base + (int64_t)p * hw) = v;
+        // (round 5) the kept planes are read in batches of up to eight with ALL of a batch's loads issued before its first store (the in-place
+        // shift reads and writes one array, so the compiler otherwise orders load p+1 behind store p-1), streaming loads and stores.  A batch's
+        // source planes lie above every plane the batch writes, and batches walk upwards, so no store can overtake a load of a later batch.
+        // Measured (tools/frame_stack_time.py, 65 536 x (4, 84, 84) float32 + a u8 plane = 13.4 GB): 2.99 ms before, 2.99 batched, 2.94 with
+        // the streaming hints = 4.56 TB/s, 0.57 of the HBM peak: the mixed read / write stream of an in-place shift, not the load order, is
+        // what holds it below a plain copy's 6.3 TB/s.
+        constexpr int kB = 8;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (int p0 = 0; p0 < keep; p0 += kB) {
+            f4 v[kB];
+#pragma unroll
+            for (int j = 0; j < kB; j++)
+                if (p0 + j < keep) v[j] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(base + (int64_t)(p0 + j + c) * hw));
+#pragma unroll
+            for (int j = 0; j < kB; j++)
+                if (p0 + j < keep) {
+                    if (mask) v[j] *= m;
+                    __builtin_nontemporal_store(v[j], reinterpret_cast<f4 *>(base + (int64_t)(p0 + j) * hw));
+                }
         }
         for (int q = 0; q < c; q++) {
             float4 v;
@@ -41,7 +55,9 @@ __global__ __launch_bounds__(256) void frame_stack_update_kernel(float *__restri
                 const uchar4 u = *reinterpret_cast<const uchar4 *>(static_cast<const uint8_t *>(obs) + env * obs_env_stride + (int64_t)q * hw + x);
                 v = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
             }
-            *reinterpret_cast<float4 *>(base + (int64_t)(keep + q) * hw) = v;
+            f4 w;
+            w.x = v.x, w.y = v.y, w.z = v.z, w.w = v.w;
+            __builtin_nontemporal_store(w, reinterpret_cast<f4 *>(base + (int64_t)(keep + q) * hw));
         }
     } else {
         for (int p = 0; p < keep; p++) {
