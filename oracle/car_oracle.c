@@ -689,6 +689,10 @@ static void isl_put_to_sleep(car_state *car) {
     }
 }
 
+#ifdef CRL_CYCLE_STATS
+static long lone_pos_hist[64];
+void car_oracle_lone_pos_hist(long *out) { memcpy(out, lone_pos_hist, sizeof(lone_pos_hist)); }
+#endif
 static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters, int pos_iters) {
     joint_tmp jt[4];
     isl_integrate_vel(car, h);
@@ -696,11 +700,23 @@ static void island_solve(car_state *car, float h, float dt_ratio, int vel_iters,
     for (int it = 0; it < vel_iters; it++) isl_joints_vel(car, jt, h);
     isl_integrate_pos(car, h);
     int solved = 0;
-    for (int it = 0; it < pos_iters; it++)
+#ifdef CRL_CYCLE_STATS
+    int used = 0;
+#endif
+    for (int it = 0; it < pos_iters; it++) {
+#ifdef CRL_CYCLE_STATS
+        used = it + 1;
+#endif
         if (isl_joints_pos(car)) {
             solved = 1;
             break;
         }
+    }
+#ifdef CRL_CYCLE_STATS
+    lone_pos_hist[used]++; /* position iterations a car on its own needed (tools/cycle_stats.py) */
+    if (!solved) lone_pos_hist[0]++;
+    for (int w = 0; w < 4; w++) if (car->limit_state[w] != LIM_INACTIVE) { lone_pos_hist[61]++; break; }
+#endif
     isl_clear_forces(car);
     if (isl_sleep_scan(car, h) >= TIME_TO_SLEEP && solved) isl_put_to_sleep(car);
 }
