@@ -1133,6 +1133,10 @@ static void contacts_vel(car_env *e, contact_vc *vc) {
 }
 
 /* b2ContactSolver::SolvePositionConstraints, one iteration; returns minSeparation >= -3*slop */
+#ifdef CRL_CYCLE_STATS
+static long pos_turn_hist[2][5];
+void car_oracle_pos_turn_hist(long *out) { memcpy(out, pos_turn_hist, sizeof(pos_turn_hist)); }
+#endif
 static int contacts_pos(car_env *e) {
     float minSep = 0.0f;
     for (int k = 0; k < e->n_contact; k++) {
@@ -1159,8 +1163,18 @@ static int contacts_pos(car_env *e) {
             float Kn = MAD(B.ii * rnB, rnB, MAD(A.ii * rnA, rnA, A.im + B.im));
             float impulse = Kn > 0.0f ? -C / Kn : 0.0f;
             v2 P = vmul(impulse, normal);
+#ifdef CRL_CYCLE_STATS
+            const float a0A = A.b->a, a0B = B.b->a;
+#endif
             A.b->cx = NMAD(A.im, P.x, A.b->cx), A.b->cy = NMAD(A.im, P.y, A.b->cy), A.b->a = NMAD(A.ii, fcross(rA, P), A.b->a);
             B.b->cx = MAD(B.im, P.x, B.b->cx), B.b->cy = MAD(B.im, P.y, B.b->cy), B.b->a = MAD(B.ii, fcross(rB, P), B.b->a);
+#ifdef CRL_CYCLE_STATS
+            for (int side = 0; side < 2; side++) { /* how far a contact point turns a body: [0] hull, [1] wheel; bins: == 0, < 2^-10, < 2^-5, < 2^-2, >= 2^-2 */
+                const float dd = fabsf(side ? B.b->a - a0B : A.b->a - a0A);
+                const int wheel = (side ? (c->pair & 7) : (c->pair >> 3)) >= 4;
+                pos_turn_hist[wheel][dd == 0.0f ? 0 : dd < 0x1p-10f ? 1 : dd < 0x1p-5f ? 2 : dd < 0x1p-2f ? 3 : 4]++;
+            }
+#endif
         }
     }
     return minSep >= -3.0f * LINEAR_SLOP;
