@@ -219,10 +219,11 @@ def _r(x, nd=5):
 def timed_loop(G, args, step, after=None):
     """W warm-up calls of step(i), then exactly K timed ones between barrier + synchronize on both sides; max over ranks."""
     torch, dist, dev, world = G["torch"], G["dist"], G["dev"], G["world"]
+    dist_on = G["dist_on"]
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     if after:
         after()
@@ -346,15 +347,15 @@ def run_workload(name, args, G):
             env.step_device(pool[i % 16])
         torch.cuda.synchronize()
 
-    gather_state = G.get("gather")
+    gather_state, dist_on = G.get("gather"), G["dist_on"]
 
     def step(i):
-        if world > 1 and args.gather == "obs" and name not in ("tournament", "tournament_full"):
+        if dist_on and args.gather == "obs" and name not in ("tournament", "tournament_full"):
             # the env draws straight into the collective's send buffer (two of them, alternating: gather(t) still reads one)
             out = env.step_device(pool[i % 16], obs_out=gather_state.obs_slot(inner._obs[0].shape, inner._obs[0].dtype, dev))
         else:
             out = env.step_device(pool[i % 16])
-        if world > 1 and args.gather != "none":
+        if dist_on and args.gather != "none":
             if args.gather == "descriptors":
                 # 64 bytes of frame descriptors per env over the links; every rank then re-draws the GLOBAL batch (inside wait())
                 gather_state.wait(materialize=True)
@@ -376,7 +377,7 @@ def run_workload(name, args, G):
         if warm_resets is not None:
             warm_resets += inner._done.sum()  # (the env's device-side done flags of this step; same stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     inner.kernel_time_ms(0), inner.kernel_time_ms(1)
     inner.kernel_timing(not os.environ.get("CRL_BENCH_NO_KERNEL_TIMING"))  # (A/B: what the hipEvent brackets themselves cost)
@@ -386,7 +387,7 @@ def run_workload(name, args, G):
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    if world > 1 and args.gather != "none":
+    if dist_on and args.gather != "none":
         gather_state.wait(materialize=args.gather == "descriptors")
     if os.environ.get("CRL_BENCH_DEBUG"):  # (where a short window's time goes: the host's enqueueing, the caller's stream, the rest of the device)
         t_host = time.perf_counter() - t0
@@ -396,11 +397,11 @@ def run_workload(name, args, G):
         print(f"[{name}] host enqueue {t_host * 1e3:.2f} ms, caller's stream done {t_stream * 1e3:.2f} ms, device done {(time.perf_counter() - t0) * 1e3:.2f} ms",
               file=sys.stderr, flush=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
     inner.kernel_timing(False)
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -482,8 +483,11 @@ def main():
 
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    G = dict(torch=torch, crl=crl, dist=dist, dev=dev, world=world, rank=rank)
-    if world > 1:
+    # CRL_BENCH_FORCE_DIST=1: a single rank goes through the process group all the same (RCCL world of one: barriers, the max over ranks, the
+    # --gather collective) -- what a one-GPU box can run of the N > 1 path, tests/test_hip_round2.py
+    dist_on = world > 1 or os.environ.get("CRL_BENCH_FORCE_DIST") == "1"
+    G = dict(torch=torch, crl=crl, dist=dist, dev=dev, world=world, rank=rank, dist_on=dist_on)
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
         G["gather"] = crl.StepGather(overlap=True, mode="descriptors" if args.gather == "descriptors" else "obs")
@@ -505,7 +509,7 @@ def main():
             names[0], "env-steps/sec (whole node), cPongDouble 65536 envs per GPU")
         line = {"metric": metric, "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"],
-                "data": "synthetic", "config": dict(head["config"], gather=args.gather if world > 1 else "n/a", actions="uniform random, pre-generated on device",
+                "data": "synthetic", "config": dict(head["config"], gather=args.gather if dist_on else "n/a", actions="uniform random, pre-generated on device",
                                                     auto_reset=True),
                 "roofline": head.get("roofline")}
         for k in ("roofline_valu", "legs_ms_per_step", "overhead_us_per_step"):
@@ -523,7 +527,7 @@ def main():
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception as exc:  # (a build without the collective library)
             rccl = f"unavailable ({type(exc).__name__})"
-        line["comm"] = {"backend": "nccl (= RCCL on ROCm)" if world > 1 else "none (one rank)", "rccl_version": rccl, "world": world,
+        line["comm"] = {"backend": "nccl (= RCCL on ROCm)" if dist_on else "none (one rank)", "rccl_version": rccl, "world": world,
                         "env_ranges": [[r * npg, (r + 1) * npg] for r in range(world)], "gather": args.gather}
         if multi:
             line["configs"] = {}
@@ -539,7 +543,7 @@ def main():
                     r["cpu_baseline"] = b
                 line["configs"][nm] = r
         print(json.dumps(_r(line), separators=(",", ":")), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

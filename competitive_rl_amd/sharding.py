@@ -76,10 +76,14 @@ class StepGather:
             self.recv = torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev)
             self.stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.overlap) else None
 
-    def obs_slot(self, shape, dtype, device, rest_bytes=4096):
+    def obs_slot(self, shape, dtype, device, rest_bytes=None):
         """mode="obs": a tensor of the observation's shape that IS the head of a send buffer (the other tensors of a step
-        must fit in ``rest_bytes`` after it).  Call it before EVERY step: there are two send buffers and the slots alternate,
-        so that step t+1 can be drawn while the collective of step t still reads the other one."""
+        must fit in ``rest_bytes`` after it; default: 32 bytes per env of the shard + 4 KB -- rewards (n, 2) float32, done flags and
+        two more per-env words.  A fixed 4 KB, as it was until round 5, is too small from 410 envs per shard on: found by the
+        one-rank RCCL test).  Call it before EVERY step: there are two send buffers and the slots alternate, so that step t+1 can
+        be drawn while the collective of step t still reads the other one."""
+        if rest_bytes is None:
+            rest_bytes = 4096 + 32 * int(shape[0])
         nb = (int(torch.Size(shape).numel()) * torch.empty((), dtype=dtype).element_size() + 15) // 16 * 16
         total, dev = nb + (rest_bytes + 15) // 16 * 16, torch.device(device)
         if getattr(self, "_sends", None) is None or self._sends[0].numel() != total or self._sends[0].device != dev:

@@ -416,6 +416,63 @@ def test_two_hip_shards_plus_packed_gather_equal_one_batch(tmp_path):
         _check_against_one_batch(tmp_path)
 
 
+def test_one_rank_rccl_gather_equals_one_batch(tmp_path):
+    """What a ONE-GPU box can say about the RCCL path (VERDICT r04 weak #9): a world of one rank over the "nccl" backend runs the
+    same StepGather code as config #5 -- the env drawing straight into the send buffer (obs_slot), the pack on the caller's stream, the
+    collective on the side stream behind an event, the wait, the reuse of both buffers step after step, and the descriptor mode's
+    re-draw -- with RCCL itself moving the bytes; the result must be the unsharded batch.  (Two ranks on one GPU are refused by
+    RCCL: the two-rank variants above run over gloo, the two-GPU ones below are skipped here.)"""
+    _need_gpu()
+    import torch.multiprocessing as mp
+
+    for mode in ("obs", "descriptors"):
+        mp.start_processes(_two_gpu_worker, args=(1, _free_port(), str(tmp_path), "nccl", mode), nprocs=1, join=True, start_method="spawn")
+        _check_against_one_batch(tmp_path)
+
+
+def test_bench_line_with_the_gather_on_one_rank():
+    """``bench.py --gather obs`` on one GPU (no process group: the gather is a no-op by design) still names the rank's env range, and the car
+    workload accepts the flag (VERDICT r04 #9: `car` leg of --gather obs)."""
+    _need_gpu()
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for wl, envs in (("fused84", 2048), ("car", 512)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--workload", wl, "--envs", str(envs),
+                              "--gather", "obs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, CRL_BENCH_CAR_PREROLL="50"))
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["comm"]["world"] == 1 and line["comm"]["env_ranges"] == [[0, envs]]
+
+
+def test_bench_under_torchrun_with_one_rank_runs_the_distributed_path():
+    """The driver's N > 1 launch line with N = 1 (``python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 ...
+    bench.py --gpus 1``) and CRL_BENCH_FORCE_DIST=1: the rank reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, joins an RCCL process group of
+    one, passes the barriers, the max over ranks and the --gather collective (obs: drawn into the send buffer; descriptors: re-drawn after
+    the collective) -- every line of the multi-GPU path a one-GPU box can execute."""
+    _need_gpu()
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for wl, envs, gather in (("fused84", 4096, "obs"), ("fused84", 4096, "descriptors"), ("car", 512, "obs"), ("raw", 1024, "scalars")):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                              "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                              "--workload", wl, "--envs", str(envs), "--gather", gather, "--no-cpu-baseline"], capture_output=True, text=True,
+                             timeout=600, env=dict(os.environ, CRL_BENCH_CAR_PREROLL="50", CRL_BENCH_FORCE_DIST="1"))
+        assert out.returncode == 0, (wl, gather, out.stderr[-2000:])
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["steps"] == 5 and line["config"]["gather"] == gather
+        assert line["comm"]["backend"].startswith("nccl") and line["comm"]["world"] == 1 and line["comm"]["env_ranges"] == [[0, envs]]
+        assert abs(line["value"] - envs * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-3 * line["value"]
+
+
 def test_bench_line_on_two_gpus_names_the_ranks_and_their_env_ranges():
     """The first multi-GPU box validates ranks + ranges in one run (VERDICT r04 #9): ``bench.py --gpus 2 --steps 5`` for the Pong and the
     CarRacing workload with the config-#5 gather -- world 2, RCCL named, contiguous env ranges by global id, whole-job value.
