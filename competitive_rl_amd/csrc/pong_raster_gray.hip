@@ -996,6 +996,54 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
         for (int i = lane; i < R * R; i += 64) out[i] = f32ref_pixel(g, fa, fb, view, i / R, i - (i / R) * R, rounded);
         return;
     }
+    // ball, left bat, right bat of both frames: source rectangle -> the output pixels it feeds; one list over the six rectangles
+    // (where two of them overlap a pixel is drawn twice, to the same value)
+    int rdx0[6], rwx[6], rdy0[6], rend[6], total = 0;
+#pragma unroll
+    for (int o = 0; o < 6; o++) {
+        const Frame &f = o < 3 ? fa : fb;
+        const int k = o % 3;
+        int x0 = k == 0 ? f.x : k == 1 ? CRL_PONG_BATL_X : CRL_PONG_BATR_X, w = k == 0 ? CRL_PONG_BALL : CRL_PONG_BAT_W;
+        int y0 = k == 0 ? f.y : k == 1 ? f.bl : f.br, h = k == 0 ? CRL_PONG_BALL : CRL_PONG_BAT_H;
+        int x1 = min(x0 + w - 1, CRL_PONG_W - 1), y1 = min(y0 + h - 1, CRL_PONG_BOTTOM - 1);
+        x0 = max(x0, 0), y0 = max(y0, CRL_PONG_TOP);  // (px_view draws the court's rows only)
+        int npx = 0;
+        rdx0[o] = rwx[o] = rdy0[o] = 0;
+        const bool twice = o >= 3 && (k == 0 ? (fb.x == fa.x && fb.y == fa.y) : k == 1 ? fb.bl == fa.bl : fb.br == fa.br);  // the same rectangle as in frame a
+        if (x0 <= x1 && y0 <= y1 && !twice) {
+            if (view == 1) {  // court rows are mirrored in the second view
+                const int m0 = CRL_PONG_W - 1 - x1, m1 = CRL_PONG_W - 1 - x0;
+                x0 = m0, x1 = m1;
+            }
+            const int dx0 = q.x_first[x0], dx1 = q.x_last[x1], dy0 = q.y_first[y0], dy1 = q.y_last[y1];
+            rdx0[o] = dx0, rwx[o] = dx1 - dx0 + 1, rdy0[o] = dy0, npx = rwx[o] * (dy1 - dy0 + 1);
+        }
+        total += npx;
+        rend[o] = total;
+    }
+    // (round 5) ... evaluated FIRST, into registers -- an output pixel is a chain of ~25 dependent LDS reads, 2-3 us for a lone wavefront, and it used to
+    // start only when the tile's 28 KB of stores had drained (the fence below); now the table loads and the stores of the copy run beside it.
+    // A lane holds at most kRedraw of them (the six rectangles cover < 64 kRedraw output pixels at every R up to 84); what does not fit is drawn behind the fence as before.
+    constexpr int kRedraw = 3;
+    int rpos[kRedraw];
+    float rval[kRedraw];
+#pragma unroll
+    for (int k = 0; k < kRedraw; k++) rpos[k] = -1, rval[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kRedraw; k++) {
+        const int i = lane + 64 * k;
+        if (i >= total || (q.debug & 16)) continue;
+        int o = 0, base = 0;
+#pragma unroll
+        for (int m = 0; m < 5; m++)
+            if (i >= rend[m]) o = m + 1, base = rend[m];
+        int dx0 = rdx0[0], wx = rwx[0], dy0 = rdy0[0];
+#pragma unroll
+        for (int m = 1; m < 6; m++)
+            if (o == m) dx0 = rdx0[m], wx = rwx[m], dy0 = rdy0[m];
+        const int j = i - base, dy = dy0 + j / wx, dx = dx0 + j % wx;
+        rpos[k] = dy * R + dx, rval[k] = f32ref_pixel(g, fa, fb, view, dy, dx, rounded);
+    }
     if (!(q.debug & 32)) {
         const float *top = q.top + (((((int64_t)(slo * 22 + sro) * 3 + kind) * 2 + view) * 2 + (rounded ? 1 : 0)) * q.band_rows) * R;
         const float *bot = q.bot + (int64_t)(rounded ? 1 : 0) * (R - q.bot0) * R;
@@ -1035,32 +1083,10 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the re-drawn pixels below overwrite what other lanes have just stored: those stores first
     if (q.debug & 16) return;
-    // ball, left bat, right bat of both frames: source rectangle -> the output pixels it feeds; one list over the six rectangles
-    // (where two of them overlap a pixel is drawn twice, to the same value)
-    int rdx0[6], rwx[6], rdy0[6], rend[6], total = 0;
 #pragma unroll
-    for (int o = 0; o < 6; o++) {
-        const Frame &f = o < 3 ? fa : fb;
-        const int k = o % 3;
-        int x0 = k == 0 ? f.x : k == 1 ? CRL_PONG_BATL_X : CRL_PONG_BATR_X, w = k == 0 ? CRL_PONG_BALL : CRL_PONG_BAT_W;
-        int y0 = k == 0 ? f.y : k == 1 ? f.bl : f.br, h = k == 0 ? CRL_PONG_BALL : CRL_PONG_BAT_H;
-        int x1 = min(x0 + w - 1, CRL_PONG_W - 1), y1 = min(y0 + h - 1, CRL_PONG_BOTTOM - 1);
-        x0 = max(x0, 0), y0 = max(y0, CRL_PONG_TOP);  // (px_view draws the court's rows only)
-        int npx = 0;
-        rdx0[o] = rwx[o] = rdy0[o] = 0;
-        const bool twice = o >= 3 && (k == 0 ? (fb.x == fa.x && fb.y == fa.y) : k == 1 ? fb.bl == fa.bl : fb.br == fa.br);  // the same rectangle as in frame a
-        if (x0 <= x1 && y0 <= y1 && !twice) {
-            if (view == 1) {  // court rows are mirrored in the second view
-                const int m0 = CRL_PONG_W - 1 - x1, m1 = CRL_PONG_W - 1 - x0;
-                x0 = m0, x1 = m1;
-            }
-            const int dx0 = q.x_first[x0], dx1 = q.x_last[x1], dy0 = q.y_first[y0], dy1 = q.y_last[y1];
-            rdx0[o] = dx0, rwx[o] = dx1 - dx0 + 1, rdy0[o] = dy0, npx = rwx[o] * (dy1 - dy0 + 1);
-        }
-        total += npx;
-        rend[o] = total;
-    }
-    for (int i = lane; i < total; i += 64) {
+    for (int k = 0; k < kRedraw; k++)
+        if (rpos[k] >= 0) out[rpos[k]] = rval[k];
+    for (int i = lane + 64 * kRedraw; i < total; i += 64) {  // (more output pixels than the registers hold: not at the sizes the wrappers use)
         int o = 0, base = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++)
