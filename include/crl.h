@@ -349,6 +349,12 @@ int crl_car_copy_info(crl_ctx *ctx, uint8_t *done_car_out_dev, int32_t *num_step
  * u8 or f32 per `obs_dtype` (crl_obs_dtype); mask: f32 (N) or NULL (= all ones).  hw = H*W. */
 int crl_frame_stack_update(float *stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
                            const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream);
+/* The same update OUT of place: dst = (src * mask) shifted, with obs as the newest planes; src is not written.  This is the
+ * reference's own data flow -- `self.current_obs = self.current_obs.roll(...)` (utils/utils.py:166-167) binds a NEW tensor on every
+ * update -- and a plain streaming copy for the memory system (no load that must stay ahead of a store to the same rows).  dst and
+ * src must not overlap (CRL_EINVAL). */
+int crl_frame_stack_update_to(float *dst_stack_dev, const float *src_stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
+                              const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream);
 
 /* ---- built-in CNN opponents of cPongTournament-v0 ----------------------------
  * Stands in for utils/policy_serving.py:10-66 `Policy(..., use_light_model=True)` as built by

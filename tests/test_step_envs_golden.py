@@ -138,18 +138,21 @@ def test_step_envs_and_frame_stack_match_reference_through_hip():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("out_of_place", [True, False])
 @pytest.mark.parametrize("dtype", ["uint8", "float32"])
-def test_frame_stack_kernel_equals_torch_ops(dtype):
-    """crl_frame_stack_update against the three torch ops it replaces, on strided uint8 / float32 observations,
-    vector and scalar paths, with and without a mask."""
+def test_frame_stack_kernel_equals_torch_ops(dtype, out_of_place):
+    """crl_frame_stack_update / crl_frame_stack_update_to against the three torch ops they replace, on strided uint8 / float32
+    observations, vector and scalar paths, with and without a mask.  Out of place (the default: the reference binds a new tensor
+    per update too) the tensor the LAST update handed out must still hold its values after this one."""
     _need_gpu()
     import competitive_rl_amd as crl
 
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(5)
     for (n, c, k, h, w) in ((37, 1, 4, 84, 84), (5, 2, 3, 7, 9), (64, 1, 1, 42, 42), (3, 3, 2, 96, 96)):
-        f = crl.FrameStackTensor(n, (c, h, w), k, dev)
+        f = crl.FrameStackTensor(n, (c, h, w), k, dev, out_of_place=out_of_place)
         ref = torch.zeros((n, c * k, h, w), device=dev)
+        last_out = last_ref = None
         for step in range(6):
             wide = torch.randint(0, 256, (n, 2, c, h, w), generator=g, device=dev, dtype=torch.uint8)
             obs = wide[:, 1] if dtype == "uint8" else wide[:, 1].float()     # a strided view, like agent 1's half
@@ -160,6 +163,30 @@ def test_frame_stack_kernel_equals_torch_ops(dtype):
             ref[:, -c:] = obs.float()
             out = f.update(obs, mask)
             assert torch.equal(out, ref), (n, c, k, h, w, step)
+            assert out.data_ptr() == f.get().data_ptr()
+            if out_of_place and last_out is not None:
+                assert out.data_ptr() != last_out.data_ptr() and torch.equal(last_out, last_ref), (n, c, k, h, w, step)
+            last_out, last_ref = out, ref.clone()
+
+
+@pytest.mark.gpu
+def test_frame_stack_update_to_rejects_overlapping_tensors():
+    _need_gpu()
+    import ctypes as C
+
+    import competitive_rl_amd as crl
+    from competitive_rl_amd import _native as N
+
+    lib = N.load()
+    buf = torch.zeros(2 * 4 * 8 * 8 + 64, device="cuda")
+    obs = torch.zeros((2, 1, 8, 8), dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.crl_frame_stack_update_to(C.c_void_p(buf.data_ptr() + 64), C.c_void_p(buf.data_ptr()), C.c_void_p(obs.data_ptr()), N.CRL_OBS_U8, 64,
+                                       None, 2, 1, 4, 64, st)
+    assert rc != 0
+    with pytest.raises(RuntimeError, match="overlap"):
+        N.check(rc)
+    assert crl.FrameStackTensor(2, (1, 8, 8), 4, "cuda").out_of_place
 
 
 @pytest.mark.gpu
