@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void frame_stack_update_kernel(float *stack, c
 #ifndef CRL_FS_U
 #define CRL_FS_U 1  // 16-byte chunks per thread (measured at 65 536 x (4, 84, 84): 1: 2.16 ms, 2: 2.27, 4: 2.42, 8: 2.52)
 #endif
+#ifndef CRL_FS_NT
+#define CRL_FS_NT 3  // bit 0: streaming loads, bit 1: streaming stores (measured: 0: 2.36 ms, 1: 2.38, 2: 2.17, 3: 2.15 -- the stores are what matters; the float32 observation kernel of pong_raster_gray.hip, which stores from LDS tiles, LOSES 5 % with streaming stores)
+#endif
 template <bool OBS_F32>
 __global__ __launch_bounds__(256) void frame_stack_copy_kernel(float *__restrict__ dst, const float *__restrict__ src, const void *__restrict__ obs,
                                                                int64_t obs_env_stride, const float *__restrict__ mask, int64_t n, int c, int k, int64_t hw) {
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void frame_stack_copy_kernel(float *__restrict
     for (int j = 0; j < U; j++) {
         const int64_t q = q0 + 256 * j;
         if (q < keepc) {
-            v[j] = __builtin_nontemporal_load(s4 + q);
+            v[j] = CRL_FS_NT & 1 ? __builtin_nontemporal_load(s4 + q) : s4[q];
         } else if (q < totc) {
             const int64_t e = (q - keepc) * 4;  // element inside the env's observation (c planes of hw)
             if (OBS_F32) {
@@ -116,9 +119,11 @@ __global__ __launch_bounds__(256) void frame_stack_copy_kernel(float *__restrict
         const int64_t q = q0 + 256 * j;
         if (q < keepc) {
             if (mask) v[j] *= m;
-            __builtin_nontemporal_store(v[j], d4 + q);
+            if (CRL_FS_NT & 2) __builtin_nontemporal_store(v[j], d4 + q);
+            else d4[q] = v[j];
         } else if (q < totc) {
-            __builtin_nontemporal_store(v[j], d4 + q);
+            if (CRL_FS_NT & 2) __builtin_nontemporal_store(v[j], d4 + q);
+            else d4[q] = v[j];
         }
     }
 }
