@@ -36,19 +36,18 @@ def _sample_runs(n, bytes_per_env, count=64, seed=0):
     return sorted(starts)
 
 
-def _pong_full_size(atlas, mode, steps, **kw):
+def _pong_full_size(atlas, mode, steps, n=65536, **kw):
     import competitive_rl_amd as crl
     from oracle import pong_oracle as po
     from tests.test_hip_pong_parity import assert_state_equal
 
-    n = 65536
     wrapped = mode == "wrapped"
     bytes_per_env = 2 * kw["frame_stack"] * kw["resized_dim"] ** 2 if wrapped else 2 * 210 * 160 * 3
     starts = _sample_runs(n, bytes_per_env)
     ids = np.concatenate([np.arange(s, s + RUN) for s in starts])
     ids_dev = torch.as_tensor(ids, device="cuda")
     boundary = [s for s in starts if any(s * bytes_per_env < (k << 32) <= (s + RUN) * bytes_per_env for k in range(1, 4))]
-    assert mode != "raw" or len(boundary) == 3, boundary  # 13.2 GB: the 2^32, 2^33 and 3 x 2^32 boundaries are sampled
+    assert mode != "raw" or n != 65536 or len(boundary) == 3, boundary  # 13.2 GB: the 2^32, 2^33 and 3 x 2^32 boundaries are sampled
     env = crl.HipPongVecEnv(n, seed=7, mode=mode, **kw)
     oras = [po.PongOracle(RUN, atlas, obs_mode=po.GRAY if wrapped else po.RAW, seed=7, env_id_base=s,
                           **({"resized_dim": kw["resized_dim"], "frame_stack": kw["frame_stack"]} if wrapped else {})) for s in starts]
@@ -97,6 +96,13 @@ def test_config3_fused84_65536_envs_sampled_against_the_oracle(atlas):
     """BASELINE config #3: 65 536 envs, fused gray + 84 x 84 + 4-stack; 48 steps = 192 frames"""
     _need_gpu()
     _pong_full_size(atlas, "wrapped", 48, resized_dim=84, frame_stack=4)
+
+
+def test_config5_global_batch_524288_envs_on_one_device_sampled_against_the_oracle(atlas):
+    """BASELINE config #5's node-wide batch (8 x 65 536 envs) as ONE context: 29.6 GB of fused observations, byte offsets up to 2^34.8
+    (six 2^32 boundaries sampled), env ids up to 2^19 -- the index arithmetic of every Pong kernel one more power of eight out."""
+    _need_gpu()
+    _pong_full_size(atlas, "wrapped", 24, n=524288, resized_dim=84, frame_stack=4)
 
 
 @pytest.mark.parametrize("solver", ["box2d", "fma"])
