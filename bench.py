@@ -238,19 +238,21 @@ def run_protocol(args, G):
     """The reference-shaped calls around the same env: (a) step_device, the library's hot-loop entry;
     (b) make_envs(...).step(device actions) -- VecEnv.step_async / step_wait with cloned outputs and lazy infos; (c) the same with
     infos[i] read for the envs that finished (one host copy of the done flags per step, the terminal observations drawn by one call);
-    (d) step_envs + FrameStackTensor.update (reference utils/utils.py:23-60, 145-173): the trainer's books, observation stack of
-    agent 0 as float32 (N, 4, 84, 84) kept on the device."""
-    torch, crl, dev, rank = G["torch"], G["crl"], G["dev"], G["rank"]
+    (d) step_envs + FrameStackTensor (reference utils/utils.py:23-60, 145-173): the trainer's books, observation stack of agent 0 as
+    float32 (N, 4, 84, 84) kept on the device -- since round 6 BOUND to the env: envs.step draws the stack's next state in the launch
+    that draws the observation (crl_step_stack) and update() is a pointer swap; (e) the same with an opt-in uint8 stack; (f) round 5's
+    path for comparison: the stack rolled and appended by a kernel of its own (13.4 GB per step).
+    Every leg: W warm-up calls, K timed ones between barrier + synchronize on both sides, max over ranks."""
+    torch, crl, dist, dev, rank, dist_on = G["torch"], G["crl"], G["dist"], G["dev"], G["rank"], G["dist_on"]
     import numpy as np
 
     n = args.envs or 65536
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = [torch.randint(0, 3, (n, 2), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
     env = crl.make_envs("cPongDouble-v0", num_envs=n, log_dir=None, seed=0, resized_dim=84, frame_stack=None, device=dev, env_id_base=rank * n)
-    env.reset()
-    fst = crl.FrameStackTensor(n, (1, 84, 84), 4, dev)
     books = dict(ep=torch.zeros((n, 2), dtype=torch.float32, device=dev), rr=[], lr=[], steps=0, episodes=0)
     sink = [0]
+    cur = {}
 
     def leg_device(i):
         env.step_device(pool[i % 16])
@@ -264,20 +266,52 @@ def run_protocol(args, G):
             sink[0] += len(infos[int(j)]["terminal_observation"])
 
     def leg_step_envs(i):
-        out = crl.step_envs(pool[i % 16], env, books["ep"], fst, books["rr"], books["lr"], books["steps"], books["episodes"], dev, False)
+        out = crl.step_envs(pool[i % 16], env, books["ep"], cur["fst"], books["rr"], books["lr"], books["steps"], books["episodes"], dev, False)
         books["episodes"], books["steps"] = out[5], out[6]
 
-    res = {}
-    for key, leg in (("step_device", leg_device), ("vec_env_step", leg_step), ("vec_env_step_infos", leg_infos), ("step_envs", leg_step_envs)):
+    def stack(dtype, bind):
+        """the training scripts' preamble: a fresh stack, the env reset, its first observation pushed"""
+        if cur.get("fst") is not None:
+            cur["fst"].unbind()
+        cur["fst"] = None
+        torch.cuda.empty_cache()
+        f = crl.FrameStackTensor(n, (1, 84, 84), 4, dev, dtype=dtype)
+        f._bind_tried = not bind  # (False: step_envs binds it on its first call)
+        f.update(env.reset()[0])
+        cur["fst"] = f
+
+    env.reset()
+    res, fused = {}, {}
+    legs = (("step_device", leg_device, None), ("vec_env_step", leg_step, None), ("vec_env_step_infos", leg_infos, None),
+            ("step_envs", leg_step_envs, (torch.float32, True)), ("step_envs_u8_stack", leg_step_envs, (torch.uint8, True)),
+            ("step_envs_unbound", leg_step_envs, (torch.float32, False)))
+    for key, leg, st in legs:
+        if st is not None:
+            stack(*st)
         t0 = timed_loop(G, args, leg)
         torch.cuda.synchronize()
-        res[key] = (time.perf_counter() - t0) / args.steps * 1e3
+        if dist_on:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res[key] = dt / args.steps * 1e3
+        if st is not None:
+            fused[key] = cur["fst"].fused_updates
     env.close()
     base = res["step_device"]
+    stack_bytes = 4 * 84 * 84 * 4
     out = {"value": G["world"] * n * args.steps / (res["step_envs"] * 1e-3 * args.steps), "unit": "env-steps/s", "ms_per_step": res["step_envs"], "dtype": "u8",
-           "config": {"workload": WORKLOADS["protocol"], "envs_per_gpu": n},
+           "config": {"workload": WORKLOADS["protocol"], "envs_per_gpu": n, "stack": "float32 (N,4,84,84), bound to the env (drawn by the step)"},
            "legs_ms_per_step": res, "overhead_us_per_step": {k: (v - base) * 1e3 for k, v in res.items() if k != "step_device"},
-           "episodes_recorded": books["episodes"]}
+           "fused_updates": fused, "episodes_recorded": books["episodes"]}
+    if rank == 0:
+        # the whole leg against the float32 stack it must produce (VERDICT r05 #1: 112 896 B/env written once)
+        ach = stack_bytes * n / (res["step_envs"] * 1e-3)
+        out["roofline"] = {"bound": "hbm", "kernel": "pong_raster_gray_env_kernel<STACK> (whole step_envs leg)", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic_of("protocol"), "bytes_per_launch": stack_bytes * n}
     return out
 
 

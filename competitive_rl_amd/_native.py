@@ -25,7 +25,7 @@ SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "cr
            "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_get_map", "crl_car_set_replay",
            "crl_policy_create", "crl_policy_create_full", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
            "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update", "crl_frame_stack_update_to", "crl_ctx_last_error",
-           "crl_obs_descriptors", "crl_render_frames_dev", "crl_car_cap_hits", "crl_selftest_sincosf"]
+           "crl_obs_descriptors", "crl_render_frames_dev", "crl_car_cap_hits", "crl_selftest_sincosf", "crl_step_stack", "crl_draw_stack"]
 
 FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
                      ("score_l", "u1"), ("score_r", "u1")])
@@ -63,6 +63,12 @@ class CrlOpts(C.Structure):
                 ("done_policy", C.c_int32), ("obs_dtype", C.c_int32), ("reserved", C.c_int32)]
 
 
+class CrlStackDesc(C.Structure):
+    """crl_stack_desc (include/crl.h): a FrameStackTensor drawn by the step."""
+    _fields_ = [("stack_dev", C.c_void_p), ("planes", C.c_int32), ("dtype", C.c_int32), ("agent", C.c_int32),
+                ("valid_planes", C.c_int32), ("alias_newest", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CrlError(RuntimeError):
     pass
 
@@ -92,6 +98,8 @@ def load():
     L.crl_seed.argtypes = [vp, u64]
     L.crl_reset.argtypes = [vp, vp, vp]
     L.crl_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.crl_step_stack.argtypes = [vp, vp, vp, vp, vp, C.POINTER(CrlStackDesc), vp]
+    L.crl_draw_stack.argtypes = [vp, vp, C.POINTER(CrlStackDesc), vp]
     L.crl_info.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.crl_render.argtypes = [vp, vp, vp]
     L.crl_copy_info.argtypes = [vp, vp, vp, vp]

@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libcrl_hip.so")
 SOURCES = ["crl_api.hip", "pong_dynamics.hip", "pong_raster_raw.hip", "pong_raster_gray.hip",
            "crl_car_api.hip", "car_step.hip", "car_contact.hip", "car_track.hip", "car_raster.hip", "car_obs.hip", "pong_policy.hip", "pong_policy_full.hip", "frame_stack.hip", "crl_selftest.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("pong_device.h", "car_device.h", "car_solver.h", "car_obs_tile.h", "crl_internal.h", "pong_policy_full.h")] + [os.path.join(ROOT, "include", "crl.h"), os.path.join(ROOT, "include", "crl_rot.h"), os.path.join(ROOT, "include", "crl_f64.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("pong_device.h", "car_device.h", "car_solver.h", "car_obs_tile.h", "crl_internal.h", "pong_policy_full.h", "pong_gray_tile.inc")] + [os.path.join(ROOT, "include", "crl.h"), os.path.join(ROOT, "include", "crl_rot.h"), os.path.join(ROOT, "include", "crl_f64.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

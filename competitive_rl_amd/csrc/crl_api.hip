@@ -450,8 +450,33 @@ int crl_seed(crl_ctx *c, uint64_t seed) {
     return CRL_OK;
 }
 
-static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
-    if (!obs_dev) return CRL_OK;
+// crl_stack_desc -> what the gray launch needs; refuses what the fused draw cannot do (the caller then keeps crl_frame_stack_update)
+static int stack_of(const crl_ctx *c, const crl_stack_desc *sd, const uint8_t *obs_dev, GrayStack *out) {
+    *out = GrayStack{};
+    if (!sd) return CRL_OK;
+    if (c->car || c->o.obs_mode != CRL_OBS_GRAY_RESIZED) return fail(CRL_ESTATE, "a fused frame stack needs a GRAY_RESIZED Pong context");
+    if (c->o.flags & CRL_FLAG_STACK_REPLICATE)
+        return fail(CRL_ESTATE, "a fused frame stack follows FrameStackTensor's zero-on-done history; this context keeps the FrameStack wrapper's (CRL_FLAG_STACK_REPLICATE)");
+    if (!sd->stack_dev || sd->reserved != 0) return fail(CRL_EINVAL, "crl_stack_desc: null stack / reserved must be 0");
+    if (sd->planes < 1 || sd->planes > 4) return fail(CRL_EINVAL, "crl_stack_desc.planes %d: the context keeps the descriptors of the last 4 planes", sd->planes);
+    if (sd->agent < 0 || sd->agent >= pong_views(c)) return fail(CRL_EINVAL, "crl_stack_desc.agent %d of %d", sd->agent, pong_views(c));
+    if (sd->valid_planes < 0) return fail(CRL_EINVAL, "crl_stack_desc.valid_planes %d", sd->valid_planes);
+    const int want_f32 = c->o.obs_dtype != CRL_OBS_U8;
+    if (sd->dtype != CRL_OBS_U8 && sd->dtype != CRL_OBS_F32) return fail(CRL_EINVAL, "crl_stack_desc.dtype %d (CRL_OBS_U8 or CRL_OBS_F32)", sd->dtype);
+    if (want_f32 && sd->dtype != CRL_OBS_F32) return fail(CRL_EINVAL, "a float32 context's stack is float32");
+    if (sd->alias_newest) {
+        if (c->o.frame_stack != 1) return fail(CRL_EINVAL, "alias_newest needs a context with frame_stack 1 (the observation IS the stack's newest plane)");
+        if ((sd->dtype == CRL_OBS_F32) != (want_f32 != 0)) return fail(CRL_EINVAL, "alias_newest needs the stack and the observation in one element type");
+    }
+    if ((uintptr_t)sd->stack_dev % 16) return fail(CRL_EINVAL, "crl_stack_desc.stack_dev must be 16-byte aligned");
+    (void)obs_dev;
+    out->out = reinterpret_cast<uint8_t *>(sd->stack_dev), out->k = sd->planes, out->view = sd->agent, out->f32 = sd->dtype == CRL_OBS_F32;
+    out->valid = std::min(sd->valid_planes, sd->planes), out->alias = sd->alias_newest ? 1 : 0;
+    return CRL_OK;
+}
+
+static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st, const GrayStack *sk = nullptr) {
+    if (!obs_dev && !(sk && sk->out)) return CRL_OK;
     begin_timed(c, 1, st);
     if (c->o.obs_mode == CRL_OBS_RAW_RGB) {
         launch_pong_raster_raw(c->s.obs_frames, c->n, c->atlas_rgb, c->ink_row0, c->ink_row1, obs_dev, pong_views(c), st);
@@ -462,6 +487,7 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st) {
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype, p.hdr = c->tile_hdr;
         p.f32_top = c->f32_top, p.f32_bot = c->f32_bot, p.f32_bot0 = c->f32_bot0, p.f32_xtaps = c->f32_xtaps, p.f32_ytaps = c->f32_ytaps;
+        if (sk) p.stack = *sk;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
@@ -519,6 +545,30 @@ int crl_step(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_
     end_timed(c, 0, st);
     HIP_TRY(hipGetLastError());
     return draw_obs(c, obs_dev, st);
+}
+
+int crl_step_stack(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev, const crl_stack_desc *stack,
+                   void *stream) {
+    CRL_ENTER(c);
+    if (!c || !actions_void) return fail(CRL_EINVAL, "null ctx/actions");
+    if (!stack) return crl_step(c, actions_void, obs_dev, rew_dev, done_dev, stream);
+    GrayStack sk;
+    if (int rc = stack_of(c, stack, obs_dev, &sk)) return rc;  // (before anything is stepped: a refused call has done no work)
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = pending_action_error(c, true)) return rc;
+    begin_timed(c, 0, st);
+    launch_pong_dynamics(c->s, c->src, (const int32_t *)actions_void, c->n, pong_mode(c), rew_dev, done_dev, st);
+    end_timed(c, 0, st);
+    HIP_TRY(hipGetLastError());
+    return draw_obs(c, obs_dev, st, &sk);
+}
+
+int crl_draw_stack(crl_ctx *c, uint8_t *obs_dev, const crl_stack_desc *stack, void *stream) {
+    CRL_ENTER(c);
+    if (!c || !stack) return fail(CRL_EINVAL, "null argument");
+    GrayStack sk;
+    if (int rc = stack_of(c, stack, obs_dev, &sk)) return rc;
+    return draw_obs(c, obs_dev, (hipStream_t)stream, &sk);
 }
 
 int crl_info(crl_ctx *c, const float **real_reward_dev, const int32_t **num_steps_dev) {

@@ -225,6 +225,15 @@ struct GrayTabOfs {
     int xa255, rowstatic, colstatic;  // 255*xalpha (f32 [5][R]); static bits of row_pack / col_pack (u32 [R])
     int box32;  // byte offset (past `total`, global memory only) of int32 copies of xf|xl|yf|yl for scalar loads
 };
+// FrameStackTensor fused into the draw (crl_step_stack / crl_draw_stack; reference utils/utils.py:145-173 called from step_envs :23-60): the k
+// planes of one agent's rolling stack drawn from the ring by the launch that draws the observation, instead of a separate roll-and-append pass.
+struct GrayStack {
+    uint8_t *out;   // (n, k, R, R) of agent `view`; nullptr = no stack
+    int k, view;    // planes oldest to newest = ring planes 4 - k .. 3
+    int f32;        // element type: 0 u8, 1 float32 (the context's float values)
+    int valid;      // updates since the stack's reset(), capped at k: the k - valid oldest planes are zeros
+    int alias;      // 1: the observation tensor's (view, newest plane) tile is not written -- its reader takes the stack's newest plane
+};
 struct GrayParams {
     const uint64_t *ring;    // [8][n] frame pairs of the 4 stack planes; plane 3 = newest (K=1 draws only it)
     int64_t n;
@@ -243,6 +252,7 @@ struct GrayParams {
     const float *f32_bot;           // [2][R - f32_bot0][R] output rows fed by the white band under the court (score-independent)
     int f32_bot0;                   // first output row with a tap under the court
     int f32_xtaps, f32_ytaps;       // entries of xsi / ysi (the kernel stages the tap tables in LDS)
+    GrayStack stack;                // fused FrameStackTensor (out == nullptr: none); obs may then be nullptr (stack only)
 };
 void launch_pong_gray_f32ref_tables(const GrayParams &p, float *top, float *bot, hipStream_t st);
 void launch_pong_raster_gray(const GrayParams &p, hipStream_t st);

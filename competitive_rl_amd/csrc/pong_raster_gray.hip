@@ -404,9 +404,13 @@ __device__ unsigned long long g_gray_ticks[8];
 // F32: the observation tensor is float32 (DummyVecEnv's buffers, utils/dummy_vec_env.py:37-44): the tile is built in
 // LDS as bytes exactly as for uint8 and widened in the store epilogue -- every store instruction still writes 1 KiB
 // contiguous (lane l reads the dword of pixels 4l..4l+3 of a 256-pixel group and stores them as one float4).
-template <int MAXT, bool DBG, int TI, bool F32>
-__global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
-                                                                   GrayGeom q, uint8_t *__restrict__ obs, int ppw) {
+// STACK (round 6): FrameStackTensor fused into the draw (GrayStack, pong_device.h).  The wavefront's tiles are then JOBS of its env:
+// first the k planes of the bound stack (one agent's view, planes oldest to newest = ring planes 4 - k .. 3; the planes older than the
+// stack's last reset() are zeros), then the tiles of the observation tensor (all but the one the stack's newest plane stands in for
+// when `alias` is set).  Same tile code, same values; only where a tile goes and its element type (SF32 for the stack) differ.
+template <int MAXT, bool DBG, int TI, bool F32, bool STACK = false, bool SF32 = false>
+__global__ __launch_bounds__(256, TI == 2 ? 6 : (STACK && !F32 && !SF32) ? 4 : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
+                                                                   GrayGeom q, uint8_t *__restrict__ obs, int ppw, GrayStack sk) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][TI * 1024];
     __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
     __shared__ uint64_t words_[4][8];
@@ -417,11 +421,15 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_ker
         for (int i = threadIdx.x; i < (q.t.total >> 4); i += 256) dst[i] = src[i];
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int K = q.K, groups = K / ppw;
+    const int K = q.K;
+    // STACK: `ppw` = jobs per wavefront out of the env's ks + (views K - alias) jobs
+    const int ks = STACK ? sk.k : 0, obs_jobs = STACK ? (obs ? q.views * K - (sk.alias ? 1 : 0) : 0) : 0, jobs = ks + obs_jobs;
+    const int alias_tile = STACK && sk.alias ? sk.view * K + K - 1 : 1 << 20;
+    const int groups = STACK ? (jobs + ppw - 1) / ppw : K / ppw;
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const bool live = wid < n * groups;
     const int64_t env = live ? wid / groups : 0;
-    const int p0 = (int)(wid - env * groups) * ppw;
+    const int p0 = (int)(wid - env * groups) * ppw;  // first plane (first job) of this wavefront
     if (live && lane < 8) words_[wave][lane] = ring[(int64_t)lane * n + env];
     __syncthreads();
     if (!live) return;
@@ -438,163 +446,33 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : 1) void pong_raster_gray_env_ker
     unsigned gtick[6] = {0, 0, 0, 0, 0, 0};
     long long gprev = (DBG && (dbg & 128)) ? __builtin_readcyclecounter() : 0;
 
-    // view-major: a wave writes its env's planes in ascending address order (the four planes of agent
-    // 0's view, then agent 1's) -- 4 % faster than alternating between the two views per plane
+    if constexpr (STACK) {
+        const int ntiles = min(ppw, jobs - p0);
 #pragma unroll 1
-    for (int view = 0; view < q.views; view++)
-#pragma unroll 1
-    for (int plane = p0; plane < p0 + ppw; plane++) {
-        const int rp = 4 - K + plane;  // ring plane
-        uint64_t pa = words_[wave][2 * rp], pb = words_[wave][2 * rp + 1];
-        pa = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pa);
-        pb = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)pb);
-        Frame fa = unpack_frame(pa), fb = unpack_frame(pb);
-        // A pair with one blank frame (the reset observation: a single frame, nothing to max with) equals
-        // the pair of the frame with itself -- max(x, 0) = x -- and then takes the fast path.
-        if (fa.sl == 255 && fb.sl != 255) fa = fb;
-        else if (fb.sl == 255 && fa.sl != 255) fb = fa;
-        const bool blank_a = fa.sl == 255, blank_b = fb.sl == 255;
-        // The score rows come pre-resized from the band table when the two kept frames show
-        // the same score pair, or pairs one point apart (a point scored between the two
-        // max-pooled frames puts two texts under the max).  Anything else (only reachable
-        // through set_state or the never-written initial buffers) is evaluated per pixel.
-        bool slow = blank_a || blank_b;
-        int variant = 0, sp = fa.sl * 22 + fa.sr;
-        if (!slow && (fa.sl != fb.sl || fa.sr != fb.sr)) {
-            const int spb = fb.sl * 22 + fb.sr;
-            if (fb.sl == fa.sl + 1 && fb.sr == fa.sr) variant = 1;
-            else if (fb.sl == fa.sl && fb.sr == fa.sr + 1) variant = 2;
-            else if (fa.sl == fb.sl + 1 && fa.sr == fb.sr) variant = 1, sp = spb;
-            else if (fa.sl == fb.sl && fa.sr == fb.sr + 1) variant = 2, sp = spb;
-            else slow = true;
-        }
-        {
-            const int64_t tile = (env * q.views + view) * K + plane;
-            uint4 *__restrict__ out = reinterpret_cast<uint4 *>(obs + tile * (int64_t)RR);
-            uint32_t *__restrict__ out32 = reinterpret_cast<uint32_t *>(obs + tile * (int64_t)RR);
-            float4 *__restrict__ outf = reinterpret_cast<float4 *>(obs) + tile * (int64_t)(RR >> 2);  // F32: RR % 4 == 0
-            if (blank_a && blank_b) {  // plane erased by a done (FrameStackTensor mask)
-                if (F32)
-                    for (int w = lane; w < (RR >> 2); w += 64) outf[w] = make_float4(0.f, 0.f, 0.f, 0.f);
-                else if (vec16)
-                    for (int c = lane; c < chunks; c += 64) out[c] = make_uint4(0, 0, 0, 0);
-                else
-                    for (int w = lane; w < (RR >> 2); w += 64) out32[w] = 0u;
-                continue;
-            }
-            GRAY_TICK(0)
-            // ---- 1. template loads into registers (L2); the box arithmetic and the row / column
-            //         words below overlap their latency, the LDS tile is filled afterwards
-            const uint4 *__restrict__ band4 =
-                reinterpret_cast<const uint4 *>(q.band) + (int64_t)((slow ? 0 : (variant * 484 + sp)) * 2 + view) * bb;
-            uint4 tv[TI];
-#pragma unroll
-            for (int it = 0; it < TI; it++) {
-                const int c = lane + 64 * it;
-                tv[it] = make_uint4(0, 0, 0, 0);
-                if (dbg & 32) continue;
-                if (c < bb) tv[it] = band4[c];
-                else if (c < chunks && (c < zc0 || c >= zc1)) tv[it] = rest4[c];
-            }
-            // ---- 2. patch: boxes of the six rectangles in view coordinates (scalar)
-            const bool m = view == 1;
-            Rects rc;
-            rc.ax = blank_a ? -1000 : (m ? CRL_PONG_W - fa.x - CRL_PONG_BALL : fa.x), rc.ay = blank_a ? -1000 : fa.y;
-            rc.bx = blank_b ? -1000 : (m ? CRL_PONG_W - fb.x - CRL_PONG_BALL : fb.x), rc.by = blank_b ? -1000 : fb.y;
-            rc.la = blank_a ? -1000 : (m ? fa.br : fa.bl), rc.ra = blank_a ? -1000 : (m ? fa.bl : fa.br);
-            rc.lb = blank_b ? -1000 : (m ? fb.br : fb.bl), rc.rb = blank_b ? -1000 : (m ? fb.bl : fb.br);
-            Box bx[6];
-            {
-                auto box = [&](bool none, int c0, int c1, int r0, int r1) {
-                    const Box b = {0, 0, 0, 0};
-                    return none ? b : rect_box_lds(tabs, q.t, c0, c1, r0, r1);
-                };
-                const bool same_ball = rc.ax == rc.bx && rc.ay == rc.by;
-                bx[0] = box(blank_a, rc.ax, rc.ax + CRL_PONG_BALL, max(rc.ay, CRL_PONG_TOP), min(rc.ay + CRL_PONG_BALL, CRL_PONG_BOTTOM));
-                bx[1] = box(blank_a, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.la, rc.la + CRL_PONG_BAT_H);
-                bx[2] = box(blank_a, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.ra, rc.ra + CRL_PONG_BAT_H);
-                bx[3] = box(blank_b || same_ball, rc.bx, rc.bx + CRL_PONG_BALL, max(rc.by, CRL_PONG_TOP), min(rc.by + CRL_PONG_BALL, CRL_PONG_BOTTOM));
-                bx[4] = box(blank_b || rc.la == rc.lb, CRL_PONG_BATL_X, CRL_PONG_BATL_X + CRL_PONG_BAT_W, rc.lb, rc.lb + CRL_PONG_BAT_H);
-                bx[5] = box(blank_b || rc.ra == rc.rb, CRL_PONG_BATR_X, CRL_PONG_BATR_X + CRL_PONG_BAT_W, rc.rb, rc.rb + CRL_PONG_BAT_H);
-            }
-            int pre[7];
-            float rw[6];
-            pre[0] = slow ? q.band_rows * R : 0;  // slow path: evaluate every pixel of the score rows
-            int ymin = R, ymax = 0, xmin = R, xmax = 0;
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                pre[i + 1] = pre[i] + bx[i].w * bx[i].h, rw[i] = 1.0f / (float)max(bx[i].w, 1);
-                if (bx[i].w * bx[i].h > 0) {
-                    ymin = min(ymin, bx[i].y0), ymax = max(ymax, bx[i].y0 + bx[i].h);
-                    xmin = min(xmin, bx[i].x0), xmax = max(xmax, bx[i].x0 + bx[i].w);
-                }
-            }
-            const int total = (dbg & 1) ? 0 : pre[6];
-            GRAY_TICK(1)
-            uint32_t *rowpack = rowpack_[wave], *colpack = colpack_[wave];
-            if (fast_ok && !(dbg & 2)) {
-                for (int dy = ymin + lane; dy < ymax; dy += 64) rowpack[dy] = row_pack<MAXT>(tabs, q.t, rc, dy);
-                for (int dx = xmin + lane; dx < xmax; dx += 64) colpack[dx] = col_pack<MAXT>(tabs, q.t, rc, dx);
-            }
-            GRAY_TICK(2)
-#pragma unroll
-            for (int it = 0; it < TI; it++)
-                if (lane + 64 * it < chunks) tl4[lane + 64 * it] = tv[it];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            GRAY_TICK(3)
-            for (int p = lane; p < total; p += 64) {
-                int dy, dx;
-                const bool band_px = p < pre[0];
-                if (band_px) {
-                    dy = p / R, dx = p - dy * R;
-                } else {
-                    // select the box without dynamic register indexing
-                    int x0 = bx[0].x0, y0 = bx[0].y0, w = bx[0].w, base = pre[0];
-                    float r = rw[0];
-#pragma unroll
-                    for (int k = 1; k < 6; k++)
-                        if (p >= pre[k]) x0 = bx[k].x0, y0 = bx[k].y0, w = bx[k].w, base = pre[k], r = rw[k];
-                    const int o = p - base;
-                    const int yy = (int)(((float)o + 0.5f) * r);  // o / w, exact for these sizes
-                    dy = y0 + yy, dx = x0 + (o - yy * w);
-                }
-                uint8_t v;
-                if (band_px || !fast_ok) v = eval_pixel(g, fa, fb, view, dy, dx);
-                else v = eval_sep<MAXT>(tabs, q.t, R, rowpack[dy], colpack[dx], dy, dx);
-                tl[dy * R + dx] = v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            GRAY_TICK(4)
-            // ---- 3. stream the tile out
-            if (F32) {
-                const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
-                constexpr int NG = TI * 4;  // 256-pixel groups of the LDS tile
-                uint32_t px[NG];
-#pragma unroll
-                for (int gi = 0; gi < NG; gi++) px[gi] = tl32[min(lane + 64 * gi, (RR >> 2) - 1)];
-#pragma unroll
-                for (int gi = 0; gi < NG; gi++)
-                    if (lane + 64 * gi < (RR >> 2))
-                        outf[lane + 64 * gi] = make_float4((float)(px[gi] & 255u), (float)((px[gi] >> 8) & 255u), (float)((px[gi] >> 16) & 255u),
-                                                           (float)(px[gi] >> 24));
-            } else if (dbg & 64) {
-#pragma unroll
-                for (int it = 0; it < TI; it++)
-                    if (lane + 64 * it < chunks) out[lane + 64 * it] = tv[it];
-            } else if (vec16) {
-                // all LDS reads first, then the stores (a rolled loop would wait for every read in turn)
-                uint4 ov[TI];
-#pragma unroll
-                for (int it = 0; it < TI; it++) ov[it] = tl4[min(lane + 64 * it, chunks - 1)];
-#pragma unroll
-                for (int it = 0; it < TI; it++)
-                    if (lane + 64 * it < chunks) out[lane + 64 * it] = ov[it];
+        for (int it = 0; it < ntiles; it++) {
+            const int j = p0 + it;
+            int view, plane, rp;
+            bool to_stack = false, erased = false;
+            if (j < ks) {
+                to_stack = true, view = sk.view, plane = j, rp = 4 - ks + j, erased = j < ks - sk.valid;
             } else {
-                const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
-                for (int w = lane; w < (RR >> 2); w += 64) out32[w] = tl32[w];
+                int t = j - ks;
+                t += t >= alias_tile ? 1 : 0;
+                view = t >= K ? 1 : 0, plane = t - view * K, rp = 4 - K + plane;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            GRAY_TICK(5)
+            const bool f32 = to_stack ? SF32 : F32;
+#include "pong_gray_tile.inc"
+        }
+    } else {
+        // view-major: a wave writes its env's planes in ascending address order (the four planes of agent
+        // 0's view, then agent 1's) -- 4 % faster than alternating between the two views per plane
+#pragma unroll 1
+        for (int view = 0; view < q.views; view++)
+#pragma unroll 1
+        for (int plane = p0; plane < p0 + ppw; plane++) {
+            const int rp = 4 - K + plane;  // ring plane
+            constexpr bool to_stack = false, erased = false, f32 = F32;
+#include "pong_gray_tile.inc"
         }
     }
     if (DBG && (dbg & 128) && lane == 0) {
@@ -960,7 +838,7 @@ struct F32RefGeom {
 };
 static constexpr int kF32MaxR = 84, kF32MaxTaps = 3 * kF32MaxR + 8;
 __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx gg, F32RefGeom q, int R, int K, int views,
-                                                               float *__restrict__ obs) {
+                                                               float *__restrict__ obs, GrayStack sk) {
     __shared__ int32_t s_xofs[kF32MaxR + 1], s_yofs[kF32MaxR + 1], s_xsi[kF32MaxTaps], s_ysi[kF32MaxTaps];
     __shared__ float s_xalpha[kF32MaxTaps], s_yalpha[kF32MaxTaps];
     if (q.debug & 64) return;
@@ -975,14 +853,25 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
     if (q.debug & 128) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    const int tiles_per_env = views * K;
+    // jobs of an env: the planes of a bound FrameStackTensor first (GrayStack, pong_device.h), then the observation's tiles
+    const int ks = sk.out ? sk.k : 0, tiles_per_env = ks + (obs ? views * K - (ks && sk.alias ? 1 : 0) : 0);
     if (tile >= n * tiles_per_env) return;
     const int64_t env = tile / tiles_per_env;
-    const int t = (int)(tile - env * tiles_per_env), view = t / K, plane = t - view * K, rp = 4 - K + plane;
+    int t = (int)(tile - env * tiles_per_env), view, plane, rp;
+    float *out;
+    bool erased = false;
+    if (t < ks) {
+        view = sk.view, plane = t, rp = 4 - ks + t, erased = t < ks - sk.valid;
+        out = reinterpret_cast<float *>(sk.out) + (env * ks + t) * (int64_t)(R * R);
+    } else {
+        t -= ks;
+        if (ks && sk.alias && t >= sk.view * K + K - 1) t++;
+        view = t / K, plane = t - view * K, rp = 4 - K + plane;
+        out = obs + ((env * views + view) * K + plane) * (int64_t)(R * R);
+    }
     const uint64_t pa = ring[(int64_t)(2 * rp) * n + env], pb = ring[(int64_t)(2 * rp + 1) * n + env];
     Frame fa = unpack_frame(pa), fb = unpack_frame(pb);
-    float *out = obs + tile * (int64_t)(R * R);
-    if (fa.sl == 255 && fb.sl == 255) {  // a plane that was never written
+    if ((fa.sl == 255 && fb.sl == 255) || erased) {  // a plane that was never written, erased by a done, or older than the bound stack's reset()
         for (int i = lane; i < R * R; i += 64) out[i] = 0.0f;
         return;
     }
@@ -1118,11 +1007,11 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     GrayCtx g = {p.atlas_gray, p.xofs, p.yofs, p.xsi, p.ysi, p.xalpha, p.yalpha};
     if (p.obs_f32 == 2) {  // CRL_OBS_F32_REF
         const int views = p.views > 0 ? p.views : 2;
-        const int64_t tiles = p.n * views * p.K;
+        const int64_t tiles = p.n * ((p.stack.out ? p.stack.k : 0) + (p.obs ? views * p.K - (p.stack.out && p.stack.alias ? 1 : 0) : 0));
         static const int dbg = CRL_ABL(getenv("CRL_GRAY_DEBUG") != nullptr) ? atoi(getenv("CRL_GRAY_DEBUG")) : 0;
         const F32RefGeom fq = {p.f32_top, p.f32_bot, p.band_rows, p.f32_bot0, x_first, x_last, y_first, y_last, p.f32_xtaps, p.f32_ytaps, dbg};
         hipLaunchKernelGGL(pong_gray_f32ref_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, fq, p.R, p.K, views,
-                           reinterpret_cast<float *>(p.obs));
+                           reinterpret_cast<float *>(p.obs), p.stack);
         return;
     }
     GrayGeom q;
@@ -1139,7 +1028,7 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         static const int dbg = getenv("CRL_GRAY_DEBUG") ? atoi(getenv("CRL_GRAY_DEBUG")) : 0;
         q.debug = dbg;
     }
-    if ((q.debug & 8) && !p.obs_f32) {
+    if ((q.debug & 8) && !p.obs_f32 && !p.stack.out) {
         hipLaunchKernelGGL(pong_raster_gray_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, q,
                            p.obs);
         return;
@@ -1148,7 +1037,7 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     // bit-exact, but 1.0-2.0 ms against the env kernel's 0.75 ms at 65 536 envs -- every block has to read per-tile metadata
     // first, and a dependent read in a store-saturated memory system takes microseconds.
     static const int sweep_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
-    if (sweep_env && !p.obs_f32 && !q.debug && p.hdr && (p.R * p.R) % 16 == 0 && tofs.max_taps <= 3 && tofs.fast_ok && tiles * (p.R * p.R >> 4) < (1ll << 31) && (p.R * p.R >> 4) <= 512) {
+    if (sweep_env && !p.obs_f32 && !p.stack.out && !q.debug && p.hdr && (p.R * p.R) % 16 == 0 && tofs.max_taps <= 3 && tofs.fast_ok && tiles * (p.R * p.R >> 4) < (1ll << 31) && (p.R * p.R >> 4) <= 512) {
         GrayTileHdr *hdr = reinterpret_cast<GrayTileHdr *>(p.hdr);
         hipLaunchKernelGGL(pong_gray_header_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, p.ring, p.n, q, hdr);
         static const int sdbg = getenv("CRL_GRAY_SWEEP_DEBUG") ? atoi(getenv("CRL_GRAY_SWEEP_DEBUG")) : 0;
@@ -1185,29 +1074,54 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     int ppw = (p.n >= 8192 && !(q.debug & 16)) ? p.K : 1;
     if (ppw_env > 0 && p.K % ppw_env == 0) ppw = ppw_env;
     static const bool small_off = CRL_ABL(getenv("CRL_GRAY_SMALL_OFF") != nullptr);  // A/B: the R <= 45 instance off
+    const GrayStack &sk = p.stack;
+    if (sk.out) {  // FrameStackTensor fused into the draw: the env's jobs = the stack's planes + the observation's tiles
+        const int jobs = sk.k + (p.obs ? q.views * p.K - (sk.alias ? 1 : 0) : 0);
+        static const int jpw_env = CRL_ABL(getenv("CRL_GRAY_JPW") ? atoi(getenv("CRL_GRAY_JPW")) : 0);
+        int jpw = p.n >= 8192 ? jobs : 1;
+        if (jpw_env > 0) jpw = jpw_env;
+        const int64_t waves = p.n * ((jobs + jpw - 1) / jpw);
+        const dim3 grid((unsigned)((waves + 3) / 4));
+        const int ti = tofs.max_taps <= 3 ? 0 : (p.R * p.R <= 2048 && !small_off) ? 1 : 2;
+#define CRL_STACK_LAUNCH(MT, TIv, OF, SF) \
+    hipLaunchKernelGGL((pong_raster_gray_env_kernel<MT, false, TIv, OF, true, SF>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, jpw, sk)
+#define CRL_STACK_TI(OF, SF)                           \
+    do {                                               \
+        if (ti == 0) CRL_STACK_LAUNCH(3, 7, OF, SF);   \
+        else if (ti == 1) CRL_STACK_LAUNCH(5, 2, OF, SF); \
+        else CRL_STACK_LAUNCH(5, 7, OF, SF);           \
+    } while (0)
+        if (p.obs_f32) CRL_STACK_TI(true, true);  // (a float32 context's stack is float32: launch_pong_raster_gray's caller checks)
+        else if (sk.f32) CRL_STACK_TI(false, true);
+        else CRL_STACK_TI(false, false);
+#undef CRL_STACK_TI
+#undef CRL_STACK_LAUNCH
+        return;
+    }
+    const GrayStack nosk{};
     const int64_t waves = p.n * (p.K / ppw);
     const dim3 grid((unsigned)((waves + 3) / 4));
     if (p.obs_f32) {
         if (tofs.max_taps <= 3)
-            hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
         else if (p.R * p.R <= 2048 && !small_off)
-            hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
         else
-            hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7, true>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
         return;
     }
 #ifdef CRL_ABLATION
     if (q.debug & ~16) {  // any ablation switch: the instrumented instance
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
         return;
     }
 #endif
     if (tofs.max_taps <= 3)
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
     else if (p.R * p.R <= 2048 && !small_off)
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
     else
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw);
+        hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
 }
 
 }  // namespace crl

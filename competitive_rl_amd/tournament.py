@@ -64,6 +64,10 @@ class TournamentEnvWrapper:
         self._act = torch.zeros((num_envs, 2), dtype=torch.int32, device=device)
         self._select("RULE_BASED" if "RULE_BASED" in self.agents else self.agent_names[0])  # the reference starts with RULE_BASED
 
+    def _stack_env(self):
+        """The env a FrameStackTensor binds to (frame_stack.py): agent 0's observation of the wrapped env is this wrapper's."""
+        return getattr(self.env, "_stack_env", lambda: None)()
+
     # ---- opponent
     def _select(self, name):
         self.current_agent_name, self.current_agent = name, self.agents[name]

@@ -14,9 +14,10 @@ What the call does, in terms of its arguments (all updated in place or returned,
 * returns ``(obs, reward, done, info, masks, total_episodes, total_steps, episode_rewards)`` with ``done``
   reduced to one flag per env and ``masks`` = 1 - done as an (N, 1) float tensor on ``device``.
 
-With the HIP env everything the step produced is already in HBM: observations go straight into the device
-``FrameStackTensor`` (one kernel), masks are built on the device, and ``episode_rewards`` may itself be a device
-tensor.  The only host traffic is the N done flags (the recorders are host lists) and, for a numpy
+With the HIP env everything the step produced is already in HBM: the device ``FrameStackTensor`` is bound to the env on
+the first call (``FrameStackTensor.bind``: ``envs.step`` then draws the stack's next state in the launch that draws the
+observation, and the update here is a pointer swap; other envs / stacks: one kernel), masks are built on the device, and
+``episode_rewards`` may itself be a device tensor.  The only host traffic is the N done flags (the recorders are host lists) and, for a numpy
 ``episode_rewards``, the N x A rewards.
 """
 import numpy as np
@@ -66,6 +67,8 @@ class _Returns:
 def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_recorder, length_recorder, total_steps,
               total_episodes, device, test):
     shape_before = episode_rewards.shape
+    if not getattr(frame_stack_tensor, "_bind_tried", True):
+        frame_stack_tensor.bind(envs)  # (once: from now on envs.step draws the stack's next state, frame_stack.py)
     obs, reward, done, info = envs.step(cpu_actions)
     learner_obs = obs[0] if isinstance(obs, tuple) else obs  # two-agent Pong: the learner is agent 0
     num_envs = learner_obs.shape[0]
@@ -91,5 +94,8 @@ def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_rec
     else:
         masks = torch.from_numpy((~ended_host).astype(np.float32)).to(device).reshape(num_envs, 1)
     stack_mask = masks if test else masks.reshape(num_envs, 1, 1, 1)
-    frame_stack_tensor.update(learner_obs, stack_mask)
+    if getattr(frame_stack_tensor, "_env", None) is not None:
+        frame_stack_tensor.update(learner_obs, stack_mask, _from_env=envs)  # (a bound stack: the pointer swap)
+    else:
+        frame_stack_tensor.update(learner_obs, stack_mask)
     return obs, reward, ended, info, masks, total_episodes, total_steps, episode_rewards

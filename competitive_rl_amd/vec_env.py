@@ -213,13 +213,19 @@ class HipPongVecEnv(VecEnv):
         self._actions = torch.zeros((n,) if self.single else (n, 2), dtype=torch.int32, device=dev)
         self.envs = _EnvList(self)
         self.waiting = False
+        # a FrameStackTensor bound to this env (frame_stack.py): step / reset then draw its next state with the observation
+        self._bound_stack = None       # weakref
+        self._last_kind = None         # "reset" | "step": what produced the newest observation
+        self._learner_obs = None       # agent 0's newest observation as handed out (torch output only)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _format_obs(self, buf):
+    def _format_obs(self, buf, learner=None):
         views = [buf[:, v] for v in range(self.V)]
+        if learner is not None:
+            views[0] = learner  # (a bound stack's newest plane stands in for agent 0's tile)
         if self.obs_dtype == "float32" and buf.dtype != torch.float32:  # raw mode only
             views = [v.float() for v in views]
         if self.output == "numpy":
@@ -229,6 +235,59 @@ class HipPongVecEnv(VecEnv):
     def _check_open(self):
         if self.closed:
             raise RuntimeError("VecEnv is closed")
+
+    # ------------------------------------------------------------------ bound FrameStackTensor (frame_stack.py)
+    def _stack_env(self):
+        return self
+
+    def _can_draw_stack(self, fst):
+        """crl_step_stack's conditions (include/crl.h): FrameStackTensor's history rule, one (1, R, R) plane per agent and step."""
+        return (self.mode == "wrapped" and not self.stack_replicate and self.K == 1 and self.output == "torch" and not self.closed
+                and fst.device == self.device and fst.num_envs == self.num_envs and fst.num_channels == 1 and 1 <= fst.frame_stack <= 4
+                and fst.plane_shape == (self.R, self.R) and (fst.dtype == torch.float32 or self._buf_dtype == torch.uint8))
+
+    def _stack_alias(self, fst):
+        """The stack's newest plane IS agent 0's observation when both are one element type: that tile is then written once."""
+        return self.K == 1 and fst.dtype == self._buf_dtype
+
+    def _stack_predraw(self, kind, alias_ok=True):
+        fst = self._bound_stack() if self._bound_stack is not None else None
+        if fst is None:
+            return None, None, None
+        pre = fst._predraw(self, kind)
+        if pre is None:
+            return None, None, None
+        buf, desc = pre
+        if not alias_ok:
+            desc.alias_newest = 0
+        return fst, buf, desc
+
+    def _draw_stack_into(self, desc):
+        with torch.cuda.device(self.device):
+            N.check(self._L.crl_draw_stack(self._h, None, C.byref(desc), self._stream()))
+
+    def _is_latest_learner_obs(self, obs):
+        mine = self._learner_obs
+        return (mine is not None and isinstance(obs, torch.Tensor) and obs.data_ptr() == mine.data_ptr() and obs.shape == mine.shape
+                and obs.dtype == mine.dtype and obs.stride() == mine.stride())
+
+    def _latest_learner_obs(self):
+        if self._learner_obs is None:
+            raise RuntimeError("the env has produced no observation yet (reset() it first)")
+        return self._learner_obs
+
+    def _note_obs(self, kind, buf, stack_buf=None, fst=None, aliased=False):
+        """Books after a reset / step that drew into `buf` (and, for a bound stack, its next state into `stack_buf`)."""
+        self._last_kind = kind
+        if self.output != "torch":
+            self._learner_obs = None
+            return None
+        k = fst.frame_stack if fst is not None else 0
+        learner = stack_buf[:, k - 1:k] if aliased else buf[:, 0]
+        self._learner_obs = learner
+        if fst is not None:
+            fst._predrawn(self, stack_buf, kind)
+        return learner
 
     # ------------------------------------------------------------------ VecEnv protocol
     def seed(self, seed=None):
@@ -241,10 +300,13 @@ class HipPongVecEnv(VecEnv):
     def reset(self):
         self._check_open()
         buf = self._obs[self._flip]
-        N.check(self._L.crl_reset(self._h, C.c_void_p(buf.data_ptr()), self._stream()))
+        fst, sbuf, desc = self._stack_predraw("reset")
+        N.check(self._L.crl_reset(self._h, None if desc is not None else C.c_void_p(buf.data_ptr()), self._stream()))
+        if desc is not None:  # the first observation and the bound stack's first state in one launch
+            N.check(self._L.crl_draw_stack(self._h, C.c_void_p(buf.data_ptr()), C.byref(desc), self._stream()))
         self._flip ^= 1
         self._serial += 1
-        return self._format_obs(buf)
+        return self._format_obs(buf, self._note_obs("reset", buf, sbuf, fst, bool(desc is not None and desc.alias_newest)))
 
     def step_async(self, actions):
         self._check_open()
@@ -275,10 +337,13 @@ class HipPongVecEnv(VecEnv):
         self.waiting = False
         # (the library first: a refused call -- e.g. the report of an earlier out-of-range action -- has not stepped the envs,
         # so the buffer flip and the serial that lazy infos check stay where they are)
-        N.check(self._L.crl_step(self._h, C.c_void_p(self._actions.data_ptr()), C.c_void_p(buf.data_ptr()),
-                                 C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+        fst, sbuf, desc = self._stack_predraw("step")
+        N.check(self._L.crl_step_stack(self._h, C.c_void_p(self._actions.data_ptr()), C.c_void_p(buf.data_ptr()),
+                                       C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                       None if desc is None else C.byref(desc), self._stream()))
         self._flip ^= 1
         self._serial += 1
+        learner = self._note_obs("step", buf, sbuf, fst, bool(desc is not None and desc.alias_newest))
         done = self._done.bool()
         if self.dones_kind == "dummy":  # scalar done broadcast over the agents (dummy_vec_env.py:39-40)
             done_out = done[:, None].expand(-1, self.V)
@@ -294,12 +359,15 @@ class HipPongVecEnv(VecEnv):
         self._prev_buf = self._obs[self._flip]  # the observation before this step (still intact)
         if self.output == "numpy":
             return self._format_obs(buf), rew.cpu().numpy(), done_out.cpu().numpy().copy(), infos
-        return self._format_obs(buf), rew, done_out.clone(), infos
+        return self._format_obs(buf, learner), rew, done_out.clone(), infos
 
     def close(self):
         if self.closed:
             return
         self.closed = True
+        fst = self._bound_stack() if self._bound_stack is not None else None
+        if fst is not None:
+            fst.unbind()  # (the stack lives on, on the generic kernel)
         torch.cuda.synchronize(self.device)
         self._L.crl_destroy(self._h)
         self._h = None
@@ -450,17 +518,29 @@ class HipPongVecEnv(VecEnv):
             if not (obs_out.is_contiguous() and obs_out.dtype == self._buf_dtype and obs_out.device == self.device
                     and obs_out.numel() == self._obs[0].numel()):
                 raise AssertionError("obs_out must be a contiguous tensor of the observation buffer's size and dtype on the env's device")
-            N.check(self._L.crl_step(self._h, C.c_void_p(actions_i32.data_ptr()), C.c_void_p(obs_out.data_ptr()),
-                                     C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+            fst, sbuf, desc = self._stack_predraw("step", alias_ok=False)
+            N.check(self._L.crl_step_stack(self._h, C.c_void_p(actions_i32.data_ptr()), C.c_void_p(obs_out.data_ptr()),
+                                           C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                           None if desc is None else C.byref(desc), self._stream()))
             self._serial += 1
-            return obs_out.view(self._obs[0].shape), self._rew, self._done
+            out = obs_out.view(self._obs[0].shape)
+            self._note_obs("step", out, sbuf, fst)
+            return out, self._rew, self._done
         buf = self._obs[self._flip]
-        N.check(self._L.crl_step(self._h, C.c_void_p(actions_i32.data_ptr()),
-                                 C.c_void_p(buf.data_ptr()) if render else None,
-                                 C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()), self._stream()))
+        # (a bound FrameStackTensor is drawn too -- FrameStackTensor.update_from_env then swaps it in; the whole observation
+        # buffer is written here, no tile is left to the stack: the caller gets `buf` itself)
+        fst, sbuf, desc = self._stack_predraw("step", alias_ok=False) if render else (None, None, None)
+        N.check(self._L.crl_step_stack(self._h, C.c_void_p(actions_i32.data_ptr()),
+                                       C.c_void_p(buf.data_ptr()) if render else None,
+                                       C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                       None if desc is None else C.byref(desc), self._stream()))
         self._prev_buf = self._obs[self._flip ^ 1]  # (after the call: a refused call has not stepped the envs)
         self._flip ^= 1
         self._serial += 1
+        if render:
+            self._note_obs("step", buf, sbuf, fst)
+        else:
+            self._last_kind, self._learner_obs = "step", None
         return buf, self._rew, self._done
 
     def kernel_timing(self, enable=True):

@@ -203,6 +203,34 @@ int crl_reset(crl_ctx *ctx, uint8_t *obs_dev, void *stream);
 int crl_step(crl_ctx *ctx, const void *actions_dev, uint8_t *obs_dev, float *rew_dev,
              uint8_t *done_dev, void *stream);
 
+/* ---- step_envs' observation stack fused into the step (utils/utils.py:23-60 calls FrameStackTensor.update :158-170 on the
+ * learner's observation with mask = 1 - done right after envs.step).  A GRAY_RESIZED Pong context keeps the descriptors of every
+ * env's last four planes with exactly that history rule (planes of an episode that ended are erased, the first observation of the
+ * next one is the newest plane), so the stack the trainer would roll and append -- 13.4 GB of traffic per step for 65 536 x
+ * (4, 84, 84) float32 -- is DRAWN by the launch that draws the observation: written once, never read.
+ *   stack_dev     (N, planes, R, R) of agent `agent`, planes oldest to newest, u8 or f32 per `dtype` (CRL_OBS_U8 | CRL_OBS_F32; a
+ *                 float32 context -- CRL_OBS_F32 / CRL_OBS_F32_REF -- writes its own float values and needs dtype = CRL_OBS_F32)
+ *   valid_planes  updates since the trainer's FrameStackTensor.reset(), capped at `planes`: the older planes are zeros
+ *   alias_newest  1: the (agent, newest plane) tile of obs_dev is NOT written -- the caller hands out the stack's newest plane as
+ *                 that agent's observation (needs a context with frame_stack = 1 and equal element types)
+ * Contexts with CRL_FLAG_STACK_REPLICATE (the FrameStack wrapper's history) and raw contexts refuse (CRL_ESTATE). */
+typedef struct crl_stack_desc {
+    void *stack_dev;
+    int32_t planes;       /* k = 1..4 */
+    int32_t dtype;        /* crl_obs_dtype: CRL_OBS_U8 or CRL_OBS_F32 */
+    int32_t agent;        /* 0 = the learner (step_envs takes obs[0], utils/utils.py:55-58) */
+    int32_t valid_planes;
+    int32_t alias_newest;
+    int32_t reserved;     /* must be 0 */
+} crl_stack_desc;
+/* crl_step + the stack: envs.step(actions) followed by frame_stack_tensor.update(obs[0], 1 - done) (utils/utils.py:30,57-58).
+ * stack == NULL is crl_step.  obs_dev may be NULL (stack only). */
+int crl_step_stack(crl_ctx *ctx, const void *actions_dev, uint8_t *obs_dev, float *rew_dev, uint8_t *done_dev,
+                   const crl_stack_desc *stack, void *stream);
+/* The stack of the CURRENT state without stepping: frame_stack_tensor.update(envs.reset()) of the training scripts, and what the
+ * host mirror compares a trainer's own tensor with before it binds it.  obs_dev (optional) is re-drawn as by crl_render. */
+int crl_draw_stack(crl_ctx *ctx, uint8_t *obs_dev, const crl_stack_desc *stack, void *stream);
+
 /* info[i]["real_reward"], info[i]["num_steps"] (ClipRewardEnv.step,
  * atari_wrappers.py:175-181) as device arrays valid until the next step:
  * real_reward f32 (N,2), num_steps i32 (N). */
