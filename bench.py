@@ -395,7 +395,10 @@ def run_workload(name, args, G):
                 gather_state.wait(materialize=True)
                 gather_state.launch(out[1:], env=inner)
             else:
-                gather_state.wait(materialize=False)  # at most one collective in flight: gather(t) overlaps simulate(t+1)
+                # at most one step's collectives in flight: gather(t) overlaps simulate(t+1).  materialize=True: the step ends holding
+                # the usable global tensors -- the observation is the collective's receive buffer itself (sharding.StepGather), so this
+                # costs the slicing of the few-bytes-per-env fields only
+                G["gathered"] = gather_state.wait(materialize=True)
                 gather_state.launch(out if args.gather == "obs" else out[1:])
 
     warm_resets = None
@@ -422,7 +425,7 @@ def run_workload(name, args, G):
     for i in range(args.steps):
         step(i)
     if dist_on and args.gather != "none":
-        gather_state.wait(materialize=args.gather == "descriptors")
+        G["gathered"] = gather_state.wait(materialize=True)
     if os.environ.get("CRL_BENCH_DEBUG"):  # (where a short window's time goes: the host's enqueueing, the caller's stream, the rest of the device)
         t_host = time.perf_counter() - t0
         torch.cuda.current_stream().synchronize()
@@ -562,7 +565,10 @@ def main():
         except Exception as exc:  # (a build without the collective library)
             rccl = f"unavailable ({type(exc).__name__})"
         line["comm"] = {"backend": "nccl (= RCCL on ROCm)" if dist_on else "none (one rank)", "rccl_version": rccl, "world": world,
-                        "env_ranges": [[r * npg, (r + 1) * npg] for r in range(world)], "gather": args.gather}
+                        "env_ranges": [[r * npg, (r + 1) * npg] for r in range(world)], "gather": args.gather,
+                        # every timed step ends with the global tensors in hand; "obs": the observation is the collective's receive buffer (no copy)
+                        "materialized": bool(dist_on and args.gather != "none"),
+                        "gathered_obs_shape": list(G["gathered"][0].shape) if G.get("gathered") else None}
         if multi:
             line["configs"] = {}
             for nm in names[1:]:  # slim: the name is the key of WORKLOADS / DESIGN.md section 7, numbers only

@@ -25,7 +25,7 @@ SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "cr
            "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_get_map", "crl_car_set_replay",
            "crl_policy_create", "crl_policy_create_full", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
            "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update", "crl_frame_stack_update_to", "crl_ctx_last_error",
-           "crl_obs_descriptors", "crl_render_frames_dev", "crl_car_cap_hits", "crl_selftest_sincosf", "crl_step_stack", "crl_draw_stack"]
+           "crl_obs_descriptors", "crl_render_frames_dev", "crl_car_cap_hits", "crl_selftest_sincosf", "crl_step_stack", "crl_draw_stack", "crl_set_flags_event"]
 
 FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
                      ("score_l", "u1"), ("score_r", "u1")])
@@ -100,6 +100,7 @@ def load():
     L.crl_step.argtypes = [vp, vp, vp, vp, vp, vp]
     L.crl_step_stack.argtypes = [vp, vp, vp, vp, vp, C.POINTER(CrlStackDesc), vp]
     L.crl_draw_stack.argtypes = [vp, vp, C.POINTER(CrlStackDesc), vp]
+    L.crl_set_flags_event.argtypes = [vp, vp]
     L.crl_info.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.crl_render.argtypes = [vp, vp, vp]
     L.crl_copy_info.argtypes = [vp, vp, vp, vp]

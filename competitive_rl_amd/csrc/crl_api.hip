@@ -101,7 +101,7 @@ struct crl_ctx {
     GrayTabOfs tofs{};
     uint8_t *tile_hdr = nullptr;  // [n * views * K] 64-byte tile headers of the address-linear gray writer
     float *f32_top = nullptr, *f32_bot = nullptr;  // CRL_OBS_F32_REF: court-without-objects tables (GrayParams)
-    int f32_bot0 = 0, f32_xtaps = 0, f32_ytaps = 0;
+    int f32_bot0 = 0, f32_xtaps = 0, f32_ytaps = 0, f32_map_row0 = 0, f32_map_rows = 0;
     // replay
     double *ru = nullptr;
     uint8_t *rbx = nullptr, *rby = nullptr;
@@ -114,6 +114,7 @@ struct crl_ctx {
     // action-containment flag (base_pong_env.py:42): host-mapped, written by the step kernel
     int32_t *bad_action_host = nullptr, *bad_action_dev = nullptr;
     std::vector<uint8_t> atlas_host;
+    hipEvent_t flags_ev = nullptr;  // crl_set_flags_event: the caller's event, recorded behind the kernel that writes rewards and done flags
     crl_car_ctx *car = nullptr;  // set for CRL_ENV_CAR_DOUBLE contexts (everything above unused then)
 };
 
@@ -286,6 +287,7 @@ static int setup_gray(crl_ctx *c) {
     HIP_TRY(hipGetLastError());
     if (c->o.obs_dtype == CRL_OBS_F32_REF) {  // the unrounded float32 path's tables: 484 score pairs x 3 kinds x 2 views x {unrounded, rounded}
         c->f32_bot0 = yf[CRL_PONG_BOTTOM], c->f32_xtaps = (int)xt.si.size(), c->f32_ytaps = (int)yt.si.size();
+        c->f32_map_row0 = yf[CRL_PONG_TOP], c->f32_map_rows = yl[CRL_PONG_BOTTOM - 1] - yf[CRL_PONG_TOP] + 1;
         p.band_rows = c->band_rows, p.f32_bot0 = c->f32_bot0;
         // x 3 "kinds": both kept frames with this score pair | the left / the right score one higher in one of them (a point scored between them)
         if ((rc = dev_alloc(c, &c->f32_top, (size_t)484 * 3 * 4 * c->band_rows * R))) return rc;
@@ -487,6 +489,7 @@ static int draw_obs(crl_ctx *c, uint8_t *obs_dev, hipStream_t st, const GrayStac
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = obs_dev, p.obs_f32 = c->o.obs_dtype, p.hdr = c->tile_hdr;
         p.f32_top = c->f32_top, p.f32_bot = c->f32_bot, p.f32_bot0 = c->f32_bot0, p.f32_xtaps = c->f32_xtaps, p.f32_ytaps = c->f32_ytaps;
+        p.f32_map_row0 = c->f32_map_row0, p.f32_map_rows = c->f32_map_rows;
         if (sk) p.stack = *sk;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
@@ -544,6 +547,7 @@ int crl_step(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float *rew_
     launch_pong_dynamics(c->s, c->src, actions_dev, c->n, pong_mode(c), rew_dev, done_dev, st);
     end_timed(c, 0, st);
     HIP_TRY(hipGetLastError());
+    if (c->flags_ev) HIP_TRY(hipEventRecord(c->flags_ev, st));
     return draw_obs(c, obs_dev, st);
 }
 
@@ -560,7 +564,16 @@ int crl_step_stack(crl_ctx *c, const void *actions_void, uint8_t *obs_dev, float
     launch_pong_dynamics(c->s, c->src, (const int32_t *)actions_void, c->n, pong_mode(c), rew_dev, done_dev, st);
     end_timed(c, 0, st);
     HIP_TRY(hipGetLastError());
+    if (c->flags_ev) HIP_TRY(hipEventRecord(c->flags_ev, st));
     return draw_obs(c, obs_dev, st, &sk);
+}
+
+int crl_set_flags_event(crl_ctx *c, void *event) {
+    CRL_ENTER(c);
+    if (!c) return fail(CRL_EINVAL, "null ctx");
+    if (c->car) return fail(CRL_ESTATE, "crl_set_flags_event is a Pong entry point");
+    c->flags_ev = (hipEvent_t)event;
+    return CRL_OK;
 }
 
 int crl_draw_stack(crl_ctx *c, uint8_t *obs_dev, const crl_stack_desc *stack, void *stream) {
@@ -629,6 +642,7 @@ static int render_ring(crl_ctx *c, const uint64_t *ring_dev, int64_t m, uint8_t 
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = out_dev, p.obs_f32 = c->o.obs_dtype;
         p.f32_top = c->f32_top, p.f32_bot = c->f32_bot, p.f32_bot0 = c->f32_bot0, p.f32_xtaps = c->f32_xtaps, p.f32_ytaps = c->f32_ytaps;
+        p.f32_map_row0 = c->f32_map_row0, p.f32_map_rows = c->f32_map_rows;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }
@@ -732,6 +746,7 @@ int crl_render_frames_dev(crl_ctx *c, const crl_pong_frame *desc_dev, int64_t co
         p.xofs = c->xofs, p.yofs = c->yofs, p.xsi = c->xsi, p.ysi = c->ysi, p.xalpha = c->xalpha, p.yalpha = c->yalpha;
         p.obs = out_dev, p.obs_f32 = c->o.obs_dtype;
         p.f32_top = c->f32_top, p.f32_bot = c->f32_bot, p.f32_bot0 = c->f32_bot0, p.f32_xtaps = c->f32_xtaps, p.f32_ytaps = c->f32_ytaps;
+        p.f32_map_row0 = c->f32_map_row0, p.f32_map_rows = c->f32_map_rows;
         launch_pong_raster_gray_ex(p, c->rest, c->zero_row0, c->zero_row1, c->x_first, c->x_last, c->y_first, c->y_last,
                                    c->band_chunks, c->tab_blob, c->tofs, st);
     }

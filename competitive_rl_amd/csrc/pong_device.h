@@ -252,6 +252,7 @@ struct GrayParams {
     const float *f32_bot;           // [2][R - f32_bot0][R] output rows fed by the white band under the court (score-independent)
     int f32_bot0;                   // first output row with a tap under the court
     int f32_xtaps, f32_ytaps;       // entries of xsi / ysi (the kernel stages the tap tables in LDS)
+    int f32_map_row0, f32_map_rows; // output rows fed by the court's source rows (where a ball or a bat can change a pixel)
     GrayStack stack;                // fused FrameStackTensor (out == nullptr: none); obs may then be nullptr (stack only)
 };
 void launch_pong_gray_f32ref_tables(const GrayParams &p, float *top, float *bot, hipStream_t st);

@@ -408,8 +408,14 @@ __device__ unsigned long long g_gray_ticks[8];
 // first the k planes of the bound stack (one agent's view, planes oldest to newest = ring planes 4 - k .. 3; the planes older than the
 // stack's last reset() are zeros), then the tiles of the observation tensor (all but the one the stack's newest plane stands in for
 // when `alias` is set).  Same tile code, same values; only where a tile goes and its element type (SF32 for the stack) differ.
+#ifndef CRL_F32_EPI
+#define CRL_F32_EPI 28  // float32 store epilogue: 256-pixel groups per batch (28 = the whole tile's LDS reads before its first store)
+#endif
+#ifndef CRL_F32_LB
+#define CRL_F32_LB 1    // float32 instances: workgroups per CU the register allocation must allow
+#endif
 template <int MAXT, bool DBG, int TI, bool F32, bool STACK = false, bool SF32 = false>
-__global__ __launch_bounds__(256, TI == 2 ? 6 : (STACK && !F32 && !SF32) ? 4 : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
+__global__ __launch_bounds__(256, TI == 2 ? 6 : (STACK && !F32 && !SF32) ? 4 : (F32 || SF32) ? CRL_F32_LB : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw, GrayStack sk) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][TI * 1024];
     __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
@@ -835,12 +841,16 @@ struct F32RefGeom {
     const uint8_t *x_first, *x_last, *y_first, *y_last;
     int xtaps, ytaps;  // entries of the x / y tap tables
     int debug;         // profiling build: 16 = no re-draw, 32 = no table copy (WRONG pixels: what each phase costs)
+    int map_row0, map_rows;  // output rows fed by the court's source rows [CRL_PONG_TOP, CRL_PONG_BOTTOM)
 };
 static constexpr int kF32MaxR = 84, kF32MaxTaps = 3 * kF32MaxR + 8;
+static constexpr int kF32MapBytes = 66 * 84;  // the output rows a court rectangle can feed (R = 84: rows 13..77), one byte per pixel
 __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx gg, F32RefGeom q, int R, int K, int views,
                                                                float *__restrict__ obs, GrayStack sk) {
     __shared__ int32_t s_xofs[kF32MaxR + 1], s_yofs[kF32MaxR + 1], s_xsi[kF32MaxTaps], s_ysi[kF32MaxTaps];
     __shared__ float s_xalpha[kF32MaxTaps], s_yalpha[kF32MaxTaps];
+    __shared__ __attribute__((aligned(16))) uint8_t s_map[4][kF32MapBytes];  // per wavefront: court pixel -> index of its re-drawn value (255: none)
+    __shared__ float s_pval[4][192];
     if (q.debug & 64) return;
     GrayCtx g = gg;
     if (R <= kF32MaxR && q.xtaps <= kF32MaxTaps && q.ytaps <= kF32MaxTaps) {  // (uniform)
@@ -910,12 +920,21 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
         total += npx;
         rend[o] = total;
     }
-    // (round 5) ... evaluated FIRST, into registers -- an output pixel is a chain of ~25 dependent LDS reads, 2-3 us for a lone wavefront, and it used to
-    // start only when the tile's 28 KB of stores had drained (the fence below); now the table loads and the stores of the copy run beside it.
-    // A lane holds at most kRedraw of them (the six rectangles cover < 64 kRedraw output pixels at every R up to 84); what does not fit is drawn behind the fence as before.
+    // The re-drawn pixels are evaluated FIRST, into registers (round 5: an output pixel is a chain of ~25 dependent LDS reads, 2-3 us for a
+    // lone wavefront; the table loads and the stores of the rows no rectangle touches run beside it), and -- round 6 -- PATCHED INTO THE
+    // PIECES before these are stored: every lane drops its pixels into a byte map of the court's rows in LDS (pixel -> index of its value),
+    // and the copy of the rows the rectangles touch looks its pieces up there.  Round 5 stored the table copy and then over-stored the
+    // ~150 pixels as 4-byte writes behind a fence: 18.1 GB written for 14.8 GB of tensor (1.36 x with the table reads); now every byte of
+    // the tile is written exactly once, in 16-byte pieces.
+    // A lane holds at most kRedraw pixels (the six rectangles cover < 64 kRedraw output pixels at every R up to 84); what does not fit is
+    // drawn behind the stores as before.
     constexpr int kRedraw = 3;
     int rpos[kRedraw];
     float rval[kRedraw];
+    int ymin = R, ymax = 0;  // output rows the rectangles touch (uniform)
+#pragma unroll
+    for (int o = 0; o < 6; o++)
+        if (rwx[o] > 0) ymin = min(ymin, rdy0[o]), ymax = max(ymax, rdy0[o] + (rend[o] - (o ? rend[o - 1] : 0)) / rwx[o]);
 #pragma unroll
     for (int k = 0; k < kRedraw; k++) rpos[k] = -1, rval[k] = 0.0f;
 #pragma unroll
@@ -933,59 +952,89 @@ __global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *_
         const int j = i - base, dy = dy0 + j / wx, dx = dx0 + j % wx;
         rpos[k] = dy * R + dx, rval[k] = f32ref_pixel(g, fa, fb, view, dy, dx, rounded);
     }
-    if (!(q.debug & 32)) {
-        const float *top = q.top + (((((int64_t)(slo * 22 + sro) * 3 + kind) * 2 + view) * 2 + (rounded ? 1 : 0)) * q.band_rows) * R;
-        const float *bot = q.bot + (int64_t)(rounded ? 1 : 0) * (R - q.bot0) * R;
-        const int ntop = q.band_rows * R, nbot0 = q.bot0 * R;
-        if (((ntop | nbot0 | (R * R)) & 3) == 0) {  // (uniform; R = 84: always) 16-byte pieces -- a tile is 28 KB, three quarters of it the empty court
-            // (round 4 copied float by float: 110 dependent load -> store pairs per lane and 4-byte stores; round 5: the table reads of a
-            // lane are issued together, 7 of them, and the tile leaves in 1-KiB wave stores)
-            const float4 *top4 = reinterpret_cast<const float4 *>(top), *bot4 = reinterpret_cast<const float4 *>(bot);
-            float4 *out4 = reinterpret_cast<float4 *>(out);
-            const int nt4 = ntop >> 2, nb4 = nbot0 >> 2, nn4 = (R * R) >> 2;
-            constexpr int kU = 6;  // table pieces in flight per lane (band: <= 5 per lane at R = 84, bottom rows: <= 3)
-            for (int i0 = lane; i0 < nt4; i0 += 64 * kU) {
-                float4 v[kU];
+    const float *top = q.top + (((((int64_t)(slo * 22 + sro) * 3 + kind) * 2 + view) * 2 + (rounded ? 1 : 0)) * q.band_rows) * R;
+    const float *bot = q.bot + (int64_t)(rounded ? 1 : 0) * (R - q.bot0) * R;
+    const int ntop = q.band_rows * R, nbot0 = q.bot0 * R;
+    // the map covers output rows [map_row0, map_row0 + map_rows): every row a court rectangle can feed
+    const bool pieces = ((ntop | nbot0 | (R * R) | R) & 3) == 0 && q.map_rows * R <= kF32MapBytes && !(q.debug & (16 | 32));  // (uniform; R = 84: always)
+    if (pieces) {
+        uint8_t *map = s_map[wave];
+        float *pval = s_pval[wave];
+        const int map0 = q.map_row0 * R;  // first pixel of the map
+        ymin = max(ymin, q.map_row0), ymax = min(max(ymax, ymin), q.map_row0 + q.map_rows);
+        // clear the rows the rectangles touch (0xFF = not re-drawn), then drop the re-drawn pixels in
+        const int c0 = (ymin * R - map0) >> 2, c1 = (ymax * R - map0) >> 2;
+        for (int c = c0 + lane; c < c1; c += 64) reinterpret_cast<uint32_t *>(map)[c] = 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-                for (int k = 0; k < kU; k++)
-                    if (i0 + 64 * k < nt4) v[k] = top4[i0 + 64 * k];
-#pragma unroll
-                for (int k = 0; k < kU; k++)
-                    if (i0 + 64 * k < nt4) out4[i0 + 64 * k] = v[k];
+        for (int k = 0; k < kRedraw; k++)
+            if (rpos[k] >= 0) {
+                pval[lane + 64 * k] = rval[k];
+                map[rpos[k] - map0] = (uint8_t)(lane + 64 * k);  // (two rectangles on one pixel: the same value twice, either index serves)
             }
-            for (int i0 = nb4 + lane; i0 < nn4; i0 += 64 * kU) {
-                float4 v[kU];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        const float4 *top4 = reinterpret_cast<const float4 *>(top), *bot4 = reinterpret_cast<const float4 *>(bot);
+        float4 *out4 = reinterpret_cast<float4 *>(out);
+        const int nt4 = ntop >> 2, nb4 = nbot0 >> 2, nn4 = (R * R) >> 2;
+        const int p0 = (ymin * R) >> 2, p1 = (ymax * R) >> 2;  // pieces of the touched rows
+        auto piece = [&](int i) -> float4 {  // piece i of the plane without ball and bats
+            if (i < nt4) return top4[i];
+            if (i >= nb4) return bot4[i - nb4];
+            return make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        constexpr int kU = 7;  // pieces in flight per lane: all loads of a batch, then its stores
+        // 1. the rows no rectangle touches: table (or zero) pieces straight out -- these stores run beside the chain above
+        for (int i0 = lane; i0 < nn4; i0 += 64 * kU) {
+            float4 v[kU];
 #pragma unroll
-                for (int k = 0; k < kU; k++)
-                    if (i0 + 64 * k < nn4) v[k] = bot4[i0 + 64 * k - nb4];
-#pragma unroll
-                for (int k = 0; k < kU; k++)
-                    if (i0 + 64 * k < nn4) out4[i0 + 64 * k] = v[k];
+            for (int k = 0; k < kU; k++) {
+                const int i = i0 + 64 * k;
+                if (i < nn4 && (i < p0 || i >= p1)) v[k] = piece(i);
             }
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = nt4 + lane; i < nb4; i += 64) out4[i] = z;
-        } else {
+#pragma unroll
+            for (int k = 0; k < kU; k++) {
+                const int i = i0 + 64 * k;
+                if (i < nn4 && (i < p0 || i >= p1)) out4[i] = v[k];
+            }
+        }
+        // 2. the touched rows: the same pieces with the re-drawn pixels put in
+        for (int i = p0 + lane; i < p1; i += 64) {
+            float4 v = piece(i);
+            const uint32_t mw = reinterpret_cast<const uint32_t *>(map)[i - (map0 >> 2)];
+            if (mw != 0xFFFFFFFFu) {
+                if ((mw & 255u) != 255u) v.x = pval[mw & 255u];
+                if (((mw >> 8) & 255u) != 255u) v.y = pval[(mw >> 8) & 255u];
+                if (((mw >> 16) & 255u) != 255u) v.z = pval[(mw >> 16) & 255u];
+                if ((mw >> 24) != 255u) v.w = pval[mw >> 24];
+            }
+            out4[i] = v;
+        }
+    } else {
+        if (!(q.debug & 32)) {
             for (int i = lane; i < ntop; i += 64) out[i] = top[i];
             for (int i = ntop + lane; i < nbot0; i += 64) out[i] = 0.0f;
             for (int i = nbot0 + lane; i < R * R; i += 64) out[i] = bot[i - nbot0];
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the re-drawn pixels below overwrite what other lanes have just stored: those stores first
+        if (q.debug & 16) return;
+#pragma unroll
+        for (int k = 0; k < kRedraw; k++)
+            if (rpos[k] >= 0) out[rpos[k]] = rval[k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the re-drawn pixels below overwrite what other lanes have just stored: those stores first
-    if (q.debug & 16) return;
+    if (total > 64 * kRedraw) {  // (more output pixels than the registers hold: not at the sizes the wrappers use)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int i = lane + 64 * kRedraw; i < total; i += 64) {
+            int o = 0, base = 0;
 #pragma unroll
-    for (int k = 0; k < kRedraw; k++)
-        if (rpos[k] >= 0) out[rpos[k]] = rval[k];
-    for (int i = lane + 64 * kRedraw; i < total; i += 64) {  // (more output pixels than the registers hold: not at the sizes the wrappers use)
-        int o = 0, base = 0;
+            for (int k = 0; k < 5; k++)
+                if (i >= rend[k]) o = k + 1, base = rend[k];
+            int dx0 = rdx0[0], wx = rwx[0], dy0 = rdy0[0];
 #pragma unroll
-        for (int k = 0; k < 5; k++)
-            if (i >= rend[k]) o = k + 1, base = rend[k];
-        int dx0 = rdx0[0], wx = rwx[0], dy0 = rdy0[0];
-#pragma unroll
-        for (int k = 1; k < 6; k++)
-            if (o == k) dx0 = rdx0[k], wx = rwx[k], dy0 = rdy0[k];
-        const int j = i - base, dy = dy0 + j / wx, dx = dx0 + j % wx;
-        out[dy * R + dx] = f32ref_pixel(g, fa, fb, view, dy, dx, rounded);
+            for (int k = 1; k < 6; k++)
+                if (o == k) dx0 = rdx0[k], wx = rwx[k], dy0 = rdy0[k];
+            const int j = i - base, dy = dy0 + j / wx, dx = dx0 + j % wx;
+            out[dy * R + dx] = f32ref_pixel(g, fa, fb, view, dy, dx, rounded);
+        }
     }
 }
 
@@ -1009,7 +1058,8 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         const int views = p.views > 0 ? p.views : 2;
         const int64_t tiles = p.n * ((p.stack.out ? p.stack.k : 0) + (p.obs ? views * p.K - (p.stack.out && p.stack.alias ? 1 : 0) : 0));
         static const int dbg = CRL_ABL(getenv("CRL_GRAY_DEBUG") != nullptr) ? atoi(getenv("CRL_GRAY_DEBUG")) : 0;
-        const F32RefGeom fq = {p.f32_top, p.f32_bot, p.band_rows, p.f32_bot0, x_first, x_last, y_first, y_last, p.f32_xtaps, p.f32_ytaps, dbg};
+        const F32RefGeom fq = {p.f32_top, p.f32_bot, p.band_rows, p.f32_bot0, x_first, x_last, y_first, y_last, p.f32_xtaps, p.f32_ytaps, dbg,
+                               p.f32_map_row0, p.f32_map_rows};
         hipLaunchKernelGGL(pong_gray_f32ref_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, p.ring, p.n, g, fq, p.R, p.K, views,
                            reinterpret_cast<float *>(p.obs), p.stack);
         return;

@@ -48,6 +48,8 @@ _MASK_OF_LAST_STEP = object()  # update_from_env: "1 - done of the env's last st
 class FrameStackTensor:
     def __init__(self, num_envs, obs_shape, frame_stack, device, out_of_place=True, dtype=torch.float32):
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:  # ("cuda" names the current device: the env it may be bound to says cuda:<i>)
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.out_of_place = bool(out_of_place)
         if dtype not in (torch.float32, torch.uint8):
             raise ValueError("FrameStackTensor holds float32 (the reference's contract) or uint8 (opt-in)")

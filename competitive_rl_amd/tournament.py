@@ -68,6 +68,10 @@ class TournamentEnvWrapper:
         """The env a FrameStackTensor binds to (frame_stack.py): agent 0's observation of the wrapped env is this wrapper's."""
         return getattr(self.env, "_stack_env", lambda: None)()
 
+    def done_host(self):
+        """The last step's done flags on the host, ahead of the observation (HipPongVecEnv.done_host)."""
+        return self.env.done_host()
+
     # ---- opponent
     def _select(self, name):
         self.current_agent_name, self.current_agent = name, self.agents[name]

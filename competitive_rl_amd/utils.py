@@ -74,7 +74,8 @@ def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_rec
     num_envs = learner_obs.shape[0]
 
     ended = _per_env_done(done)
-    ended_host = ended.cpu().numpy() if isinstance(ended, torch.Tensor) else ended
+    early = getattr(envs, "done_host", None)  # the HIP Pong env hands the flags over while the step's draw still runs (vec_env.py)
+    ended_host = early() if early is not None else (ended.cpu().numpy() if isinstance(ended, torch.Tensor) else ended)
 
     returns = _Returns(episode_rewards)
     returns.add(reward)

@@ -213,6 +213,12 @@ class HipPongVecEnv(VecEnv):
         self._actions = torch.zeros((n,) if self.single else (n, 2), dtype=torch.int32, device=dev)
         self.envs = _EnvList(self)
         self.waiting = False
+        # the done flags on the host while the step's draw still runs (crl_set_flags_event; step_envs reads them every step)
+        self._flags_event = None
+        self._flags_side = None
+        self._flags_host = None
+        self._flags_serial = -1
+        self._flags_armed = -1
         # a FrameStackTensor bound to this env (frame_stack.py): step / reset then draw its next state with the observation
         self._bound_stack = None       # weakref
         self._last_kind = None         # "reset" | "step": what produced the newest observation
@@ -235,6 +241,37 @@ class HipPongVecEnv(VecEnv):
     def _check_open(self):
         if self.closed:
             raise RuntimeError("VecEnv is closed")
+
+    # ------------------------------------------------------------------ early done flags
+    def done_host(self):
+        """The last step's done flags as a host bool array (N,), WITHOUT waiting for the step's observation: the library records an
+        event right behind the kernel that writes them, a side stream copies them into pinned memory behind that event, and the host
+        waits for the copy only -- the 0.2-1.5 ms draw of the observation (and of a bound frame stack) keeps running under the
+        caller's bookkeeping.  What ``step_envs`` walks after every step (reference utils/utils.py:33-42)."""
+        self._check_open()
+        if self._last_kind != "step":
+            raise RuntimeError("done_host() reads the flags of the last step(): step the env first")
+        if self._flags_serial != self._serial:
+            with torch.cuda.device(self.device):
+                if self._flags_event is None:
+                    self._flags_host = torch.empty((self.num_envs,), dtype=torch.uint8, pin_memory=True)
+                    self._flags_side = torch.cuda.Stream(device=self.device)
+                cur = torch.cuda.current_stream(self.device)
+                if self._flags_event is None or self._flags_armed != self._serial:
+                    # the event was not armed for this step (first use): order the copy behind everything enqueued so far
+                    self._flags_side.wait_stream(cur)
+                else:
+                    self._flags_side.wait_event(self._flags_event)
+                with torch.cuda.stream(self._flags_side):
+                    self._flags_host.copy_(self._done, non_blocking=True)
+                self._flags_side.synchronize()
+                if self._flags_event is None:  # from now on every step records it
+                    self._flags_event = torch.cuda.Event()
+                    self._flags_event.record(cur)  # (creates the handle)
+                    handle = self._flags_event.cuda_event
+                    N.check(self._L.crl_set_flags_event(self._h, C.c_void_p(getattr(handle, "value", handle))))
+            self._flags_serial = self._serial
+        return self._flags_host.numpy().astype(bool)
 
     # ------------------------------------------------------------------ bound FrameStackTensor (frame_stack.py)
     def _stack_env(self):
@@ -343,6 +380,7 @@ class HipPongVecEnv(VecEnv):
                                        None if desc is None else C.byref(desc), self._stream()))
         self._flip ^= 1
         self._serial += 1
+        self._flags_armed = self._serial if self._flags_event is not None else -1
         learner = self._note_obs("step", buf, sbuf, fst, bool(desc is not None and desc.alias_newest))
         done = self._done.bool()
         if self.dones_kind == "dummy":  # scalar done broadcast over the agents (dummy_vec_env.py:39-40)
@@ -523,6 +561,7 @@ class HipPongVecEnv(VecEnv):
                                            C.c_void_p(self._rew.data_ptr()), C.c_void_p(self._done.data_ptr()),
                                            None if desc is None else C.byref(desc), self._stream()))
             self._serial += 1
+            self._flags_armed = self._serial if self._flags_event is not None else -1
             out = obs_out.view(self._obs[0].shape)
             self._note_obs("step", out, sbuf, fst)
             return out, self._rew, self._done
@@ -537,6 +576,7 @@ class HipPongVecEnv(VecEnv):
         self._prev_buf = self._obs[self._flip ^ 1]  # (after the call: a refused call has not stepped the envs)
         self._flip ^= 1
         self._serial += 1
+        self._flags_armed = self._serial if self._flags_event is not None else -1
         if render:
             self._note_obs("step", buf, sbuf, fst)
         else:

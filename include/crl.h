@@ -231,6 +231,12 @@ int crl_step_stack(crl_ctx *ctx, const void *actions_dev, uint8_t *obs_dev, floa
  * host mirror compares a trainer's own tensor with before it binds it.  obs_dev (optional) is re-drawn as by crl_render. */
 int crl_draw_stack(crl_ctx *ctx, uint8_t *obs_dev, const crl_stack_desc *stack, void *stream);
 
+/* A hipEvent_t of the caller's (NULL: none) that every crl_step / crl_step_stack records on the step's stream right BEHIND the kernel
+ * that writes rew_dev / done_dev and IN FRONT of the observation's draw.  The reference's step_envs walks the done flags on the host
+ * after every step (utils/utils.py:33-42); a stream that waits for this event can copy them out while the step's 1-2 ms of raster
+ * still run, so the host's books and the next step's launch overlap the draw instead of following it.  Pong contexts. */
+int crl_set_flags_event(crl_ctx *ctx, void *event);
+
 /* info[i]["real_reward"], info[i]["num_steps"] (ClipRewardEnv.step,
  * atari_wrappers.py:175-181) as device arrays valid until the next step:
  * real_reward f32 (N,2), num_steps i32 (N). */

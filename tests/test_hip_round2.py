@@ -323,8 +323,11 @@ def _two_gpu_worker(rank, world, port, out_dir, backend="nccl", mode="obs"):
                 out = env.step_device(a, obs_out=slot)
             else:
                 out = tuple(x.cpu() for x in env.step_device(a))
-            g.launch(out)                       # ONE packed all-gather (on a side stream when it runs on the GPU) ...
-            got.append([x.cpu().numpy().copy() for x in g.wait()])
+            g.launch(out)                       # the observation's all-gather + the packed small one (on a side stream when they run on the GPU) ...
+            res = g.wait()
+            # what a consumer gets for the observation IS the collective's receive buffer, (world * n, ...) in global env order
+            assert res[0].data_ptr() == g.obs_recv.data_ptr() and res[0].is_contiguous() and res[0].shape[0] == world * sh.count
+            got.append([x.cpu().numpy().copy() for x in res])
     if rank == 0:
         np.savez(os.path.join(out_dir, "g.npz"), obs=np.stack([o[0] for o in got]), rew=np.stack([o[1] for o in got]),
                  done=np.stack([o[2] for o in got]))

@@ -319,3 +319,32 @@ def test_full_size_bound_stack_against_the_generic_one():
         assert torch.equal(fa.get(), fb.get()), t
     assert fa.fused_updates == 8 and ba["episodes"] == bb["episodes"] and ba["episodes"] > 0
     a.close(), b.close()
+
+
+def test_done_host_hands_over_the_flags_of_the_last_step():
+    """crl_set_flags_event: the host copy of the done flags is ordered behind the dynamics kernel only, and is what step() returned."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 4096
+    env = crl.make_envs("cPongDouble-v0", num_envs=n, log_dir=None, seed=3, resized_dim=84, frame_stack=None)
+    env.reset()
+    with pytest.raises(RuntimeError):
+        env.done_host()
+    rs = np.random.RandomState(9)
+    seen = 0
+    for t in range(40):
+        if t % 7 == 3:
+            _near_the_end(env, np.flatnonzero(rs.random_sample(n) < 0.3))
+        x = torch.as_tensor(rs.randint(0, 3, (n, 2)).astype(np.int32)).to(env.device)
+        if t % 2:
+            _, _, done, _ = env.step(x)
+            done = done[:, 0]
+        else:
+            _, _, done = env.step_device(x)
+        h = env.done_host()
+        assert h.dtype == bool and np.array_equal(h, done.cpu().numpy().astype(bool)), t
+        assert env.done_host() is not None  # (a second call is served from the same copy)
+        seen += int(h.sum())
+    assert seen > n // 4
+    env.close()

@@ -69,6 +69,9 @@ def _race_worker(rank, world, port, out_dir):
         rew.fill_(-1.0)                                          # the next step rewrites the single reward / done buffers at once
         done.fill_(9)
         o, r, d = g.wait()
+        # the gathered observation IS the collective's receive buffer (global env order by construction), not a copy of it
+        ok &= o.data_ptr() == g.obs_recv.data_ptr() and tuple(o.shape) == (world * n, 2, 1, 8, 8) and o.is_contiguous()
+        ok &= o[rank * n:(rank + 1) * n].data_ptr() != slot.data_ptr()   # (send and receive sides are different buffers: step t+1 draws into the other slot)
         for k in range(world):
             ok &= bool((o[k * n:(k + 1) * n] == (t + k) % 251).all()) and bool((r[k * n:(k + 1) * n] == t + 10 * k).all())
             ok &= bool((d[k * n:(k + 1) * n] == (t + k) % 2).all())
