@@ -77,17 +77,41 @@ def spawn_ranks(args):
 
 
 # =============================================================================================== CPU baselines
+def effective_cores():
+    """The CPUs this process may actually keep busy: its affinity mask, capped by the cgroup's CPU quota.  (Round 6: the GPU boxes show 256
+    hardware threads in the affinity mask under a quota of 16 CPUs -- `cpu.max` = 1600000 100000 --, so rounds 1-5's 256 workers / 256 OpenMP
+    threads were throttled 16-fold and time-sliced: the same C code does 49 k env-steps/s on 16 threads and 14 k on 256, tools/cpu_legs.py.)"""
+    visible = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    cores = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
+    return cores, visible, quota
+
+
 def cpu_baselines(workloads, budget_s=8.0):
     """Rank 0, one GPU only, BEFORE the GPU is touched: the oracle timed on this host's cores on bounded samples of
     the same workloads -- (a) in the reference's SubprocVecEnv architecture (one process per env, pipes, pickled
     observations; oracle/subproc_baseline.py), which is the reported ``value``; (b) as one OpenMP batch over all
-    cores (upper bound of a compiled port); plus BASELINE config #1 (4 envs, synchronous).  Never the product path."""
+    cores (upper bound of a compiled port); plus BASELINE config #1 (4 envs, synchronous).  ``cores`` = effective_cores(): the
+    affinity mask capped by the cgroup's CPU quota -- one worker / one thread per CPU the process can really use.  Never the product path."""
     import numpy as np
 
     from oracle import pong_oracle as po
     from oracle import subproc_baseline as sb
 
-    cores = len(os.sched_getaffinity(0))
+    cores, visible, quota = effective_cores()
+    host = {"host_threads_visible": visible, "cpu_quota": quota}
     atlas = np.load(os.path.join(ROOT, "competitive_rl_amd", "assets", "pong_score_atlas.npz"))["atlas"]
     out = {}
 
@@ -134,7 +158,7 @@ def cpu_baselines(workloads, budget_s=8.0):
             b = cpu_baseline_tournament(po, atlas, cores, budget_s * 0.8, full=True)
         else:
             continue
-        out[wl] = b
+        out[wl] = dict(b, **host)
     if "raw" in workloads:  # BASELINE config #1: make_envs(num_envs=4, asynchronous=False), 42x42, 1000 steps
         v, k, dt = sb.time_dummy("gray_42", 4, 1000)
         out["raw"]["config1_dummy_n4"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": f"{k} steps x 4 envs, one process, {dt:.1f} s"}
@@ -444,6 +468,7 @@ def run_workload(name, args, G):
         dt = float(t.item())
     dyn_ms, dyn_n = inner.kernel_time_ms(0)
     ras_ms, ras_n = inner.kernel_time_ms(1)
+    touch_ms, touch_n, touch_max = inner.kernel_time_stats(2) if is_car else (0.0, 0, 0.0)
     final_state = env.get_state() if episodes_before is not None else None
     resets = int(final_state["episode"].astype("int64").sum() - episodes_before - int(warm_resets.item())) if episodes_before is not None else None
     env.close()
@@ -482,7 +507,7 @@ def run_workload(name, args, G):
         drawn = 1.0 - float((final_state["coupled"] != 0).mean()) - resets / max(args.steps, 1) / n
     ach = bytes_per_env * n * drawn / ras_s if ras_s > 0 else 0.0
     res["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                       "traffic": traffic_of("car" if is_car else name), "bytes_per_launch": bytes_per_env * n * drawn, "avg_kernel_us": ras_s * 1e6,
+                       "traffic": traffic_of(name) or (traffic_of("car") if is_car else None), "bytes_per_launch": bytes_per_env * n * drawn, "avg_kernel_us": ras_s * 1e6,
                        "launches_timed": ras_n, "dynamics_kernel_avg_us": dyn_ms / max(dyn_n, 1) * 1e3}
     if is_car:
         flop = CAR_FLOP_MODEL
@@ -491,12 +516,18 @@ def run_workload(name, args, G):
             flop = json.load(open(ff))["f32_flop_per_env_step"]
         fl = flop * res["value"] / world
         res["roofline"]["envs_drawn_by_timed_launch"] = drawn
+        # what bounds the STEP: SURVEY 8(d)'s formula -- env-steps/s x 24 900 B over the HBM peak -- and the kernel the step's
+        # period follows: the touching solve, lone wavefronts on the caller's stream (hipEvents on that stream, crl_kernel_time_stats slot 2)
+        res["roofline"]["step_frac"] = CAR_BYTES * res["value"] / world / HBM_PEAK
+        res["roofline"]["critical_path"] = {"kernel": "car_touch_kernel", "bound": "dependent-issue latency of lone wavefronts (Gauss-Seidel islands)",
+                                            "mean_us": touch_ms / max(touch_n, 1) * 1e3, "max_us": touch_max * 1e3, "launches_timed": touch_n,
+                                            "step_us": dt / args.steps * 1e6}
         res["roofline_valu"] = {"bound": "valu_fp32", "achieved": fl / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / FP32_PEAK,
                                 "flop_per_env_step": flop}
     return res
 
 
-ALL = ["raw", "fused84", "fused84_f32", "fused84_f32_ref", "car", "car_fma", "tournament", "tournament_full", "protocol"]
+ALL = ["raw", "fused84", "fused84_newest", "fused84_f32", "fused84_f32_ref", "car", "car_fma", "tournament", "tournament_full", "protocol"]
 
 
 def main():
@@ -577,7 +608,7 @@ def main():
                 if r.get("roofline"):
                     r["roofline"] = {k: v for k, v in r["roofline"].items() if k not in ("bytes_per_launch", "launches_timed", "dynamics_kernel_avg_us")}
                 if nm in cpu:
-                    b = {k: v for k, v in cpu[nm].items() if k in ("value", "unit", "cores", "kind", "sample")}
+                    b = {k: v for k, v in cpu[nm].items() if k in ("value", "unit", "cores", "kind", "sample", "cpu_quota")}
                     if "openmp_port" in cpu[nm]:
                         b["openmp_port_value"] = cpu[nm]["openmp_port"]["value"]
                     r["cpu_baseline"] = b

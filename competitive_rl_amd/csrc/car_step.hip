@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) void car_step_kernel(CarSoA s, CarConsts K, con
 // its commit is about to make current on another stream.
 // touching_now / manifolds_now (optional): the kernel runs BEFORE this step's touching solve is in (beside it, so that only the
 // narrow phase follows the solve): an env whose cars touch in this step -- its poses are not final yet -- is filed as coupled
-// without a test.  The flag only routes: the narrow phase decides what touches, and a coupled env in which nothing does is solved
+// without a test (class 3: tested on its staged bodies, but filed behind the solve all the same -- see `late` below).  The flag only routes: the narrow phase decides what touches, and a coupled env in which nothing does is solved
 // as two islands of their own, bit for bit like the per-car kernel.
 __global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K, const float *__restrict__ fresh_body,
                                                        const uint8_t *__restrict__ cls, const int32_t *__restrict__ touching_now,
@@ -335,7 +335,10 @@ __global__ __launch_bounds__(64) void car_broad_kernel(CarSoA s, CarConsts K, co
     // Two lists in one array (round 5): the envs whose poses are FINAL now go to the front (count [0]) -- their narrow phase runs right
     // behind this kernel, beside the touching solve --, the envs that touch in this step (filed untested above) to the back, from the end
     // downwards (count [7]): only their narrow phase is left behind the solve.
-    const bool late = coupled && touching_now && !(cls && cls[env] == 3) && touching_now[env] && manifolds_now[env] > 0;
+    // (round 6, ADVICE r05: an env that finished while its cars touch -- class 3, collided on its staged bodies -- goes to the back as well: the
+    // narrow phase writes the env's single-buffered manifold count and manifolds, which a late pass of THIS step's touching solve still
+    // reads when its lists are longer than one pass of its grid; the narrow phase picks the staged bodies by class in either phase)
+    const bool late = coupled && touching_now && touching_now[env] && manifolds_now[env] > 0;
     const int lane = threadIdx.x & 63;
     const unsigned long long m = __ballot(coupled && !late), ml = __ballot(late);
     if (m) {

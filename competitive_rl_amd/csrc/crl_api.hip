@@ -432,7 +432,7 @@ void crl_destroy(crl_ctx *c) {
 #endif
     if (c->car) crl_car_destroy(c->car);
     for (void *p : c->allocs) hipFree(p);
-    for (int w = 0; w < 2; w++)
+    for (int w = 0; w < kTimerSlots; w++)
         for (auto &p : c->tm.ev[w]) hipEventDestroy(p.a), hipEventDestroy(p.b);
     for (auto &p : c->tm.pool) hipEventDestroy(p.a), hipEventDestroy(p.b);
     if (c->ru) hipFree(c->ru);
@@ -901,22 +901,28 @@ int crl_kernel_timing(crl_ctx *c, int enable) {
     return CRL_OK;
 }
 
-int crl_kernel_time_ms(crl_ctx *c, int which, double *total_ms, int64_t *launches) {
+int crl_kernel_time_stats(crl_ctx *c, int which, double *total_ms, int64_t *launches, double *max_ms) {
     CRL_ENTER(c);
-    if (!c || which < 0 || which > 1) return fail(CRL_EINVAL, "bad argument");
+    if (!c || which < 0 || which >= kTimerSlots) return fail(CRL_EINVAL, "bad argument");
     crl_timer &t = c->tm;
     for (auto &p : t.ev[which]) {
         HIP_TRY(hipEventSynchronize(p.b));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
         t.ms[which] += ms, t.cnt[which]++;
+        t.max_ms[which] = std::max(t.max_ms[which], (double)ms);
         t.pool.push_back(p);
     }
     t.ev[which].clear();
     if (total_ms) *total_ms = t.ms[which];
     if (launches) *launches = t.cnt[which];
-    t.ms[which] = 0, t.cnt[which] = 0;
+    if (max_ms) *max_ms = t.max_ms[which];
+    t.ms[which] = 0, t.cnt[which] = 0, t.max_ms[which] = 0;
     return CRL_OK;
+}
+
+int crl_kernel_time_ms(crl_ctx *c, int which, double *total_ms, int64_t *launches) {
+    return crl_kernel_time_stats(c, which, total_ms, launches, nullptr);
 }
 
 int crl_car_get_state(crl_ctx *c, crl_car_env_state *out, int64_t first, int64_t count, void *stream) {

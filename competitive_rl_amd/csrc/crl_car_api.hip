@@ -612,7 +612,9 @@ int crl_car_step(crl_car_ctx *c, const float *actions_dev, uint8_t *obs_dev, flo
         {
             CarSoA sv2 = c->s;
             sv2.touch_view = touch_view;
+            crl_timer_begin(tm, 2, crit);  // (crl_kernel_time_stats slot 2: on this stream nothing but the touching solve lies between the two records)
             launch_car_coupled(sv2, c->K_, crit, c->side2, nullptr, true);  // near-only solve on side2, touching solve on crit
+            crl_timer_end(tm, 2, crit);
         }
         hipEventRecord(c->ev_coupled, crit);
         const int64_t exp_coupled = c->class_count_host[0], exp_done = c->class_count_host[1];

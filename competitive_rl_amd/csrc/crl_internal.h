@@ -23,12 +23,15 @@ struct crl_event_pair {
 };
 
 // hipEvent brackets around the kernels of a step, on the launch stream (crl_kernel_timing)
+// slots: 0 = dynamics (CarRacing: everything in front of the frame launch on the bulk stream), 1 = the observation's draw, 2 = CarRacing's
+// touching solve (the kernel that ends a steady-state step: crl_kernel_time_stats reports its mean and its longest launch)
+static constexpr int kTimerSlots = 3;
 struct crl_timer {
     bool on = false;
-    std::vector<crl_event_pair> ev[2];
+    std::vector<crl_event_pair> ev[kTimerSlots];
     std::vector<crl_event_pair> pool;  // recycled events
-    double ms[2] = {0, 0};
-    int64_t cnt[2] = {0, 0};
+    double ms[kTimerSlots] = {0, 0, 0}, max_ms[kTimerSlots] = {0, 0, 0};
+    int64_t cnt[kTimerSlots] = {0, 0, 0};
 };
 void crl_timer_begin(crl_timer *t, int which, hipStream_t st);
 void crl_timer_end(crl_timer *t, int which, hipStream_t st);

@@ -591,6 +591,12 @@ class HipPongVecEnv(VecEnv):
         N.check(self._L.crl_kernel_time_ms(self._h, which, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def kernel_time_stats(self, which):
+        """(total ms, launches, longest launch in ms) of timing slot `which` (include/crl.h crl_kernel_time_stats; 2 = CarRacing's touching solve)"""
+        ms, cnt, mx = C.c_double(), C.c_int64(), C.c_double()
+        N.check(self._L.crl_kernel_time_stats(self._h, which, C.byref(ms), C.byref(cnt), C.byref(mx)))
+        return ms.value, cnt.value, mx.value
+
 
 class _EnvList:
     def __init__(self, venv):

@@ -275,6 +275,11 @@ class HipCarVecEnv(VecEnv):
         st = sd["env_state"] if isinstance(sd, dict) else sd  # (a bare get_state() array is accepted too)
         if isinstance(sd, dict) and (sd.get("kind") != "cCarRacing" or int(sd.get("num_envs", -1)) != self.num_envs or int(sd.get("players", self.P)) != self.P):
             raise ValueError(f"state_dict of a {sd.get('kind')} batch of {sd.get('num_envs')} envs does not fit this env")
+        if isinstance(sd, dict) and sd.get("solver", self.solver) != self.solver:
+            #  the two arithmetics of the island solver leave one state at different successors (velocities up to 2.7e-5 apart per
+            # step): a run resumed in the other one silently leaves the recorded trajectory
+            raise ValueError(f"state_dict was written by a solver={sd['solver']!r} env; this env runs solver={self.solver!r} "
+                             "(HipCarVecEnv(solver=...)): the resumed run would not reproduce the original")
         self.set_state(st)
 
     def get_track(self, env):
@@ -337,3 +342,9 @@ class HipCarVecEnv(VecEnv):
         ms, cnt = C.c_double(), C.c_int64()
         N.check(self._L.crl_kernel_time_ms(self._h, which, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def kernel_time_stats(self, which):
+        """(total ms, launches, longest launch in ms) of timing slot `which` (include/crl.h crl_kernel_time_stats; 2 = CarRacing's touching solve)"""
+        ms, cnt, mx = C.c_double(), C.c_int64(), C.c_double()
+        N.check(self._L.crl_kernel_time_stats(self._h, which, C.byref(ms), C.byref(cnt), C.byref(mx)))
+        return ms.value, cnt.value, mx.value

@@ -76,6 +76,9 @@ def main():
         cr.seeding.np_random = lambda s=None: (stream(s), s)
         env = Env(num_player=players, verbose=0, action_repeat=repeat)
         draws_before = len(draws[-1].u)
+        # reset() shuffles the birth places with the GLOBAL numpy generator (car_racing_multi_players.py:508-509): seeded here, or the recorded
+        # start positions (+- 5 in x) differ from run to run (found by tests/test_golden_regenerates.py, round 6)
+        np.random.seed(seed)
         env.reset()
         u = np.array(draws[-1].u[draws_before:])
         assert len(u) % 24 == 0

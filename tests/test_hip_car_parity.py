@@ -873,3 +873,74 @@ def test_car_step_device_draws_into_the_callers_tensor():
             if len(idx):
                 assert torch.equal(torch.stack(a.terminal_observation(idx)), torch.stack(b.terminal_observation(idx)))
         a.close(), b.close()
+
+
+def test_finished_touching_envs_behind_the_first_pass_of_the_touching_solve():
+    """the touching solve's grid covers 2 048 one-manifold islands (256 multi-manifold ones) per pass and loops
+    over the rest; the NEXT step's narrow phase runs beside it on another stream and rewrites an env's manifold count / manifolds
+    (single-buffered) for the envs whose poses are final.  An env that FINISHES in this step while its cars touch is collided on its
+    staged (new-episode) bodies -- it must wait for this step's solve like every other touching env, or a late pass of the solve reads
+    the new episode's manifold count (usually 0) and its terminal state / terminal observation are no longer what the sequential step
+    computes.  Here car 0 of 7 000 envs pushes car 1 nose to tail (7 000 touching islands: four passes of the solve) while the other
+    envs' cars are far apart (the stream that runs the next narrow phase has little else to do and reaches it while the solve is in
+    its first pass), a staggered TimeLimit ends ~25 of the pushing envs per step, and the pipelined context must equal the one-stream
+    context (CRL_CAR_NO_OVERLAP=1: no collide-ahead, nothing concurrent) step for step.
+    (What the hazard could change is one solve of an env that is reset right behind it: only its terminal observation shows the bodies, and
+    one step without the contact moves a car by a fraction of a pixel -- the test passed on the code before the fix too.  It covers the
+    scenario; the fix is by construction: car_broad_kernel files every env that touches now behind the solve.)"""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, steps, parked = 16384, 40, 7000
+    a = crl.HipCarVecEnv(n, seed=33)
+    os.environ["CRL_CAR_NO_OVERLAP"] = "1"
+    try:
+        b = crl.HipCarVecEnv(n, seed=33)
+    finally:
+        del os.environ["CRL_CAR_NO_OVERLAP"]
+    a.reset(), b.reset()
+    st = a.get_state()
+    c0, c1 = st["car"][:, 0], st["car"][:, 1]
+    ang = c0["hull"]["a"].astype(np.float64)
+    ahead = np.where(np.arange(n) < parked, 4.55, 60.0)[:, None] * np.stack([-np.sin(ang), np.cos(ang)], 1)  # nose to tail | far away
+    for body in ("hull", "wheel"):
+        for f in ("a", "vx", "vy", "w"):
+            c1[body][f] = c0[body][f]
+        c1[body]["cx"] = c0[body]["cx"] + (ahead[:, 0] if body == "hull" else ahead[:, 0][:, None]).astype(np.float32)
+        c1[body]["cy"] = c0[body]["cy"] + (ahead[:, 1] if body == "hull" else ahead[:, 1][:, None]).astype(np.float32)
+    # ~25 of the pushing envs end per step from step 10 on (the bench's steady state has 16; with hundreds the finished envs' reset -> map ->
+    # first-frame chain outlasts the touching solve and the next narrow phase starts behind it anyway)
+    i = np.arange(n)
+    st["elapsed"] = np.where((i < parked) & (i % 8 == 0), 1000 - 10 - (i // 8 * 7) % (steps - 10), 0)
+    a.set_state(st), b.set_state(st)
+    act = torch.zeros((n, 2, 2), device="cuda")
+    act[:, 0, 1], act[:, 1, 1] = 1.0, -0.6   # car 0: full gas, car 1: brake
+    finished_touching = finished = looping = 0
+    for t in range(steps):
+        nc_before = a.get_state()["n_contact"]
+        touching_before = nc_before > 0
+        oa, ra, da = a.step_device(act)
+        ob, rb, db = b.step_device(act)
+        assert torch.equal(da, db) and torch.equal(ra, rb), t
+        bad = (oa != ob).reshape(n, -1).any(1)
+        assert not bad.any(), (t, "frames differ in envs", torch.nonzero(bad).reshape(-1)[:8].tolist())
+        idx = torch.nonzero(da).reshape(-1)
+        if len(idx):
+            ta, tb = torch.stack(a.terminal_observation(idx)), torch.stack(b.terminal_observation(idx))
+            bad = (ta != tb).reshape(len(idx), -1).any(1)
+            assert not bad.any(), (t, "terminal observations differ in envs", idx[bad][:8].tolist(), "touching before the step:",
+                                   touching_before[idx[bad][:8].cpu().numpy()].tolist())
+        sa, sb = a.get_state(), b.get_state()
+        # ("coupled" only routes -- the pipelined context's is the NEXT step's flag, set without a test for an env that touches now; the
+        # one-stream context's is this step's)
+        sa["coupled"] = sb["coupled"] = 0
+        if sa.tobytes() != sb.tobytes():
+            raise AssertionError((t, "state differs in envs", np.nonzero([x.tobytes() != y.tobytes() for x, y in zip(sa, sb)])[0][:8].tolist()))
+        d = da.cpu().numpy().astype(bool)
+        finished += int(d.sum())
+        per_class = (int((nc_before == 1).sum()), int((nc_before == 2).sum()), int((nc_before >= 3).sum()))
+        if per_class[0] > 2 * 2048 or per_class[1] > 2 * 256 or per_class[2] > 2 * 256:  # three passes or more: 2 048 one-manifold islands per pass, 256 of the others
+            looping += 1
+            finished_touching += int((d & touching_before).sum())
+    assert looping >= steps // 2 and finished_touching > 200, (finished, finished_touching, looping)  # (finished while touching, in steps whose solve looped)
+    a.close(), b.close()

@@ -71,4 +71,11 @@ def test_car_resume_from_state_dict_reproduces_the_run(solver):
         got = env.step_device(a)
         assert all(torch.equal(x, y) for x, y in zip(got, w))
     assert env.get_state().tobytes() == final.tobytes()
+    #  a checkpoint of the OTHER arithmetic of the island solver is refused, not silently resumed on another trajectory
+    other = crl.HipCarVecEnv(n, seed=5, solver="fma" if solver == "box2d" else "box2d")
+    other.reset()
+    with pytest.raises(ValueError, match="solver"):
+        other.load_state_dict(sd)
+    other.load_state_dict(sd["env_state"])  # (a bare state array carries no claim about the solver: accepted)
+    other.close()
     env.close()

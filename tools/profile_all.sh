@@ -24,4 +24,5 @@ tail -c 300 gpurun_out/${RND}_bench_car_long.json; tail -c 300 gpurun_out/${RND}
 for sv in box2d fma; do
   CRL_LIB_VARIANT=abl CRL_CAR_STAMPS=1 QUICK_SOLVER=$sv PYTHONPATH=. timeout 100 python3 tools/car_quick.py 16384 1500 500 > gpurun_out/${RND}_car_stamps_$sv.txt 2>&1
 done
+[ -x tools/solve_chain_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I include tools/solve_chain_probe.hip -o tools/solve_chain_probe  # (git-ignored binary: built on first use)
 timeout 60 ./tools/solve_chain_probe > gpurun_out/${RND}_solve_chain_probe.txt 2>&1
