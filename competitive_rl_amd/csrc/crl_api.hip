@@ -277,7 +277,7 @@ static int setup_gray(crl_ctx *c) {
     if ((rc = dev_upload(c, &c->atlas_gray, c->atlas_host))) return rc;
     if ((rc = dev_alloc(c, &c->band, (size_t)3 * 484 * 2 * c->band_chunks * 16))) return rc;
     if ((rc = dev_alloc(c, &c->rest, (size_t)chunks * 16))) return rc;
-    if ((rc = dev_alloc(c, &c->tile_hdr, (size_t)c->n * pong_views(c) * c->o.frame_stack * (64 + 8)))) return rc;
+    if ((rc = dev_alloc(c, &c->tile_hdr, (size_t)c->n * pong_views(c) * c->o.frame_stack * (64 + 8 + 2)))) return rc;
     HIP_TRY(hipMemset(c->rest, 0, (size_t)chunks * 16));
     GrayParams p{};
     p.R = R, p.K = c->o.frame_stack, p.atlas_gray = c->atlas_gray;

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) void pong_gray_header_kernel(const uint64_t *_
     if (fa.sl == 255) {  // both blank: plane erased by a done
         hdr[tile] = h;
         reinterpret_cast<uint2 *>(hdr + n * tiles_per_env)[tile] = make_uint2(h.band_off, h.kind);
+        reinterpret_cast<uint16_t *>(reinterpret_cast<uint2 *>(hdr + n * tiles_per_env) + n * tiles_per_env)[tile] = 0;
         return;
     }
     bool slow = false;
@@ -577,6 +578,8 @@ __global__ __launch_bounds__(256) void pong_gray_header_kernel(const uint64_t *_
     h.chunkmask = mask;
     hdr[tile] = h;
     reinterpret_cast<uint2 *>(hdr + n * tiles_per_env)[tile] = make_uint2(h.band_off, h.kind);  // dense copy (skeleton experiment)
+    reinterpret_cast<uint16_t *>(reinterpret_cast<uint2 *>(hdr + n * tiles_per_env) + n * tiles_per_env)[tile] =
+        (uint16_t)((h.band_off / (uint32_t)q.band_chunks) | ((uint32_t)h.kind << 12));  // 2-byte record
 }
 
 // One wavefront per 1-KiB-ALIGNED block of the output tensor (chunks [64 b, 64 b + 64) of the whole tensor), NB blocks per
@@ -598,9 +601,24 @@ __device__ inline int opaque_zero() {  // a zero the compiler must treat as per-
 // Measurement only (CRL_GRAY_SWEEP=2, wrong pixels wherever a ball or bat is): the SKELETON of an address-linear writer with
 // real per-tile metadata -- tile index, one 16-byte header read, the template chunk, an aligned 1-KiB store -- and none of the
 // box path, i.e. what a writer that got its box pixels for free could at best cost.  NB blocks per wavefront, a grid apart.
-template <int NB>
+// F32OUT (round 6): the same blocks widened to float32 on the way out -- a block is 1 024 pixels either way (one 16-byte chunk of bytes per
+// lane), so the float32 writer pays the per-block bookkeeping once per 4 KiB instead of once per KiB: the block goes through 1 KiB of LDS
+// and leaves as four 1-KiB wave stores (store k, lane l: the float4 of pixels 256 k + 4 l .. + 3).
+__device__ inline void store_block_f32(const uint8_t *tl, float4 *__restrict__ outf, int64_t first_chunk, int lane, int64_t total_chunks) {
+    const uint32_t *tl32 = reinterpret_cast<const uint32_t *>(tl);
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) px[k] = tl32[64 * k + lane];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (first_chunk + 16 * k + (lane >> 2) < total_chunks)
+            outf[first_chunk * 4 + 64 * k + lane] = make_float4((float)(px[k] & 255u), (float)((px[k] >> 8) & 255u), (float)((px[k] >> 16) & 255u), (float)(px[k] >> 24));
+}
+
+template <int NB, bool F32OUT = false>
 __global__ __launch_bounds__(256) void pong_gray_sweep_skeleton_kernel(const GrayTileHdr *__restrict__ hdrs, int n_tiles, GrayGeom q,
                                                                        uint8_t *__restrict__ obs, int stride, int dense) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[F32OUT ? 4 : 1][F32OUT ? 1024 : 16];
     constexpr int R = 84, chunks = R * R >> 4;
     const int total = n_tiles * chunks;
     const int bb = q.band_chunks;
@@ -614,7 +632,12 @@ __global__ __launch_bounds__(256) void pong_gray_sweep_skeleton_kernel(const Gra
         gl[i] = ((int)blockIdx.x * 256 + (int)threadIdx.x) + i * stride * 64;
         const int gg = min(gl[i], total - 1), tile = gg / chunks;
         c[i] = gg - tile * chunks;
-        h[i] = dense ? reinterpret_cast<const uint2 *>(hdrs + n_tiles)[tile] : *reinterpret_cast<const uint2 *>(hdrs + tile);  // band offset, kind
+        if (dense == 2) {  // 2 bytes per tile (1 MB for 524 288 tiles: resident in every L2): band-table row | kind << 12
+            const uint32_t m16 = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint2 *>(hdrs + n_tiles) + n_tiles)[tile];
+            h[i] = make_uint2((m16 & 4095u) * (uint32_t)bb, m16 >> 12);
+        } else {
+            h[i] = dense ? reinterpret_cast<const uint2 *>(hdrs + n_tiles)[tile] : *reinterpret_cast<const uint2 *>(hdrs + tile);  // band offset, kind
+        }
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) {
@@ -623,11 +646,19 @@ __global__ __launch_bounds__(256) void pong_gray_sweep_skeleton_kernel(const Gra
             if (c[i] < bb) v = band4[h[i].x + c[i]];
             else if (c[i] < zc0 || c[i] >= zc1) v = rest4[c[i]];
         }
-        if (gl[i] < total) reinterpret_cast<uint4 *>(obs)[gl[i]] = v;
+        if (F32OUT) {
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            reinterpret_cast<uint4 *>(lds[wave])[lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            store_block_f32(lds[wave], reinterpret_cast<float4 *>(obs), (int64_t)gl[i] - lane, lane, total);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        } else if (gl[i] < total) {
+            reinterpret_cast<uint4 *>(obs)[gl[i]] = v;
+        }
     }
 }
 
-template <int RT, int NB>
+template <int RT, int NB, bool F32OUT = false>
 __global__ __launch_bounds__(256) void pong_raster_gray_sweep_kernel(const GrayTileHdr *__restrict__ hdrs, int n_tiles, GrayCtx g, GrayGeom q,
                                                                      uint8_t *__restrict__ obs, int dbg, const uint64_t *__restrict__ ring,
                                                                      int64_t n, int stride) {
@@ -668,7 +699,14 @@ __global__ __launch_bounds__(256) void pong_raster_gray_sweep_kernel(const GrayT
         const uint32_t mword = (c[i] >> 3) < 32 ? h[i].z : h[i].w;
         const bool mine = active && (kind == 2 || (kind == 1 && ((mword >> ((c[i] >> 3) & 31)) & 1u) && !(dbg & 1)));
         if (!__any(mine)) {  // most blocks: the template, stored straight away
-            if (active) *out = v[i];
+            if (F32OUT) {
+                reinterpret_cast<uint4 *>(lds[wave])[lane] = v[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                store_block_f32(lds[wave], reinterpret_cast<float4 *>(obs), (int64_t)gl[i] - lane, lane, total);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            } else if (active) {
+                *out = v[i];
+            }
             continue;
         }
         // ---- a block with box pixels: compose it in LDS, segment by segment (wave-uniform tile each)
@@ -741,7 +779,8 @@ __global__ __launch_bounds__(256) void pong_raster_gray_sweep_kernel(const GrayT
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (active) *out = reinterpret_cast<const uint4 *>(tl)[lane];
+        if (F32OUT) store_block_f32(tl, reinterpret_cast<float4 *>(obs), (int64_t)gl[i] - lane, lane, total);
+        else if (active) *out = reinterpret_cast<const uint4 *>(tl)[lane];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the LDS block is reused by the wave's next block
     }
 }
@@ -1087,7 +1126,7 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     // bit-exact, but 1.0-2.0 ms against the env kernel's 0.75 ms at 65 536 envs -- every block has to read per-tile metadata
     // first, and a dependent read in a store-saturated memory system takes microseconds.
     static const int sweep_env = getenv("CRL_GRAY_SWEEP") ? atoi(getenv("CRL_GRAY_SWEEP")) : 0;
-    if (sweep_env && !p.obs_f32 && !p.stack.out && !q.debug && p.hdr && (p.R * p.R) % 16 == 0 && tofs.max_taps <= 3 && tofs.fast_ok && tiles * (p.R * p.R >> 4) < (1ll << 31) && (p.R * p.R >> 4) <= 512) {
+    if (sweep_env && p.obs_f32 != 2 && (!p.obs_f32 || p.R == 84) && !p.stack.out && !q.debug && p.hdr && (p.R * p.R) % 16 == 0 && tofs.max_taps <= 3 && tofs.fast_ok && tiles * (p.R * p.R >> 4) < (1ll << 31) && (p.R * p.R >> 4) <= 512) {
         GrayTileHdr *hdr = reinterpret_cast<GrayTileHdr *>(p.hdr);
         hipLaunchKernelGGL(pong_gray_header_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, st, p.ring, p.n, q, hdr);
         static const int sdbg = getenv("CRL_GRAY_SWEEP_DEBUG") ? atoi(getenv("CRL_GRAY_SWEEP_DEBUG")) : 0;
@@ -1097,11 +1136,20 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         const int stride = (int)(((wblocks + nb - 1) / nb + 3) / 4 * 4);  // blocks per round, a multiple of the 4 waves of a workgroup
         const dim3 grid((unsigned)(stride / 4));
         const int sweep_mode = sweep_env;
-        if ((sweep_mode == 2 || sweep_mode == 3) && p.R == 84) {
-            const int dense = sweep_mode == 3;
-            if (nb == 1) hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<1>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);
-            else if (nb == 2) hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<2>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);
-            else hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<4>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense);
+        if ((sweep_mode == 2 || sweep_mode == 3 || sweep_mode == 4) && p.R == 84) {  // skeletons: 64-byte headers | dense 8-byte records | dense 2-byte records
+            const int dense = sweep_mode - 2;
+#define CRL_SKEL(NBv) do { if (p.obs_f32) hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<NBv, true>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense); \
+                           else hipLaunchKernelGGL((pong_gray_sweep_skeleton_kernel<NBv, false>), grid, dim3(256), 0, st, hdr, (int)tiles, q, p.obs, stride, dense); } while (0)
+            if (nb == 1) CRL_SKEL(1);
+            else if (nb == 2) CRL_SKEL(2);
+            else CRL_SKEL(4);
+#undef CRL_SKEL
+            return;
+        }
+        if (p.obs_f32) {  // float32 output (round 6): R = 84 only
+            if (nb == 1) hipLaunchKernelGGL((pong_raster_gray_sweep_kernel<84, 1, true>), grid, dim3(256), 0, st, hdr, (int)tiles, g, q, p.obs, sdbg, p.ring, p.n, stride);
+            else if (nb == 2) hipLaunchKernelGGL((pong_raster_gray_sweep_kernel<84, 2, true>), grid, dim3(256), 0, st, hdr, (int)tiles, g, q, p.obs, sdbg, p.ring, p.n, stride);
+            else hipLaunchKernelGGL((pong_raster_gray_sweep_kernel<84, 4, true>), grid, dim3(256), 0, st, hdr, (int)tiles, g, q, p.obs, sdbg, p.ring, p.n, stride);
             return;
         }
 #define CRL_SWEEP(RTv, NBv) hipLaunchKernelGGL((pong_raster_gray_sweep_kernel<RTv, NBv>), grid, dim3(256), 0, st, hdr, (int)tiles, g, q, p.obs, sdbg, p.ring, p.n, stride)

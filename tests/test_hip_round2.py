@@ -522,16 +522,16 @@ import competitive_rl_amd as crl
 from competitive_rl_amd import _native
 from oracle import pong_oracle as po
 atlas = _native.load_score_atlas()
-for K, n in ((4, 130), (1, 67)):
-    env = crl.HipPongVecEnv(n, seed=5, mode="wrapped", resized_dim=84, frame_stack=K)
+for K, n, dt in ((4, 130, "uint8"), (1, 67, "uint8"), (4, 70, "float32")):   # (float32: round 6, the same blocks widened on the way out)
+    env = crl.HipPongVecEnv(n, seed=5, mode="wrapped", resized_dim=84, frame_stack=K, obs_dtype=dt)
     ora = po.PongOracle(n, atlas, obs_mode=po.GRAY, resized_dim=84, frame_stack=K, seed=5)
-    assert np.array_equal(torch.stack(env.reset(), 1).cpu().numpy(), ora.reset())
+    assert np.array_equal(torch.stack(env.reset(), 1).cpu().numpy(), ora.reset().astype(dt))
     rs = np.random.RandomState(K)
     for t in range(150):
         a = rs.randint(0, 3, (n, 2))
         obs, rew, done, _ = env.step(a)
         oo, orew, odone = ora.step(a)
-        assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo), (K, t)
+        assert np.array_equal(torch.stack(obs, 1).cpu().numpy(), oo.astype(dt)), (K, t, dt)
     env.close()
 print("sweep ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
