@@ -414,8 +414,11 @@ __device__ unsigned long long g_gray_ticks[8];
 #ifndef CRL_F32_LB
 #define CRL_F32_LB 1    // float32 instances: workgroups per CU the register allocation must allow
 #endif
-template <int MAXT, bool DBG, int TI, bool F32, bool STACK = false, bool SF32 = false>
-__global__ __launch_bounds__(256, TI == 2 ? 6 : (STACK && !F32 && !SF32) ? 4 : (F32 || SF32) ? CRL_F32_LB : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
+// EPWV (round 6): envs per wavefront of the K = 1 launch (make_envs("cPongDouble-v0")'s own observation: one plane per agent).  A wavefront that
+// draws ONE env's two tiles pays the workgroup's table staging, its ring read and its launch for 14 KB of output; EPWV consecutive envs per
+// wavefront amortise them like the four-plane stack does.
+template <int MAXT, bool DBG, int TI, bool F32, bool STACK = false, bool SF32 = false, int EPWV = 1>
+__global__ __launch_bounds__(256, TI == 2 ? 6 : ((STACK || EPWV > 1) && !F32 && !SF32) ? 4 : (F32 || SF32) ? CRL_F32_LB : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw, GrayStack sk) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][TI * 1024];
     __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
@@ -433,9 +436,9 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : (STACK && !F32 && !SF32) ? 4 : (
     const int alias_tile = STACK && sk.alias ? sk.view * K + K - 1 : 1 << 20;
     const int groups = STACK ? (jobs + ppw - 1) / ppw : K / ppw;
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-    const bool live = wid < n * groups;
-    const int64_t env = live ? wid / groups : 0;
-    const int p0 = (int)(wid - env * groups) * ppw;  // first plane (first job) of this wavefront
+    const bool live = EPWV > 1 ? wid * EPWV < n : wid < n * groups;   // (EPWV > 1: whole envs, groups = 1)
+    const int64_t env = live ? (EPWV > 1 ? wid * EPWV : wid / groups) : 0;
+    const int p0 = EPWV > 1 ? 0 : (int)(wid - env * groups) * ppw;  // first plane (first job) of this wavefront
     if (live && lane < 8) words_[wave][lane] = ring[(int64_t)lane * n + env];
     __syncthreads();
     if (!live) return;
@@ -468,6 +471,26 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : (STACK && !F32 && !SF32) ? 4 : (
             }
             const bool f32 = to_stack ? SF32 : F32;
 #include "pong_gray_tile.inc"
+        }
+    } else if constexpr (EPWV > 1) {
+        const int64_t env_first = env;
+#pragma unroll 1
+        for (int e = 0; e < EPWV; e++) {
+            const int64_t env = env_first + e;   // (the tile code's `env`)
+            if (env >= n) break;
+            if (e > 0) {  // the next env's ring words (this wavefront's own LDS row: a wavefront's LDS operations complete in order)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (lane < 8) words_[wave][lane] = ring[(int64_t)lane * n + env];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+#pragma unroll 1
+            for (int view = 0; view < q.views; view++)
+#pragma unroll 1
+            for (int plane = 0; plane < K; plane++) {
+                const int rp = 4 - K + plane;  // ring plane
+                constexpr bool to_stack = false, erased = false, f32 = F32;
+#include "pong_gray_tile.inc"
+            }
         }
     } else {
         // view-major: a wave writes its env's planes in ascending address order (the four planes of agent
@@ -1214,6 +1237,21 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
         return;
     }
 #endif
+    // one plane per agent (the observation make_envs("cPongDouble-v0") itself returns) in a batch that fills the chip several times over: four
+    // envs per wavefront (CRL_GRAY_EPWV=1 in the profiling build: one)
+    static const int epwv_env = CRL_ABL(getenv("CRL_GRAY_EPWV") ? atoi(getenv("CRL_GRAY_EPWV")) : 0);
+#ifndef CRL_GRAY_EPWV_N
+#define CRL_GRAY_EPWV_N 4  // (measured at 65 536 envs, 84 x 84: 1 / 4 envs per wavefront 237 / 221 us)
+#endif
+    if (p.K == 1 && ppw == 1 && p.n >= 8192 * CRL_GRAY_EPWV_N && epwv_env != 1 && (tofs.max_taps <= 3 || (p.R * p.R <= 2048 && !small_off))) {
+        constexpr int E = CRL_GRAY_EPWV_N;
+        const dim3 grid4((unsigned)(((p.n + E - 1) / E + 3) / 4));
+        if (tofs.max_taps <= 3)
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, false, false, false, E>), grid4, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
+        else
+            hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, false, 2, false, false, false, E>), grid4, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
+        return;
+    }
     if (tofs.max_taps <= 3)
         hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, false, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
     else if (p.R * p.R <= 2048 && !small_off)

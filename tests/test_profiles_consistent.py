@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_kernel_stats_csv_matches_summary():
     checked = 0
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[345]_*_kernel_stats.csv"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3456]_*_kernel_stats.csv"))):
         summ = f.replace("_kernel_stats.csv", "_summary.txt")
         assert os.path.exists(summ), summ
         rows = list(csv.DictReader(open(f)))

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One script, one HEAD: every judged artefact under profiles/ comes from this run (tools/collect_profiles.py copies them).
-#   gpurun --timeout 3000 -- 'bash tools/profile_all.sh r05'
-RND=${1:-r05}
-for wl in raw fused84 fused84_f32 fused84_f32_ref car car_fma tournament; do
+#   gpurun --timeout 3000 -- 'bash tools/profile_all.sh r06'
+RND=${1:-r06}
+for wl in raw fused84 fused84_newest fused84_f32 fused84_f32_ref car car_fma tournament protocol; do
   echo "=== $wl ==="
   bash tools/profile_gpu.sh $wl ${RND}_$wl 2>&1 | tail -6
 done
