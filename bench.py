@@ -605,10 +605,14 @@ def main():
             for nm in names[1:]:  # slim: the name is the key of WORKLOADS / DESIGN.md section 7, numbers only
                 r = {k: v for k, v in results[nm].items() if k != "unit"}
                 r["config"] = {k: v for k, v in r["config"].items() if k != "workload"}
+                r.pop("overhead_us_per_step", None)  # (= legs_ms_per_step minus its first entry)
+                r.pop("episodes_recorded", None)
                 if r.get("roofline"):
                     r["roofline"] = {k: v for k, v in r["roofline"].items() if k not in ("bytes_per_launch", "launches_timed", "dynamics_kernel_avg_us")}
+                    if "critical_path" in r["roofline"]:  # kernel, mean / max / step in us (what bounds it: DESIGN.md 4.4)
+                        r["roofline"]["critical_path"] = {k: v for k, v in r["roofline"]["critical_path"].items() if k in ("kernel", "mean_us", "max_us", "step_us")}
                 if nm in cpu:
-                    b = {k: v for k, v in cpu[nm].items() if k in ("value", "unit", "cores", "kind", "sample", "cpu_quota")}
+                    b = {k: v for k, v in cpu[nm].items() if k in ("value", "cores", "kind")}  # (unit: env-steps/s; the sample is described in DESIGN.md 7)
                     if "openmp_port" in cpu[nm]:
                         b["openmp_port_value"] = cpu[nm]["openmp_port"]["value"]
                     r["cpu_baseline"] = b
