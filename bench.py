@@ -99,7 +99,7 @@ def effective_cores():
     return cores, visible, quota
 
 
-def cpu_baselines(workloads, budget_s=8.0):
+def cpu_baselines(workloads, budget_s=float(os.environ.get("CRL_BENCH_CPU_BUDGET_S", "8.0"))):
     """Rank 0, one GPU only, BEFORE the GPU is touched: the oracle timed on this host's cores on bounded samples of
     the same workloads -- (a) in the reference's SubprocVecEnv architecture (one process per env, pipes, pickled
     observations; oracle/subproc_baseline.py), which is the reported ``value``; (b) as one OpenMP batch over all
@@ -309,11 +309,23 @@ def run_protocol(args, G):
     legs = (("step_device", leg_device, None), ("vec_env_step", leg_step, None), ("vec_env_step_infos", leg_infos, None),
             ("step_envs", leg_step_envs, (torch.float32, True)), ("step_envs_u8_stack", leg_step_envs, (torch.uint8, True)),
             ("step_envs_unbound", leg_step_envs, (torch.float32, False)))
+    kernel_us = {}
     for key, leg, st in legs:
         if st is not None:
             stack(*st)
-        t0 = timed_loop(G, args, leg)
+        timed = key in ("step_envs", "step_envs_u8_stack") and not os.environ.get("CRL_BENCH_NO_KERNEL_TIMING")
+
+        def arm():  # hipEvents around the draw of the timed steps only (the warm-up's launches are not counted)
+            if timed:
+                env.kernel_time_ms(1)
+                env.kernel_timing(True)
+
+        t0 = timed_loop(G, args, leg, after=arm)
         torch.cuda.synchronize()
+        if timed:
+            env.kernel_timing(False)
+            ms, cnt = env.kernel_time_ms(1)
+            kernel_us[key] = ms / max(cnt, 1) * 1e3
         if dist_on:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -331,11 +343,15 @@ def run_protocol(args, G):
            "config": {"workload": WORKLOADS["protocol"], "envs_per_gpu": n, "stack": "float32 (N,4,84,84), bound to the env (drawn by the step)"},
            "legs_ms_per_step": res, "overhead_us_per_step": {k: (v - base) * 1e3 for k, v in res.items() if k != "step_device"},
            "fused_updates": fused, "episodes_recorded": books["episodes"]}
-    if rank == 0:
-        # the whole leg against the float32 stack it must produce (112 896 B/env written once)
-        ach = stack_bytes * n / (res["step_envs"] * 1e-3)
-        out["roofline"] = {"bound": "hbm", "kernel": "pong_raster_gray_env_kernel<STACK> (whole step_envs leg)", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic_of("protocol"), "bytes_per_launch": stack_bytes * n}
+    if rank == 0 and kernel_us.get("step_envs"):
+        # the launch that draws the float32 stack AND the uint8 observation: 4 x 28 224 + 2 x 7 056 B per env, by hipEvents on its stream;
+        # leg_frac: the stack alone (112 896 B/env written once) over the WHOLE step_envs leg
+        per_env = stack_bytes + 2 * 84 * 84
+        ach = per_env * n / (kernel_us["step_envs"] * 1e-6)
+        out["roofline"] = {"bound": "hbm", "kernel": "pong_raster_gray_env_kernel<STACK>", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK, "traffic": traffic_of("protocol"), "bytes_per_launch": per_env * n, "avg_kernel_us": kernel_us["step_envs"],
+                           "leg_frac": stack_bytes * n / (res["step_envs"] * 1e-3) / HBM_PEAK,
+                           "u8_stack_kernel_us": kernel_us.get("step_envs_u8_stack")}
     return out
 
 

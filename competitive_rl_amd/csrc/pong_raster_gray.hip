@@ -392,7 +392,7 @@ __device__ inline uint8_t eval_sep(const uint8_t *__restrict__ tabs, const GrayT
 }
 
 // CRL_GRAY_DEBUG & 128 (instrumented instance): s_memtime stamps around the phases of a tile, summed over all wavefronts
-__device__ unsigned long long g_gray_ticks[8];
+__device__ unsigned long long g_gray_ticks[1024][8];  // (1 024 rows, one per workgroup index mod 1 024: every wavefront adding to ONE row took 4.7 ms of atomics per launch)
 #define GRAY_TICK(Kk)                                        \
     if (DBG && (dbg & 128)) {                                \
         const long long now_ = __builtin_readcyclecounter(); \
@@ -418,7 +418,10 @@ __device__ unsigned long long g_gray_ticks[8];
 // draws ONE env's two tiles pays the workgroup's table staging, its ring read and its launch for 14 KB of output; EPWV consecutive envs per
 // wavefront amortise them like the four-plane stack does.
 template <int MAXT, bool DBG, int TI, bool F32, bool STACK = false, bool SF32 = false, int EPWV = 1>
-__global__ __launch_bounds__(256, TI == 2 ? 6 : ((STACK || EPWV > 1) && !F32 && !SF32) ? 4 : (F32 || SF32) ? CRL_F32_LB : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
+#ifndef CRL_GRAY_SMALL_LB
+#define CRL_GRAY_SMALL_LB 6  // R <= 45 instances: workgroups per CU the register allocation must allow
+#endif
+__global__ __launch_bounds__(256, TI == 2 ? CRL_GRAY_SMALL_LB : ((STACK || EPWV > 1) && !F32 && !SF32) ? 4 : (F32 || SF32) ? CRL_F32_LB : 1) void pong_raster_gray_env_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx g,
                                                                    GrayGeom q, uint8_t *__restrict__ obs, int ppw, GrayStack sk) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[4][TI * 1024];
     __shared__ __attribute__((aligned(16))) uint8_t tabs[kTabLds];
@@ -505,8 +508,9 @@ __global__ __launch_bounds__(256, TI == 2 ? 6 : ((STACK || EPWV > 1) && !F32 && 
         }
     }
     if (DBG && (dbg & 128) && lane == 0) {
-        for (int i = 0; i < 6; i++) atomicAdd(&g_gray_ticks[i], (unsigned long long)gtick[i]);
-        atomicAdd(&g_gray_ticks[7], 1ull);
+        unsigned long long *row = g_gray_ticks[blockIdx.x & 1023];
+        for (int i = 0; i < 6; i++) atomicAdd(&row[i], (unsigned long long)gtick[i]);
+        atomicAdd(&row[7], 1ull);
     }
 }
 
@@ -809,9 +813,13 @@ __global__ __launch_bounds__(256) void pong_raster_gray_sweep_kernel(const GrayT
 }
 
 void pong_gray_print_ticks() {
-    unsigned long long t[8];
-    if (hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gray_ticks), sizeof(t)) != hipSuccess || !t[7]) return;
-    fprintf(stderr, "gray env kernel, mean cycles per wavefront (8 tiles) over %llu wavefronts: loop top/ring words %llu | template issue + boxes %llu | "
+    static unsigned long long rows[1024][8];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_gray_ticks), sizeof(rows)) != hipSuccess) return;
+    unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < 1024; r++)
+        for (int i = 0; i < 8; i++) t[i] += rows[r][i];
+    if (!t[7]) return;
+    fprintf(stderr, "gray env kernel, mean cycles per wavefront (all its tiles) over %llu wavefronts: loop top/ring words %llu | template issue + boxes %llu | "
             "row/col words %llu | LDS fill %llu | patch %llu | stream-out %llu\n", t[7], t[0] / t[7], t[1] / t[7], t[2] / t[7], t[3] / t[7], t[4] / t[7], t[5] / t[7]);
 }
 
@@ -1233,7 +1241,8 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     }
 #ifdef CRL_ABLATION
     if (q.debug & ~16) {  // any ablation switch: the instrumented instance
-        hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
+        if (tofs.max_taps <= 3) hipLaunchKernelGGL((pong_raster_gray_env_kernel<3, true, 7, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
+        else hipLaunchKernelGGL((pong_raster_gray_env_kernel<5, true, 2, false>), grid, dim3(256), 0, st, p.ring, p.n, g, q, p.obs, ppw, nosk);
         return;
     }
 #endif

@@ -699,3 +699,29 @@ def test_car_full_resets_with_the_walk_ahead_running_give_the_same_tracks():
             assert ta["n"] == tb["n"] and np.array_equal(ta["tile_poly"], tb["tile_poly"]), (rnd, i)
     a.close()
     b.close()
+
+
+def test_default_bench_line_fits_the_drivers_buffer():
+    """``python bench.py`` (every workload, CPU baselines included) prints ONE JSON line, and the driver keeps 8 KB of stdout: the line
+    must stay well under that whatever digits the numbers have (small batches here: the line's structure does not depend on the size)."""
+    _need_gpu()
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--envs", "2048"], capture_output=True, text=True,
+                         timeout=900, env=dict(os.environ, CRL_BENCH_CAR_PREROLL="20", CRL_BENCH_CPU_BUDGET_S="1.0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    assert len(lines[0]) < 6800, len(lines[0])
+    line = json.loads(lines[0])
+    assert set(line["configs_brief"]) == {"raw", "fused84", "fused84_newest", "fused84_f32", "fused84_f32_ref", "car", "car_fma", "tournament",
+                                          "tournament_full", "protocol"}
+    assert line["roofline"] and line["cpu_baseline"]["cores"] >= 1 and "cpu_quota" in line["cpu_baseline"]
+    car = line["configs"]["car"]["roofline"]
+    assert car["step_frac"] > 0 and car["critical_path"]["kernel"] == "car_touch_kernel" and car["critical_path"]["max_us"] >= car["critical_path"]["mean_us"] > 0
+    legs = line["configs"]["protocol"]["legs_ms_per_step"]
+    assert {"step_envs", "step_envs_u8_stack", "step_envs_unbound"} <= set(legs) and line["configs"]["protocol"]["fused_updates"]["step_envs"] == 4

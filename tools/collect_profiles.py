@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOMINANT = {"raw": "pong_raster_raw_sweep_kernel", "fused84": "pong_raster_gray", "fused84_newest": "pong_raster_gray", "fused84_f32": "pong_raster_gray",
             "fused84_f32_ref": "pong_gray_f32ref_kernel", "car": "car_obs_third_kernel", "car_fma": "car_obs_third_kernel", "tournament": "pong_policy_mfma_kernel",
             # protocol: the instance that draws the bound float32 frame stack + the uint8 observation (STACK, SF32)
-            "protocol": "pong_raster_gray_env_kernel<3, false, 7, false, true, true>"}
+            "protocol": "pong_raster_gray_env_kernel<3, false, 7, false, true, true,"}
 
 
 def main():
