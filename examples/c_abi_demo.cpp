@@ -7,7 +7,8 @@
 //   examples/c_abi_demo [num_envs] [steps]
 //
 // Steps cPongDouble-v0 (raw frames) with a fixed action pattern, prints throughput and
-// order-independent checksums of rewards / dones / the last frames; exit code 0 on success.
+// order-independent checksums of rewards / dones / the last frames; then the trainer's float32 frame stack, once drawn by
+// the step (crl_step_stack) and once rolled and appended (crl_frame_stack_update_to), compared; exit code 0 on success.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -86,9 +87,94 @@ int main(int argc, char **argv) {
            crl_version(), (long long)n, steps, dt, n * (double)steps / dt / 1e6, rsum, (long long)dsum, (long long)white,
            (long long)frames);
     // zero-sum rewards, a frame that is mostly the white borders + black court
-    const bool ok = rsum == 0.0 && white > 3 * CRL_PONG_W * (CRL_PONG_TOP + CRL_PONG_H - CRL_PONG_BOTTOM) && white < CRL_PONG_FRAME_BYTES / 2;
+    bool ok = rsum == 0.0 && white > 3 * CRL_PONG_W * (CRL_PONG_TOP + CRL_PONG_H - CRL_PONG_BOTTOM) && white < CRL_PONG_FRAME_BYTES / 2;
     crl_destroy(ctx);
-    (void)hipFree(obs), (void)hipFree(done), (void)hipFree(rew), (void)hipFree(act);
+    (void)hipFree(obs), (void)hipFree(done), (void)hipFree(rew);
+
+    // ---- the trainer's frame stack, twice (reference utils/utils.py:23-60, 145-173): context A has the step DRAW agent 0's float32
+    // (4, 84, 84) stack (crl_step_stack: two buffers, alternating); context B steps and then rolls-and-appends it with the generic kernel
+    // (crl_frame_stack_update_to, mask = 1 - done built on the host from flags that crl_set_flags_event hands over ahead of the draw).
+    // Same seed, same actions: the two stacks must be the same bytes.
+    {
+        const int64_t m = n < 512 ? n : 512;
+        const int R = 84, K = 4, steps2 = steps < 300 ? steps : 300;
+        crl_opts g = {};
+        g.env_kind = CRL_ENV_PONG_DOUBLE, g.obs_mode = CRL_OBS_GRAY_RESIZED, g.resized_dim = R, g.frame_stack = 1;
+        g.num_envs = m, g.seed = 11, g.device = 0;
+        crl_ctx *A = nullptr, *B = nullptr;
+        CRL_OK_(crl_create(&g, atlas.data(), &A));
+        CRL_OK_(crl_create(&g, atlas.data(), &B));
+        const size_t plane = (size_t)R * R, stack_elems = (size_t)m * K * plane;
+        uint8_t *obsA, *obsB, *doneA, *doneB, *done_pinned;
+        float *rewA, *rewB, *sa[2], *sb[2], *mask;
+        HIP_OK(hipMalloc(&obsA, m * 2 * plane));
+        HIP_OK(hipMalloc(&obsB, m * 2 * plane));
+        HIP_OK(hipMalloc(&doneA, m));
+        HIP_OK(hipMalloc(&doneB, m));
+        HIP_OK(hipMalloc(&rewA, m * 2 * sizeof(float)));
+        HIP_OK(hipMalloc(&rewB, m * 2 * sizeof(float)));
+        HIP_OK(hipMalloc(&mask, m * sizeof(float)));
+        HIP_OK(hipHostMalloc((void **)&done_pinned, m, hipHostMallocDefault));
+        for (int k = 0; k < 2; k++) {
+            HIP_OK(hipMalloc(&sa[k], stack_elems * sizeof(float)));
+            HIP_OK(hipMalloc(&sb[k], stack_elems * sizeof(float)));
+            HIP_OK(hipMemset(sa[k], 0, stack_elems * sizeof(float)));
+            HIP_OK(hipMemset(sb[k], 0, stack_elems * sizeof(float)));
+        }
+        hipStream_t side;
+        hipEvent_t flags_ready;
+        HIP_OK(hipStreamCreate(&side));
+        HIP_OK(hipEventCreateWithFlags(&flags_ready, hipEventDisableTiming));
+        CRL_OK_(crl_set_flags_event(B, flags_ready));
+        crl_stack_desc sd = {};
+        sd.planes = K, sd.dtype = CRL_OBS_F32, sd.agent = 0;
+        // frame_stack_tensor.update(envs.reset()[0]): A draws it, B appends it
+        CRL_OK_(crl_reset(A, nullptr, st));
+        sd.stack_dev = sa[0], sd.valid_planes = 1;
+        CRL_OK_(crl_draw_stack(A, obsA, &sd, st));
+        CRL_OK_(crl_reset(B, obsB, st));
+        CRL_OK_(crl_frame_stack_update_to(sb[0], sb[1], obsB, CRL_OBS_U8, (int64_t)2 * plane, nullptr, m, 1, K, (int64_t)plane, st));
+        {   // a third of the envs one round before the end of their episode (21 rounds, pong/register.py:20-22): the erase path runs
+            std::vector<crl_pong_env_state> es(m);
+            for (crl_ctx *c : {A, B}) {
+                CRL_OK_(crl_get_state(c, es.data(), 0, m, st));
+                for (int64_t i = 0; i < m; i += 3) es[i].num_rounds = 20;
+                CRL_OK_(crl_set_state(c, es.data(), 0, m, st));
+            }
+        }
+        int cur = 0, ends = 0;
+        std::vector<float> hm(m);
+        for (int t = 0; t < steps2; t++) {
+            const int nxt = cur ^ 1;
+            sd.stack_dev = sa[nxt], sd.valid_planes = t + 2 < K ? t + 2 : K;
+            CRL_OK_(crl_step_stack(A, act, obsA, rewA, doneA, &sd, st));   // envs.step + frame_stack_tensor.update in one launch
+            CRL_OK_(crl_step(B, act, obsB, rewB, doneB, st));
+            HIP_OK(hipStreamWaitEvent(side, flags_ready, 0));             // the flags, behind the dynamics kernel only
+            HIP_OK(hipMemcpyAsync(done_pinned, doneB, m, hipMemcpyDeviceToHost, side));
+            HIP_OK(hipStreamSynchronize(side));
+            for (int64_t i = 0; i < m; i++) hm[i] = done_pinned[i] ? 0.0f : 1.0f, ends += done_pinned[i];
+            HIP_OK(hipMemcpyAsync(mask, hm.data(), m * sizeof(float), hipMemcpyHostToDevice, st));
+            CRL_OK_(crl_frame_stack_update_to(sb[nxt], sb[cur], obsB, CRL_OBS_U8, (int64_t)2 * plane, mask, m, 1, K, (int64_t)plane, st));
+            HIP_OK(hipStreamSynchronize(st));  // (hm is reused by the next step)
+            cur = nxt;
+        }
+        std::vector<float> ha(stack_elems), hb(stack_elems);
+        HIP_OK(hipMemcpy(ha.data(), sa[cur], stack_elems * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(hb.data(), sb[cur], stack_elems * sizeof(float), hipMemcpyDeviceToHost));
+        size_t diff = 0, nonzero = 0;
+        for (size_t i = 0; i < stack_elems; i++) diff += ha[i] != hb[i], nonzero += ha[i] != 0.0f;
+        printf("frame stack drawn by the step vs rolled and appended: %lld envs x %d steps, %d episode ends, %zu of %zu elements differ (%zu non-zero)\n",
+               (long long)m, steps2, ends, diff, stack_elems, nonzero);
+        ok = ok && diff == 0 && nonzero > 0 && ends > 0;
+        // what the fused draw refuses is an error code with a text, not a crash
+        sd.planes = 5;
+        if (crl_draw_stack(A, nullptr, &sd, st) != CRL_EINVAL || !crl_ctx_last_error(A)[0]) ok = false;
+        crl_destroy(A), crl_destroy(B);
+        (void)hipEventDestroy(flags_ready), (void)hipStreamDestroy(side), (void)hipHostFree(done_pinned);
+        (void)hipFree(obsA), (void)hipFree(obsB), (void)hipFree(doneA), (void)hipFree(doneB), (void)hipFree(rewA), (void)hipFree(rewB), (void)hipFree(mask);
+        for (int k = 0; k < 2; k++) (void)hipFree(sa[k]), (void)hipFree(sb[k]);
+    }
+    (void)hipFree(act);
     (void)hipStreamDestroy(st);
     return ok ? 0 : 1;
 }

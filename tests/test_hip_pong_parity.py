@@ -431,7 +431,8 @@ def test_raw_single_player_and_ragged_sizes(atlas, n):
 
 def test_c_abi_demo_runs_without_python_in_the_loop():
     """The standalone C++ caller of include/crl.h: steps 2 048 envs through crl_create / crl_reset /
-    crl_step / crl_get_state and checks zero-sum rewards and a plausible frame itself (exit code)."""
+    crl_step / crl_get_state and checks zero-sum rewards and a plausible frame itself (exit code); then the frame stack drawn by
+    the step (crl_step_stack) against the rolled-and-appended one (crl_frame_stack_update_to) on 512 envs through episode ends."""
     _need_gpu()
     import subprocess
 
@@ -441,6 +442,8 @@ def test_c_abi_demo_runs_without_python_in_the_loop():
     r = subprocess.run([exe, "2048", "120"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "env-steps/s" in r.stdout
+    # round 6: the demo also runs the trainer's float32 frame stack through crl_step_stack / crl_draw_stack / crl_set_flags_event from plain C
+    assert "0 of " in r.stdout and "elements differ" in r.stdout, r.stdout
 
 
 def test_step_envs_device_and_host_flows_agree():
