@@ -929,7 +929,10 @@ struct F32RefGeom {
 };
 static constexpr int kF32MaxR = 84, kF32MaxTaps = 3 * kF32MaxR + 8;
 static constexpr int kF32MapBytes = 66 * 84;  // the output rows a court rectangle can feed (R = 84: rows 13..77), one byte per pixel
-__global__ __launch_bounds__(256) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx gg, F32RefGeom q, int R, int K, int views,
+#ifndef CRL_F32REF_LB
+#define CRL_F32REF_LB 5  // workgroups per CU the register allocation must allow (round 6: 102 -> 96 VGPRs, 4 -> 5 wavefronts per SIMD: 2 795 -> 2 698 us; 30 KB of LDS per workgroup allow no more)
+#endif
+__global__ __launch_bounds__(256, CRL_F32REF_LB) void pong_gray_f32ref_kernel(const uint64_t *__restrict__ ring, int64_t n, GrayCtx gg, F32RefGeom q, int R, int K, int views,
                                                                float *__restrict__ obs, GrayStack sk) {
     __shared__ int32_t s_xofs[kF32MaxR + 1], s_yofs[kF32MaxR + 1], s_xsi[kF32MaxTaps], s_ysi[kF32MaxTaps];
     __shared__ float s_xalpha[kF32MaxTaps], s_yalpha[kF32MaxTaps];
