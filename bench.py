@@ -405,7 +405,7 @@ def run_workload(name, args, G):
               "fused84_newest": dict(mode="wrapped", resized_dim=84, frame_stack=1)}[name]
         env = inner = crl.HipPongVecEnv(n, seed=0, device=dev, env_id_base=base, **kw)
         pool = [torch.randint(0, 3, (n, 2), generator=gen, device=dev, dtype=torch.int32) for _ in range(16)]
-        kernel = "pong_raster_raw_sweep_kernel" if name == "raw" else "pong_raster_gray_env_kernel"
+        kernel = "pong_raster_raw_sweep_kernel" if name == "raw" else "pong_gray_f32ref_kernel" if name == "fused84_f32_ref" else "pong_raster_gray_env_kernel"
         dtype = "f32" if name in ("fused84_f32", "fused84_f32_ref") else "u8"
     env.reset()
     episodes_before = None
