@@ -87,3 +87,43 @@ def test_car_batches_of_every_awkward_size_match_the_oracle(n, solver):
             assert np.array_equal(got[i, v], e.render(v)), (n, i, v)
     co.set_text(None)
     hip.close()
+
+
+@pytest.mark.parametrize("R,n", [(84, 32768 + 3), (42, 32768 + 1), (84, 65536 + 2)])
+def test_four_envs_per_wavefront_launch_at_ragged_sizes(R, n):
+    """Round 6: from 32 768 envs on, the K = 1 launch (one plane per agent: make_envs("cPongDouble-v0")'s own observation) runs FOUR
+    consecutive envs per wavefront -- here with env counts that are not multiples of four, so the last wavefront has one to three envs.
+    The tail and a sample of the batch against SMALL contexts that hold the same global envs (env_id_base: the serve sampler is keyed by
+    the global id, so they play the same games) and go through the one-env-per-wavefront launch; the head of the batch against the oracle."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+    from competitive_rl_amd import _native as N
+    from oracle import pong_oracle as po
+
+    steps = 24
+    big = crl.HipPongVecEnv(n, seed=5, mode="wrapped", resized_dim=R, frame_stack=1)
+    spans = [(0, 6), (n // 2 - 3, 8), (n - 9, 9)]   # (global id of the first env, count): head, middle, tail incl. the ragged wavefront
+    small = [crl.HipPongVecEnv(c, seed=5, mode="wrapped", resized_dim=R, frame_stack=1, env_id_base=b) for b, c in spans]
+    ora = po.PongOracle(spans[0][1], N.load_score_atlas(), obs_mode=po.GRAY, resized_dim=R, frame_stack=1, seed=5)
+    got = torch.stack(big.reset(), 1)
+    assert np.array_equal(got[:spans[0][1]].cpu().numpy(), ora.reset())
+    for (b, c), s in zip(spans, small):
+        assert torch.equal(got[b:b + c], torch.stack(s.reset(), 1)), ("reset", b)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(steps):
+        a = torch.randint(0, 3, (n, 2), generator=g, device="cuda", dtype=torch.int32)
+        buf, rew, done = big.step_device(a)
+        for (b, c), s in zip(spans, small):
+            sb, sr, sd = s.step_device(a[b:b + c].contiguous())
+            assert torch.equal(buf[b:b + c], sb) and torch.equal(rew[b:b + c], sr) and torch.equal(done[b:b + c], sd), (t, b)
+        oo, orew, odone = ora.step(a[:spans[0][1]].cpu().numpy())
+        assert np.array_equal(buf[:spans[0][1]].cpu().numpy(), oo) and np.array_equal(rew[:spans[0][1]].cpu().numpy(), orew), t
+    # nothing was written past the tensor: the launch's last wavefront stops at env n - 1 (a guard plane behind the buffer stays as it was)
+    guard = torch.full((n + 4, 2, 1, R, R), 77, dtype=torch.uint8, device="cuda")
+    view = guard[:n]
+    big.step_device(torch.zeros((n, 2), dtype=torch.int32, device="cuda"), obs_out=view)
+    assert bool((guard[n:] == 77).all())
+    big.close()
+    for s in small:
+        s.close()
+    ora.close()
