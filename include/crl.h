@@ -236,7 +236,8 @@ int crl_draw_stack(crl_ctx *ctx, uint8_t *obs_dev, const crl_stack_desc *stack, 
 /* A hipEvent_t of the caller's (NULL: none) that every crl_step / crl_step_stack records on the step's stream right BEHIND the kernel
  * that writes rew_dev / done_dev and IN FRONT of the observation's draw.  The reference's step_envs walks the done flags on the host
  * after every step (utils/utils.py:33-42); a stream that waits for this event can copy them out while the step's 1-2 ms of raster
- * still run, so the host's books and the next step's launch overlap the draw instead of following it.  Pong contexts. */
+ * still run, so the host's books and the next step's launch overlap the draw instead of following it.  Pong contexts.  The event is
+ * the caller's: it must belong to the context's device and stay alive until the context is destroyed or the event is unset (NULL). */
 int crl_set_flags_event(crl_ctx *ctx, void *event);
 
 /* info[i]["real_reward"], info[i]["num_steps"] (ClipRewardEnv.step,
