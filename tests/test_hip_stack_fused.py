@@ -348,3 +348,30 @@ def test_done_host_hands_over_the_flags_of_the_last_step():
         seen += int(h.sum())
     assert seen > n // 4
     env.close()
+
+
+@pytest.mark.parametrize("obs_dtype,stack_dtype", [("uint8", torch.float32), ("uint8", torch.uint8), ("float32_ref", torch.float32)])
+def test_bound_stack_long_run_with_natural_episode_ends(obs_dtype, stack_dtype):
+    """1 500 steps x 2 048 envs of random play: episodes end on their own (21 rounds), at every score pair a game passes through, with
+    points scored between the two kept frames of a plane (the score-transition tables) -- the bound stack against the generic one, every step."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n, R, k, steps = 2048, 84, 4, 1500
+    a, b = _twins(n, R, obs_dtype, seed=23)
+    dev = a.device
+    fa, fb = crl.FrameStackTensor(n, (1, R, R), k, dev, dtype=stack_dtype), crl.FrameStackTensor(n, (1, R, R), k, dev)
+    fb._bind_tried = True
+    ba, bb = _books(n, dev), _books(n, dev)
+    fa.update(a.reset()[0]), fb.update(b.reset()[0])
+    gen = torch.Generator(device=dev).manual_seed(4)
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for t in range(steps):
+        acts = torch.randint(0, 3, (n, 2), generator=gen, device=dev, dtype=torch.int32)
+        _step_envs(crl, a, fa, acts, ba, dev), _step_envs(crl, b, fb, acts, bb, dev)
+        bad += (fa.get().float() != fb.get()).any().to(torch.int64)   # (no host synchronisation per step: summed on the device)
+    assert int(bad) == 0, int(bad)
+    assert fa.fused_updates == steps and ba["episodes"] == bb["episodes"] and ba["episodes"] > n, (fa.fused_updates, ba["episodes"])
+    st = a.get_state()
+    assert st["score_l"].max() >= 10 and st["score_r"].max() >= 10   # (late-game score pairs were on the screen)
+    a.close(), b.close()
