@@ -1223,9 +1223,12 @@ void launch_pong_raster_gray_ex(const GrayParams &p, const uint8_t *rest, int ze
     const GrayStack &sk = p.stack;
     if (sk.out) {  // FrameStackTensor fused into the draw: the env's jobs = the stack's planes + the observation's tiles
         const int jobs = sk.k + (p.obs ? q.views * p.K - (sk.alias ? 1 : 0) : 0);
-        static const int jpw_env = CRL_ABL(getenv("CRL_GRAY_JPW") ? atoi(getenv("CRL_GRAY_JPW")) : 0);
-        int jpw = p.n >= 8192 ? jobs : 1;
+        static const int jpw_env = CRL_ABL(getenv("CRL_GRAY_JPW") != nullptr) ? atoi(getenv("CRL_GRAY_JPW")) : 0;
+        // jobs per wavefront: a uint8 stack is fastest with the whole env in one wavefront (497 us; two / three jobs: 655 / 576); a float32
+        // stack with two (five alternating pairs, tools/ab/r06_stack_jpw2.sh: - 1.2 ... - 7.5 % against the whole env, mean - 3 %)
+        int jpw = p.n >= 8192 ? (sk.f32 ? 2 : jobs) : 1;
         if (jpw_env > 0) jpw = jpw_env;
+        if (jpw_env < 0) jpw = jobs;  // (profiling build: CRL_GRAY_JPW=-1 = all of the env's jobs)
         const int64_t waves = p.n * ((jobs + jpw - 1) / jpw);
         const dim3 grid((unsigned)((waves + 3) / 4));
         const int ti = tofs.max_taps <= 3 ? 0 : (p.R * p.R <= 2048 && !small_off) ? 1 : 2;
