@@ -119,9 +119,9 @@ class FrameStackTensor:
         content cannot be explained by the env's history stays generic until it can."""
         self._bind_tried = True
         env = getattr(envs, "_stack_env", lambda: None)()
-        if env is None or self._lib is None or not self.out_of_place:
+        if env is None or not self.out_of_place:
             return False
-        if not env._can_draw_stack(self):
+        if not env._can_draw_stack(self):  # (the HIP env asks for its own device: a host-resident stack never binds to it)
             return False
         other = env._bound_stack() if env._bound_stack is not None else None
         if other is not None and other is not self:
