@@ -501,8 +501,8 @@ def run_workload(name, args, G):
                            "frac": ach / FP32_PEAK, "traffic": None, "avg_kernel_us": k_us, "launches_timed": len(policy_events)}
         return res
     if name == "tournament":
-        if os.environ.get("CRL_LIB_VARIANT") and os.environ.get("CRL_POLICY_MFMA", "1") != "1":
-            return res  # (profiling build with the packed-FMA network selected: the matrix-pipe instruction mix priced below is not what ran)
+        if os.environ.get("CRL_LIB_VARIANT") and os.environ.get("CRL_POLICY_MFMA", "3") != "3":
+            return res  # (profiling build with another form of the network selected -- 0 packed FMA, 1 conv1 on the fp32 matrix instruction: the bf16 x 3 instruction mix priced below is not what ran)
         k_us = sum(a.elapsed_time(b) for a, b in policy_events) / max(len(policy_events), 1) * 1e3
         # matrix-pipe kernel: per tile of 16 conv2 positions (6.25 tiles per env) conv1 = 24 v_mfma_f32_16x16x32_bf16 (three exact
         # bf16 products per tap, 16 cycles each), conv2 = 16 v_mfma_f32_16x16x4_f32 (32 cycles): EXECUTED matrix FLOP against the issue-rate
