@@ -10,8 +10,8 @@ from .frame_stack import FrameStackTensor
 from .tournament import TournamentEnvWrapper
 from .policy_serving import Policy
 from .competitive_car import make_competitive_car_racing
-from .utils import step_envs
+from .utils import evaluate, step_envs
 from .sharding import ShardSpec, StepGather, all_gather_step, shard_of
 
-__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "step_envs", "CHEAT_CODES",
+__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "step_envs", "evaluate", "CHEAT_CODES",
            "ShardSpec", "shard_of", "all_gather_step", "StepGather"]

@@ -23,7 +23,7 @@ observation, and the update here is a pointer swap; other envs / stacks: one ker
 import numpy as np
 import torch
 
-__all__ = ["step_envs"]
+__all__ = ["step_envs", "evaluate"]
 
 
 def _per_env_done(done):
@@ -100,3 +100,40 @@ def step_envs(cpu_actions, envs, episode_rewards, frame_stack_tensor, reward_rec
     else:
         frame_stack_tensor.update(learner_obs, stack_mask)
     return obs, reward, ended, info, masks, total_episodes, total_steps, episode_rewards
+
+
+def evaluate(trainer, eval_envs, frame_stack, num_episodes=10, seed=0):
+    """Runs ``trainer``'s greedy policy on ``eval_envs`` until ``num_episodes`` episodes have ended and returns
+    ``(reward_recorder, episode_length_recorder)`` -- the reference's evaluation loop (utils/utils.py:102-142), call for call:
+    a fresh ``FrameStackTensor``, ``eval_envs.seed(seed)``, ``reset()``, the first observation pushed, then ``step_envs`` with the
+    actions of ``trainer.compute_action(stack, deterministic=True)[1]``.
+
+    With the HIP env nothing of the loop crosses PCIe but the done flags: the stack is bound to the env by the first ``step_envs``
+    call (drawn by the step), the actions go from the policy to the env as a device tensor, the running returns live on the device.
+    ``trainer`` needs ``.device`` and ``.compute_action(obs, deterministic=True) -> (..., actions, ...)`` as the reference's trainers have."""
+    from .frame_stack import FrameStackTensor
+
+    device = torch.device(trainer.device)
+    fst = FrameStackTensor(eval_envs.num_envs, eval_envs.observation_space.shape, frame_stack, device)
+    on_device = device.type == "cuda"
+
+    def get_action():
+        obs = fst.get()
+        with torch.no_grad():
+            act = trainer.compute_action(obs, deterministic=True)[1]
+        act = torch.as_tensor(act).reshape(-1)
+        return act.to(device=device, dtype=torch.int32) if on_device else act.cpu().numpy()
+
+    reward_recorder, episode_length_recorder = [], []
+    episode_rewards = torch.zeros((eval_envs.num_envs, 1), dtype=torch.float32, device=device) if on_device else np.zeros([eval_envs.num_envs, 1], dtype=np.float64)
+    total_steps = total_episodes = 0
+    eval_envs.seed(seed)
+    obs = eval_envs.reset()
+    fst.update(obs[0] if isinstance(obs, tuple) else obs)
+    while True:
+        out = step_envs(get_action(), eval_envs, episode_rewards, fst, reward_recorder, episode_length_recorder, total_steps, total_episodes,
+                        device, frame_stack == 1)
+        total_episodes, total_steps, episode_rewards = out[5], out[6], out[7]
+        if total_episodes >= num_episodes:
+            break
+    return reward_recorder, episode_length_recorder
