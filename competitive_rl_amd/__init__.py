@@ -11,7 +11,8 @@ from .tournament import TournamentEnvWrapper
 from .policy_serving import Policy
 from .competitive_car import make_competitive_car_racing
 from .utils import evaluate, step_envs
+from .pong_evaluate import evaluate_two_policies, evaluate_two_policies_in_batch
 from .sharding import ShardSpec, StepGather, all_gather_step, shard_of
 
-__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "step_envs", "evaluate", "CHEAT_CODES",
+__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "step_envs", "evaluate", "evaluate_two_policies", "evaluate_two_policies_in_batch", "CHEAT_CODES",
            "ShardSpec", "shard_of", "all_gather_step", "StepGather"]

@@ -59,3 +59,31 @@ class Tuple(Space):
 
     def __repr__(self):
         return "Tuple(" + ", ".join(map(repr, self.spaces)) + ")"
+
+
+class Dict(Space):
+    """gym.spaces.Dict as the reference uses it for the two cars' actions (car_racing_multi_players.py:245: ``{0: Box, 1: Box}``)."""
+
+    def __init__(self, spaces):
+        self.spaces = dict(spaces)
+
+    def __len__(self):
+        return len(self.spaces)
+
+    def __getitem__(self, k):
+        return self.spaces[k]
+
+    def __iter__(self):
+        return iter(self.spaces)
+
+    def keys(self):
+        return self.spaces.keys()
+
+    def contains(self, x):
+        return isinstance(x, dict) and x.keys() == self.spaces.keys() and all(s.contains(x[k]) for k, s in self.spaces.items())
+
+    def sample(self):
+        return {k: s.sample() for k, s in self.spaces.items()}
+
+    def __repr__(self):
+        return "Dict(" + ", ".join(f"{k}:{s!r}" for k, s in self.spaces.items()) + ")"

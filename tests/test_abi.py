@@ -126,3 +126,18 @@ def test_shipped_library_carries_no_debug_switches_or_superseded_kernels():
     assert kernels and not (kernels & dead), sorted(kernels & dead)
     assert {"car_obs_kernel", "car_touch_kernel", "pong_raster_raw_sweep_kernel", "pong_raster_gray_env_kernel", "pong_policy_mfma_kernel"} <= kernels
     assert os.path.basename(N.LIB_PATH) == "libcrl_hip.so" or os.environ.get("CRL_LIB_VARIANT")
+
+
+def test_spaces_mirror_the_gym_classes_the_reference_builds():
+    """Box / Discrete / Tuple / Dict: constructor arguments, ``sample`` / ``contains`` and indexing as the reference uses them
+    (pong/base_pong_env.py:91-101; car_racing_multi_players.py:237-245: two cars' actions are a Dict {0: Box(2,), 1: Box(2,)})."""
+    from competitive_rl_amd import spaces
+
+    one = spaces.Box(-1, 1, (2,), dtype=np.float32)
+    both = spaces.Dict({i: one for i in range(2)})
+    a = both.sample()
+    assert list(a.keys()) == [0, 1] and all(v.shape == (2,) and v.dtype == np.float32 for v in a.values())
+    assert both.contains(a) and not both.contains({0: a[0]}) and not both.contains({0: a[0], 1: np.array([2.0, 0.0], np.float32)})
+    assert both[0] is one and len(both) == 2 and list(both) == [0, 1]
+    t = spaces.Tuple([spaces.Discrete(3), spaces.Discrete(3)])
+    assert len(t) == 2 and t[1].n == 3 and all(0 <= x < 3 for x in t.sample())

@@ -1,0 +1,71 @@
+"""The reference's own test scripts (competitive_rl/test/test_pong.py, test_car_racing.py), call for call, through this package's
+``make_envs`` on the GPU: same arguments, same attribute accesses, the shapes the reference prints.  (test_make_car_racing_double.py builds
+ONE gym env through ``make_car_racing_double(...)()``: the single-env facade is not on the vectorised hot path -- the same env as a
+batch of one is ``make_envs("cCarRacingDouble-v0", num_envs=1, ...)``, exercised below.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on the MI355X box")
+
+
+def test_reference_test_pong_script(tmp_path):
+    _need_gpu()
+    from competitive_rl_amd import make_envs
+
+    envs = make_envs(
+        env_id="cPong-v0",
+        seed=0,
+        log_dir=str(tmp_path / "demo"),  # this will create a "demo" directory
+        num_envs=1,
+        asynchronous=False,
+        resized_dim=42
+    )
+    env = envs.envs[0]
+    obs = envs.reset()
+    env.close()
+    assert os.path.isdir(tmp_path / "demo")
+    assert tuple(obs.shape) == (1, 4, 42, 42)          # (the reference prints this: FrameStack(4) of (1, 42, 42) frames, one env)
+    assert env.observation_space.shape == (4, 42, 42) and env.action_space.n == 3
+    envs.close()
+
+
+def test_reference_test_car_racing_script(tmp_path):
+    _need_gpu()
+    from competitive_rl_amd import make_envs
+
+    envs = make_envs(
+        env_id="cCarRacing-v0",
+        seed=0,
+        log_dir=str(tmp_path / "demo"),  # this will create a "demo" directory
+        num_envs=5,
+        asynchronous=True,
+        resized_dim=42
+    )
+    obs = envs.reset()
+    assert tuple(obs.shape) == (5, 4, 96, 96)          # frame_stack defaults to 4; resized_dim does not apply to CarRacing (96 x 96 as rendered)
+    assert os.path.isdir(tmp_path / "demo")
+    envs.close()
+
+
+def test_reference_make_car_racing_double_as_a_batch_of_one():
+    """make_car_racing_double(0, 0, 4, None)(); reset(); step(action_space.sample()); close()  -- as one env of the vector backend"""
+    _need_gpu()
+    from competitive_rl_amd import make_envs
+
+    e = make_envs("cCarRacingDouble-v0", seed=0, log_dir=None, num_envs=1, frame_stack=4, action_repeat=None)
+    obs = e.reset()
+    a = e.action_space.sample()                        # the reference's Dict {0: Box(2,), 1: Box(2,)} (car_racing_multi_players.py:237-245)
+    assert set(a.keys()) == {0, 1} and all(np.asarray(v).shape == (2,) for v in a.values()) and e.action_space.contains(a)
+    obs2, rew, done, info = e.step([a])                # one env: a list of one per-env action, indexed by car key as the reference does
+    assert tuple(obs.shape) == tuple(obs2.shape) and obs.shape[0] == 1 and tuple(rew.shape) == (1, 2)
+    obs3, rew3, _, _ = e.step(np.stack([a[0], a[1]])[None])     # the same action as an (N, 2, 2) array
+    assert tuple(obs3.shape) == tuple(obs.shape)
+    e.close()
