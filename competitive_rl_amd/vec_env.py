@@ -51,9 +51,27 @@ class VecEnv(ABC):
         self.step_async(actions)
         return self.step_wait()
 
+    def get_images(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def render(self, mode="rgb_array", *args, **kwargs):
+        """utils/base_vec_env.py:173-192 and DummyVecEnv.render (dummy_vec_env.py:87-102): one env -> its own image, several ->
+        all of them tiled into one picture (``tile_images``).  mode="human" would open a window (cv2.imshow): there is no display
+        on a GPU node."""
+        imgs = self.get_images(*args, **kwargs)
+        if mode == "rgb_array":
+            return imgs[0] if self.num_envs == 1 else tile_images(imgs)
+        raise NotImplementedError("only mode='rgb_array' is available on the GPU backend")
+
     @property
     def unwrapped(self):
-        return self
+        return self.venv.unwrapped if isinstance(self, VecEnvWrapper) else self
+
+    def getattr_depth_check(self, name, already_found):
+        """Name of this class when it holds ``name`` and a wrapper above already did (base_vec_env.py:201-212)."""
+        if hasattr(self, name) and already_found:
+            return "{0}.{1}".format(type(self).__module__, type(self).__name__)
+        return None
 
     def _get_indices(self, indices):
         if indices is None:
@@ -61,6 +79,92 @@ class VecEnv(ABC):
         elif isinstance(indices, int):
             indices = [indices]
         return indices
+
+
+def tile_images(img_nhwc):
+    """N images of one size as ONE picture of P x Q cells, row-major, P = ceil(sqrt(N)) rows and Q = ceil(N / P) columns, the
+    unused cells black (what ``VecEnv.render`` shows for several envs, utils/base_vec_env.py:10-38).  Gray (N, H, W) frames --
+    CarRacing's -- give an (P H, Q W) picture."""
+    imgs = np.asarray(img_nhwc)
+    gray = imgs.ndim == 3
+    if gray:
+        imgs = imgs[..., None]
+    n, h, w, c = imgs.shape
+    rows = int(np.ceil(np.sqrt(n)))
+    cols = int(np.ceil(float(n) / rows))
+    sheet = np.zeros((rows * cols, h, w, c), imgs.dtype)
+    sheet[:n] = imgs
+    big = sheet.reshape(rows, cols, h, w, c).swapaxes(1, 2).reshape(rows * h, cols * w, c)
+    return big[..., 0] if gray else big
+
+
+class VecEnvWrapper(VecEnv):
+    """Base class of wrappers around a vector env (utils/base_vec_env.py:255-374): forwards ``step_async``, ``seed``, ``close``,
+    ``render``, ``get_images``, ``get_attr`` / ``set_attr`` / ``env_method`` to ``venv``; a subclass provides ``reset`` and
+    ``step_wait``.  Attributes the wrapper does not have are looked up down the chain of wrappers; one that a wrapper AND something
+    below it define is refused as ambiguous, as in the reference."""
+
+    def __init__(self, venv, observation_space=None, action_space=None):
+        self.venv = venv
+        VecEnv.__init__(self, num_envs=venv.num_envs, observation_space=observation_space or venv.observation_space,
+                        action_space=action_space or venv.action_space)
+        self.class_attributes = {k for klass in type(self).__mro__ for k in vars(klass)}
+
+    def step_async(self, actions):
+        self.venv.step_async(actions)
+
+    @abstractmethod
+    def reset(self):
+        pass
+
+    @abstractmethod
+    def step_wait(self):
+        pass
+
+    def seed(self, seed=None):
+        return self.venv.seed(seed)
+
+    def close(self):
+        return self.venv.close()
+
+    def render(self, *args, **kwargs):
+        return self.venv.render(*args, **kwargs)
+
+    def get_images(self, *args, **kwargs):
+        return self.venv.get_images(*args, **kwargs)
+
+    def get_attr(self, attr_name, indices=None):
+        return self.venv.get_attr(attr_name, indices)
+
+    def set_attr(self, attr_name, value, indices=None):
+        return self.venv.set_attr(attr_name, value, indices)
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        return self.venv.env_method(method_name, *method_args, indices=indices, **method_kwargs)
+
+    def _own(self, name):
+        return name in self.__dict__ or name in self.class_attributes
+
+    def __getattr__(self, name):  # (only reached when normal lookup failed)
+        if name in ("venv", "class_attributes"):
+            raise AttributeError(name)
+        blocked = self.getattr_depth_check(name, already_found=False)
+        if blocked is not None:
+            raise AttributeError("Error: Recursive attribute lookup for {0} from {1}.{2} is ambiguous and hides attribute from {3}".format(
+                name, type(self).__module__, type(self).__name__, blocked))
+        return self.getattr_recursive(name)
+
+    def getattr_recursive(self, name):
+        if self._own(name):
+            return getattr(self, name)
+        if hasattr(self.venv, "getattr_recursive"):
+            return self.venv.getattr_recursive(name)
+        return getattr(self.venv, name)
+
+    def getattr_depth_check(self, name, already_found):
+        if self._own(name) and already_found:
+            return "{0}.{1}".format(type(self).__module__, type(self).__name__)
+        return self.venv.getattr_depth_check(name, already_found or self._own(name))
 
 
 class LazyInfos:
@@ -433,12 +537,6 @@ class HipPongVecEnv(VecEnv):
         for k in ("ball_x", "ball_y", "bat_l_y", "bat_r_y", "score_l", "score_r"):
             frames[k] = st[k]
         return list(self.render_frames(frames)[:, 0].cpu().numpy())
-
-    def render(self, mode="rgb_array", *args, **kwargs):
-        imgs = self.get_images()
-        if mode == "rgb_array":
-            return imgs[0] if self.num_envs == 1 else np.stack(imgs)
-        raise NotImplementedError("only mode='rgb_array' is available on the GPU backend")
 
     # ------------------------------------------------------------------ extras (parity tests, checkpoint)
     def terminal_observation(self, env_indices):

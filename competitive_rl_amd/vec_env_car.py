@@ -232,12 +232,6 @@ class HipCarVecEnv(VecEnv):
         """Agent 0's newest 96 x 96 frame of every env (what the reference's get_observation(0) returned last)."""
         return list(self._obs[self._flip ^ 1][:, self.K - 1].cpu().numpy())
 
-    def render(self, mode="rgb_array", *args, **kwargs):
-        imgs = self.get_images()
-        if mode == "rgb_array":
-            return imgs[0] if self.num_envs == 1 else np.stack(imgs)
-        raise NotImplementedError("only mode='rgb_array' is available on the GPU backend")
-
     def terminal_observation(self, env_indices):
         """Observation (P*K, 96, 96) each listed env's episode ended on, at its most recent done step.  ``env_indices``
         may be a device tensor (``torch.nonzero(done)``): one gather kernel, no host round trip."""

@@ -141,3 +141,84 @@ def test_spaces_mirror_the_gym_classes_the_reference_builds():
     assert both[0] is one and len(both) == 2 and list(both) == [0, 1]
     t = spaces.Tuple([spaces.Discrete(3), spaces.Discrete(3)])
     assert len(t) == 2 and t[1].n == 3 and all(0 <= x < 3 for x in t.sample())
+
+
+def test_tile_images_and_vec_env_wrapper_follow_the_reference_contract():
+    """``tile_images`` (utils/base_vec_env.py:10-38) and ``VecEnvWrapper`` (:255-374) on a toy vector env: the grid shape and cell order,
+    forwarding, attribute lookup down the chain, the ambiguity error, ``unwrapped``."""
+    import pytest
+
+    from competitive_rl_amd import VecEnv, VecEnvWrapper, spaces, tile_images
+
+    imgs = [np.full((2, 3, 3), k + 1, np.uint8) for k in range(5)]          # 5 images -> 3 rows x 2 columns, last cell black
+    big = tile_images(imgs)
+    assert big.shape == (6, 6, 3) and (big[:2, :3] == 1).all() and (big[:2, 3:] == 2).all() and (big[2:4, :3] == 3).all()
+    assert (big[4:, :3] == 5).all() and (big[4:, 3:] == 0).all()
+    assert tile_images(np.ones((4, 2, 2, 1))).shape == (4, 4, 1) and tile_images(np.ones((1, 2, 2, 3))).shape == (2, 2, 3)
+    assert tile_images(np.ones((3, 96, 96), np.uint8)).shape == (192, 192)   # gray frames (CarRacing)
+
+    class Toy(VecEnv):
+        color = "red"
+
+        def __init__(self):
+            VecEnv.__init__(self, 3, spaces.Box(0, 255, (1, 4, 4), dtype=np.uint8), spaces.Discrete(3))
+            self.sent, self.closed, self.depth = None, False, 0
+
+        def reset(self):
+            return np.zeros((3, 1, 4, 4), np.uint8)
+
+        def step_async(self, actions):
+            self.sent = actions
+
+        def step_wait(self):
+            return self.reset(), np.ones(3, np.float32), np.zeros(3, bool), [{} for _ in range(3)]
+
+        def close(self):
+            self.closed = True
+
+        def seed(self, seed=None):
+            return [seed + i for i in range(3)]
+
+        def get_images(self):
+            return [np.full((4, 4, 3), i, np.uint8) for i in range(3)]
+
+        def get_attr(self, name, indices=None):
+            return [getattr(self, name)] * len(self._get_indices(indices))
+
+        def set_attr(self, name, value, indices=None):
+            setattr(self, name, value)
+
+        def env_method(self, name, *a, indices=None, **k):
+            return [name] * len(self._get_indices(indices))
+
+    class Scale(VecEnvWrapper):
+        def __init__(self, venv, k):
+            VecEnvWrapper.__init__(self, venv)
+            self.k = k
+
+        def reset(self):
+            return self.venv.reset()
+
+        def step_wait(self):
+            o, r, d, i = self.venv.step_wait()
+            return o, r * self.k, d, i
+
+    toy = Toy()
+    w = Scale(Scale(toy, 2.0), 3.0)
+    assert w.num_envs == 3 and w.observation_space is toy.observation_space and w.action_space is toy.action_space
+    _, r, _, _ = w.step([0, 1, 2])
+    assert toy.sent == [0, 1, 2] and (r == 6.0).all()
+    assert w.seed(5) == [5, 6, 7] and w.get_attr("color", 1) == ["red"] and w.env_method("foo", indices=[0, 2]) == ["foo", "foo"]
+    assert w.render("rgb_array").shape == (8, 8, 3) and len(w.get_images()) == 3 and w.unwrapped is toy and toy.unwrapped is toy
+    assert w.color == "red" and w.depth == 0          # found two levels down
+    w.set_attr("depth", 4)
+    assert toy.depth == 4
+    with pytest.raises(AttributeError, match="ambiguous"):
+        w.getattr_depth_check  # noqa: B018  (resolves normally: defined on the class)
+        Scale.__getattr__(w, "k")                     # both wrappers own `k`: the lookup from above is refused
+    with pytest.raises(AttributeError):
+        w.no_such_thing
+    w.close()
+    assert toy.closed
+    with pytest.raises(TypeError):
+        VecEnvWrapper(toy)                            # abstract: reset / step_wait are the subclass's

@@ -286,8 +286,9 @@ def test_car_api_surface_and_time_limit():
     assert len(envs.envs) == 6 and envs.get_attr("action_space", [0, 2])[0] is envs.action_space
     envs.set_attr("note", 7, indices=1)
     assert envs.env_method("seed", 3, indices=[1]) == [None]
-    img = envs.render("rgb_array")
-    assert img.shape == (6, 96, 96) and img.dtype == np.uint8 and np.array_equal(img[2], envs.envs[2].render())
+    img = envs.render("rgb_array")   # six envs tiled 3 x 2, row-major (VecEnv.render -> tile_images, utils/base_vec_env.py:10-38,173-192)
+    assert img.shape == (288, 192) and img.dtype == np.uint8 and np.array_equal(img[96:192, :96], envs.envs[2].render())
+    assert np.array_equal(np.stack(envs.get_images())[5], img[192:, 96:])
     with pytest.raises(NotImplementedError):
         envs.render("human")
     envs.close()
@@ -295,7 +296,7 @@ def test_car_api_surface_and_time_limit():
     one = crl.make_envs("cCarRacing-v0", num_envs=2, frame_stack=4, log_dir=None)
     o = one.reset()
     assert tuple(o.shape) == (2, 4, 96, 96) and len(one.get_attr("observation_space")) == 2
-    assert one.render().shape == (2, 96, 96) and np.array_equal(one.render()[0], o[0, 3].cpu().numpy())
+    assert one.render().shape == (192, 96) and np.array_equal(one.render()[:96], o[0, 3].cpu().numpy())
     # TimeLimit.truncated follows the device's counter when step_device and step() are mixed, and across set_state
     st = one.get_state()
     st["elapsed"][:] = 997

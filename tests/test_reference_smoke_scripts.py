@@ -69,3 +69,32 @@ def test_reference_make_car_racing_double_as_a_batch_of_one():
     obs3, rew3, _, _ = e.step(np.stack([a[0], a[1]])[None])     # the same action as an (N, 2, 2) array
     assert tuple(obs3.shape) == tuple(obs.shape)
     e.close()
+
+
+def test_render_tiles_and_a_vec_env_wrapper_over_the_hip_env():
+    """``envs.render("rgb_array")`` of several envs is ONE tiled picture (VecEnv.render -> tile_images, utils/base_vec_env.py:10-38,173-192);
+    a user's ``VecEnvWrapper`` subclass (:255-374) wraps what ``make_envs`` returns and finds the env's attributes through the chain."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    envs = crl.make_envs("cPongDouble-v0", num_envs=3, frame_stack=None, log_dir=None, resized_dim=42)
+
+    class ClipObs(crl.VecEnvWrapper):
+        def reset(self):
+            return self.venv.reset()
+
+        def step_wait(self):
+            o, r, d, i = self.venv.step_wait()
+            return o, r * 2, d, i
+
+    w = ClipObs(envs)
+    o = w.reset()
+    o2, r, d, info = w.step(np.array([[0, 1], [2, 0], [999, 999]]))
+    assert tuple(o2[0].shape) == tuple(o[0].shape) == (3, 1, 42, 42) and tuple(r.shape) == (3, 2)
+    big = w.render("rgb_array")
+    each = envs.get_images()
+    assert big.shape == (2 * 210, 2 * 160, 3) and big.dtype == np.uint8
+    assert np.array_equal(big[:210, 160:], each[1]) and np.array_equal(big[210:, :160], each[2]) and not big[210:, 160:].any()
+    assert w.unwrapped is envs and w.device == envs.device and w.num_envs == 3
+    assert crl.make_envs("cPongDouble-v0", num_envs=1, frame_stack=None, log_dir=None).render().shape == (210, 160, 3)
+    w.close()
