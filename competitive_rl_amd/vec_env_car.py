@@ -101,10 +101,9 @@ class HipCarVecEnv(VecEnv):
         self._h = h
         n = int(num_envs)
         obs_space = spaces.Box(0, 255, (self.P * self.K, 96, 96), dtype=np.uint8)
-        # car_racing_multi_players.py:237-245: Box(-1, 1, (2,)) per car, a Dict {0: Box, 1: Box} for two players
-        act_space = spaces.Box(-1, 1, (2,), dtype=np.float32)
-        if self.P == 2:
-            act_space = spaces.Dict({i: act_space for i in range(2)})
+        # Box(-1, 1, (2,)) per car (car_racing_multi_players.py:237); the raw two-car env's Dict {0: Box, 1: Box} (:245) becomes
+        # Box(-1, 1, (num_players, 2)) under FlattenMultiAgentObservation (utils/atari_wrappers.py:316), which make_car_racing_double applies
+        act_space = spaces.Box(-1, 1, (2, 2) if self.P == 2 else (2,), dtype=np.float32)
         VecEnv.__init__(self, n, obs_space, act_space)
         dev = self.device
         self._obs = [torch.empty((n, self.P * self.K, 96, 96), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -145,7 +144,7 @@ class HipCarVecEnv(VecEnv):
             a = actions.to(device=self.device, dtype=torch.float32)
         else:
             if self.P == 2 and len(actions) and isinstance(actions[0], dict):
-                # the reference indexes an env's action by car key (car_racing_multi_players.py:550-555): action_space.sample() dicts work
+                # the reference indexes an env's action by car key (utils/atari_wrappers.py:325, car_racing_multi_players.py:550-555): per-env dicts {0: a0, 1: a1} work too
                 actions = [[a[k] for k in range(self.P)] for a in actions]
             a = torch.as_tensor(np.asarray(actions, dtype=np.float32)).to(self.device)
         if self.P == 1 and tuple(a.shape) == (self.num_envs, 2):

@@ -62,11 +62,13 @@ def test_reference_make_car_racing_double_as_a_batch_of_one():
 
     e = make_envs("cCarRacingDouble-v0", seed=0, log_dir=None, num_envs=1, frame_stack=4, action_repeat=None)
     obs = e.reset()
-    a = e.action_space.sample()                        # the reference's Dict {0: Box(2,), 1: Box(2,)} (car_racing_multi_players.py:237-245)
-    assert set(a.keys()) == {0, 1} and all(np.asarray(v).shape == (2,) for v in a.values()) and e.action_space.contains(a)
-    obs2, rew, done, info = e.step([a])                # one env: a list of one per-env action, indexed by car key as the reference does
-    assert tuple(obs.shape) == tuple(obs2.shape) and obs.shape[0] == 1 and tuple(rew.shape) == (1, 2)
-    obs3, rew3, _, _ = e.step(np.stack([a[0], a[1]])[None])     # the same action as an (N, 2, 2) array
+    a = e.action_space.sample()                        # Box(-1, 1, (2, 2)): FlattenMultiAgentObservation's action space (utils/atari_wrappers.py:316)
+    assert np.asarray(a).shape == (2, 2) and e.action_space.contains(a)
+    obs2, rew, done, info = e.step([a])                # one env: a list of one per-env action
+    # reward = car 0's (FlattenMultiAgentObservation returns r[0], :329), DummyVecEnv's (N, 1) buffers; both cars' in the infos
+    assert tuple(obs.shape) == tuple(obs2.shape) == (1, 8, 96, 96) and tuple(rew.shape) == (1, 1) and tuple(done.shape) == (1, 1)
+    assert float(info[0][0]["reward"]) == float(rew[0, 0]) and "reward" in info[0][1]
+    obs3, rew3, _, _ = e.step([{0: a[0], 1: a[1]}])    # the raw env's Dict form {car: action} (car_racing_multi_players.py:245) is indexed the same way
     assert tuple(obs3.shape) == tuple(obs.shape)
     e.close()
 
