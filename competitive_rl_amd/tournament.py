@@ -30,6 +30,20 @@ def get_builtin_agent_names():
     return BUILTIN_AGENT_NAMES
 
 
+def get_rule_based_policy(num_envs=1):
+    """pong/builtin_policies.py:44-48: the cheat code for one env, a list of it for several (the step kernel resolves 999 = auto_action)."""
+    if num_envs == 1:
+        return lambda _: CHEAT_CODES
+    return lambda _: [CHEAT_CODES] * num_envs
+
+
+def get_random_policy(num_envs=1):
+    """pong/builtin_policies.py:51-58 (numpy's global generator, as there)."""
+    if num_envs == 1:
+        return lambda obs: np.random.randint(3)
+    return lambda obs: [np.random.randint(3) for _ in range(num_envs)]
+
+
 def get_compute_action_function(agent_name, num_envs=1, device=None):
     """pong/builtin_policies.py:61-91."""
     if agent_name in BUILTIN_CHECKPOINTS:

@@ -222,3 +222,26 @@ def test_tile_images_and_vec_env_wrapper_follow_the_reference_contract():
     assert toy.closed
     with pytest.raises(TypeError):
         VecEnvWrapper(toy)                            # abstract: reset / step_wait are the subclass's
+
+
+def test_package_exports_the_reference_packages_top_level_names():
+    """``import competitive_rl_amd as competitive_rl`` finds what ``competitive_rl/__init__.py:1-6`` exports (PrintConsole, the trainer's
+    console printer, excepted: host bookkeeping outside the path), with the reference's calling conventions for the small policies."""
+    import competitive_rl_amd as crl
+
+    for name in ("make_envs", "get_random_policy", "get_rule_based_policy", "get_compute_action_function", "get_builtin_agent_names",
+                 "evaluate_two_policies_in_batch", "evaluate_two_policies", "register_pong", "register_car_racing", "register_competitive_envs",
+                 "FrameStackTensor", "make_competitive_car_racing", "TournamentEnvWrapper"):
+        assert callable(getattr(crl, name)), name
+    assert crl.register_competitive_envs() is None
+    assert crl.get_rule_based_policy()(None) == crl.CHEAT_CODES == 999 and crl.get_rule_based_policy(3)(None) == [999] * 3
+    a = crl.get_random_policy(5)(None)
+    assert len(a) == 5 and all(x in (0, 1, 2) for x in a) and crl.get_random_policy()(None) in (0, 1, 2)
+    assert set(crl.get_builtin_agent_names()) >= {"RANDOM", "WEAK", "MEDIUM", "RULE_BASED"}
+    assert crl.get_compute_action_function("RULE_BASED", 2)(None).tolist() == [999, 999]
+    try:
+        crl.get_compute_action_function("NOBODY")
+    except ValueError as e:
+        assert "Unknown agent name" in str(e)
+    else:
+        raise AssertionError("unknown agent accepted")
