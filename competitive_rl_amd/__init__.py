@@ -3,7 +3,7 @@
 Importing the package does not touch the GPU; constructing an env loads libcrl_hip.so and
 fails loudly if it is missing (no CPU fallback exists in this package).
 """
-from .make_envs import make_envs
+from .make_envs import DummyVecEnv, EnvThunk, SubprocVecEnv, make_car_racing, make_car_racing_double, make_env_a2c_atari, make_envs
 from .vec_env import CHEAT_CODES, HipPongVecEnv, LazyInfos, VecEnv, VecEnvWrapper, tile_images
 from .vec_env_car import HipCarVecEnv
 from .frame_stack import FrameStackTensor
@@ -32,6 +32,6 @@ def register_competitive_envs():
     register_car_racing()
 
 
-__all__ = ["make_envs", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "VecEnvWrapper", "tile_images", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "step_envs", "evaluate", "evaluate_two_policies", "evaluate_two_policies_in_batch", "CHEAT_CODES", "get_builtin_agent_names", "get_compute_action_function", "get_random_policy", "get_rule_based_policy",
+__all__ = ["make_envs", "DummyVecEnv", "SubprocVecEnv", "make_env_a2c_atari", "make_car_racing", "make_car_racing_double", "EnvThunk", "HipPongVecEnv", "HipCarVecEnv", "VecEnv", "VecEnvWrapper", "tile_images", "LazyInfos", "FrameStackTensor", "TournamentEnvWrapper", "Policy", "make_competitive_car_racing", "step_envs", "evaluate", "evaluate_two_policies", "evaluate_two_policies_in_batch", "CHEAT_CODES", "get_builtin_agent_names", "get_compute_action_function", "get_random_policy", "get_rule_based_policy",
            "register_pong", "register_car_racing", "register_competitive_envs",
            "ShardSpec", "shard_of", "all_gather_step", "StepGather"]

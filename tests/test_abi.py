@@ -245,3 +245,32 @@ def test_package_exports_the_reference_packages_top_level_names():
         assert "Unknown agent name" in str(e)
     else:
         raise AssertionError("unknown agent accepted")
+
+
+def test_thunk_factories_and_vec_env_constructors_without_a_gpu():
+    """``DummyVecEnv([make_env_a2c_atari(...) for i in range(n)])`` -- the reference's own way to build a batch (make_envs.py:100-117) --
+    validates its thunks on the host and then fails loudly without a GPU, like every env constructor of the package."""
+    import pytest
+    import torch
+
+    import competitive_rl_amd as crl
+
+    t = [crl.make_env_a2c_atari("cPongDouble-v0", 0, i, None, 42, None) for i in range(3)]
+    assert [x.rank for x in t] == [0, 1, 2] and t[0].key() == t[2].key() and isinstance(t[0], crl.EnvThunk)
+    with pytest.raises(ValueError, match="consecutive"):
+        crl.DummyVecEnv([t[0], t[2]])
+    with pytest.raises(ValueError, match="one batch"):
+        crl.SubprocVecEnv([t[0], crl.make_env_a2c_atari("cPongDouble-v0", 0, 1, None, 84, None)])
+    with pytest.raises(TypeError):
+        crl.DummyVecEnv([lambda: None])
+    with pytest.raises(TypeError):
+        crl.DummyVecEnv([])
+    with pytest.raises(AssertionError):
+        crl.make_car_racing("cPong-v0", 0, 0)
+    c = crl.make_car_racing_double(5, 2, frame_stack=4, action_repeat=2)
+    assert (c.env_id, c.seed, c.rank, c.frame_stack, c.action_repeat) == ("cCarRacingDouble-v0", 5, 2, 4, 2)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="GPU"):
+            crl.DummyVecEnv(t)
+        with pytest.raises(RuntimeError, match="GPU"):
+            t[1]()

@@ -100,3 +100,34 @@ def test_render_tiles_and_a_vec_env_wrapper_over_the_hip_env():
     assert w.unwrapped is envs and w.device == envs.device and w.num_envs == 3
     assert crl.make_envs("cPongDouble-v0", num_envs=1, frame_stack=None, log_dir=None).render().shape == (210, 160, 3)
     w.close()
+
+
+def test_vec_env_constructors_over_thunks_equal_make_envs():
+    """The reference builds its batches as ``DummyVecEnv([make_env_a2c_atari(id, seed, i, log_dir, R, K) for i in range(n)])``
+    (make_envs.py:100-117; SubprocVecEnv when asynchronous): the same calls here give the batch ``make_envs`` gives -- same observations
+    step for step --, a thunk called by itself is env ``rank`` of that batch, and a SubprocVecEnv of ONE env keeps the worker convention."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    n = 5
+    a = crl.DummyVecEnv([crl.make_env_a2c_atari("cPongDouble-v0", 7, i, None, 42, None) for i in range(n)])
+    b = crl.make_envs("cPongDouble-v0", seed=7, log_dir=None, num_envs=n, resized_dim=42, frame_stack=None)
+    one = crl.make_env_a2c_atari("cPongDouble-v0", 7, 3, None, 42, None)()          # env 3 of the batch, on its own
+    sub = crl.SubprocVecEnv([crl.make_env_a2c_atari("cPongDouble-v0", 7, 0, None, 42, None)])
+    oa, ob, o1 = a.reset(), b.reset(), one.reset()
+    sub.reset()
+    rs = np.random.RandomState(0)
+    for t in range(300):
+        act = rs.randint(0, 3, (n, 2))
+        (oa, ra, da, _), (ob, rb, db, _) = a.step(act), b.step(act)
+        o1, r1, d1, _ = one.step(act[3:4])
+        _, _, ds, _ = sub.step(act[:1])
+        assert all(torch.equal(x, y) for x, y in zip(oa, ob)) and torch.equal(ra, rb) and torch.equal(da, db), t
+        assert torch.equal(o1[0][0], oa[0][3]) and torch.equal(o1[1][0], oa[1][3]) and torch.equal(r1[0], ra[3]), t
+        assert tuple(da.shape) == (n, 2) and tuple(ds.shape) == (1,)
+    cars = crl.SubprocVecEnv([crl.make_car_racing_double(1, i, frame_stack=4) for i in range(2)])
+    oc = cars.reset()
+    oc2, rc, dc, _ = cars.step(np.zeros((2, 2, 2), np.float32))
+    assert tuple(oc2.shape) == tuple(oc.shape) == (2, 8, 96, 96) and tuple(dc.shape) == (2,) and tuple(rc.shape) == (2,)
+    for e in (a, b, one, sub, cars):
+        e.close()
