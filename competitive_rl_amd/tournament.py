@@ -50,9 +50,9 @@ def get_compute_action_function(agent_name, num_envs=1, device=None):
         return Policy(single_obs_space, single_act_space, num_envs, BUILTIN_CHECKPOINTS[agent_name], use_light_model=True,
                       device=device)
     if agent_name == "RANDOM":
-        return lambda obs: np.random.randint(0, 3, size=num_envs)
+        return get_random_policy(num_envs)
     if agent_name == "RULE_BASED":
-        return lambda obs: np.full(num_envs, CHEAT_CODES, dtype=np.int64)
+        return get_rule_based_policy(num_envs)
     raise ValueError("Unknown agent name: {}".format(agent_name))
 
 

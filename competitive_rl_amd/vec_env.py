@@ -230,8 +230,12 @@ class LazyInfos:
 
 
 class _EnvHandle:
-    """What ``DummyVecEnv.envs[i]`` offers to the reference's scripts (vis.py:30-31,
-    test/test_pong.py:13): close() and render()."""
+    """What ``DummyVecEnv.envs[i]`` offers to the reference's scripts (vis.py:28-46, test/test_pong.py:13): ``close()``, ``render()`` and
+    -- for a batch of ONE env, which is what vis.py builds -- the gym calls ``reset()`` / ``step(action)`` of that env: the observation
+    without the batch axis (a tuple of the two agents' for Pong), the reward row, a scalar ``done``, the env's info dict.  The vector env
+    restarts a finished env by itself; the handle returns the episode's LAST observation with ``done`` (gym's contract) and its next
+    ``reset()`` hands out the restarted episode's first observation instead of resetting a second time -- the env sees exactly the
+    resets a gym loop (``while not done: step``, then ``reset``) would issue."""
 
     def __init__(self, venv, idx):
         self._venv, self._idx = venv, idx
@@ -246,6 +250,39 @@ class _EnvHandle:
 
     def seed(self, seed=None):
         return None
+
+    def _alone(self):
+        if self._venv.num_envs != 1:
+            raise NotImplementedError("a GPU batch steps as a whole (envs.reset() / envs.step(actions)); envs.envs[i].reset() / .step() exist for "
+                                      "a batch of ONE env, make_envs(..., num_envs=1)")
+        return self._venv
+
+    @staticmethod
+    def _first(obs):
+        return tuple(o[0] for o in obs) if isinstance(obs, tuple) else obs[0]
+
+    def reset(self):
+        v = self._alone()
+        pending = getattr(v, "_handle_restarted", None)
+        v._handle_restarted = None
+        if pending is not None and pending[0] == v._serial:  # the episode ended on the last step: the vector env has already restarted it
+            return self._first(pending[1])
+        return self._first(v.reset())
+
+    def step(self, action):
+        v = self._alone()
+        space = v.action_space
+        shape = (len(space),) if hasattr(space, "spaces") else tuple(space.shape or ())
+        scalar = lambda x: x.reshape(-1)[0].item() if isinstance(x, torch.Tensor) else np.asarray(x).reshape(-1)[0]  # noqa: E731
+        a = np.asarray([scalar(x) for x in action] if hasattr(space, "spaces") else (action.cpu().numpy() if isinstance(action, torch.Tensor) else action))
+        obs, rew, done, info = v.step(a.reshape((1,) + shape))
+        d = bool(np.asarray(done.cpu() if isinstance(done, torch.Tensor) else done).reshape(-1).all())
+        i0 = info[0]
+        ob = self._first(obs)
+        if d:
+            v._handle_restarted = (v._serial, obs)
+            ob = i0["terminal_observation"]
+        return ob, rew[0], d, i0
 
 
 class HipPongVecEnv(VecEnv):
