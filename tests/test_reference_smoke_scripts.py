@@ -131,3 +131,18 @@ def test_vec_env_constructors_over_thunks_equal_make_envs():
     assert tuple(oc2.shape) == tuple(oc.shape) == (2, 8, 96, 96) and tuple(dc.shape) == (2,) and tuple(rc.shape) == (2,)
     for e in (a, b, one, sub, cars):
         e.close()
+
+
+def test_vis_script_runs_a_match_between_builtin_agents(tmp_path):
+    """examples/vis.py = the reference's vis.py (minus the window): RULE_BASED against the MEDIUM network for one episode on ONE env."""
+    _need_gpu()
+    import ast
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "vis.py"), "--left", "RULE_BASED", "--right", "MEDIUM", "-N", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    left, right = ast.literal_eval(out.stdout.strip().splitlines()[-1])
+    assert sum(left[:3]) == 1 and left[0] == right[2] and left[2] == right[0] and left[3] == -right[3] and not os.path.exists(tmp_path / "tmp_vis")
