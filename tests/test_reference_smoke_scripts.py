@@ -144,5 +144,8 @@ def test_vis_script_runs_a_match_between_builtin_agents(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "examples", "vis.py"), "--left", "RULE_BASED", "--right", "MEDIUM", "-N", "1"],
                          capture_output=True, text=True, timeout=300, cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=root))
     assert out.returncode == 0, out.stderr[-2000:]
-    left, right = ast.literal_eval(out.stdout.strip().splitlines()[-1])
+    import re
+
+    last = re.sub(r"np\.float(32|64)\(([^)]*)\)", r"\2", out.stdout.strip().splitlines()[-1])   # (numpy 2 prints its scalars as np.float32(-21.0))
+    left, right = ast.literal_eval(last)
     assert sum(left[:3]) == 1 and left[0] == right[2] and left[2] == right[0] and left[3] == -right[3] and not os.path.exists(tmp_path / "tmp_vis")
