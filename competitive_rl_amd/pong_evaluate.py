@@ -111,6 +111,8 @@ def evaluate_two_policies(compute_action0, compute_action1, env, num_episode, re
                 reward = (reward.cpu().numpy() if isinstance(reward, torch.Tensor) else np.asarray(reward))[0]
             else:
                 obs, reward, done, _ = env.step([compute_action0(obs[0]), compute_action1(obs[1])])
+                if isinstance(reward, torch.Tensor):  # (envs.envs[0] of the HIP env hands out device tensors: the books are host floats, as the reference's)
+                    reward = reward.detach().cpu().numpy()
             matchTotalReward[0] += reward[0]
             matchTotalReward[1] += reward[1]
             if render:
