@@ -274,3 +274,62 @@ def test_thunk_factories_and_vec_env_constructors_without_a_gpu():
             crl.DummyVecEnv(t)
         with pytest.raises(RuntimeError, match="GPU"):
             t[1]()
+
+
+def test_single_env_handle_follows_gyms_reset_step_contract_on_a_fake_batch_of_one():
+    """``envs.envs[0].reset() / .step(action)`` of a one-env batch (vis.py's flow): the batch axis comes off, ``done`` is a scalar, the step that
+    ends an episode returns the TERMINAL observation, and the ``reset()`` that follows it hands out the restarted episode's first
+    observation without resetting the (already restarted) env again; a batch of several envs refuses per-env stepping."""
+    import pytest
+
+    from competitive_rl_amd import spaces
+    from competitive_rl_amd.vec_env import _EnvHandle
+
+    class Fake:
+        def __init__(self, n=1):
+            self.num_envs, self._serial, self.resets, self.t = n, 0, 0, 0
+            self.observation_space = spaces.Tuple([spaces.Box(0, 255, (1, 2, 2), dtype=np.uint8)] * 2)
+            self.action_space = spaces.Tuple([spaces.Discrete(3), spaces.Discrete(3)])
+            self.sent = []
+
+        def _obs(self, v):
+            return tuple(np.full((self.num_envs, 1, 2, 2), v + k, np.int32) for k in range(2))
+
+        def reset(self):
+            self.resets += 1
+            self.t = 0
+            return self._obs(100 * self.resets)
+
+        def step(self, actions):
+            self.sent.append(np.asarray(actions).copy())
+            self._serial += 1
+            self.t += 1
+            done = self.t == 3
+            info = [{}]
+            if done:  # the vector env restarts by itself and keeps the last observation in the infos
+                info[0]["terminal_observation"] = tuple(o[0] for o in self._obs(50 + self.t))
+                self.resets += 1
+                self.t = 0
+                obs = self._obs(100 * self.resets)
+            else:
+                obs = self._obs(10 + self.t)
+            return obs, np.array([[1.0, -1.0]], np.float32), np.array([[done, done]]), info
+
+    v = Fake()
+    e = _EnvHandle(v, 0)
+    o = e.reset()
+    assert isinstance(o, tuple) and o[0].shape == (1, 2, 2) and o[0][0, 0, 0] == 100 and v.resets == 1
+    for t in range(1, 4):
+        o, r, d, i = e.step([np.array([2]), 1])
+        assert v.sent[-1].shape == (1, 2) and v.sent[-1].tolist() == [[2, 1]] and r.tolist() == [1.0, -1.0] and d is (t == 3)
+    assert o[0][0, 0, 0] == 53 and "terminal_observation" in i       # the episode's last observation, not the next episode's first
+    o = e.reset()
+    assert o[0][0, 0, 0] == 200 and v.resets == 2                     # the restart the vector env already did: no second reset
+    o = e.reset()
+    assert o[0][0, 0, 0] == 300 and v.resets == 3                     # (a reset that does not follow a finished episode is a reset)
+    e.step([0, 0])
+    assert e.reset()[0][0, 0, 0] == 400
+    with pytest.raises(NotImplementedError):
+        _EnvHandle(Fake(2), 0).reset()
+    with pytest.raises(NotImplementedError):
+        _EnvHandle(Fake(2), 1).step([0, 0])
