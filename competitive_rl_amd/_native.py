@@ -24,7 +24,7 @@ SYMBOLS = ["crl_create", "crl_destroy", "crl_seed", "crl_reset", "crl_step", "cr
            "crl_obs_bytes_per_env", "crl_kernel_timing", "crl_kernel_time_ms", "crl_last_error", "crl_version",
            "crl_car_get_state", "crl_car_set_state", "crl_car_get_track", "crl_car_set_track", "crl_car_get_map", "crl_car_set_replay",
            "crl_policy_create", "crl_policy_create_full", "crl_policy_destroy", "crl_policy_reset", "crl_policy_act", "crl_policy_get_stack",
-           "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update", "crl_frame_stack_update_to", "crl_ctx_last_error",
+           "crl_policy_set_stack", "crl_terminal_observation_dev", "crl_check", "crl_car_info", "crl_car_copy_info", "crl_frame_stack_update", "crl_frame_stack_update_to", "crl_frame_stack_update_u8", "crl_ctx_last_error",
            "crl_obs_descriptors", "crl_render_frames_dev", "crl_car_cap_hits", "crl_selftest_sincosf", "crl_step_stack", "crl_draw_stack", "crl_set_flags_event", "crl_kernel_time_stats"]
 
 FRAME_DT = np.dtype([("ball_x", "<i2"), ("ball_y", "<i2"), ("bat_l_y", "u1"), ("bat_r_y", "u1"),
@@ -111,6 +111,7 @@ def load():
     L.crl_car_copy_info.argtypes = [vp, vp, vp, vp, vp]
     L.crl_frame_stack_update.argtypes = [vp, vp, i32, i64, vp, i64, i32, i32, i64, vp]
     L.crl_frame_stack_update_to.argtypes = [vp, vp, vp, i32, i64, vp, i64, i32, i32, i64, vp]
+    L.crl_frame_stack_update_u8.argtypes = [vp, vp, vp, i32, i64, vp, i64, i32, i32, i64, vp]
     L.crl_get_state.argtypes = [vp, vp, i64, i64, vp]
     L.crl_set_state.argtypes = [vp, vp, i64, i64, vp]
     L.crl_set_replay.argtypes = [vp, vp, vp, vp, i64]

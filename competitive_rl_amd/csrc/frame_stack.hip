@@ -128,6 +128,56 @@ __global__ __launch_bounds__(256) void frame_stack_copy_kernel(float *__restrict
     }
 }
 
+// The generic update of a uint8 stack (FrameStackTensor(dtype=torch.uint8): opt-in, a quarter of the bytes; its hot path is the stack drawn
+// by the step, this is what serves foreign observations, masks of the caller's own, skipped updates).  Same column walk as
+// frame_stack_update_kernel: a thread owns one 16-byte (or one-byte) column position of one env and walks up the planes, so the shift is
+// safe in place (dst == src) and out of place alike.  A mask entry of 0 erases the env's history, anything else keeps it (bytes cannot be
+// scaled); a float32 observation holds 0..255 integers and is truncated like a tensor cast.
+template <int VEC, bool OBS_F32>
+__global__ __launch_bounds__(256) void frame_stack_update_u8_kernel(uint8_t *dst, const uint8_t *src, const void *__restrict__ obs, int64_t obs_env_stride,
+                                                                    const float *__restrict__ mask, int64_t n, int c, int k, int64_t hw) {
+    const int64_t per_env = hw / VEC;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * per_env) return;
+    const int64_t env = t / per_env, x = (t - env * per_env) * VEC;
+    const int planes = c * k, keep = planes - c;
+    const bool erase = mask && mask[env] == 0.0f;
+    uint8_t *base = dst + env * planes * hw + x;
+    const uint8_t *sbase = src + env * planes * hw + x;
+    if (VEC == 16) {
+        for (int p = 0; p < keep; p++) {
+            uint4 v = *reinterpret_cast<const uint4 *>(sbase + (int64_t)(p + c) * hw);
+            if (erase) v = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(base + (int64_t)p * hw) = v;
+        }
+        for (int q = 0; q < c; q++) {
+            uint4 v;
+            if (OBS_F32) {
+                const float4 *f = reinterpret_cast<const float4 *>(static_cast<const float *>(obs) + env * obs_env_stride + (int64_t)q * hw + x);
+                uint32_t wds[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float4 a = f[i];
+                    wds[i] = (uint32_t)(uint8_t)(int)a.x | (uint32_t)(uint8_t)(int)a.y << 8 | (uint32_t)(uint8_t)(int)a.z << 16 | (uint32_t)(uint8_t)(int)a.w << 24;
+                }
+                v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+            } else {
+                v = *reinterpret_cast<const uint4 *>(static_cast<const uint8_t *>(obs) + env * obs_env_stride + (int64_t)q * hw + x);
+            }
+            *reinterpret_cast<uint4 *>(base + (int64_t)(keep + q) * hw) = v;
+        }
+    } else {
+        for (int p = 0; p < keep; p++) {
+            const uint8_t v = sbase[(int64_t)(p + c) * hw];
+            base[(int64_t)p * hw] = erase ? (uint8_t)0 : v;
+        }
+        for (int q = 0; q < c; q++) {
+            const int64_t o = env * obs_env_stride + (int64_t)q * hw + x;
+            base[(int64_t)(keep + q) * hw] = OBS_F32 ? (uint8_t)(int)static_cast<const float *>(obs)[o] : static_cast<const uint8_t *>(obs)[o];
+        }
+    }
+}
+
 }  // namespace crl
 
 static int frame_stack_update_impl(float *stack_dev, const float *src_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
@@ -178,4 +228,32 @@ extern "C" int crl_frame_stack_update(float *stack_dev, const void *obs_dev, int
 extern "C" int crl_frame_stack_update_to(float *dst_stack_dev, const float *src_stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
                                          const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream) {
     return frame_stack_update_impl(dst_stack_dev, src_stack_dev, obs_dev, obs_dtype, obs_env_stride, mask_dev, n, c, k, hw, stream);
+}
+
+extern "C" int crl_frame_stack_update_u8(uint8_t *dst_stack_dev, const uint8_t *src_stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
+                                         const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream) {
+    crl_fail_no_ctx();
+    if (!dst_stack_dev || !src_stack_dev || !obs_dev) return crl_fail(CRL_EINVAL, "frame_stack_update_u8: null tensor");
+    if (n <= 0 || c <= 0 || k <= 0 || hw <= 0) return crl_fail(CRL_EINVAL, "frame_stack_update_u8: bad shape n=%lld c=%d k=%d hw=%lld", (long long)n, c, k, (long long)hw);
+    if (obs_dtype != CRL_OBS_U8 && obs_dtype != CRL_OBS_F32) return crl_fail(CRL_EINVAL, "frame_stack_update_u8: obs_dtype %d", obs_dtype);
+    if (obs_env_stride < (int64_t)c * hw) return crl_fail(CRL_EINVAL, "frame_stack_update_u8: obs_env_stride %lld < c*hw", (long long)obs_env_stride);
+    if (src_stack_dev != dst_stack_dev) {  // two tensors: they must not overlap at all (the same tensor = the in-place update)
+        const int64_t bytes = n * c * k * hw;
+        const uintptr_t a = (uintptr_t)dst_stack_dev, b = (uintptr_t)src_stack_dev;
+        if (a < b + (uintptr_t)bytes && b < a + (uintptr_t)bytes) return crl_fail(CRL_EINVAL, "frame_stack_update_u8: destination and source stacks overlap");
+    }
+    const bool f32 = obs_dtype == CRL_OBS_F32;
+    const bool vec = hw % 16 == 0 && ((uintptr_t)dst_stack_dev % 16) == 0 && ((uintptr_t)src_stack_dev % 16) == 0 && ((uintptr_t)obs_dev % 16) == 0 &&
+                     (obs_env_stride * (f32 ? 4 : 1)) % 16 == 0;
+    const int64_t threads = n * (vec ? hw / 16 : hw);
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    using namespace crl;
+    if (vec && f32) hipLaunchKernelGGL((frame_stack_update_u8_kernel<16, true>), grid, block, 0, st, dst_stack_dev, src_stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    else if (vec) hipLaunchKernelGGL((frame_stack_update_u8_kernel<16, false>), grid, block, 0, st, dst_stack_dev, src_stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    else if (f32) hipLaunchKernelGGL((frame_stack_update_u8_kernel<1, true>), grid, block, 0, st, dst_stack_dev, src_stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    else hipLaunchKernelGGL((frame_stack_update_u8_kernel<1, false>), grid, block, 0, st, dst_stack_dev, src_stack_dev, obs_dev, obs_env_stride, mask_dev, n, c, k, hw);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return crl_fail(CRL_EHIP, "frame_stack_update_u8: %s", hipGetErrorString(e));
+    return CRL_OK;
 }

@@ -89,7 +89,7 @@ class FrameStackTensor:
         if self._try_commit(obs, mask, _from_env):
             return self.current_obs
         o, m = self._as_obs(obs), self._as_mask(mask)
-        if self._lib is not None and self.dtype == torch.float32:
+        if self._lib is not None:
             self._update_hip(o, m)
         else:
             self._update_host(o, m)
@@ -241,7 +241,12 @@ class FrameStackTensor:
         tail = (N.CRL_OBS_F32 if o.dtype == torch.float32 else N.CRL_OBS_U8, int(stride), None if m is None else C.c_void_p(m.data_ptr()),
                 self.num_envs, self.num_channels, self.frame_stack, self._hw, st)
         with torch.cuda.device(self.device):
-            if self.out_of_place:
+            if self.dtype == torch.uint8:  # the opt-in byte stack: one entry point, in place (dst == src) or into the other buffer
+                dst = self._other_buffer() if self.out_of_place else self.current_obs
+                N.check(self._lib.crl_frame_stack_update_u8(C.c_void_p(dst.data_ptr()), C.c_void_p(self.current_obs.data_ptr()), C.c_void_p(o.data_ptr()), *tail))
+                if self.out_of_place:
+                    self._spare, self.current_obs = self.current_obs, dst
+            elif self.out_of_place:
                 # the reference's own data flow (`self.current_obs = self.current_obs.roll(...)`: a new tensor per update), as a ping-pong of two
                 # buffers: the tensor handed out by the LAST update stays intact through this one and is recycled by the next
                 dst = self._other_buffer()
@@ -252,7 +257,7 @@ class FrameStackTensor:
                 N.check(self._lib.crl_frame_stack_update(C.c_void_p(self.current_obs.data_ptr()), C.c_void_p(o.data_ptr()), *tail))
 
     def _update_host(self, o, m):
-        """Plain tensor arithmetic: host-resident stacks, and the generic update of a uint8 stack (whose hot path is the bound one)."""
+        """Plain tensor arithmetic: host-resident stacks only (device="cpu", numpy observations)."""
         c, buf = self.num_channels, self.current_obs
         kept = buf[:, c:]
         if m is not None:

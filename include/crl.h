@@ -395,6 +395,12 @@ int crl_frame_stack_update(float *stack_dev, const void *obs_dev, int32_t obs_dt
  * src must not overlap (CRL_EINVAL). */
 int crl_frame_stack_update_to(float *dst_stack_dev, const float *src_stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
                               const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream);
+/* The same update of a UINT8 stack (N, C*k, H, W) -- `FrameStackTensor(..., dtype=torch.uint8)`, an opt-in beside the reference's float32
+ * contract (utils/utils.py:145-157 allocates float32) --, in place (dst == src) or into another tensor (no overlap: CRL_EINVAL).  Bytes
+ * cannot be scaled: a mask entry of 0 erases the env's history, any other value keeps it (the masks of step_envs are 1 - done,
+ * utils/utils.py:55-57); a float32 observation holds 0..255 integers and is truncated as a tensor cast would. */
+int crl_frame_stack_update_u8(uint8_t *dst_stack_dev, const uint8_t *src_stack_dev, const void *obs_dev, int32_t obs_dtype, int64_t obs_env_stride,
+                              const float *mask_dev, int64_t n, int32_t c, int32_t k, int64_t hw, void *stream);
 
 /* ---- built-in CNN opponents of cPongTournament-v0 ----------------------------
  * Stands in for utils/policy_serving.py:10-66 `Policy(..., use_light_model=True)` as built by

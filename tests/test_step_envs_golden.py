@@ -170,6 +170,38 @@ def test_frame_stack_kernel_equals_torch_ops(dtype, out_of_place):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("out_of_place", [True, False])
+@pytest.mark.parametrize("dtype", ["uint8", "float32"])
+def test_uint8_frame_stack_kernel_equals_tensor_ops(dtype, out_of_place):
+    """crl_frame_stack_update_u8 (the generic update of the opt-in byte stack, in place and into the other buffer) against the tensor
+    operations it stands for: history kept or erased by the mask's zeros, planes shifted by C, the observation (uint8, or float32 holding
+    integers; strided) as the newest planes -- 16-byte and one-byte paths."""
+    _need_gpu()
+    import competitive_rl_amd as crl
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(6)
+    for (n, c, k, h, w) in ((37, 1, 4, 84, 84), (5, 2, 3, 7, 9), (64, 1, 1, 42, 42), (3, 3, 2, 96, 96), (9, 1, 4, 42, 42)):
+        f = crl.FrameStackTensor(n, (c, h, w), k, dev, out_of_place=out_of_place, dtype=torch.uint8)
+        ref = torch.zeros((n, c * k, h, w), device=dev, dtype=torch.uint8)
+        last_out = last_ref = None
+        for step in range(6):
+            wide = torch.randint(0, 256, (n, 2, c, h, w), generator=g, device=dev, dtype=torch.uint8)
+            obs = wide[:, 1] if dtype == "uint8" else wide[:, 1].float()
+            mask = None if step % 3 == 0 else (torch.rand((n, 1, 1, 1), generator=g, device=dev) > 0.3).float()
+            if mask is not None:
+                ref = ref * (mask != 0).to(torch.uint8)
+            ref = ref.roll(shifts=-c, dims=1)
+            ref[:, -c:] = wide[:, 1]
+            out = f.update(obs, mask)
+            assert out.dtype == torch.uint8 and torch.equal(out, ref), (n, c, k, h, w, step)
+            assert out.data_ptr() == f.get().data_ptr()
+            if out_of_place and last_out is not None:
+                assert out.data_ptr() != last_out.data_ptr() and torch.equal(last_out, last_ref), (n, c, k, h, w, step)
+            last_out, last_ref = out, ref.clone()
+
+
+@pytest.mark.gpu
 def test_frame_stack_update_to_rejects_overlapping_tensors():
     _need_gpu()
     import ctypes as C
