@@ -36,6 +36,8 @@ def make_envs(env_id="cPong-v0", seed=0, log_dir="data", num_envs=3, asynchronou
     :param dones: GPU extra -- "dummy" / "subproc": the return convention whatever ``asynchronous`` and ``num_envs`` say (what the
         ``DummyVecEnv`` / ``SubprocVecEnv`` constructors below pass: a SubprocVecEnv of ONE env still returns (N,) dones).
     """
+    if dones not in (None, "dummy", "subproc"):
+        raise ValueError(f"dones must be None, 'dummy' or 'subproc', got {dones!r}")
     asynchronous = (asynchronous and num_envs > 1) if dones is None else dones == "subproc"
     if backend != "hip":
         raise ValueError("competitive_rl_amd only provides backend='hip'")
