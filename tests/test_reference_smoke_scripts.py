@@ -149,3 +149,37 @@ def test_vis_script_runs_a_match_between_builtin_agents(tmp_path):
     last = re.sub(r"np\.float(32|64)\(([^)]*)\)", r"\2", out.stdout.strip().splitlines()[-1])   # (numpy 2 prints its scalars as np.float32(-21.0))
     left, right = ast.literal_eval(last)
     assert sum(left[:3]) == 1 and left[0] == right[2] and left[2] == right[0] and left[3] == -right[3] and not os.path.exists(tmp_path / "tmp_vis")
+
+
+def test_reference_car_racing_blackbox_and_action_repetition_scripts():
+    """car_racing/test_car_racing.py (``test_blackbox``: 100 sampled actions with ``reset()`` on done; ``test_action_repetition``: the same
+    constant action [0.0, 1] for 200 frames as 200 steps of action_repeat=1 and as 40 steps of action_repeat=5) through the single-env
+    handle -- the window (``render("human")``) left out.  With action_repeat=5 a step is five physics frames: five times the per-frame
+    penalty of a standing start, and the car is further along after the same number of steps."""
+    _need_gpu()
+    from competitive_rl_amd import make_envs
+
+    e = make_envs("cCarRacing-v0", seed=0, log_dir=None, num_envs=1, frame_stack=None).envs[0]
+    o = e.reset()
+    assert tuple(o.shape) == (1, 96, 96)
+    for _ in range(100):
+        o, r, d, info = e.step(e.action_space.sample())
+        assert isinstance(d, bool) and tuple(o.shape) == (1, 96, 96)
+        if d:
+            e.reset()
+    e.close()
+    rets = {}
+    for rep, steps in ((1, 200), (5, 40)):
+        envs = make_envs("cCarRacing-v0", seed=0, log_dir=None, num_envs=1, frame_stack=None, action_repeat=rep)
+        e = envs.envs[0]
+        e.seed(0)
+        e.reset()
+        total = 0.0
+        for _ in range(steps):
+            ret = e.step([0.0, 1])
+            total += float(ret[1].reshape(-1)[0])
+        rets[rep] = (total, int(ret[3]["num_steps"]) if "num_steps" in ret[3] else None, envs.get_state())
+        envs.close()
+    # 200 physics frames either way (CarRacing.step_count counts frames), full throttle from a standing start on the same track
+    assert rets[1][1] == rets[5][1] == 200 or rets[1][1] is None
+    assert np.isfinite(rets[1][0]) and np.isfinite(rets[5][0])
