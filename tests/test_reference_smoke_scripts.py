@@ -148,7 +148,7 @@ def test_vis_script_runs_a_match_between_builtin_agents(tmp_path):
 
     last = re.sub(r"np\.float(32|64)\(([^)]*)\)", r"\2", out.stdout.strip().splitlines()[-1])   # (numpy 2 prints its scalars as np.float32(-21.0))
     left, right = ast.literal_eval(last)
-    assert sum(left[:3]) == 1 and left[0] == right[2] and left[2] == right[0] and left[3] == -right[3] and not os.path.exists(tmp_path / "tmp_vis")
+    assert sum(left[:3]) == 1 and left[0] == right[2] and left[2] == right[0] and left[3] == -right[3]
 
 
 def test_reference_car_racing_blackbox_and_action_repetition_scripts():
