@@ -176,8 +176,25 @@ class Policy:
         torch.cuda.current_stream(self.device).synchronize()
 
     def compute_action(self, obs, deterministic=True):
-        raise NotImplementedError("the device policy is called with single frames (Policy.__call__ / act_device); "
-                                  "sampling (deterministic=False) is not used by the built-in opponents")
+        """Reference protocol (policy_serving.py:48-56): actions (N, 1) for a whole STACKED observation (N, 4, 42, 42) -- greedy, or
+        sampled from the softmax of the logits -- without touching the policy's own frame stack (which only ``__call__`` / ``act_device``
+        advance).  The network runs as in ``act_device``: the stack is put into the kernel's ring shifted by one plane, the newest plane
+        is pushed (the ring then holds exactly ``obs``), and the ring is restored afterwards.  Not a hot path (three small copies)."""
+        o = torch.from_numpy(np.ascontiguousarray(obs)) if isinstance(obs, np.ndarray) else obs
+        o = o.to(self.device)
+        if tuple(o.shape) != (self.num_envs, 4, 42, 42):
+            raise ValueError(f"compute_action takes the stacked observation ({self.num_envs}, 4, 42, 42), got {tuple(o.shape)}")
+        if o.dtype != torch.uint8:
+            o = o.to(torch.uint8)  # (0..255 integers, as FrameStackTensor holds them)
+        saved = self.get_stack()
+        self.set_stack(torch.roll(o, shifts=1, dims=1))          # planes 0..2 of `obs` in ring positions 1..3; position 0 rolls out
+        greedy = self.act_device(o[:, 3].contiguous(), out=torch.empty((self.num_envs,), dtype=torch.int32, device=self.device), want_logits=True)
+        if deterministic:
+            actions = greedy.to(torch.int64)
+        else:
+            actions = torch.distributions.Categorical(logits=self._logits).sample()
+        self.set_stack(saved)
+        return actions.view(-1, 1)
 
     def __call__(self, obs):
         """Reference protocol (policy_serving.py:58-66): numpy (N, 1) int64, or an int for one env."""
