@@ -235,7 +235,6 @@ def test_compute_action_on_a_stacked_observation():
             ora(f)
         own = pol.get_stack().clone()
         stack = np.concatenate(frames[2:], 1)                         # (n, 4, 42, 42): another situation altogether
-        probe = P.PolicyOracle(ora.w, n) if hasattr(ora, "w") else None
         a = pol.compute_action(stack, deterministic=True)
         assert tuple(a.shape) == (n, 1) and a.dtype == torch.int64 and a.is_cuda
         assert torch.equal(pol.get_stack(), own)
@@ -253,6 +252,5 @@ def test_compute_action_on_a_stacked_observation():
         assert np.abs(freq - p).max() < 0.15, (freq, p)
         assert torch.equal(pol.get_stack(), own)
         pol.close(), ref.close()
-        del probe
     with pytest.raises(ValueError):
         get_compute_action_function("WEAK", 2).compute_action(np.zeros((2, 1, 42, 42), np.uint8))
